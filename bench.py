@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s closest-hit on the 1M-triangle scene (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload = "S1M_bounce16M", BASELINE.json configs[2]): scene S1M
+(1 000 300 triangles), 16 777 216 incoherent cosine-hemisphere bounce rays generated from
+the 4096x4096 primary hits of one camera, closest hit.  One "step" = one pass of the hot
+path (vt_trace_closest_dev) over the whole ray batch, rays and hits resident in HBM.
+With N > 1 ranks the BVH is replicated, every rank traces its own 16 Mi-ray batch (camera =
+rank; weak scaling) and the hit records are gathered to rank 0 over RCCL inside the step.
+
+The printed JSON line also carries
+  roofline     -- algorithmic bytes (32+16+64*steps+64*tests per ray, counters from the
+                  device stats kernel, cross-checked with the CPU oracle on the sample)
+                  / mean kernel time (HIP events on the launch stream) vs the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle (oracle/, a port: the reference itself cannot be built
+                  here) on all host cores over a bounded sample of the same rays.
+Data is synthetic (seeded generator, vistrace_amd/workloads.py); nothing reads /root/reference.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="S1M")
+    ap.add_argument("--side", type=int, default=4096, help="primary image side; rays per GPU = side*side")
+    ap.add_argument("--kind", default="bounce", choices=["bounce", "primary"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--mode", default=None, choices=[None, "persistent", "static"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import vistrace_amd as va
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    from vistrace_amd._lib import HIT, HIT_ATTRS, RAY, RAY_STATS
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the traversal has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    # ---- scene: CPU build once, upload once (Rebuild) -----------------------------------
+    t0 = time.time()
+    verts = W.make_scene(args.scene)
+    tris = va.tris_setup(verts)
+    t1 = time.time()
+    bvh = va.HostBvh(tris)
+    t2 = time.time()
+    host_scene = va.HostScene(bvh)
+    engine = va.Engine(local_rank)
+    if args.mode is not None:
+        engine.set_option("persistent", 1 if args.mode == "persistent" else 0)
+    scene = va.Scene(engine, host_scene)
+    t3 = time.time()
+    log(f"[bench] scene {args.scene}: {len(tris)} tris, {host_scene.pair_count} pairs, depth {host_scene.max_depth}, "
+        f"{scene.device_bytes / 1e6:.1f} MB on device; gen {t1 - t0:.2f}s build {t2 - t1:.2f}s upload {t3 - t2:.2f}s")
+
+    # ---- rays: primary pass on the GPU, bounce rays from its hit records ----------------
+    side = args.side
+    n = side * side
+    cams = W.camera_positions(args.scene)
+    cam = cams[rank % len(cams)]
+    prim_rays = W.primary_rays(side, side, pos=cam)
+    d_prim = tp.to_device(prim_rays, device)
+    if args.kind == "primary":
+        d_rays, rays_host = d_prim, prim_rays
+    else:
+        d_hits0 = tp.trace_closest(scene, d_prim, n)
+        attrs = tp.to_host(tp.hit_attrs(scene, d_prim, d_hits0, n), HIT_ATTRS)
+        miss = int((attrs["hit"] == 0).sum())
+        rays_host = W.bounce_rays(attrs, W.SEED + 3 + 1000 * rank)
+        d_rays = tp.to_device(rays_host, device)
+        del attrs, d_hits0, d_prim
+        log(f"[bench] bounce rays: {n} from {side}x{side} primary hits ({miss} primary misses re-filled)")
+    d_hits = tp.empty_records(n, HIT, device)
+    gather_list = None
+    if world > 1 and rank == 0:
+        gather_list = [tp.empty_records(n, HIT, device) for _ in range(world)]
+    t4 = time.time()
+    log(f"[bench] ray set-up {t4 - t3:.2f}s")
+
+    # ---- algorithmic bytes: exact counters from the stats kernel (untimed) --------------
+    _, d_stats = tp.trace_stats(scene, d_rays, n)
+    torch.cuda.synchronize(device)
+    stats = tp.to_host(d_stats, RAY_STATS)
+    tot_steps = int(stats["steps"].sum(dtype=np.uint64))
+    tot_tests = int(stats["tests"].sum(dtype=np.uint64))
+    del d_stats
+    alg_bytes = n * (32 + 16) + 64 * (tot_steps + tot_tests)
+    log(f"[bench] steps/ray {tot_steps / n:.2f} tests/ray {tot_tests / n:.2f} -> {alg_bytes / n:.0f} B/ray algorithmic")
+
+    # ---- timed region -------------------------------------------------------------------
+    engine.set_timing(True)
+
+    def step():
+        tp.trace_closest(scene, d_rays, n, d_hits)
+        if world > 1:
+            dist.gather(d_hits, gather_list, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms = []
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(engine.last_kernel_ms())  # HIP events on the launch stream
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    engine.set_timing(False)
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * n * args.steps / elapsed / 1e6
+    k_ms = float(np.mean(kernel_ms))
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "Mrays/s closest-hit, 1M-triangle scene",
+        "value": round(value, 2),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.scene}_{args.kind}{n}",
+            "scene_triangles": int(len(tris)),
+            "rays_per_gpu": n,
+            "query": "closest-hit",
+            "ray_kind": "cosine-hemisphere bounce (incoherent)" if args.kind == "bounce" else "pinhole primary",
+            "parallelism": f"rays sharded x{world}, BVH replicated" + (", RCCL gather of hits to rank 0" if world > 1 else ""),
+            "kernel_mode": "persistent" if engine.get_option("persistent") else "static",
+            "launch": engine.launch_info(),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "kernel": "vt::trace_kernel<false,false,true>" if engine.get_option("persistent") else "vt::trace_kernel<false,false,false>",
+            "kernel_ms": round(k_ms, 4),
+            "alg_bytes_per_ray": round(alg_bytes / n, 1),
+            "steps_per_ray": round(tot_steps / n, 2),
+            "tests_per_ray": round(tot_tests / n, 2),
+        },
+    }
+
+    # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) -------------------
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import binding as O
+        nodes = bvh.nodes().view(O.NODE)
+        pidx = bvh.prim_indices()
+        otris = O.tris_from_tri64(tris)
+        pilot = min(n, 1 << 15)
+        tp0 = time.perf_counter()
+        O.traverse_batch(nodes, pidx, otris, rays_host[:pilot])
+        rate = pilot / (time.perf_counter() - tp0)
+        sample = int(min(n, max(pilot, rate * args.cpu_seconds)))
+        sample = max(4096, (sample // 4096) * 4096) if n >= 4096 else n
+        tc0 = time.perf_counter()
+        ref, ref_stats, s_steps, s_tests, threads = O.traverse_batch(nodes, pidx, otris, rays_host[:sample], want_stats=True)
+        cpu_s = time.perf_counter() - tc0
+        gpu = tp.to_host(d_hits[: sample * HIT.itemsize], HIT)
+        same_prim = bool((gpu["prim"] == ref["prim"]).all())
+        same_tuv = all(bool((gpu[k].view(np.uint32) == ref[k].view(np.uint32)).all()) for k in ("t", "u", "v"))
+        same_stats = bool((stats[:sample]["steps"] == ref_stats[:, 0]).all() and (stats[:sample]["tests"] == ref_stats[:, 1]).all())
+        cpu_model = ""
+        try:
+            with open("/proc/cpuinfo") as f:
+                for line in f:
+                    if line.startswith("model name"):
+                        cpu_model = line.split(":", 1)[1].strip()
+                        break
+        except OSError:
+            pass
+        result["cpu_baseline"] = {
+            "value": round(sample / cpu_s / 1e6, 4),
+            "unit": "Mrays/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": f"first {sample} rays of the same batch, same tree, OpenMP schedule(dynamic,4096), {cpu_s:.1f}s",
+            "cpu": cpu_model,
+        }
+        result["parity_sample"] = {"rays": sample, "prim_bit_exact": same_prim, "tuv_bit_exact": same_tuv,
+                                   "counters_equal": same_stats}
+        if not (same_prim and same_tuv):
+            log("[bench] PARITY FAILURE on the sample")
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

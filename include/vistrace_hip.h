@@ -1,0 +1,167 @@
+/*
+ * vistrace_hip.h -- C ABI of the MI355X (gfx950) ray-tracing core for VisTrace.
+ *
+ * This is the drop-in boundary for ONE path of Derpius/VisTrace:
+ * AccelStruct::Traverse and the BVH hand-over that feeds it.  The reference has
+ * no FFI for this path (it calls madmann91/bvh in-process), so every entry point
+ * below names the reference code it replaces (paths relative to the reference
+ * tree).  The host C++ class vistrace::AccelStruct (vistrace_amd/csrc/host/) sits
+ * above this header and keeps the reference's GLua surface; INTEGRATION.md shows
+ * the three-line patch a VisTrace maintainer would apply.
+ *
+ * Conventions: plain pointers and sizes, POD structs, `int` status (0 = ok),
+ * no exceptions or longjmp across the boundary, caller owns every host buffer.
+ * All calls are synchronous unless the name ends in `_dev` (device pointers,
+ * enqueued on the given HIP stream, no host sync).  There is NO CPU fallback:
+ * if no HIP device is usable the call fails with VT_ERR_HIP.
+ */
+#ifndef VISTRACE_HIP_H
+#define VISTRACE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VT_ABI_VERSION 1
+
+enum vt_status {
+    VT_OK              = 0,
+    VT_ERR_INVALID_ARG = 1,
+    VT_ERR_HIP         = 2, /* HIP runtime/driver error or no device   */
+    VT_ERR_UNSUPPORTED = 3, /* e.g. alpha-tested triangles (see below) */
+    VT_ERR_NOMEM       = 4,
+    VT_ERR_STACK       = 5  /* tree deeper than the traversal stack    */
+};
+
+#define VT_MISS 0xFFFFFFFFu
+
+/* triangle flags, resolved from Material::flags at upload time */
+#define VT_TRI_CULL_BACKFACE 1u /* oneSided && !(mat.flags & nocull): source/objects/Primitives.h:174 */
+#define VT_TRI_ALPHATEST     2u /* mat.flags & alphatest: source/objects/Primitives.h:196 (not yet on device) */
+
+/* bvh::Ray<float> without the pAccel pointer: source/objects/Primitives.h:11-33.  32 B. */
+typedef struct vt_ray { float org[3]; float dir[3]; float tmin; float tmax; } vt_ray;
+
+/* What mpTraverser->traverse() returns (source/objects/AccelStruct.cpp:818-820):
+ * primitive_index + Intersection{t,u,v} (source/objects/Primitives.h:47-51).
+ * prim == VT_MISS <=> std::nullopt.  16 B. */
+typedef struct vt_hit { uint32_t prim; float t; float u; float v; } vt_hit;
+
+/* bvh::Bvh<float>::Node of madmann91/bvh v1 (type alias source/objects/AccelStruct.h:27):
+ * bounds = {minx,maxx,miny,maxy,minz,maxz}; prim_count != 0 <=> leaf; `first` is
+ * the first child (inner) or the first slot in prim_indices (leaf).  32 B.
+ * nodes[0] is the root, the two children of an inner node are adjacent. */
+typedef struct vt_bvh_node { float bounds[6]; uint32_t prim_count; uint32_t first; } vt_bvh_node;
+
+/* Device node record: one sibling pair, 64 B, 64-B aligned.  For an inner child
+ * `first` is the index of ITS pair; for a leaf child it is the first record in
+ * the leaf-ordered vt_tri64 array. */
+typedef struct vt_node_pair { vt_bvh_node child[2]; } vt_node_pair;
+
+/* Device triangle record, 64 B: the fields TriangleBackfaceCull::intersect reads
+ * (source/objects/Primitives.h:56,168-215) + the original triangle index the
+ * reference reports as hit->primitive_index. */
+typedef struct vt_tri64 {
+    float p0[3]; float e1[3]; float e2[3]; float n[3];
+    uint32_t prim; uint32_t flags; uint32_t pad[2];
+} vt_tri64;
+
+/* Per-ray traversal counters = bvh v1 Statistics{traversal_steps, intersections}. */
+typedef struct vt_ray_stats { uint32_t steps; uint32_t tests; } vt_ray_stats;
+
+/* Batched TraceResult core (source/objects/TraceResult.cpp:45-86, 255-262). 64 B. */
+typedef struct vt_hit_attrs {
+    float pos[3];   float t;        /* GetPos() :255-262 ; distance :52            */
+    float ngeo[3];  uint32_t prim;  /* geometricNormal :71                          */
+    float uvw[3];   uint32_t front; /* uvw :70 ; frontFacing :85                    */
+    float wo[3];    uint32_t hit;   /* wo :56 ; hit = 1, or 0 for a miss (all zero) */
+} vt_hit_attrs;
+
+typedef struct vt_bvh        vt_bvh;        /* host: v1-layout tree                 */
+typedef struct vt_host_scene vt_host_scene; /* host: linearised pairs + tri records */
+typedef struct vt_engine     vt_engine;     /* one HIP device + stream              */
+typedef struct vt_scene      vt_scene;      /* device-resident scene                */
+
+/* Thread-local description of the last error on this thread ("" if none). */
+const char* vt_last_error(void);
+int         vt_abi_version(void);
+
+/* ---- host side: Rebuild (CPU, as in the reference) --------------------------------- */
+
+/* Triangle constructor + ComputeNormalAndLoD: source/objects/Primitives.h:75-102.
+ * verts = n x {p0,p1,p2} (9 floats); flags may be NULL (all 0); out[i].prim = i. */
+int vt_tris_setup(const float* verts, const uint8_t* flags, uint32_t n, vt_tri64* out);
+
+/* BVH build tail of AccelStruct::PopulateAccel, source/objects/AccelStruct.cpp:763-770:
+ * bounding boxes + centres (Primitives.h:107-118), Morton-32 sort, PLOC (search
+ * radius 14), SAH leaf collapse.  tris in ORIGINAL order.  n == 0 gives an empty
+ * tree (every trace misses).  nthreads <= 0: OpenMP default. */
+int             vt_bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, vt_bvh** out);
+void            vt_bvh_free(vt_bvh* bvh);
+uint32_t        vt_bvh_node_count(const vt_bvh* bvh);
+uint32_t        vt_bvh_prim_count(const vt_bvh* bvh);
+const vt_bvh_node* vt_bvh_nodes(const vt_bvh* bvh);
+const uint32_t* vt_bvh_prim_indices(const vt_bvh* bvh);
+
+/* Re-pack for the device (replaces `new Intersector(mAccel, mTriangles.data())` /
+ * `new Traverser(mAccel)`, source/objects/AccelStruct.cpp:772-773): sibling pairs
+ * in depth-first order, triangles pre-shuffled into leaf order. */
+int                 vt_scene_linearise(const vt_bvh* bvh, const vt_tri64* tris, vt_host_scene** out);
+void                vt_host_scene_free(vt_host_scene* hs);
+uint32_t            vt_host_scene_pair_count(const vt_host_scene* hs);
+uint32_t            vt_host_scene_tri_count(const vt_host_scene* hs);
+uint32_t            vt_host_scene_max_depth(const vt_host_scene* hs);
+uint32_t            vt_host_scene_root_leaf_count(const vt_host_scene* hs);
+const vt_node_pair* vt_host_scene_pairs(const vt_host_scene* hs);
+const vt_tri64*     vt_host_scene_tris(const vt_host_scene* hs);
+
+/* ---- device side ---------------------------------------------------------------------- */
+
+int  vt_device_count(int* count);
+int  vt_engine_open(int device, vt_engine** out);
+void vt_engine_close(vt_engine* e);
+
+/* Upload once per Rebuild (north star: "uploaded once per Rebuild"). */
+int  vt_scene_upload(vt_engine* e, const vt_host_scene* hs, vt_scene** out);
+void vt_scene_free(vt_scene* s);
+uint64_t vt_scene_device_bytes(const vt_scene* s);
+
+/* The call at source/objects/AccelStruct.cpp:818, batched: closest hit per ray. */
+int vt_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_hit* hits);
+/* bvh v1 AnyPrimitiveIntersector semantics (any_hit early-out): occluded[i] = 0/1. */
+int vt_trace_any(vt_scene* s, const vt_ray* rays, uint64_t n, uint8_t* occluded);
+
+/* Device-pointer variants: d_rays/d_hits live on the scene's device; enqueued on
+ * `stream` (a hipStream_t; NULL = the engine's own stream); no host sync. */
+int vt_trace_closest_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* stream);
+int vt_trace_any_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_occluded, void* stream);
+/* Closest hit + per-ray counters (diagnostic kernel; same visitation order). */
+int vt_trace_stats_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits,
+                       void* d_ray_stats, void* stream);
+/* TraceResult batch materialisation from hits (d_attrs: n x vt_hit_attrs). */
+int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64_t n,
+                     void* d_attrs, void* stream);
+
+/* Launch configuration. Keys: "persistent" (0/1), "lds_entries" (stack entries per lane
+ * kept in LDS), "blocks_per_cu", "block_rays" (rays handed to a wave at a time),
+ * "refill_threshold" (idle lanes that trigger a re-fill); read-only: "cu_count", "device".
+ * Results never depend on these, only speed does. */
+int vt_engine_set_option(vt_engine* e, const char* key, int64_t value);
+int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value);
+/* Wait for everything enqueued on the engine's own stream. */
+int vt_engine_synchronize(vt_engine* e);
+
+/* When enabled, every trace launch is bracketed by HIP events on its stream;
+ * vt_engine_last_kernel_ms synchronises on the last pair and returns its time. */
+int vt_engine_set_timing(vt_engine* e, int enabled);
+int vt_engine_last_kernel_ms(vt_engine* e, float* ms);
+/* Launch geometry actually used (for DESIGN.md / bench reporting). */
+int vt_engine_launch_info(vt_engine* e, uint32_t* blocks, uint32_t* threads, uint32_t* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

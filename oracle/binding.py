@@ -1,0 +1,137 @@
+"""ctypes binding of oracle/_build/libvt_oracle.so (see oracle/vt_oracle.h).
+
+TEST INFRASTRUCTURE ONLY.  Import this from tests/, from __graft_entry__.smoke() and
+from bench.py's cpu_baseline leg -- never from the vistrace_amd package.
+Parity status: "parity unpinned" (the reference holds no golden vectors for this path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libvt_oracle.so")
+
+MISS = 0xFFFFFFFF
+RAY = np.dtype([("org", "<f4", 3), ("dir", "<f4", 3), ("tmin", "<f4"), ("tmax", "<f4")])
+TRI = np.dtype([("p0", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3), ("n", "<f4", 3), ("flags", "<u4")])
+NODE = np.dtype([("bounds", "<f4", 6), ("prim_count", "<u4"), ("first", "<u4")])
+HIT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+ATTRS = np.dtype([("pos", "<f4", 3), ("uvw", "<f4", 3), ("ngeo", "<f4", 3), ("wo", "<f4", 3), ("front", "<u4")])
+
+
+class _Stats(C.Structure):
+    _fields_ = [("steps", C.c_uint64), ("tests", C.c_uint64)]
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+        L.vto_tri_setup.argtypes = [vp, vp, vp, u32, vp]
+        L.vto_tri_intersect.argtypes = [vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
+        L.vto_tri_intersect.restype = C.c_int
+        L.vto_trace_brute.argtypes = [vp, u32, vp, u64, C.c_int, vp, C.c_int]
+        L.vto_min_t_set.argtypes = [vp, u32, vp, vp, vp, u32]
+        L.vto_min_t_set.restype = u32
+        L.vto_traverse.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
+        L.vto_traverse.restype = C.c_int
+        L.vto_traverse_batch.argtypes = [vp, vp, vp, vp, u64, C.c_int, vp, vp, vp, C.c_int]
+        L.vto_traverse_batch.restype = C.c_int
+        L.vto_hit_attrs.argtypes = [vp, vp, C.c_float, C.c_float, vp]
+        L.vto_calc_ray_origin.argtypes = [vp, vp, vp]
+        L.vto_hemisphere_cos.argtypes = [C.c_float, C.c_float, vp]
+        _lib = L
+    return _lib
+
+
+def tris_setup(verts: np.ndarray, flags=None) -> np.ndarray:
+    """(n,3,3) float32 -> oracle triangle records (Primitives.h:75-102)."""
+    verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3, 3)
+    out = np.zeros(len(verts), TRI)
+    L = lib()
+    for i in range(len(verts)):
+        f = int(flags[i]) if flags is not None else 0
+        L.vto_tri_setup(verts[i, 0].ctypes.data, verts[i, 1].ctypes.data, verts[i, 2].ctypes.data, f,
+                        out[i:i + 1].ctypes.data)
+    return out
+
+
+def tris_from_tri64(tri64: np.ndarray) -> np.ndarray:
+    """Re-use records set up by the product (fields are compared separately in tests)."""
+    out = np.zeros(len(tri64), TRI)
+    for k in ("p0", "e1", "e2", "n", "flags"):
+        out[k] = tri64[k]
+    return out
+
+
+def trace_brute(tris: np.ndarray, rays: np.ndarray, any_hit: bool = False, nthreads: int = 0) -> np.ndarray:
+    assert tris.dtype == TRI
+    rays = np.ascontiguousarray(rays).view(RAY) if rays.dtype != RAY else np.ascontiguousarray(rays)
+    hits = np.zeros(len(rays), HIT)
+    lib().vto_trace_brute(tris.ctypes.data, len(tris), rays.ctypes.data, len(rays), int(any_hit), hits.ctypes.data,
+                          nthreads)
+    return hits
+
+
+def min_t_set(tris: np.ndarray, ray: np.ndarray, max_ids: int = 16):
+    ids = np.zeros(max_ids, np.uint32)
+    t = C.c_float(0)
+    ray = np.ascontiguousarray(ray)
+    n = lib().vto_min_t_set(tris.ctypes.data, len(tris), ray.ctypes.data, C.addressof(t), ids.ctypes.data, max_ids)
+    return t.value, ids[:min(n, max_ids)].copy(), n
+
+
+def traverse_batch(nodes: np.ndarray, prim_indices: np.ndarray, tris: np.ndarray, rays: np.ndarray,
+                   any_hit: bool = False, want_stats: bool = False, nthreads: int = 0):
+    """Returns (hits, per_ray_stats or None, total_steps, total_tests, threads_used)."""
+    assert nodes.dtype == NODE and tris.dtype == TRI
+    nodes = np.ascontiguousarray(nodes)
+    prim_indices = np.ascontiguousarray(prim_indices, np.uint32)
+    rays = np.ascontiguousarray(rays)
+    hits = np.zeros(len(rays), HIT)
+    st = np.zeros((len(rays), 2), np.uint32) if want_stats else None
+    tot = _Stats()
+    used = lib().vto_traverse_batch(nodes.ctypes.data, prim_indices.ctypes.data, tris.ctypes.data, rays.ctypes.data,
+                                    len(rays), int(any_hit), hits.ctypes.data,
+                                    st.ctypes.data if st is not None else None, C.addressof(tot), nthreads)
+    return hits, st, int(tot.steps), int(tot.tests), used
+
+
+def hit_attrs(tris: np.ndarray, rays: np.ndarray, hits: np.ndarray) -> np.ndarray:
+    out = np.zeros(len(hits), ATTRS)
+    L = lib()
+    for i in range(len(hits)):
+        if hits["prim"][i] == MISS:
+            continue
+        L.vto_hit_attrs(tris[int(hits["prim"][i]):].ctypes.data, rays["dir"][i].ctypes.data, float(hits["u"][i]),
+                        float(hits["v"][i]), out[i:i + 1].ctypes.data)
+    return out
+
+
+def calc_ray_origin(pos, normal) -> np.ndarray:
+    pos = np.ascontiguousarray(pos, np.float32)
+    normal = np.ascontiguousarray(normal, np.float32)
+    out = np.zeros(3, np.float32)
+    lib().vto_calc_ray_origin(pos.ctypes.data, normal.ctypes.data, out.ctypes.data)
+    return out
+
+
+def hemisphere_cos(r1: float, r2: float) -> np.ndarray:
+    out = np.zeros(3, np.float32)
+    lib().vto_hemisphere_cos(float(r1), float(r2), out.ctypes.data)
+    return out

@@ -1,0 +1,343 @@
+/*
+ * vt_oracle.c -- CPU ORACLE (test infrastructure; see vt_oracle.h).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp  (oracle/Makefile)
+ * All arithmetic is IEEE fp32, one rounding per operation, exactly as a
+ * baseline-x86-64 build of the reference evaluates it (no FMA: the reference's
+ * shipped binaries target baseline x86-64 and bvh v1's fast_multiply_add is a
+ * plain a*b+c unless FP_FAST_FMAF is defined).
+ *
+ * PARITY STATUS: parity unpinned (no reference tests/vectors exist; libs/bvh
+ * is absent).  See the header.
+ */
+#include "vt_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- bvh v1 vector helpers [UPSTREAM-RECALL bvh/vector.hpp] ---------------
+ * dot:   sum = a0*b0; sum += a1*b1; sum += a2*b2      (left to right)
+ * cross: c[i] = a[j]*b[k] - a[k]*b[j], j=(i+1)%3, k=(i+2)%3            */
+static inline float dot3(const float a[3], const float b[3])
+{
+    float s = a[0] * b[0];
+    s = s + a[1] * b[1];
+    s = s + a[2] * b[2];
+    return s;
+}
+
+static inline void cross3(const float a[3], const float b[3], float c[3])
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* ---- Primitives.h:75-102 ---------------------------------------------------
+ * ctor: p0(p0), e1(p0 - p1), e2(p2 - p0); ComputeNormalAndLoD: n = cross(e1,e2)
+ * (LeftHandedNormal = true).  lod / nNorm are not read by intersect(). */
+void vto_tri_setup(const float p0[3], const float p1[3], const float p2[3],
+                   uint32_t flags, vto_tri* out)
+{
+    for (int a = 0; a < 3; ++a) {
+        out->p0[a] = p0[a];
+        out->e1[a] = p0[a] - p1[a];   /* Primitives.h:82 */
+        out->e2[a] = p2[a] - p0[a];   /* Primitives.h:82 */
+    }
+    cross3(out->e1, out->e2, out->n); /* Primitives.h:93 */
+    out->flags = flags;
+}
+
+/* ---- Primitives.h:168-215 --------------------------------------------------*/
+int vto_tri_intersect(const vto_tri* tri, const float org[3], const float dir[3],
+                      float tmin, float tmax, float* t_out, float* u_out, float* v_out)
+{
+    float nDotDir = dot3(tri->n, dir);                               /* :173 */
+    if ((tri->flags & VTO_TRI_CULL_BACKFACE) && nDotDir > 0.0f)      /* :174 */
+        return 0;
+
+    float c[3], r[3];
+    for (int a = 0; a < 3; ++a) c[a] = tri->p0[a] - org[a];          /* :176 */
+    cross3(dir, c, r);                                               /* :177 */
+    float inv_det = 1.0f / nDotDir;                                  /* :178 */
+
+    float u = dot3(r, tri->e2) * inv_det;                            /* :180 */
+    float v = dot3(r, tri->e1) * inv_det;                            /* :181 */
+    float w = 1.0f - u - v;                                          /* :182 */
+
+    /* tolerance = 0 (NonZeroTolerance=false); NaN makes every test false :186-187 */
+    if (u >= 0.0f && v >= 0.0f && w >= 0.0f) {
+        float t = dot3(tri->n, c) * inv_det;                         /* :188 */
+        if (t >= tmin && t <= tmax) {                                /* :189 */
+            /* :196-208 alpha-test branch is not restated;
+             * callers never build oracle scenes with VTO_TRI_ALPHATEST. */
+            *t_out = t; *u_out = u; *v_out = v;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* ---- brute force (independent ground truth) -------------------------------*/
+static void brute_one(const vto_tri* tris, uint32_t ntris, const vto_ray* ray,
+                      int any_hit, vto_hit* hit)
+{
+    float tmax = ray->tmax;
+    hit->prim = VTO_MISS; hit->t = 0.f; hit->u = 0.f; hit->v = 0.f;
+    for (uint32_t i = 0; i < ntris; ++i) {
+        float t, u, v;
+        if (vto_tri_intersect(&tris[i], ray->org, ray->dir, ray->tmin, tmax, &t, &u, &v)) {
+            hit->prim = i; hit->t = t; hit->u = u; hit->v = v;
+            if (any_hit) return;
+            tmax = t;
+        }
+    }
+}
+
+void vto_trace_brute(const vto_tri* tris, uint32_t ntris, const vto_ray* rays,
+                     uint64_t nrays, int any_hit, vto_hit* hits, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads)
+    for (int64_t i = 0; i < (int64_t)nrays; ++i)
+        brute_one(tris, ntris, &rays[i], any_hit, &hits[i]);
+}
+
+uint32_t vto_min_t_set(const vto_tri* tris, uint32_t ntris, const vto_ray* ray,
+                       float* tmin_hit, uint32_t* ids, uint32_t max_ids)
+{
+    float best = ray->tmax;
+    int found = 0;
+    for (uint32_t i = 0; i < ntris; ++i) {
+        float t, u, v;
+        if (vto_tri_intersect(&tris[i], ray->org, ray->dir, ray->tmin, best, &t, &u, &v)) {
+            best = t; found = 1;
+        }
+    }
+    if (!found) { *tmin_hit = 0.f; return 0; }
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < ntris; ++i) {
+        float t, u, v;
+        if (vto_tri_intersect(&tris[i], ray->org, ray->dir, ray->tmin, best, &t, &u, &v) && t == best) {
+            if (cnt < max_ids) ids[cnt] = i;
+            ++cnt;
+        }
+    }
+    *tmin_hit = best;
+    return cnt;
+}
+
+/* ---- bvh v1 utilities [UPSTREAM-RECALL bvh/utilities.hpp] -------------------
+ * safe_inverse(x) = |x| <= FLT_EPSILON ? copysign(1/FLT_EPSILON, x) : 1/x
+ * robust_max(a,b) = a > b ? a : b ;  robust_min(a,b) = a < b ? a : b
+ * fast_multiply_add(a,b,c) = a*b + c  (unfused; FP_FAST_FMAF not defined)     */
+static inline float safe_inverse(float x)
+{
+    return fabsf(x) <= FLT_EPSILON ? copysignf(1.0f / FLT_EPSILON, x) : 1.0f / x;
+}
+static inline float robust_max(float a, float b) { return a > b ? a : b; }
+static inline float robust_min(float a, float b) { return a < b ? a : b; }
+
+/* FastNodeIntersector [UPSTREAM-RECALL bvh/node_intersectors.hpp] */
+typedef struct {
+    int   oct[3];
+    float inv_dir[3];
+    float scaled_org[3];
+} node_isect;
+
+static inline void node_isect_init(node_isect* ni, const vto_ray* ray)
+{
+    for (int a = 0; a < 3; ++a) {
+        ni->oct[a]        = signbit(ray->dir[a]) ? 1 : 0;
+        ni->inv_dir[a]    = safe_inverse(ray->dir[a]);
+        ni->scaled_org[a] = -ray->org[a] * ni->inv_dir[a];
+    }
+}
+
+static inline void node_slab(const node_isect* ni, const vto_node* node,
+                             float tmin, float tmax, float* first, float* second)
+{
+    float entry[3], exit_[3];
+    for (int a = 0; a < 3; ++a) {
+        entry[a] = node->bounds[2 * a + ni->oct[a]]     * ni->inv_dir[a] + ni->scaled_org[a];
+        exit_[a] = node->bounds[2 * a + 1 - ni->oct[a]] * ni->inv_dir[a] + ni->scaled_org[a];
+    }
+    *first  = robust_max(entry[0], robust_max(entry[1], robust_max(entry[2], tmin)));
+    *second = robust_min(exit_[0], robust_min(exit_[1], robust_min(exit_[2], tmax)));
+}
+
+#define VTO_STACK_CAP 256 /* upstream: 64, overflow unchecked; we abort instead */
+
+/* intersect_leaf of SingleRayTraverser: ascending leaf-slot order; Closest:
+ * best = hit, ray.tmax = t; Any: return at once.  Returns 1 if the traversal
+ * must stop (any-hit found). */
+static inline int leaf_isect(const vto_node* leaf, const uint32_t* prim_indices,
+                             const vto_tri* tris, const vto_ray* ray, float* tmax,
+                             int any_hit, vto_hit* best, int* found, uint64_t* tests)
+{
+    uint32_t begin = leaf->first, end = begin + leaf->prim_count;
+    for (uint32_t i = begin; i < end; ++i) {
+        uint32_t idx = prim_indices[i];            /* ClosestPrimitiveIntersector, PreShuffled=false */
+        float t, u, v;
+        ++*tests;
+        if (vto_tri_intersect(&tris[idx], ray->org, ray->dir, ray->tmin, *tmax, &t, &u, &v)) {
+            best->prim = idx; best->t = t; best->u = u; best->v = v;
+            *found = 1;
+            if (any_hit) return 1;
+            *tmax = t;
+        }
+    }
+    return 0;
+}
+
+int vto_traverse(const vto_node* nodes, const uint32_t* prim_indices,
+                 const vto_tri* tris, const vto_ray* ray, int any_hit,
+                 vto_hit* best, vto_stats* stats)
+{
+    uint64_t steps = 0, tests = 0;
+    int found = 0;
+    float tmax = ray->tmax;            /* traverse() takes the ray by value */
+    best->prim = VTO_MISS; best->t = 0.f; best->u = 0.f; best->v = 0.f;
+
+    if (nodes[0].prim_count != 0) {    /* root is a leaf: no slab test at all */
+        leaf_isect(&nodes[0], prim_indices, tris, ray, &tmax, any_hit, best, &found, &tests);
+        goto done;
+    }
+
+    {
+        node_isect ni;
+        node_isect_init(&ni, ray);
+        uint32_t stack[VTO_STACK_CAP];
+        int sp = 0;
+        const vto_node* left = &nodes[nodes[0].first];
+        for (;;) {
+            const vto_node* right = left + 1;
+            ++steps;
+            float fl, sl, fr, sr;
+            /* both children are slab-tested BEFORE either leaf is intersected */
+            node_slab(&ni, left,  ray->tmin, tmax, &fl, &sl);
+            node_slab(&ni, right, ray->tmin, tmax, &fr, &sr);
+
+            if (fl <= sl) {
+                if (left->prim_count != 0) {
+                    if (leaf_isect(left, prim_indices, tris, ray, &tmax, any_hit, best, &found, &tests))
+                        goto done;
+                    left = NULL;
+                }
+            } else left = NULL;
+
+            if (fr <= sr) {
+                if (right->prim_count != 0) {
+                    if (leaf_isect(right, prim_indices, tris, ray, &tmax, any_hit, best, &found, &tests))
+                        goto done;
+                    right = NULL;
+                }
+            } else right = NULL;
+
+            if (left) {
+                if (right) {
+                    if (fl > fr) { const vto_node* tmp = left; left = right; right = tmp; }
+                    if (sp >= VTO_STACK_CAP) { fprintf(stderr, "vt_oracle: stack overflow\n"); abort(); }
+                    stack[sp++] = right->first;     /* far inner node's first-child index */
+                }
+                left = &nodes[left->first];
+            } else if (right) {
+                left = &nodes[right->first];
+            } else {
+                if (sp == 0) break;
+                left = &nodes[stack[--sp]];
+            }
+        }
+    }
+done:
+    if (stats) { stats->steps = steps; stats->tests = tests; }
+    return found;
+}
+
+int vto_traverse_batch(const vto_node* nodes, const uint32_t* prim_indices,
+                       const vto_tri* tris, const vto_ray* rays, uint64_t nrays,
+                       int any_hit, vto_hit* hits, uint32_t* per_ray_stats,
+                       vto_stats* total, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+    uint64_t tsteps = 0, ttests = 0;
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(nthreads) reduction(+ : tsteps, ttests)
+    for (int64_t i = 0; i < (int64_t)nrays; ++i) {
+        vto_stats st;
+        vto_traverse(nodes, prim_indices, tris, &rays[i], any_hit, &hits[i], &st);
+        if (per_ray_stats) {
+            per_ray_stats[2 * i]     = (uint32_t)st.steps;
+            per_ray_stats[2 * i + 1] = (uint32_t)st.tests;
+        }
+        tsteps += st.steps; ttests += st.tests;
+    }
+    if (total) { total->steps = tsteps; total->tests = ttests; }
+    return nthreads;
+}
+
+/* ---- TraceResult.cpp:45-86, 255-262 ---------------------------------------*/
+void vto_hit_attrs(const vto_tri* tri, const float dir[3], float u, float v, vto_attrs* out)
+{
+    /* AccelStruct.cpp:826 glm::normalize(dir) = dir * (1/sqrt(dot(dir,dir))) */
+    float d2 = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];
+    float inv = 1.0f / sqrtf(d2);
+    for (int a = 0; a < 3; ++a) out->wo[a] = -(dir[a] * inv);          /* TraceResult.cpp:56 */
+
+    float w = 1.0f - u - v;                                            /* :70 */
+    out->uvw[0] = u; out->uvw[1] = v; out->uvw[2] = w;
+
+    /* Primitives.h:98-100 nNorm = n / length(n) */
+    float len = sqrtf(dot3(tri->n, tri->n));
+    for (int a = 0; a < 3; ++a) out->ngeo[a] = tri->n[a] / len;        /* :71 */
+
+    /* v0 = p0, v1 = p0 - e1, v2 = p0 + e2 (Primitives.h:104-105, TraceResult.cpp:65-68)
+     * pos = uvw.z*v0 + uvw.x*v1 + uvw.y*v2                              (:258) */
+    for (int a = 0; a < 3; ++a) {
+        float v0 = tri->p0[a], v1 = tri->p0[a] - tri->e1[a], v2 = tri->p0[a] + tri->e2[a];
+        out->pos[a] = (w * v0 + u * v1) + v * v2;
+    }
+    out->front = dot3(out->wo, out->ngeo) >= 0.0f ? 1u : 0u;           /* :85 */
+}
+
+/* ---- VisTrace.cpp:1495-1517 ------------------------------------------------*/
+void vto_calc_ray_origin(const float pos[3], const float normal[3], float out[3])
+{
+    const float origin = 1.f / 32.f;
+    const float fScale = 1.f / 65536.f;
+    const float iScale = 256.f;
+    for (int a = 0; a < 3; ++a) {
+        int32_t iOff = (int32_t)(normal[a] * iScale);          /* ivec3(normal * iScale) */
+        int32_t bits;
+        memcpy(&bits, &pos[a], 4);
+        bits += (pos[a] < 0.f) ? -iOff : iOff;
+        float iPos;
+        memcpy(&iPos, &bits, 4);
+        float fOff = normal[a] * fScale;
+        out[a] = fabsf(pos[a]) < origin ? pos[a] + fOff : iPos;
+    }
+}
+
+/* ---- BSDF.cpp:69-77 ---------------------------------------------------------*/
+void vto_hemisphere_cos(float r1, float r2, float out[3])
+{
+    const float z = sqrtf(r1);
+    const float sinTheta = sqrtf(1.f - r1);
+    const float phi = 2.f * 3.14159265358979323846264338327950288f * r2;
+    out[0] = sinTheta * cosf(phi);
+    out[1] = sinTheta * sinf(phi);
+    out[2] = z;
+}

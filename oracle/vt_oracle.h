@@ -1,0 +1,119 @@
+/*
+ * vt_oracle.h -- CPU ORACLE for the AccelStruct::Traverse hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke
+ * check in __graft_entry__.py and bench.py's cpu_baseline leg may load it.
+ * The shipped library (vistrace_amd/lib/libvistrace_hip.so) never links,
+ * loads or calls anything in oracle/.
+ *
+ * It restates, in plain C (fp32, no FMA contraction, no fast-math):
+ *   - the in-tree triangle set-up and ray/triangle test of the reference
+ *       source/objects/Primitives.h:75-102   (ctor, ComputeNormalAndLoD)
+ *       source/objects/Primitives.h:168-215  (intersect)
+ *   - the single-ray BVH walk of madmann91/bvh (v1 API), which the reference
+ *     calls at source/objects/AccelStruct.cpp:818 through the types declared
+ *     at source/objects/AccelStruct.h:27-31.  libs/bvh is an EMPTY, UNPINNED
+ *     submodule under /root/reference (.gitmodules:4-6), so that part follows
+ *     the library's published algorithm as recorded in SURVEY.md section 3.2
+ *     ("UPSTREAM-RECALL").
+ *   - the hit-record derivations of source/objects/TraceResult.cpp:45-86,255-262
+ *   - the two helpers that define the bounce-ray workload:
+ *       vistrace.CalcRayOrigin  source/VisTrace.cpp:1495-1517
+ *       hemisphere_cos          source/libraries/BSDF.cpp:69-77
+ *
+ * PARITY STATUS: "parity unpinned" -- the reference holds no tests, golden
+ * vectors or fixtures for this path and cannot be
+ * compiled here (all of libs/ is empty).  The oracle is pinned instead by
+ * analytic known-answer tests and by an independent brute-force intersector
+ * (vto_trace_brute) that uses only the in-tree arithmetic of Primitives.h.
+ */
+#ifndef VT_ORACLE_H
+#define VT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VTO_MISS 0xFFFFFFFFu
+
+/* flags of a triangle as the intersector sees them */
+#define VTO_TRI_CULL_BACKFACE 1u /* oneSided && !(mat.flags & nocull)   Primitives.h:174 */
+#define VTO_TRI_ALPHATEST     2u /* mat.flags & alphatest (Primitives.h:196); NOT restated */
+
+/* bvh::Ray<float> minus the pAccel back-pointer (Primitives.h:11-33) */
+typedef struct { float org[3]; float dir[3]; float tmin; float tmax; } vto_ray;
+
+/* The fields of TriangleBackfaceCull<float> that intersect() reads
+ * (Primitives.h:56-57): p0, e1 = p0-p1, e2 = p2-p0, n = cross(e1,e2). */
+typedef struct { float p0[3]; float e1[3]; float e2[3]; float n[3]; uint32_t flags; } vto_tri;
+
+/* bvh::Bvh<float>::Node (v1): bounds interleaved {minx,maxx,miny,maxy,minz,maxz},
+ * primitive_count (!=0 <=> leaf), first_child_or_primitive.  32 bytes. */
+typedef struct { float bounds[6]; uint32_t prim_count; uint32_t first; } vto_node;
+
+typedef struct { uint32_t prim; float t; float u; float v; } vto_hit;
+
+/* bvh v1 Statistics: traversal_steps (loop iterations), intersections (triangles tested) */
+typedef struct { uint64_t steps; uint64_t tests; } vto_stats;
+
+/* Derived hit attributes: TraceResult.cpp:56-85, 255-262 */
+typedef struct {
+    float pos[3];       /* GetPos():  w*v0 + u*v1 + v*v2                          */
+    float uvw[3];       /* (u, v, 1-u-v)                      TraceResult.cpp:70   */
+    float ngeo[3];      /* nNorm = n/|n|                      Primitives.h:100     */
+    float wo[3];        /* -normalize(dir)       AccelStruct.cpp:826, TraceResult.cpp:56 */
+    uint32_t front;     /* dot(wo, ngeo) >= 0                 TraceResult.cpp:85   */
+} vto_attrs;
+
+/* Primitives.h:75-102 */
+void vto_tri_setup(const float p0[3], const float p1[3], const float p2[3],
+                   uint32_t flags, vto_tri* out);
+
+/* Primitives.h:168-215.  Returns 1 and writes t,u,v on an accepted hit. */
+int vto_tri_intersect(const vto_tri* tri, const float org[3], const float dir[3],
+                      float tmin, float tmax, float* t, float* u, float* v);
+
+/* Independent ground truth: test EVERY triangle in ascending index order with
+ * the same accept rule (t <= current tmax, so a later equal-t triangle
+ * replaces an earlier one).  any_hit!=0 stops at the first accepted hit. */
+void vto_trace_brute(const vto_tri* tris, uint32_t ntris,
+                     const vto_ray* rays, uint64_t nrays, int any_hit,
+                     vto_hit* hits, int nthreads);
+
+/* For a ray, the minimum accepted t over all triangles and how many distinct
+ * triangles reach exactly that t (the admissible set for a tie-broken index).
+ * ids receives up to max_ids of them. Returns the count. */
+uint32_t vto_min_t_set(const vto_tri* tris, uint32_t ntris, const vto_ray* ray,
+                       float* tmin_hit, uint32_t* ids, uint32_t max_ids);
+
+/* bvh v1 SingleRayTraverser<Bvh,64,FastNodeIntersector>::traverse with
+ * ClosestPrimitiveIntersector (any_hit=0) or AnyPrimitiveIntersector
+ * (any_hit=1); SURVEY.md section 3.2.  nodes[0] is the root; prim_indices maps
+ * leaf slot -> triangle index.  Returns 1 on hit. stats may be NULL. */
+int vto_traverse(const vto_node* nodes, const uint32_t* prim_indices,
+                 const vto_tri* tris, const vto_ray* ray, int any_hit,
+                 vto_hit* hit, vto_stats* stats);
+
+/* OpenMP loop over rays around vto_traverse: schedule(dynamic,4096).
+ * per_ray_stats (2*nrays uint32: steps,tests) and total may be NULL.
+ * nthreads <= 0 -> omp default. Returns the thread count used. */
+int vto_traverse_batch(const vto_node* nodes, const uint32_t* prim_indices,
+                       const vto_tri* tris, const vto_ray* rays, uint64_t nrays,
+                       int any_hit, vto_hit* hits, uint32_t* per_ray_stats,
+                       vto_stats* total, int nthreads);
+
+/* TraceResult.cpp:45-86 + GetPos :255-262 for hit {prim,u,v} of ray dir */
+void vto_hit_attrs(const vto_tri* tri, const float dir[3], float u, float v, vto_attrs* out);
+
+/* vistrace.CalcRayOrigin, VisTrace.cpp:1495-1517 */
+void vto_calc_ray_origin(const float pos[3], const float normal[3], float out[3]);
+
+/* hemisphere_cos, BSDF.cpp:69-77 (r1, r2 are the two sampler floats, in call order) */
+void vto_hemisphere_cos(float r1, float r2, float out[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,113 @@
+"""ctypes binding of include/vistrace_hip.h (the C ABI of libvistrace_hip.so).
+
+The library is built in-tree by ``__graft_entry__.build()`` (``make -C vistrace_amd/csrc``).
+There is no Python or CPU fallback: if the shared object is missing, importing this
+module raises, and every tracing call needs a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvistrace_hip.so")
+
+VT_OK = 0
+VT_ERR_INVALID_ARG = 1
+VT_ERR_HIP = 2
+VT_ERR_UNSUPPORTED = 3
+VT_ERR_NOMEM = 4
+VT_ERR_STACK = 5
+VT_MISS = 0xFFFFFFFF
+VT_TRI_CULL_BACKFACE = 1
+VT_TRI_ALPHATEST = 2
+
+# POD layouts of include/vistrace_hip.h
+RAY = np.dtype([("org", "<f4", 3), ("dir", "<f4", 3), ("tmin", "<f4"), ("tmax", "<f4")])
+HIT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+BVH_NODE = np.dtype([("bounds", "<f4", 6), ("prim_count", "<u4"), ("first", "<u4")])
+NODE_PAIR = np.dtype([("child", BVH_NODE, 2)])
+TRI64 = np.dtype([("p0", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3), ("n", "<f4", 3),
+                  ("prim", "<u4"), ("flags", "<u4"), ("pad", "<u4", 2)])
+RAY_STATS = np.dtype([("steps", "<u4"), ("tests", "<u4")])
+HIT_ATTRS = np.dtype([("pos", "<f4", 3), ("t", "<f4"), ("ngeo", "<f4", 3), ("prim", "<u4"),
+                      ("uvw", "<f4", 3), ("front", "<u4"), ("wo", "<f4", 3), ("hit", "<u4")])
+assert RAY.itemsize == 32 and HIT.itemsize == 16 and BVH_NODE.itemsize == 32
+assert NODE_PAIR.itemsize == 64 and TRI64.itemsize == 64 and HIT_ATTRS.itemsize == 64
+
+# every symbol include/vistrace_hip.h declares: (restype, argtypes)
+_vp = C.c_void_p
+_u32 = C.c_uint32
+_u64 = C.c_uint64
+_pp = C.POINTER(C.c_void_p)
+SYMBOLS = {
+    "vt_last_error": (C.c_char_p, []),
+    "vt_abi_version": (C.c_int, []),
+    "vt_tris_setup": (C.c_int, [_vp, _vp, _u32, _vp]),
+    "vt_bvh_build": (C.c_int, [_vp, _u32, C.c_int, _pp]),
+    "vt_bvh_free": (None, [_vp]),
+    "vt_bvh_node_count": (_u32, [_vp]),
+    "vt_bvh_prim_count": (_u32, [_vp]),
+    "vt_bvh_nodes": (_vp, [_vp]),
+    "vt_bvh_prim_indices": (_vp, [_vp]),
+    "vt_scene_linearise": (C.c_int, [_vp, _vp, _pp]),
+    "vt_host_scene_free": (None, [_vp]),
+    "vt_host_scene_pair_count": (_u32, [_vp]),
+    "vt_host_scene_tri_count": (_u32, [_vp]),
+    "vt_host_scene_max_depth": (_u32, [_vp]),
+    "vt_host_scene_root_leaf_count": (_u32, [_vp]),
+    "vt_host_scene_pairs": (_vp, [_vp]),
+    "vt_host_scene_tris": (_vp, [_vp]),
+    "vt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "vt_engine_open": (C.c_int, [C.c_int, _pp]),
+    "vt_engine_close": (None, [_vp]),
+    "vt_scene_upload": (C.c_int, [_vp, _vp, _pp]),
+    "vt_scene_free": (None, [_vp]),
+    "vt_scene_device_bytes": (_u64, [_vp]),
+    "vt_trace_closest": (C.c_int, [_vp, _vp, _u64, _vp]),
+    "vt_trace_any": (C.c_int, [_vp, _vp, _u64, _vp]),
+    "vt_trace_closest_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
+    "vt_trace_any_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
+    "vt_trace_stats_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
+    "vt_hit_attrs_dev": (C.c_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    "vt_engine_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "vt_engine_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
+    "vt_engine_synchronize": (C.c_int, [_vp]),
+    "vt_engine_set_timing": (C.c_int, [_vp, C.c_int]),
+    "vt_engine_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "vt_engine_launch_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+}
+
+
+class VisTraceError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"vistrace_hip error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C vistrace_amd/csrc). vistrace_amd has no pure-Python or CPU tracing path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int) -> None:
+    if rc != VT_OK:
+        raise VisTraceError(rc, lib.vt_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a: np.ndarray) -> int:
+    return a.ctypes.data

@@ -1,0 +1,222 @@
+"""Thin Python objects over the C ABI (include/vistrace_hip.h).
+
+Mirrors the shape of the reference's path: ``tris_setup`` (Primitives.h:75-102) ->
+``build_bvh`` (AccelStruct.cpp:763-770) -> ``linearise`` + ``Scene`` upload
+(AccelStruct.cpp:772-775) -> ``Scene.trace_closest`` (AccelStruct.cpp:818).
+numpy arrays use the POD dtypes of ``_lib``; device-pointer calls take raw addresses
+(e.g. ``torch.Tensor.data_ptr()``) so that torch stays plumbing only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import (BVH_NODE, HIT, HIT_ATTRS, NODE_PAIR, RAY, RAY_STATS, TRI64, check, lib, ptr)
+
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def _copy_from(addr: Optional[int], count: int, dtype: np.dtype) -> np.ndarray:
+    if not addr or count == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (count * dtype.itemsize)).from_address(addr)
+    return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+
+def make_rays(org, dir, tmin=0.0, tmax=FLT_MAX) -> np.ndarray:
+    """Pack origins/directions (n,3) into vt_ray records; defaults = AccelStruct.cpp:790-794."""
+    org = np.asarray(org, dtype=np.float32).reshape(-1, 3)
+    dir = np.asarray(dir, dtype=np.float32).reshape(-1, 3)
+    n = max(org.shape[0], dir.shape[0])
+    rays = np.zeros(n, dtype=RAY)
+    rays["org"] = org
+    rays["dir"] = dir
+    rays["tmin"] = np.float32(tmin) if np.isscalar(tmin) else np.asarray(tmin, np.float32)
+    rays["tmax"] = np.float32(tmax) if np.isscalar(tmax) else np.asarray(tmax, np.float32)
+    return rays
+
+
+def tris_setup(verts: np.ndarray, flags: Optional[np.ndarray] = None) -> np.ndarray:
+    """(n,3,3) float32 vertices -> vt_tri64 records in original order."""
+    verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
+    n = verts.shape[0]
+    out = np.zeros(n, dtype=TRI64)
+    fl = None
+    if flags is not None:
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        assert fl.shape == (n,)
+    check(lib.vt_tris_setup(ptr(verts), ptr(fl) if fl is not None else None, n, ptr(out)))
+    return out
+
+
+class HostBvh:
+    """v1-layout tree (bvh::Bvh<float>): nodes[0] = root, siblings adjacent."""
+
+    def __init__(self, tris: np.ndarray, nthreads: int = 0):
+        assert tris.dtype == TRI64
+        self._tris = np.ascontiguousarray(tris)
+        h = C.c_void_p()
+        check(lib.vt_bvh_build(ptr(self._tris) if len(self._tris) else None, len(self._tris), nthreads, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.vt_bvh_free(self._h)
+            self._h = None
+
+    @property
+    def tris(self) -> np.ndarray:
+        return self._tris
+
+    def nodes(self) -> np.ndarray:
+        return _copy_from(lib.vt_bvh_nodes(self._h), lib.vt_bvh_node_count(self._h), BVH_NODE)
+
+    def prim_indices(self) -> np.ndarray:
+        return _copy_from(lib.vt_bvh_prim_indices(self._h), lib.vt_bvh_prim_count(self._h), np.dtype("<u4"))
+
+
+class HostScene:
+    """Linearised pairs + leaf-ordered triangle records, ready for upload."""
+
+    def __init__(self, bvh: HostBvh):
+        self.bvh = bvh
+        h = C.c_void_p()
+        check(lib.vt_scene_linearise(bvh._h, ptr(bvh.tris) if len(bvh.tris) else None, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.vt_host_scene_free(self._h)
+            self._h = None
+
+    @property
+    def pair_count(self) -> int:
+        return lib.vt_host_scene_pair_count(self._h)
+
+    @property
+    def tri_count(self) -> int:
+        return lib.vt_host_scene_tri_count(self._h)
+
+    @property
+    def max_depth(self) -> int:
+        return lib.vt_host_scene_max_depth(self._h)
+
+    @property
+    def root_leaf_count(self) -> int:
+        return lib.vt_host_scene_root_leaf_count(self._h)
+
+    def pairs(self) -> np.ndarray:
+        return _copy_from(lib.vt_host_scene_pairs(self._h), self.pair_count, NODE_PAIR)
+
+    def tris(self) -> np.ndarray:
+        return _copy_from(lib.vt_host_scene_tris(self._h), self.tri_count, TRI64)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib.vt_device_count(C.byref(n)))
+    return n.value
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        check(lib.vt_engine_open(device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.vt_engine_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_option(self, key: str, value: int) -> None:
+        check(lib.vt_engine_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int64(0)
+        check(lib.vt_engine_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def synchronize(self) -> None:
+        check(lib.vt_engine_synchronize(self._h))
+
+    def set_timing(self, on: bool) -> None:
+        check(lib.vt_engine_set_timing(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float(0)
+        check(lib.vt_engine_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def launch_info(self) -> dict:
+        b, t, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib.vt_engine_launch_info(self._h, C.byref(b), C.byref(t), C.byref(l)))
+        return {"blocks": b.value, "threads": t.value, "lds_bytes": l.value}
+
+
+class Scene:
+    """Device-resident scene: upload once per Rebuild, trace many batches."""
+
+    def __init__(self, engine: Engine, host_scene: HostScene):
+        self.engine = engine
+        self.host_scene = host_scene
+        h = C.c_void_p()
+        check(lib.vt_scene_upload(engine._h, host_scene._h, C.byref(h)))
+        self._h = h
+
+    def free(self):
+        if getattr(self, "_h", None):
+            lib.vt_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.free()
+
+    @property
+    def device_bytes(self) -> int:
+        return lib.vt_scene_device_bytes(self._h)
+
+    # host-buffer entry points ------------------------------------------------------------
+    def trace_closest(self, rays: np.ndarray) -> np.ndarray:
+        assert rays.dtype == RAY
+        rays = np.ascontiguousarray(rays)
+        hits = np.zeros(len(rays), dtype=HIT)
+        check(lib.vt_trace_closest(self._h, ptr(rays), len(rays), ptr(hits)))
+        return hits
+
+    def trace_any(self, rays: np.ndarray) -> np.ndarray:
+        assert rays.dtype == RAY
+        rays = np.ascontiguousarray(rays)
+        occ = np.zeros(len(rays), dtype=np.uint8)
+        check(lib.vt_trace_any(self._h, ptr(rays), len(rays), ptr(occ)))
+        return occ
+
+    # device-pointer entry points (addresses of buffers on this engine's device) -----------
+    def trace_closest_dev(self, d_rays: int, n: int, d_hits: int, stream: int = 0) -> None:
+        check(lib.vt_trace_closest_dev(self._h, d_rays, n, d_hits, stream or None))
+
+    def trace_any_dev(self, d_rays: int, n: int, d_occ: int, stream: int = 0) -> None:
+        check(lib.vt_trace_any_dev(self._h, d_rays, n, d_occ, stream or None))
+
+    def trace_stats_dev(self, d_rays: int, n: int, d_hits: int, d_stats: int, stream: int = 0) -> None:
+        check(lib.vt_trace_stats_dev(self._h, d_rays, n, d_hits, d_stats, stream or None))
+
+    def hit_attrs_dev(self, d_rays: int, d_hits: int, n: int, d_attrs: int, stream: int = 0) -> None:
+        check(lib.vt_hit_attrs_dev(self._h, d_rays, d_hits, n, d_attrs, stream or None))
+
+
+def build_scene(engine: Engine, verts: np.ndarray, flags: Optional[np.ndarray] = None, nthreads: int = 0) -> Scene:
+    """verts (n,3,3) -> setup -> PLOC build -> linearise -> upload."""
+    tris = tris_setup(verts, flags)
+    return Scene(engine, HostScene(HostBvh(tris, nthreads)))
+
+
+__all__ = ["Engine", "Scene", "HostBvh", "HostScene", "tris_setup", "build_scene", "make_rays", "device_count",
+           "RAY", "HIT", "TRI64", "BVH_NODE", "NODE_PAIR", "RAY_STATS", "HIT_ATTRS", "FLT_MAX", "_lib"]

@@ -1,0 +1,305 @@
+// bvh_build.cpp -- CPU BVH build for Rebuild (stays on the host, as in the reference).
+//
+// Replaces the tail of AccelStruct::PopulateAccel, source/objects/AccelStruct.cpp:763-770:
+//     LocallyOrderedClusteringBuilder<BVH, uint32_t> builder(mAccel);
+//     compute_bounding_boxes_and_centers / compute_bounding_boxes_union
+//     builder.build(...);  LeafCollapser(mAccel).collapse();
+// The builder library (madmann91/bvh v1) is an empty submodule in the reference tree,
+// so this is an independent implementation of the same published pipeline
+// (Meister & Bittner, "Parallel Locally-Ordered Clustering for BVH Construction", 2018):
+// 32-bit Morton sort of triangle centres, bottom-up nearest-neighbour merging inside a
+// +-14 window, then SAH-driven collapsing of sibling leaves.  The output uses the v1
+// node layout (32-B nodes, root at 0, siblings adjacent, parents before children).
+// Tree shape only affects speed and tie-broken indices; the CPU oracle and the GPU
+// kernel always walk the SAME tree produced here.
+#include "vt_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace vt {
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+};
+
+inline Box box_union(const Box& a, const Box& b)
+{
+    Box r;
+    for (int k = 0; k < 3; ++k) {
+        r.lo[k] = a.lo[k] < b.lo[k] ? a.lo[k] : b.lo[k];
+        r.hi[k] = a.hi[k] > b.hi[k] ? a.hi[k] : b.hi[k];
+    }
+    return r;
+}
+
+// half surface area: (dx + dy) * dz + dx * dy
+inline float half_area(const Box& b)
+{
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return (dx + dy) * dz + dx * dy;
+}
+
+inline Box node_box(const vt_bvh_node& n)
+{
+    return Box{{n.bounds[0], n.bounds[2], n.bounds[4]}, {n.bounds[1], n.bounds[3], n.bounds[5]}};
+}
+
+inline void set_node_box(vt_bvh_node& n, const Box& b)
+{
+    for (int k = 0; k < 3; ++k) {
+        n.bounds[2 * k]     = b.lo[k];
+        n.bounds[2 * k + 1] = b.hi[k];
+    }
+}
+
+// Triangle::bounding_box()/center(), source/objects/Primitives.h:104-118: the box is
+// taken over p0, p1() = p0 - e1 and p2() = p0 + e2 (the re-derived vertices).
+inline void tri_box_center(const vt_tri64& t, Box& b, float c[3])
+{
+    for (int k = 0; k < 3; ++k) {
+        float p0 = t.p0[k], p1 = t.p0[k] - t.e1[k], p2 = t.p0[k] + t.e2[k];
+        float lo = p0, hi = p0;
+        lo = p1 < lo ? p1 : lo;  hi = p1 > hi ? p1 : hi;
+        lo = p2 < lo ? p2 : lo;  hi = p2 > hi ? p2 : hi;
+        b.lo[k] = lo;  b.hi[k] = hi;
+        c[k] = (p0 + p1 + p2) * (1.0f / 3.0f);
+    }
+}
+
+// spread the low 10 bits of x so that there are two zero bits between each
+inline uint32_t spread10(uint32_t x)
+{
+    x &= 0x3FFu;
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8))  & 0x0300F00Fu;
+    x = (x | (x << 4))  & 0x030C30C3u;
+    x = (x | (x << 2))  & 0x09249249u;
+    return x;
+}
+
+// stable LSD radix sort of (key, value) pairs; keys have 30 significant bits
+void radix_sort_pairs(std::vector<uint32_t>& keys, std::vector<uint32_t>& vals)
+{
+    const size_t n = keys.size();
+    std::vector<uint32_t> k2(n), v2(n);
+    std::vector<size_t> hist(1025);
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = pass * 10;
+        std::fill(hist.begin(), hist.end(), size_t(0));
+        for (size_t i = 0; i < n; ++i) ++hist[((keys[i] >> shift) & 1023u) + 1];
+        for (int b = 0; b < 1024; ++b) hist[b + 1] += hist[b];
+        for (size_t i = 0; i < n; ++i) {
+            size_t d = hist[(keys[i] >> shift) & 1023u]++;
+            k2[d] = keys[i];
+            v2[d] = vals[i];
+        }
+        keys.swap(k2);
+        vals.swap(v2);
+    }
+}
+
+constexpr int   kSearchRadius  = 14;   // bvh v1 LocallyOrderedClusteringBuilder::search_radius
+constexpr float kTraversalCost = 1.0f; // bvh v1 LeafCollapser::traversal_cost
+
+// SAH leaf collapse (bvh v1 LeafCollapser): bottom-up, an inner node whose two children
+// are (possibly already collapsed) leaves becomes a leaf when
+//     half_area(node) * (n_left + n_right - traversal_cost)
+//         <= half_area(left) * n_left + half_area(right) * n_right.
+// Parents precede children in `nodes`, so a descending index sweep is bottom-up.
+void collapse_leaves(std::vector<vt_bvh_node>& nodes, std::vector<uint32_t>& prim_indices)
+{
+    const size_t nc = nodes.size();
+    if (nc == 0 || nodes[0].prim_count != 0) return;
+
+    std::vector<uint32_t> pcount(nc);      // > 0: (collapsed) leaf with that many prims
+    std::vector<uint8_t>  removed(nc, 0);
+    for (size_t k = nc; k-- > 0;) {
+        const vt_bvh_node& nd = nodes[k];
+        if (nd.prim_count != 0) { pcount[k] = nd.prim_count; continue; }
+        const uint32_t l = nd.first, r = nd.first + 1;
+        pcount[k] = 0;
+        if (pcount[l] > 0 && pcount[r] > 0) {
+            const float total = float(pcount[l] + pcount[r]);
+            const float collapse_cost = half_area(node_box(nd)) * (total - kTraversalCost);
+            const float base_cost = half_area(node_box(nodes[l])) * float(pcount[l]) +
+                                    half_area(node_box(nodes[r])) * float(pcount[r]);
+            if (collapse_cost <= base_cost) {
+                pcount[k]  = pcount[l] + pcount[r];
+                removed[l] = removed[r] = 1;
+            }
+        }
+    }
+    // nodes below a removed node are removed as well
+    for (size_t k = 0; k < nc; ++k)
+        if (removed[k] && nodes[k].prim_count == 0) removed[nodes[k].first] = removed[nodes[k].first + 1] = 1;
+
+    // new index = old index - (#removed before it); removed nodes go in sibling pairs,
+    // so siblings stay adjacent and parents still precede children
+    std::vector<uint32_t> new_index(nc);
+    uint32_t kept = 0;
+    for (size_t k = 0; k < nc; ++k) { new_index[k] = kept; kept += removed[k] ? 0u : 1u; }
+
+    std::vector<vt_bvh_node> out_nodes(kept);
+    std::vector<uint32_t> out_prims;
+    out_prims.reserve(prim_indices.size());
+    std::vector<uint32_t> stack;
+    for (size_t k = 0; k < nc; ++k) {
+        if (removed[k]) continue;
+        vt_bvh_node nd = nodes[k];
+        if (pcount[k] == 0) {
+            nd.first = new_index[nd.first];
+        } else {
+            // gather the subtree's primitives, left before right
+            const uint32_t first = uint32_t(out_prims.size());
+            stack.assign(1, uint32_t(k));
+            while (!stack.empty()) {
+                const uint32_t s = stack.back();
+                stack.pop_back();
+                const vt_bvh_node& sn = nodes[s];
+                if (sn.prim_count != 0) {
+                    for (uint32_t q = 0; q < sn.prim_count; ++q) out_prims.push_back(prim_indices[sn.first + q]);
+                } else {
+                    stack.push_back(sn.first + 1);
+                    stack.push_back(sn.first);
+                }
+            }
+            nd.prim_count = pcount[k];
+            nd.first      = first;
+        }
+        out_nodes[new_index[k]] = nd;
+    }
+    nodes.swap(out_nodes);
+    prim_indices.swap(out_prims);
+}
+
+} // namespace
+
+int bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out)
+{
+    out.nodes.clear();
+    out.prim_indices.clear();
+    if (n == 0) return VT_OK;
+    if (n > 0x7FFFFFFFu) return fail(VT_ERR_INVALID_ARG, "vt_bvh_build: more than 2^31-1 triangles");
+    if (!tris) return fail(VT_ERR_INVALID_ARG, "vt_bvh_build: tris is NULL");
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+
+    // 1. boxes, centres, scene box
+    std::vector<Box> boxes(n);
+    std::vector<float> centers(size_t(n) * 3);
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t i = 0; i < int64_t(n); ++i) tri_box_center(tris[i], boxes[i], &centers[size_t(i) * 3]);
+
+    Box global = boxes[0];
+    for (uint32_t i = 1; i < n; ++i) global = box_union(global, boxes[i]);
+
+    // 2. Morton codes on a 1024^3 grid over the scene box, stable sort
+    std::vector<uint32_t> codes(n), order(n);
+    {
+        const float dim = 1024.0f;
+        float scale[3], offset[3];
+        for (int k = 0; k < 3; ++k) {
+            scale[k]  = dim * (1.0f / (global.hi[k] - global.lo[k]));
+            offset[k] = -global.lo[k] * scale[k];
+        }
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+        for (int64_t i = 0; i < int64_t(n); ++i) {
+            uint32_t g[3];
+            for (int k = 0; k < 3; ++k) {
+                float p = centers[size_t(i) * 3 + k] * scale[k] + offset[k];
+                float q = p > 0.0f ? p : 0.0f; // also maps NaN (flat scene axis) to cell 0
+                q = q < dim - 1.0f ? q : dim - 1.0f;
+                g[k] = uint32_t(q);
+            }
+            codes[i] = spread10(g[0]) | (spread10(g[1]) << 1) | (spread10(g[2]) << 2);
+            order[i] = uint32_t(i);
+        }
+        radix_sort_pairs(codes, order);
+    }
+
+    // 3. PLOC.  `nodes` is filled from the back: each round puts the children it merges
+    // in front of those emitted by earlier rounds, so the root lands at index 0 and
+    // every parent precedes its two adjacent children.
+    const size_t node_count = size_t(2) * n - 1;
+    std::vector<vt_bvh_node> nodes(node_count);
+    std::vector<vt_bvh_node> cur(n), next;
+    next.reserve(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        set_node_box(cur[i], boxes[order[i]]);
+        cur[i].prim_count = 1;
+        cur[i].first      = i; // slot in `order`, which becomes prim_indices
+    }
+    std::vector<Box>().swap(boxes);
+    std::vector<float>().swap(centers);
+    std::vector<uint32_t>().swap(codes);
+
+    size_t tail = node_count;
+    std::vector<uint32_t> nbr(n), slot(n);
+    while (cur.size() > 1) {
+        const int64_t m = int64_t(cur.size());
+        // nearest neighbour = smallest union half-area within [i-14, i+14]; lowest index wins ties
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (m > 4096)
+        for (int64_t i = 0; i < m; ++i) {
+            const int64_t b = i > kSearchRadius ? i - kSearchRadius : 0;
+            const int64_t e = i + kSearchRadius + 1 < m ? i + kSearchRadius + 1 : m;
+            const Box bi = node_box(cur[i]);
+            float best = std::numeric_limits<float>::max();
+            int64_t best_j = -1;
+            for (int64_t j = b; j < e; ++j) {
+                if (j == i) continue;
+                const float d = half_area(box_union(bi, node_box(cur[j])));
+                if (d < best) { best = d; best_j = j; }
+            }
+            if (best_j < 0) best_j = (i + 1 < m) ? i + 1 : i - 1; // every distance inf/NaN
+            nbr[i] = uint32_t(best_j);
+        }
+        // leaders (lower index of a mutual pair) get consecutive child slots
+        size_t merged = 0;
+        for (int64_t i = 0; i < m; ++i) {
+            const uint32_t j = nbr[i];
+            if (nbr[j] == uint32_t(i) && uint32_t(i) < j) slot[i] = uint32_t(merged++);
+        }
+        if (merged == 0) return fail(VT_ERR_INVALID_ARG, "vt_bvh_build: clustering made no progress");
+        const size_t children_begin = tail - 2 * merged;
+        next.clear();
+        for (int64_t i = 0; i < m; ++i) {
+            const uint32_t j = nbr[i];
+            if (nbr[j] != uint32_t(i)) { next.push_back(cur[i]); continue; } // unmerged: carried over
+            if (uint32_t(i) < j) continue;                                    // leader: emitted at j
+            // follower: the parent takes this position
+            const uint32_t lead = j;
+            const size_t fc = children_begin + 2 * size_t(slot[lead]);
+            nodes[fc]     = cur[lead];
+            nodes[fc + 1] = cur[i];
+            vt_bvh_node parent;
+            set_node_box(parent, box_union(node_box(cur[i]), node_box(cur[lead])));
+            parent.prim_count = 0;
+            parent.first      = uint32_t(fc);
+            next.push_back(parent);
+        }
+        tail = children_begin;
+        cur.swap(next);
+    }
+    nodes[0] = cur[0]; // tail == 1 here
+
+    // 4. SAH leaf collapse
+    collapse_leaves(nodes, order);
+
+    out.nodes.swap(nodes);
+    out.prim_indices.swap(order);
+    return VT_OK;
+}
+
+} // namespace vt

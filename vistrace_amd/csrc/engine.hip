@@ -1,0 +1,439 @@
+// engine.hip -- device half of the C ABI in include/vistrace_hip.h.
+//
+// vt_engine  = one HIP device + one stream + launch configuration + staging buffers.
+// vt_scene   = the linearised tree and triangle records resident in that device's HBM
+//              (uploaded once per Rebuild, source/objects/AccelStruct.cpp:762-775).
+// vt_trace_* = the call at source/objects/AccelStruct.cpp:818, batched.
+// There is no CPU fallback anywhere in this file: without a usable device every entry
+// point returns VT_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "trace_kernels.h"
+#include "vt_internal.h"
+
+using namespace vt;
+
+#define VT_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t err__ = (call);                                                                \
+        if (err__ != hipSuccess)                                                                  \
+            return fail(VT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(err__));        \
+    } while (0)
+
+struct vt_engine {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    int         cu_count = 0;
+    size_t      lds_per_block_max = 0;
+
+    // launch configuration (vt_engine_set_option)
+    int      persistent       = 1;
+    uint32_t lds_entries      = 16;   // stack entries per lane in LDS (rest spills to global)
+    uint32_t blocks_per_cu    = 8;    // persistent grid = cu_count * blocks_per_cu
+    uint32_t block_rays       = 1024; // consecutive rays handed to a wave at a time
+    uint32_t refill_threshold = 16;   // idle lanes that trigger a re-fill
+
+    // per-launch scratch
+    uint32_t* d_cursor = nullptr;
+    uint32_t* d_overflow = nullptr;
+    size_t    overflow_words = 0;
+
+    // staging for the host-pointer entry points
+    void*  d_rays = nullptr;  size_t d_rays_bytes = 0;
+    void*  d_out  = nullptr;  size_t d_out_bytes = 0;
+
+    // timing
+    int        timing = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool       ev_valid = false;
+
+    // last launch geometry
+    uint32_t last_blocks = 0, last_threads = 0, last_lds = 0;
+};
+
+struct vt_scene {
+    vt_engine*    engine = nullptr;
+    vt_node_pair* d_pairs = nullptr;
+    vt_tri64*     d_tris = nullptr;
+    uint32_t*     d_prim_to_slot = nullptr;
+    uint32_t      npairs = 0, ntris = 0, max_depth = 0, root_leaf_count = 0;
+    uint64_t      bytes = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int ensure_bytes(void** ptr, size_t* have, size_t need)
+{
+    if (*have >= need) return VT_OK;
+    if (*ptr) { VT_HIP(hipFree(*ptr)); *ptr = nullptr; *have = 0; }
+    size_t cap = std::max(need, size_t(1) << 20);
+    VT_HIP(hipMalloc(ptr, cap));
+    *have = cap;
+    return VT_OK;
+}
+
+struct LaunchPlan {
+    bool     persistent;
+    uint32_t grid_blocks;
+    uint32_t lds_entries;
+    size_t   lds_bytes;
+    uint32_t ovf_entries;
+};
+
+int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, LaunchPlan& p)
+{
+    // stack entries a ray can need = inner levels below the root pair
+    const uint32_t need = s->max_depth;
+    p.persistent = e->persistent != 0;
+    const uint64_t blocks_for_rays = (n + kBlockThreads - 1) / kBlockThreads;
+    if (p.persistent) {
+        p.grid_blocks = uint32_t(std::min<uint64_t>(uint64_t(e->cu_count) * e->blocks_per_cu, blocks_for_rays));
+        p.lds_entries = std::min(std::max(e->lds_entries, 1u), std::max(need, 1u));
+        p.ovf_entries = need > p.lds_entries ? need - p.lds_entries : 0;
+    } else {
+        if (blocks_for_rays > 0x7FFFFFFFull) return fail(VT_ERR_INVALID_ARG, "too many rays for one launch");
+        p.grid_blocks = uint32_t(blocks_for_rays);
+        p.lds_entries = std::max(need, 1u); // whole stack in LDS, no overflow area
+        p.ovf_entries = 0;
+    }
+    p.lds_bytes = size_t(p.lds_entries) * 64 * sizeof(uint32_t) * (kBlockThreads / 64);
+    if (p.lds_bytes > e->lds_per_block_max)
+        return fail(VT_ERR_STACK, "tree depth " + std::to_string(need) + " needs more LDS stack than one block can hold");
+    return VT_OK;
+}
+
+int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_occ, void* d_stats, bool any_hit,
+           bool stats, hipStream_t stream)
+{
+    vt_engine* e = s->engine;
+    if (n == 0) return VT_OK;
+    LaunchPlan p;
+    int rc = plan_launch(e, s, n, p);
+    if (rc != VT_OK) return rc;
+
+    const size_t ovf_words = size_t(p.ovf_entries) * p.grid_blocks * kBlockThreads;
+    if (ovf_words > e->overflow_words) {
+        // grow (rare: first launch on a deeper tree); must not race with in-flight launches
+        VT_HIP(hipStreamSynchronize(stream));
+        if (e->d_overflow) VT_HIP(hipFree(e->d_overflow));
+        e->d_overflow = nullptr; e->overflow_words = 0;
+        VT_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_overflow), ovf_words * sizeof(uint32_t)));
+        e->overflow_words = ovf_words;
+    }
+
+    TraceArgs a{};
+    a.pairs = s->d_pairs;
+    a.tris = s->d_tris;
+    a.rays = static_cast<const vt_ray*>(d_rays);
+    a.hits = static_cast<vt_hit*>(d_hits);
+    a.occluded = static_cast<uint8_t*>(d_occ);
+    a.ray_stats = static_cast<vt_ray_stats*>(d_stats);
+    a.overflow = e->d_overflow;
+    a.block_cursor = e->d_cursor;
+    a.nrays = n;
+    a.npairs = s->npairs;
+    a.root_leaf_count = s->root_leaf_count;
+    a.lds_entries = p.lds_entries;
+    a.block_rays = std::max(64u, (e->block_rays / 64u) * 64u);
+    a.refill_threshold = std::min(std::max(e->refill_threshold, 1u), 64u);
+
+    if (p.persistent) VT_HIP(hipMemsetAsync(e->d_cursor, 0, sizeof(uint32_t), stream));
+    if (e->timing) VT_HIP(hipEventRecord(e->ev_start, stream));
+    VT_HIP(launch_trace(a, any_hit, stats, p.persistent, p.grid_blocks, p.lds_bytes, stream));
+    if (e->timing) { VT_HIP(hipEventRecord(e->ev_stop, stream)); e->ev_valid = true; }
+    e->last_blocks = p.grid_blocks; e->last_threads = kBlockThreads; e->last_lds = uint32_t(p.lds_bytes);
+    return VT_OK;
+}
+
+long env_long(const char* name, long dflt)
+{
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    return std::strtol(v, nullptr, 10);
+}
+
+} // namespace
+
+extern "C" {
+
+int vt_device_count(int* count)
+{
+    if (!count) return fail(VT_ERR_INVALID_ARG, "vt_device_count: NULL");
+    *count = 0;
+    VT_HIP(hipGetDeviceCount(count));
+    return VT_OK;
+}
+
+int vt_engine_open(int device, vt_engine** out)
+{
+    if (!out) return fail(VT_ERR_INVALID_ARG, "vt_engine_open: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    VT_HIP(hipGetDeviceCount(&count));
+    if (count <= 0) return fail(VT_ERR_HIP, "vt_engine_open: no HIP device (this library has no CPU fallback)");
+    if (device < 0 || device >= count) return fail(VT_ERR_INVALID_ARG, "vt_engine_open: bad device index");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_engine_open: hipSetDevice failed");
+
+    hipDeviceProp_t prop;
+    VT_HIP(hipGetDeviceProperties(&prop, device));
+    vt_engine* e = new vt_engine();
+    e->device = device;
+    e->cu_count = prop.multiProcessorCount;
+    e->lds_per_block_max = prop.sharedMemPerBlock; // 64 KiB default window; plenty for the stack
+    e->persistent = int(env_long("VT_PERSISTENT", e->persistent));
+    e->lds_entries = uint32_t(env_long("VT_LDS_ENTRIES", e->lds_entries));
+    e->blocks_per_cu = uint32_t(env_long("VT_BLOCKS_PER_CU", e->blocks_per_cu));
+    e->block_rays = uint32_t(env_long("VT_BLOCK_RAYS", e->block_rays));
+    e->refill_threshold = uint32_t(env_long("VT_REFILL_THRESHOLD", e->refill_threshold));
+    hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->d_cursor), 256);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev_start);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev_stop);
+    if (err != hipSuccess) {
+        vt_engine_close(e);
+        return fail(VT_ERR_HIP, std::string("vt_engine_open: ") + hipGetErrorString(err));
+    }
+    *out = e;
+    return VT_OK;
+}
+
+void vt_engine_close(vt_engine* e)
+{
+    if (!e) return;
+    DeviceGuard guard(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->d_cursor) (void)hipFree(e->d_cursor);
+    if (e->d_overflow) (void)hipFree(e->d_overflow);
+    if (e->d_rays) (void)hipFree(e->d_rays);
+    if (e->d_out) (void)hipFree(e->d_out);
+    if (e->ev_start) (void)hipEventDestroy(e->ev_start);
+    if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int vt_engine_set_option(vt_engine* e, const char* key, int64_t value)
+{
+    if (!e || !key) return fail(VT_ERR_INVALID_ARG, "vt_engine_set_option: NULL");
+    const std::string k(key);
+    if (k == "persistent") e->persistent = value != 0;
+    else if (k == "lds_entries" && value >= 1 && value <= 4096) e->lds_entries = uint32_t(value);
+    else if (k == "blocks_per_cu" && value >= 1 && value <= 64) e->blocks_per_cu = uint32_t(value);
+    else if (k == "block_rays" && value >= 64 && value <= (1 << 24)) e->block_rays = uint32_t(value);
+    else if (k == "refill_threshold" && value >= 1 && value <= 64) e->refill_threshold = uint32_t(value);
+    else return fail(VT_ERR_INVALID_ARG, "vt_engine_set_option: unknown key or value out of range: " + k);
+    return VT_OK;
+}
+
+int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
+{
+    if (!e || !key || !value) return fail(VT_ERR_INVALID_ARG, "vt_engine_get_option: NULL");
+    const std::string k(key);
+    if (k == "persistent") *value = e->persistent;
+    else if (k == "lds_entries") *value = e->lds_entries;
+    else if (k == "blocks_per_cu") *value = e->blocks_per_cu;
+    else if (k == "block_rays") *value = e->block_rays;
+    else if (k == "refill_threshold") *value = e->refill_threshold;
+    else if (k == "cu_count") *value = e->cu_count;
+    else if (k == "device") *value = e->device;
+    else return fail(VT_ERR_INVALID_ARG, "vt_engine_get_option: unknown key: " + k);
+    return VT_OK;
+}
+
+int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
+{
+    if (!e || !hsw || !out) return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: NULL argument");
+    *out = nullptr;
+    const HostScene& hs = hsw->hs;
+    for (const vt_tri64& t : hs.tris)
+        if (t.flags & VT_TRI_ALPHATEST)
+            return fail(VT_ERR_UNSUPPORTED,
+                        "vt_scene_upload: alpha-tested triangles (Primitives.h:196-208) are not supported on the device yet");
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_upload: hipSetDevice failed");
+
+    vt_scene* s = new vt_scene();
+    s->engine = e;
+    s->npairs = uint32_t(hs.pairs.size());
+    s->ntris = uint32_t(hs.tris.size());
+    s->max_depth = hs.max_depth;
+    s->root_leaf_count = hs.root_leaf_count;
+
+    std::vector<uint32_t> prim_to_slot(hs.tris.size());
+    for (size_t i = 0; i < hs.tris.size(); ++i) {
+        if (hs.tris[i].prim >= hs.tris.size()) { delete s; return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: bad prim index"); }
+        prim_to_slot[hs.tris[i].prim] = uint32_t(i);
+    }
+
+    auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+        if (bytes == 0) return hipSuccess;
+        hipError_t err = hipMalloc(dst, bytes);
+        if (err != hipSuccess) return err;
+        s->bytes += bytes;
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    hipError_t err = up(reinterpret_cast<void**>(&s->d_pairs), hs.pairs.data(), hs.pairs.size() * sizeof(vt_node_pair));
+    if (err == hipSuccess) err = up(reinterpret_cast<void**>(&s->d_tris), hs.tris.data(), hs.tris.size() * sizeof(vt_tri64));
+    if (err == hipSuccess)
+        err = up(reinterpret_cast<void**>(&s->d_prim_to_slot), prim_to_slot.data(), prim_to_slot.size() * sizeof(uint32_t));
+    if (err != hipSuccess) {
+        vt_scene_free(s);
+        return fail(VT_ERR_HIP, std::string("vt_scene_upload: ") + hipGetErrorString(err));
+    }
+    *out = s;
+    return VT_OK;
+}
+
+void vt_scene_free(vt_scene* s)
+{
+    if (!s) return;
+    DeviceGuard guard(s->engine->device);
+    (void)hipStreamSynchronize(s->engine->stream);
+    if (s->d_pairs) (void)hipFree(s->d_pairs);
+    if (s->d_tris) (void)hipFree(s->d_tris);
+    if (s->d_prim_to_slot) (void)hipFree(s->d_prim_to_slot);
+    delete s;
+}
+
+uint64_t vt_scene_device_bytes(const vt_scene* s) { return s ? s->bytes : 0; }
+
+static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, size_t out_elem, bool any_hit)
+{
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_trace: scene is NULL");
+    if (n == 0) return VT_OK;
+    if (!rays || !out) return fail(VT_ERR_INVALID_ARG, "vt_trace: NULL buffer");
+    vt_engine* e = s->engine;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_trace: hipSetDevice failed");
+    const uint64_t chunk = uint64_t(1) << 24; // 16 Mi rays = 512 MiB of rays per staging pass
+    for (uint64_t off = 0; off < n; off += chunk) {
+        const uint64_t m = std::min(chunk, n - off);
+        int rc = ensure_bytes(&e->d_rays, &e->d_rays_bytes, m * sizeof(vt_ray));
+        if (rc == VT_OK) rc = ensure_bytes(&e->d_out, &e->d_out_bytes, m * out_elem);
+        if (rc != VT_OK) return rc;
+        VT_HIP(hipMemcpyAsync(e->d_rays, rays + off, m * sizeof(vt_ray), hipMemcpyHostToDevice, e->stream));
+        rc = launch(s, e->d_rays, m, any_hit ? nullptr : e->d_out, any_hit ? e->d_out : nullptr, nullptr, any_hit, false,
+                    e->stream);
+        if (rc != VT_OK) return rc;
+        VT_HIP(hipMemcpyAsync(static_cast<char*>(out) + off * out_elem, e->d_out, m * out_elem, hipMemcpyDeviceToHost,
+                              e->stream));
+        VT_HIP(hipStreamSynchronize(e->stream));
+    }
+    return VT_OK;
+}
+
+int vt_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_hit* hits)
+{
+    return trace_host(s, rays, n, hits, sizeof(vt_hit), false);
+}
+
+int vt_trace_any(vt_scene* s, const vt_ray* rays, uint64_t n, uint8_t* occluded)
+{
+    return trace_host(s, rays, n, occluded, sizeof(uint8_t), true);
+}
+
+static int trace_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_occ, void* d_stats, bool any_hit,
+                     bool stats, void* stream)
+{
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_trace_dev: scene is NULL");
+    if (n == 0) return VT_OK;
+    if (!d_rays || (!d_hits && !d_occ)) return fail(VT_ERR_INVALID_ARG, "vt_trace_dev: NULL device buffer");
+    vt_engine* e = s->engine;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_trace_dev: hipSetDevice failed");
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : e->stream;
+    return launch(s, d_rays, n, d_hits, d_occ, d_stats, any_hit, stats, st);
+}
+
+int vt_trace_closest_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* stream)
+{
+    return trace_dev(s, d_rays, n, d_hits, nullptr, nullptr, false, false, stream);
+}
+
+int vt_trace_any_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_occluded, void* stream)
+{
+    return trace_dev(s, d_rays, n, nullptr, d_occluded, nullptr, true, false, stream);
+}
+
+int vt_trace_stats_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_ray_stats, void* stream)
+{
+    if (!d_ray_stats) return fail(VT_ERR_INVALID_ARG, "vt_trace_stats_dev: d_ray_stats is NULL");
+    return trace_dev(s, d_rays, n, d_hits, nullptr, d_ray_stats, false, true, stream);
+}
+
+int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64_t n, void* d_attrs, void* stream)
+{
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_hit_attrs_dev: scene is NULL");
+    if (n == 0) return VT_OK;
+    if (!d_rays || !d_hits || !d_attrs) return fail(VT_ERR_INVALID_ARG, "vt_hit_attrs_dev: NULL device buffer");
+    vt_engine* e = s->engine;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_hit_attrs_dev: hipSetDevice failed");
+    HitAttrsArgs a{};
+    a.tris = s->d_tris;
+    a.prim_to_slot = s->d_prim_to_slot;
+    a.rays = static_cast<const vt_ray*>(d_rays);
+    a.hits = static_cast<const vt_hit*>(d_hits);
+    a.attrs = static_cast<vt_hit_attrs*>(d_attrs);
+    a.n = n;
+    VT_HIP(launch_hit_attrs(a, stream ? static_cast<hipStream_t>(stream) : e->stream));
+    return VT_OK;
+}
+
+int vt_engine_synchronize(vt_engine* e)
+{
+    if (!e) return fail(VT_ERR_INVALID_ARG, "vt_engine_synchronize: NULL");
+    DeviceGuard guard(e->device);
+    VT_HIP(hipStreamSynchronize(e->stream));
+    return VT_OK;
+}
+
+int vt_engine_set_timing(vt_engine* e, int enabled)
+{
+    if (!e) return fail(VT_ERR_INVALID_ARG, "vt_engine_set_timing: NULL");
+    e->timing = enabled != 0;
+    e->ev_valid = false;
+    return VT_OK;
+}
+
+int vt_engine_last_kernel_ms(vt_engine* e, float* ms)
+{
+    if (!e || !ms) return fail(VT_ERR_INVALID_ARG, "vt_engine_last_kernel_ms: NULL");
+    if (!e->ev_valid) return fail(VT_ERR_INVALID_ARG, "vt_engine_last_kernel_ms: no timed launch yet");
+    DeviceGuard guard(e->device);
+    VT_HIP(hipEventSynchronize(e->ev_stop));
+    VT_HIP(hipEventElapsedTime(ms, e->ev_start, e->ev_stop));
+    return VT_OK;
+}
+
+int vt_engine_launch_info(vt_engine* e, uint32_t* blocks, uint32_t* threads, uint32_t* lds_bytes)
+{
+    if (!e) return fail(VT_ERR_INVALID_ARG, "vt_engine_launch_info: NULL");
+    if (blocks) *blocks = e->last_blocks;
+    if (threads) *threads = e->last_threads;
+    if (lds_bytes) *lds_bytes = e->last_lds;
+    return VT_OK;
+}
+
+} // extern "C"

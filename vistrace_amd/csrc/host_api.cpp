@@ -1,0 +1,99 @@
+// host_api.cpp -- the host-only half of the C ABI in include/vistrace_hip.h
+// (error state, triangle set-up, BVH build, linearise).  No HIP calls in this file, so
+// these entry points work on a machine without a GPU; everything that traces is in
+// engine.hip and fails loudly there when no device is present.
+#include "vt_internal.h"
+
+#include <exception>
+#include <new>
+
+namespace vt {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+} // namespace vt
+
+using namespace vt;
+
+extern "C" {
+
+const char* vt_last_error(void) { return g_last_error.c_str(); }
+int vt_abi_version(void) { return VT_ABI_VERSION; }
+
+int vt_tris_setup(const float* verts, const uint8_t* flags, uint32_t n, vt_tri64* out)
+{
+    if (n != 0 && (!verts || !out)) return fail(VT_ERR_INVALID_ARG, "vt_tris_setup: NULL argument");
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < int64_t(n); ++i) {
+        const float* v = verts + size_t(i) * 9;
+        tri_setup(v, v + 3, v + 6, uint32_t(i), flags ? flags[i] : 0u, out[i]);
+    }
+    return VT_OK;
+}
+
+int vt_bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, vt_bvh** out)
+{
+    if (!out) return fail(VT_ERR_INVALID_ARG, "vt_bvh_build: out is NULL");
+    *out = nullptr;
+    try {
+        vt_bvh* b = new vt_bvh();
+        int rc = bvh_build(tris, n, nthreads, b->bvh);
+        if (rc != VT_OK) { delete b; return rc; }
+        *out = b;
+        return VT_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(VT_ERR_NOMEM, "vt_bvh_build: out of host memory");
+    } catch (const std::exception& e) {
+        return fail(VT_ERR_INVALID_ARG, std::string("vt_bvh_build: ") + e.what());
+    }
+}
+
+void vt_bvh_free(vt_bvh* bvh) { delete bvh; }
+uint32_t vt_bvh_node_count(const vt_bvh* b) { return b ? uint32_t(b->bvh.nodes.size()) : 0; }
+uint32_t vt_bvh_prim_count(const vt_bvh* b) { return b ? uint32_t(b->bvh.prim_indices.size()) : 0; }
+const vt_bvh_node* vt_bvh_nodes(const vt_bvh* b) { return b && !b->bvh.nodes.empty() ? b->bvh.nodes.data() : nullptr; }
+const uint32_t* vt_bvh_prim_indices(const vt_bvh* b)
+{
+    return b && !b->bvh.prim_indices.empty() ? b->bvh.prim_indices.data() : nullptr;
+}
+
+int vt_scene_linearise(const vt_bvh* bvh, const vt_tri64* tris, vt_host_scene** out)
+{
+    if (!out || !bvh) return fail(VT_ERR_INVALID_ARG, "vt_scene_linearise: NULL argument");
+    *out = nullptr;
+    try {
+        vt_host_scene* hs = new vt_host_scene();
+        int rc = scene_linearise(bvh->bvh, tris, hs->hs);
+        if (rc != VT_OK) { delete hs; return rc; }
+        *out = hs;
+        return VT_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(VT_ERR_NOMEM, "vt_scene_linearise: out of host memory");
+    } catch (const std::exception& e) {
+        return fail(VT_ERR_INVALID_ARG, std::string("vt_scene_linearise: ") + e.what());
+    }
+}
+
+void vt_host_scene_free(vt_host_scene* hs) { delete hs; }
+uint32_t vt_host_scene_pair_count(const vt_host_scene* hs) { return hs ? uint32_t(hs->hs.pairs.size()) : 0; }
+uint32_t vt_host_scene_tri_count(const vt_host_scene* hs) { return hs ? uint32_t(hs->hs.tris.size()) : 0; }
+uint32_t vt_host_scene_max_depth(const vt_host_scene* hs) { return hs ? hs->hs.max_depth : 0; }
+uint32_t vt_host_scene_root_leaf_count(const vt_host_scene* hs) { return hs ? hs->hs.root_leaf_count : 0; }
+const vt_node_pair* vt_host_scene_pairs(const vt_host_scene* hs)
+{
+    return hs && !hs->hs.pairs.empty() ? hs->hs.pairs.data() : nullptr;
+}
+const vt_tri64* vt_host_scene_tris(const vt_host_scene* hs)
+{
+    return hs && !hs->hs.tris.empty() ? hs->hs.tris.data() : nullptr;
+}
+
+} // extern "C"

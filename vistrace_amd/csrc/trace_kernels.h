@@ -1,0 +1,44 @@
+// trace_kernels.h -- launch interface between engine.hip and trace_kernels.hip
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "vistrace_hip.h"
+
+namespace vt {
+
+constexpr uint32_t kBlockThreads = 256; // 4 waves of 64
+
+struct TraceArgs {
+    const vt_node_pair* pairs;
+    const vt_tri64*     tris;
+    const vt_ray*       rays;
+    vt_hit*             hits;        // closest-hit output (or nullptr for any-hit)
+    uint8_t*            occluded;    // any-hit output
+    vt_ray_stats*       ray_stats;   // STATS kernels only
+    uint32_t*           overflow;    // per-lane stack overflow area: entry k of thread g at [k*gstride + g]
+    uint32_t*           block_cursor;// persistent mode: next block of rays to hand out
+    uint64_t            nrays;
+    uint32_t            npairs;
+    uint32_t            root_leaf_count;
+    uint32_t            lds_entries; // stack entries per lane kept in LDS
+    uint32_t            block_rays;  // rays per block handed to a wave (multiple of 64)
+    uint32_t            refill_threshold; // re-fill a wave once this many lanes are idle
+};
+
+struct HitAttrsArgs {
+    const vt_tri64* tris;
+    const uint32_t* prim_to_slot;
+    const vt_ray*   rays;
+    const vt_hit*   hits;
+    vt_hit_attrs*   attrs;
+    uint64_t        n;
+};
+
+hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, uint32_t grid_blocks,
+                        size_t lds_bytes, hipStream_t stream);
+hipError_t launch_hit_attrs(const HitAttrsArgs& a, hipStream_t stream);
+
+} // namespace vt

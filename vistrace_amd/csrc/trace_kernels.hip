@@ -1,0 +1,314 @@
+// trace_kernels.hip -- CDNA4 (gfx950) traversal kernels for AccelStruct::Traverse.
+//
+// One lane = one ray.  The per-ray algorithm is EXACTLY the single-ray walk the reference
+// runs at source/objects/AccelStruct.cpp:818 (madmann91/bvh v1 SingleRayTraverser +
+// FastNodeIntersector + Closest/AnyPrimitiveIntersector) with the
+// in-tree triangle test of source/objects/Primitives.h:168-215, in the same visitation
+// order (the tie-broken primitive index depends on it) and with the same fp32 rounding
+// (no FMA contraction, IEEE divide).  What is MI355X-specific is everything around it:
+//
+//  * node pairs and triangles are 64-B records (vt_node_pair / vt_tri64), fetched as four
+//    16-B loads per lane from ONE address stream (a lane is either on a node or on a
+//    triangle, never both);
+//  * the walk is a two-state machine per lane (NODE step / TRI test) so that a wave never
+//    sits in one lane's leaf loop: leaves found by a node step become a pending
+//    [tri_cur, tri_end) range (the two leaf children of a pair are contiguous in the
+//    leaf-ordered triangle array) that is drained one triangle per iteration before the
+//    lane's next node step -- the order of slab tests and triangle tests per ray is
+//    unchanged;
+//  * the traversal stack lives in LDS as stack[entry][lane] (bank = lane, conflict-free),
+//    `lds_entries` deep, with a per-lane global overflow area for deeper trees;
+//  * persistent waves: a wave pulls blocks of consecutive rays from a global cursor and
+//    re-fills idle lanes (ballot + mbcnt prefix) once enough of them have retired, so
+//    divergent ray lengths do not leave lanes empty.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "trace_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace vt {
+
+namespace {
+
+constexpr uint32_t kDone = 0xFFFFFFFFu; // node cursor: nothing left to walk
+
+__device__ __forceinline__ uint32_t lane_id()
+{
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ uint32_t prefix_count(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
+
+// bvh v1 utilities: safe_inverse / robust_min / robust_max
+__device__ __forceinline__ float safe_inverse(float x)
+{
+    return fabsf(x) <= FLT_EPSILON ? copysignf(1.0f / FLT_EPSILON, x) : 1.0f / x;
+}
+__device__ __forceinline__ float robust_max(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float robust_min(float a, float b) { return a < b ? a : b; }
+
+struct Lane {
+    // ray (bvh::Ray, Primitives.h:11-33); tmax shrinks as hits are found
+    float ox, oy, oz, dx, dy, dz, tmin, tmax;
+    // FastNodeIntersector state
+    float ix, iy, iz, sx, sy, sz;
+    // best hit
+    uint32_t prim;
+    float u, v;
+    // cursors
+    uint32_t node;             // pair index to visit next, or kDone
+    uint32_t tri_cur, tri_end; // pending leaf triangles
+    uint32_t sp;               // stack entries in use
+    uint32_t steps, tests;
+};
+
+} // namespace
+
+template <bool ANY_HIT, bool STATS, bool PERSISTENT>
+__global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t* const st_lds = lds_stack + size_t(wave) * a.lds_entries * 64 + lane; // entry k at [k*64]
+    const uint32_t gthread = blockIdx.x * kBlockThreads + threadIdx.x;
+    const uint32_t gstride = gridDim.x * kBlockThreads;
+    uint32_t* const st_ovf = a.overflow + gthread;                                  // entry k at [k*gstride]
+
+    const float4* const pairs4 = reinterpret_cast<const float4*>(a.pairs);
+    const float4* const tris4  = reinterpret_cast<const float4*>(a.tris);
+
+    Lane L;
+    uint64_t ray_idx = 0;
+    bool has_ray = false;
+
+    // wave-uniform block cursor (PERSISTENT)
+    uint64_t blk_cur = 0, blk_end = 0;
+    bool exhausted = false;
+
+    auto start_ray = [&](uint64_t idx) {
+        const float4* r4 = reinterpret_cast<const float4*>(a.rays + idx);
+        const float4 r0 = r4[0], r1 = r4[1];
+        L.ox = r0.x; L.oy = r0.y; L.oz = r0.z; L.dx = r0.w;
+        L.dy = r1.x; L.dz = r1.y; L.tmin = r1.z; L.tmax = r1.w;
+        L.ix = safe_inverse(L.dx); L.iy = safe_inverse(L.dy); L.iz = safe_inverse(L.dz);
+        L.sx = -L.ox * L.ix; L.sy = -L.oy * L.iy; L.sz = -L.oz * L.iz;
+        L.prim = VT_MISS; L.u = 0.f; L.v = 0.f;
+        L.sp = 0; L.steps = 0; L.tests = 0;
+        if (a.root_leaf_count != 0) {        // the root is a leaf: no slab test at all
+            L.node = kDone; L.tri_cur = 0; L.tri_end = a.root_leaf_count;
+        } else {
+            L.node = a.npairs != 0 ? 0u : kDone; L.tri_cur = 0; L.tri_end = 0;
+        }
+        ray_idx = idx;
+        has_ray = true;
+    };
+
+    auto finish_ray = [&]() {
+        if constexpr (ANY_HIT) {
+            a.occluded[ray_idx] = L.prim != VT_MISS ? 1 : 0;
+        } else {
+            float4 h;
+            h.x = __uint_as_float(L.prim);
+            h.y = L.prim != VT_MISS ? L.tmax : 0.f;
+            h.z = L.u; h.w = L.v;
+            reinterpret_cast<float4*>(a.hits)[ray_idx] = h;
+        }
+        if constexpr (STATS) {
+            a.ray_stats[ray_idx] = vt_ray_stats{L.steps, L.tests};
+        }
+        has_ray = false;
+    };
+
+    if constexpr (!PERSISTENT) {
+        const uint64_t idx = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
+        if (idx < a.nrays) start_ray(idx);
+    }
+
+    for (;;) {
+        if constexpr (PERSISTENT) {
+            const uint64_t idle = __ballot(!has_ray);
+            if (idle != 0 && !exhausted) {
+                const uint32_t nidle = __popcll(idle);
+                if (nidle >= a.refill_threshold || idle == ~0ull) {
+                    if (blk_cur == blk_end) { // acquire the next block of consecutive rays
+                        uint32_t b = 0;
+                        if (lane == 0) b = atomicAdd(a.block_cursor, 1u);
+                        b = __builtin_amdgcn_readfirstlane(b);
+                        blk_cur = uint64_t(b) * a.block_rays;
+                        blk_end = blk_cur + a.block_rays < a.nrays ? blk_cur + a.block_rays : a.nrays;
+                        if (blk_cur >= a.nrays) { exhausted = true; blk_cur = blk_end = 0; }
+                    }
+                    if (!exhausted) {
+                        const uint64_t avail = blk_end - blk_cur;
+                        const uint32_t mine = prefix_count(idle);
+                        if (!has_ray && mine < avail) start_ray(blk_cur + mine);
+                        blk_cur += nidle < avail ? nidle : avail;
+                    }
+                }
+            }
+            if (exhausted && __ballot(has_ray) == 0) break;
+        } else {
+            if (__ballot(has_ray) == 0) break;
+        }
+
+        if (has_ray) {
+            if (L.tri_cur < L.tri_end) {
+                // ---- TRI: TriangleBackfaceCull::intersect, Primitives.h:168-215 ----------
+                const float4* t4 = tris4 + size_t(L.tri_cur) * 4;
+                const float4 q0 = t4[0], q1 = t4[1], q2 = t4[2], q3 = t4[3];
+                ++L.tri_cur;
+                if constexpr (STATS) ++L.tests;
+                const float p0x = q0.x, p0y = q0.y, p0z = q0.z;
+                const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
+                const float e2x = q1.z, e2y = q1.w, e2z = q2.x;
+                const float nx = q2.y, ny = q2.z, nz = q2.w;
+                const uint32_t tprim = __float_as_uint(q3.x), tflags = __float_as_uint(q3.y);
+
+                const float nDotDir = (nx * L.dx + ny * L.dy) + nz * L.dz;                 // :173
+                const bool culled = (tflags & VT_TRI_CULL_BACKFACE) && nDotDir > 0.0f;     // :174
+                const float cx = p0x - L.ox, cy = p0y - L.oy, cz = p0z - L.oz;             // :176
+                const float rx = L.dy * cz - L.dz * cy;                                    // :177
+                const float ry = L.dz * cx - L.dx * cz;
+                const float rz = L.dx * cy - L.dy * cx;
+                const float inv_det = 1.0f / nDotDir;                                      // :178
+                const float u = ((rx * e2x + ry * e2y) + rz * e2z) * inv_det;              // :180
+                const float v = ((rx * e1x + ry * e1y) + rz * e1z) * inv_det;              // :181
+                const float w = 1.0f - u - v;                                              // :182
+                const float t = ((nx * cx + ny * cy) + nz * cz) * inv_det;                 // :188
+                if (!culled && u >= 0.0f && v >= 0.0f && w >= 0.0f &&                      // :187
+                    t >= L.tmin && t <= L.tmax) {                                          // :189
+                    L.prim = tprim; L.u = u; L.v = v; L.tmax = t;
+                    if constexpr (ANY_HIT) { L.tri_cur = L.tri_end; L.node = kDone; }
+                }
+            } else {
+                // ---- NODE: one iteration of SingleRayTraverser::traverse ---------------
+                const float4* p4 = pairs4 + size_t(L.node) * 4;
+                const float4 n0 = p4[0], n1 = p4[1], n2 = p4[2], n3 = p4[3];
+                if constexpr (STATS) ++L.steps;
+                const bool ox = __float_as_uint(L.dx) >> 31, oy = __float_as_uint(L.dy) >> 31,
+                           oz = __float_as_uint(L.dz) >> 31; // octant = signbit(dir)
+                // left child: bounds {n0.x n0.y | n0.z n0.w | n1.x n1.y}, count n1.z, first n1.w
+                float e0 = (ox ? n0.y : n0.x) * L.ix + L.sx, x0 = (ox ? n0.x : n0.y) * L.ix + L.sx;
+                float e1 = (oy ? n0.w : n0.z) * L.iy + L.sy, x1 = (oy ? n0.z : n0.w) * L.iy + L.sy;
+                float e2 = (oz ? n1.y : n1.x) * L.iz + L.sz, x2 = (oz ? n1.x : n1.y) * L.iz + L.sz;
+                const float fl = robust_max(e0, robust_max(e1, robust_max(e2, L.tmin)));
+                const float sl = robust_min(x0, robust_min(x1, robust_min(x2, L.tmax)));
+                // right child: bounds {n2.x n2.y | n2.z n2.w | n3.x n3.y}, count n3.z, first n3.w
+                e0 = (ox ? n2.y : n2.x) * L.ix + L.sx; x0 = (ox ? n2.x : n2.y) * L.ix + L.sx;
+                e1 = (oy ? n2.w : n2.z) * L.iy + L.sy; x1 = (oy ? n2.z : n2.w) * L.iy + L.sy;
+                e2 = (oz ? n3.y : n3.x) * L.iz + L.sz; x2 = (oz ? n3.x : n3.y) * L.iz + L.sz;
+                const float fr = robust_max(e0, robust_max(e1, robust_max(e2, L.tmin)));
+                const float sr = robust_min(x0, robust_min(x1, robust_min(x2, L.tmax)));
+
+                const uint32_t lcount = __float_as_uint(n1.z), lfirst = __float_as_uint(n1.w);
+                const uint32_t rcount = __float_as_uint(n3.z), rfirst = __float_as_uint(n3.w);
+                const bool hit_l = fl <= sl, hit_r = fr <= sr;
+                const bool leaf_l = lcount != 0, leaf_r = rcount != 0;
+
+                // leaves that were hit become the pending triangle range, left before right;
+                // two leaf siblings are contiguous in the leaf-ordered triangle array
+                uint32_t tc = 0, te = 0;
+                if (hit_l && leaf_l) { tc = lfirst; te = lfirst + lcount; }
+                if (hit_r && leaf_r) { if (te == 0) tc = rfirst; te = rfirst + rcount; }
+                L.tri_cur = tc; L.tri_end = te;
+
+                const bool go_l = hit_l && !leaf_l, go_r = hit_r && !leaf_r;
+                uint32_t next;
+                if (go_l && go_r) {
+                    // near child first (ties keep left first); push the far child's pair
+                    const bool swap = fl > fr;
+                    next = swap ? rfirst : lfirst;
+                    const uint32_t far = swap ? lfirst : rfirst;
+                    if (L.sp < a.lds_entries) st_lds[L.sp * 64] = far;
+                    else st_ovf[size_t(L.sp - a.lds_entries) * gstride] = far;
+                    ++L.sp;
+                } else if (go_l) {
+                    next = lfirst;
+                } else if (go_r) {
+                    next = rfirst;
+                } else if (L.sp != 0) {
+                    --L.sp;
+                    next = L.sp < a.lds_entries ? st_lds[L.sp * 64]
+                                                : st_ovf[size_t(L.sp - a.lds_entries) * gstride];
+                } else {
+                    next = kDone;
+                }
+                L.node = next;
+            }
+            if (L.node == kDone && L.tri_cur >= L.tri_end) finish_ray();
+        }
+    }
+}
+
+// ---- TraceResult batch core: TraceResult.cpp:45-86, 255-262 -----------------------------
+__global__ __launch_bounds__(kBlockThreads) void hit_attrs_kernel(HitAttrsArgs a)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
+    if (i >= a.n) return;
+    const vt_hit h = a.hits[i];
+    vt_hit_attrs o;
+    if (h.prim == VT_MISS) {
+        o = vt_hit_attrs{};
+    } else {
+        const vt_tri64 T = a.tris[a.prim_to_slot[h.prim]];
+        const vt_ray r = a.rays[i];
+        // AccelStruct.cpp:826 glm::normalize(dir); TraceResult.cpp:56 wo = -direction
+        const float d2 = (r.dir[0] * r.dir[0] + r.dir[1] * r.dir[1]) + r.dir[2] * r.dir[2];
+        const float inv = 1.0f / sqrtf(d2);
+        o.wo[0] = -(r.dir[0] * inv); o.wo[1] = -(r.dir[1] * inv); o.wo[2] = -(r.dir[2] * inv);
+        const float w = 1.0f - h.u - h.v;                               // TraceResult.cpp:70
+        o.uvw[0] = h.u; o.uvw[1] = h.v; o.uvw[2] = w;
+        const float len = sqrtf((T.n[0] * T.n[0] + T.n[1] * T.n[1]) + T.n[2] * T.n[2]);
+        for (int k = 0; k < 3; ++k) {
+            o.ngeo[k] = T.n[k] / len;                                   // Primitives.h:100
+            const float v0 = T.p0[k], v1 = T.p0[k] - T.e1[k], v2 = T.p0[k] + T.e2[k];
+            o.pos[k] = (w * v0 + h.u * v1) + h.v * v2;                  // TraceResult.cpp:258
+        }
+        o.t = h.t;
+        o.prim = h.prim;
+        o.front = ((o.wo[0] * o.ngeo[0] + o.wo[1] * o.ngeo[1]) + o.wo[2] * o.ngeo[2]) >= 0.0f ? 1u : 0u; // :85
+        o.hit = 1;
+    }
+    a.attrs[i] = o;
+}
+
+// ---- launchers ---------------------------------------------------------------------------
+template <bool ANY_HIT, bool STATS, bool PERSISTENT>
+static hipError_t launch_one(const TraceArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL((trace_kernel<ANY_HIT, STATS, PERSISTENT>), grid, dim3(kBlockThreads), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, uint32_t grid_blocks,
+                        size_t lds_bytes, hipStream_t stream)
+{
+    const dim3 grid(grid_blocks);
+    if (persistent) {
+        if (any_hit) return launch_one<true, false, true>(a, grid, lds_bytes, stream);
+        if (stats)   return launch_one<false, true, true>(a, grid, lds_bytes, stream);
+        return launch_one<false, false, true>(a, grid, lds_bytes, stream);
+    }
+    if (any_hit) return launch_one<true, false, false>(a, grid, lds_bytes, stream);
+    if (stats)   return launch_one<false, true, false>(a, grid, lds_bytes, stream);
+    return launch_one<false, false, false>(a, grid, lds_bytes, stream);
+}
+
+hipError_t launch_hit_attrs(const HitAttrsArgs& a, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    const uint64_t blocks = (a.n + kBlockThreads - 1) / kBlockThreads;
+    hipLaunchKernelGGL(hit_attrs_kernel, dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace vt

@@ -1,0 +1,44 @@
+// vt_internal.h -- shared declarations of the host-side pieces behind include/vistrace_hip.h
+#pragma once
+
+#include "vistrace_hip.h"
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+static_assert(sizeof(vt_ray) == 32, "vt_ray must be 32 bytes");
+static_assert(sizeof(vt_hit) == 16, "vt_hit must be 16 bytes");
+static_assert(sizeof(vt_bvh_node) == 32, "vt_bvh_node must be 32 bytes");
+static_assert(sizeof(vt_node_pair) == 64, "vt_node_pair must be 64 bytes");
+static_assert(sizeof(vt_tri64) == 64, "vt_tri64 must be 64 bytes");
+static_assert(sizeof(vt_hit_attrs) == 64, "vt_hit_attrs must be 64 bytes");
+
+namespace vt {
+
+// v1-layout tree (what bvh::Bvh<float> holds in the reference: source/objects/AccelStruct.h:67)
+struct Bvh {
+    std::vector<vt_bvh_node> nodes;        // nodes[0] = root; empty <=> no triangles
+    std::vector<uint32_t>    prim_indices; // leaf slot -> original triangle index
+};
+
+// device-ready scene
+struct HostScene {
+    std::vector<vt_node_pair> pairs;   // depth-first order; pairs[0] = the root's children
+    std::vector<vt_tri64>     tris;    // leaf order
+    uint32_t max_depth       = 0;      // deepest inner level = stack entries a ray can need
+    uint32_t root_leaf_count = 0;      // != 0: the root itself is a leaf over tris[0..count)
+};
+
+int  bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out);
+int  scene_linearise(const Bvh& bvh, const vt_tri64* tris, HostScene& out);
+void tri_setup(const float p0[3], const float p1[3], const float p2[3], uint32_t prim,
+               uint32_t flags, vt_tri64& out);
+
+void set_error(const std::string& msg);
+int  fail(int code, const std::string& msg);
+
+} // namespace vt
+
+struct vt_bvh        { vt::Bvh bvh; };
+struct vt_host_scene { vt::HostScene hs; };

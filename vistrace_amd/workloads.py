@@ -1,0 +1,246 @@
+"""Deterministic synthetic scenes and ray sets for the BASELINE.json configs.
+
+Scenes: a closed axis-aligned room [-1000,1000]^3 (Source-unit scale) whose six walls are
+tessellated k x k x 2 triangles, filled with M icospheres.  Rays: pinhole primary rays,
+uniform-sphere rays, cosine-hemisphere bounce rays (origin offset = vistrace.CalcRayOrigin,
+source/VisTrace.cpp:1495-1517; direction mapping = hemisphere_cos,
+source/libraries/BSDF.cpp:69-77) and point-light shadow rays.  RNG: splitmix64, counter
+based, seed 0x5EED + config id.  Everything here is numpy on the host; nothing is traced.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ._lib import HIT_ATTRS, RAY
+
+SEED = 0x5EED
+ROOM = 1000.0
+FLT_MAX = np.float32(np.finfo(np.float32).max)
+
+#            spheres, subdivisions, wall k
+SCENES = {
+    "S1k": (3, 2, 4),          # 3*320 + 192      = 1 152     (fixtures / fast tests)
+    "S10k": (7, 3, 9),         # 8 960 + 972      = 9 932
+    "S100k": (77, 3, 11),      # 98 560 + 1 452   = 100 012
+    "S1M": (770, 3, 35),       # 985 600 + 14 700 = 1 000 300
+    "S10M": (1950, 4, 52),     # 9 984 000 + 32 448 = 10 016 448
+}
+SCENE_IDS = {"S1k": 0, "S10k": 1, "S100k": 2, "S1M": 3, "S10M": 5}
+
+
+# ---- RNG ------------------------------------------------------------------------------------
+def splitmix64(seed: int, start: int, count: int) -> np.ndarray:
+    """Outputs number start .. start+count-1 (0-based) of the splitmix64 stream `seed`."""
+    with np.errstate(over="ignore"):
+        i = np.arange(start + 1, start + count + 1, dtype=np.uint64)
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed: int, start: int, count: int) -> np.ndarray:
+    """float32 in [0,1): top 24 bits of the splitmix64 outputs."""
+    return ((splitmix64(seed, start, count) >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
+
+
+# ---- geometry ---------------------------------------------------------------------------------
+def icosphere(subdiv: int) -> np.ndarray:
+    """Unit icosphere as (20*4^subdiv, 3, 3) float64 triangles, outward winding."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2],
+                  [10, 7, 6], [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5],
+                  [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]])
+    tris = v[f]
+    for _ in range(subdiv):
+        a, b, c = tris[:, 0], tris[:, 1], tris[:, 2]
+        ab, bc, ca = a + b, b + c, c + a
+        ab /= np.linalg.norm(ab, axis=1, keepdims=True)
+        bc /= np.linalg.norm(bc, axis=1, keepdims=True)
+        ca /= np.linalg.norm(ca, axis=1, keepdims=True)
+        tris = np.concatenate([np.stack([a, ab, ca], 1), np.stack([b, bc, ab], 1), np.stack([c, ca, bc], 1),
+                               np.stack([ab, bc, ca], 1)], 0)
+    return tris
+
+
+def room_walls(k: int, half: float = ROOM) -> np.ndarray:
+    """Six walls of the cube [-half,half]^3, each k x k quads x 2 triangles: (12k^2,3,3)."""
+    g = np.linspace(-half, half, k + 1)
+    a0, b0 = np.meshgrid(g[:-1], g[:-1], indexing="ij")
+    a1, b1 = np.meshgrid(g[1:], g[1:], indexing="ij")
+    a0, b0, a1, b1 = a0.ravel(), b0.ravel(), a1.ravel(), b1.ravel()
+    out = []
+    for axis in range(3):
+        for side in (-half, half):
+            def P(a, b):
+                p = np.empty((a.size, 3))
+                p[:, axis] = side
+                p[:, (axis + 1) % 3] = a
+                p[:, (axis + 2) % 3] = b
+                return p
+            q00, q10, q11, q01 = P(a0, b0), P(a1, b0), P(a1, b1), P(a0, b1)
+            out.append(np.stack([q00, q10, q11], 1))
+            out.append(np.stack([q00, q11, q01], 1))
+    return np.concatenate(out, 0)
+
+
+def camera_positions(name: str, count: int = 128) -> np.ndarray:
+    """Camera 0 is the room centre; the others are seeded positions in [-800,800]^3."""
+    u = uniform01(SEED + 100 + SCENE_IDS[name], 0, 3 * count).reshape(count, 3)
+    pos = (u * 1600.0 - 800.0).astype(np.float32)
+    pos[0] = 0.0
+    return pos
+
+
+def light_positions(name: str, count: int = 16) -> np.ndarray:
+    u = uniform01(SEED + 200 + SCENE_IDS[name], 0, 3 * count).reshape(count, 3)
+    return (u * 1600.0 - 800.0).astype(np.float32)
+
+
+def make_scene(name: str) -> np.ndarray:
+    """(n,3,3) float32 triangles of scene `name` (all two-sided, one material, flags 0)."""
+    m, subdiv, k = SCENES[name]
+    seed = SEED + SCENE_IDS[name]
+    keep_out = np.concatenate([camera_positions(name), light_positions(name)], 0).astype(np.float64)
+    unit = icosphere(subdiv)
+    centres = np.empty((m, 3))
+    radii = np.empty(m)
+    draw = 0
+    for i in range(m):
+        while True:  # re-draw until no camera/light is within 150 units of the centre
+            u = uniform01(seed, 4 * draw, 4).astype(np.float64)
+            draw += 1
+            r = 20.0 + 60.0 * u[3]
+            c = (u[:3] * 2.0 - 1.0) * (ROOM - r)
+            if np.min(np.linalg.norm(keep_out - c, axis=1)) >= 150.0:
+                break
+        centres[i], radii[i] = c, r
+    spheres = (unit[None] * radii[:, None, None, None] + centres[:, None, None, :]).reshape(-1, 3, 3)
+    return np.concatenate([spheres, room_walls(k)], 0).astype(np.float32)
+
+
+def make_terrain(k: int = 24, seed: int = SEED + 50, half: float = 100.0):
+    """2.5-D heightfield, every triangle oneSided (VT_TRI_CULL_BACKFACE): (2k^2,3,3), flags."""
+    h = (uniform01(seed, 0, (k + 1) * (k + 1)).reshape(k + 1, k + 1) * 20.0).astype(np.float64)
+    g = np.linspace(-half, half, k + 1)
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    P = np.stack([X, Y, h], -1)
+    q00, q10, q11, q01 = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    t0 = np.stack([q00, q10, q11], -2).reshape(-1, 3, 3)
+    t1 = np.stack([q00, q11, q01], -2).reshape(-1, 3, 3)
+    verts = np.concatenate([t0, t1], 0).astype(np.float32)
+    return verts, np.ones(len(verts), dtype=np.uint8)
+
+
+# ---- rays -------------------------------------------------------------------------------------
+def _pack(org, dirs, tmin=0.0, tmax=FLT_MAX) -> np.ndarray:
+    rays = np.zeros(len(dirs), dtype=RAY)
+    rays["org"] = org
+    rays["dir"] = dirs
+    rays["tmin"] = tmin
+    rays["tmax"] = tmax
+    return rays
+
+
+def primary_rays(width: int, height: int, pos=(0.0, 0.0, 0.0), forward=(1.0, 0.0, 0.0), up=(0.0, 0.0, 1.0),
+                 vfov_deg: float = 60.0) -> np.ndarray:
+    """Pinhole camera, pixel-centre rays, row-major, normalised directions, [0, FLT_MAX]."""
+    f = np.asarray(forward, np.float64); f /= np.linalg.norm(f)
+    r = np.cross(f, np.asarray(up, np.float64)); r /= np.linalg.norm(r)
+    u = np.cross(r, f)
+    th = np.tan(np.radians(vfov_deg) / 2.0)
+    px = ((np.arange(width) + 0.5) / width * 2.0 - 1.0) * th * (width / height)
+    py = (1.0 - (np.arange(height) + 0.5) / height * 2.0) * th
+    d = f[None, None, :] + px[None, :, None] * r[None, None, :] + py[:, None, None] * u[None, None, :]
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    return _pack(np.asarray(pos, np.float32), d.reshape(-1, 3).astype(np.float32))
+
+
+def sphere_rays(n: int, seed: int, origin=(0.0, 0.0, 0.0)) -> np.ndarray:
+    """Uniform directions on the sphere from one origin."""
+    u = uniform01(seed, 0, 2 * n).astype(np.float64).reshape(n, 2)
+    z = 1.0 - 2.0 * u[:, 0]
+    s = np.sqrt(np.maximum(0.0, 1.0 - z * z))
+    phi = 2.0 * np.pi * u[:, 1]
+    d = np.stack([s * np.cos(phi), s * np.sin(phi), z], 1)
+    return _pack(np.asarray(origin, np.float32), d.astype(np.float32))
+
+
+def calc_ray_origin(pos: np.ndarray, normal: np.ndarray) -> np.ndarray:
+    """vistrace.CalcRayOrigin, source/VisTrace.cpp:1495-1517, vectorised (float32 in/out)."""
+    pos = np.ascontiguousarray(pos, np.float32)
+    normal = np.ascontiguousarray(normal, np.float32)
+    origin, f_scale, i_scale = np.float32(1 / 32), np.float32(1 / 65536), np.float32(256)
+    i_off = (normal * i_scale).astype(np.int32)            # ivec3(normal * iScale): truncation
+    bits = pos.view(np.int32) + np.where(pos < 0, -i_off, i_off)
+    i_pos = bits.view(np.float32)
+    f_off = normal * f_scale
+    return np.where(np.abs(pos) < origin, pos + f_off, i_pos).astype(np.float32)
+
+
+def hemisphere_cos(r1: np.ndarray, r2: np.ndarray) -> np.ndarray:
+    """hemisphere_cos, source/libraries/BSDF.cpp:69-77 (local frame, z = normal)."""
+    r1 = r1.astype(np.float32); r2 = r2.astype(np.float32)
+    z = np.sqrt(r1)
+    sin_t = np.sqrt(np.float32(1) - r1)
+    phi = np.float32(2) * np.float32(np.pi) * r2
+    return np.stack([sin_t * np.cos(phi), sin_t * np.sin(phi), z], -1).astype(np.float32)
+
+
+def _onb(n: np.ndarray):
+    """Branch-light orthonormal basis around unit normals (Duff et al. 2017)."""
+    n = n.astype(np.float32)
+    sign = np.where(n[:, 2] >= 0, np.float32(1), np.float32(-1))
+    a = np.float32(-1) / (sign + n[:, 2])
+    b = n[:, 0] * n[:, 1] * a
+    b1 = np.stack([np.float32(1) + sign * n[:, 0] * n[:, 0] * a, sign * b, -sign * n[:, 0]], 1)
+    b2 = np.stack([b, sign + n[:, 1] * n[:, 1] * a, -n[:, 1]], 1)
+    return b1.astype(np.float32), b2.astype(np.float32)
+
+
+def _facing_normals(attrs: np.ndarray) -> np.ndarray:
+    """Geometric normal flipped towards wo (the side the ray arrived from)."""
+    ng = attrs["ngeo"].astype(np.float32)
+    return np.where((attrs["front"] != 0)[:, None], ng, -ng).astype(np.float32)
+
+
+def fill_misses(attrs: np.ndarray) -> np.ndarray:
+    """Replace missed records by the previous hit in ray order (keeps N exact)."""
+    assert attrs.dtype == HIT_ATTRS
+    hit = attrs["hit"] != 0
+    if hit.all():
+        return attrs
+    idx = np.where(hit, np.arange(len(attrs)), -1)
+    idx = np.maximum.accumulate(idx)
+    first = int(np.argmax(hit))
+    idx[idx < 0] = first
+    return attrs[idx]
+
+
+def bounce_rays(attrs: np.ndarray, seed: int) -> np.ndarray:
+    """One cosine-hemisphere bounce ray per primary hit record, order left as generated."""
+    attrs = fill_misses(attrs)
+    n = len(attrs)
+    nrm = _facing_normals(attrs)
+    org = calc_ray_origin(attrs["pos"], nrm)
+    u = uniform01(seed, 0, 2 * n).reshape(n, 2)
+    loc = hemisphere_cos(u[:, 0], u[:, 1])
+    b1, b2 = _onb(nrm)
+    d = b1 * loc[:, 0:1] + b2 * loc[:, 1:2] + nrm * loc[:, 2:3]
+    return _pack(org, d.astype(np.float32))
+
+
+def shadow_rays(attrs: np.ndarray, lights: np.ndarray, seed: int, per_hit: int = 4) -> np.ndarray:
+    """per_hit shadow rays per hit record towards seeded point lights; tmax = dist*(1-1e-4)."""
+    attrs = fill_misses(attrs)
+    n = len(attrs)
+    nrm = _facing_normals(attrs)
+    org = np.repeat(calc_ray_origin(attrs["pos"], nrm), per_hit, axis=0)
+    pick = (splitmix64(seed, 0, n * per_hit) % np.uint64(len(lights))).astype(np.int64)
+    to = lights[pick].astype(np.float32) - org
+    dist = np.sqrt((to * to).sum(1, dtype=np.float32)).astype(np.float32)
+    d = (to / dist[:, None]).astype(np.float32)
+    return _pack(org, d, 0.0, (dist * np.float32(1.0 - 1e-4)).astype(np.float32))
