@@ -135,7 +135,9 @@ int vt_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_hit* hits);
 int vt_trace_any(vt_scene* s, const vt_ray* rays, uint64_t n, uint8_t* occluded);
 
 /* Device-pointer variants: d_rays/d_hits live on the scene's device; enqueued on
- * `stream` (a hipStream_t; NULL = the engine's own stream); no host sync. */
+ * `stream`, a hipStream_t with HIP's own meaning (NULL = the legacy default stream, so a
+ * caller that works on the default stream stays ordered); no host sync.
+ * vt_engine_stream() returns the engine's private non-blocking stream. */
 int vt_trace_closest_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* stream);
 int vt_trace_any_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_occluded, void* stream);
 /* Closest hit + per-ray counters (diagnostic kernel; same visitation order). */
@@ -151,6 +153,7 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
  * Results never depend on these, only speed does. */
 int vt_engine_set_option(vt_engine* e, const char* key, int64_t value);
 int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value);
+void* vt_engine_stream(vt_engine* e);
 /* Wait for everything enqueued on the engine's own stream. */
 int vt_engine_synchronize(vt_engine* e);
 

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/s1k_golden.npz.
+
+The reference has no golden vectors for this path and cannot be built here (SURVEY.md 0.2,
+0.4), so these vectors are produced by the CPU oracle (oracle/vt_oracle.c) after it has been
+cross-checked against the independent brute-force intersector on the same rays: hit t/u/v
+bit-identical, primitive index inside the min-t set.  They pin (a) the oracle against
+accidental change, (b) the host BVH builder's determinism, (c) the HIP path.
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import vistrace_amd as va  # noqa: E402
+from oracle import binding as O  # noqa: E402
+from vistrace_amd import workloads as W  # noqa: E402
+
+
+def main():
+    verts = W.make_scene("S1k")
+    tris = va.tris_setup(verts)
+    bvh = va.HostBvh(tris)
+    nodes, pidx = bvh.nodes(), bvh.prim_indices()
+    otris = O.tris_from_tri64(tris)
+
+    prim = W.primary_rays(64, 32)
+    sph = W.sphere_rays(1024, W.SEED + 11, origin=(300.0, -200.0, 100.0))
+    h0, _, _, _, _ = O.traverse_batch(nodes.view(O.NODE), pidx, otris, prim)
+    a0 = O.hit_attrs(otris, prim, h0)
+    attrs = np.zeros(len(a0), va.HIT_ATTRS)
+    for k in ("pos", "ngeo", "uvw", "wo", "front"):
+        attrs[k] = a0[k]
+    attrs["hit"] = h0["prim"] != O.MISS
+    bounce = W.bounce_rays(attrs[:1024], W.SEED + 12)
+    rays = np.concatenate([prim, sph, bounce])
+    # a few windowed rays (tmin/tmax inside the scene) to exercise the range tests
+    win = rays[2048:2304].copy()
+    win["tmin"], win["tmax"] = 400.0, 1100.0
+    rays = np.concatenate([rays, win])
+
+    hits, stats, _, _, _ = O.traverse_batch(nodes.view(O.NODE), pidx, otris, rays, want_stats=True)
+    brute = O.trace_brute(otris, rays)
+    assert (brute["t"].view(np.uint32) == hits["t"].view(np.uint32)).all()
+    ties = 0
+    for i in np.nonzero(brute["prim"] != hits["prim"])[0]:
+        _, ids, n = O.min_t_set(otris, rays[i:i + 1])
+        assert hits["prim"][i] in ids[:n]
+        ties += 1
+    any_hits, _, _, _, _ = O.traverse_batch(nodes.view(O.NODE), pidx, otris, rays, any_hit=True)
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "s1k_golden.npz")
+    np.savez_compressed(out, verts=verts, nodes=nodes, prim_indices=pidx, rays=rays, hits=hits, stats=stats,
+                        occluded=(any_hits["prim"] != O.MISS).astype(np.uint8))
+    print(f"wrote {out}: {len(rays)} rays, {int((hits['prim'] != O.MISS).sum())} hits, {ties} tie-broken indices, "
+          f"{os.path.getsize(out) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

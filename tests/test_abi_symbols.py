@@ -1,0 +1,50 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/vistrace_hip.h
+declares; POD sizes match the header; device entry points fail loudly without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vistrace_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(va):
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    lib = C.CDLL(va._lib.LIB_PATH)
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, f"declared in the header but not exported: {missing}"
+    assert set(va._lib.SYMBOLS) == set(syms), "python binding table and header disagree"
+
+
+def test_pod_sizes(va):
+    L = va._lib
+    assert (L.RAY.itemsize, L.HIT.itemsize, L.BVH_NODE.itemsize, L.NODE_PAIR.itemsize, L.TRI64.itemsize,
+            L.RAY_STATS.itemsize, L.HIT_ATTRS.itemsize) == (32, 16, 32, 64, 64, 8, 64)
+    assert L.lib.vt_abi_version() == 1
+
+
+def test_no_product_import_of_oracle():
+    """The shipped package must not import, load or link anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "vistrace_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "vt_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_device_calls_fail_loudly_without_gpu(va):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(va._lib.VisTraceError) as e:
+        va.Engine(0)
+    assert e.value.code == va._lib.VT_ERR_HIP

@@ -1,0 +1,290 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle.
+
+Bar (BASELINE.json north_star): primitive index bit-exact; t, u, v and Pos() within 1e-5
+relative -- these tests hold the stronger property that t, u, v are BIT-IDENTICAL (both
+sides evaluate the same unfused fp32 expression tree).  Counters (traversal steps and
+triangle tests per ray) must match the oracle exactly too: same visitation order.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FLT_MAX = np.finfo(np.float32).max
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "s1k_golden.npz")
+REL_TOL = 1e-5   # north_star tolerance for floating-point outputs derived on the device (Pos, normal)
+
+
+def assert_hits_equal(got, ref):
+    assert (got["prim"] == ref["prim"]).all(), f"{int((got['prim'] != ref['prim']).sum())} primitive indices differ"
+    for k in ("t", "u", "v"):
+        assert (got[k].view(np.uint32) == ref[k].view(np.uint32)).all(), f"{k} not bit-identical"
+
+
+def upload(va, engine, bundle):
+    return va.Scene(engine, bundle.host_scene)
+
+
+def stats_on_device(va, scene, rays):
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    dev = torch.device("cuda", 0)
+    d_rays = tp.to_device(rays, dev)
+    d_hits, d_stats = tp.trace_stats(scene, d_rays, len(rays))
+    torch.cuda.synchronize()
+    return tp.to_host(d_hits, va.HIT), tp.to_host(d_stats, va.RAY_STATS)
+
+
+# ---- golden vectors ----------------------------------------------------------------------------
+def test_golden_vectors(va, engine):
+    gold = np.load(GOLDEN)
+    tris = va.tris_setup(gold["verts"])
+    scene = va.Scene(engine, va.HostScene(va.HostBvh(tris)))
+    rays = gold["rays"].view(va.RAY)
+    assert_hits_equal(scene.trace_closest(rays), gold["hits"].view(va.HIT))
+    assert (scene.trace_any(rays) == gold["occluded"]).all()
+    _, st = stats_on_device(va, scene, rays)
+    assert (st["steps"] == gold["stats"][:, 0]).all() and (st["tests"] == gold["stats"][:, 1]).all()
+
+
+# ---- analytic known answers, on the device ---------------------------------------------------------
+TRI = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32)
+
+
+def one_ray(va, org, d, tmin=0.0, tmax=FLT_MAX):
+    return va.make_rays([org], [d], tmin, tmax)
+
+
+def test_single_triangle_kats(va, engine):
+    scene = va.build_scene(engine, TRI)                      # root is a leaf: no slab test at all
+    h = scene.trace_closest(one_ray(va, [0.25, 0.5, 1], [0, 0, -1]))
+    assert h["prim"][0] == 0 and h["t"][0] == 1.0 and h["u"][0] == 0.25 and h["v"][0] == 0.5
+    for x, y, hit in [(0, 0, 1), (1, 0, 1), (0, 1, 1), (0.5, 0.5, 1), (-0.001, 0.5, 0), (0.51, 0.51, 0)]:
+        assert (scene.trace_closest(one_ray(va, [x, y, 1], [0, 0, -1]))["prim"][0] != va._lib.VT_MISS) == bool(hit)
+    assert scene.trace_closest(one_ray(va, [0.2, 0.2, 0], [1, 0, 0]))["prim"][0] == va._lib.VT_MISS   # 0/0
+    for tmin, tmax, hit in [(0, 1.0, 1), (1.0, 2.0, 1), (0, 0.999, 0), (1.001, 5, 0)]:
+        h = scene.trace_closest(one_ray(va, [0.25, 0.25, 1], [0, 0, -1], tmin, tmax))
+        assert (h["prim"][0] != va._lib.VT_MISS) == bool(hit)
+    one_sided = va.build_scene(engine, TRI, np.array([1], np.uint8))
+    assert one_sided.trace_closest(one_ray(va, [0.2, 0.2, 1], [0, 0, -1]))["prim"][0] == va._lib.VT_MISS
+    assert one_sided.trace_closest(one_ray(va, [0.2, 0.2, -1], [0, 0, 1]))["prim"][0] == 0
+
+
+def test_coincident_triangles_tie_break(va, engine, O):
+    verts = np.concatenate([TRI] * 6)                        # six identical triangles: every t ties
+    b_tris = va.tris_setup(verts)
+    bvh = va.HostBvh(b_tris)
+    scene = va.Scene(engine, va.HostScene(bvh))
+    rays = one_ray(va, [0.25, 0.25, 1], [0, 0, -1])
+    ref, _, _, _, _ = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(b_tris), rays)
+    assert_hits_equal(scene.trace_closest(rays), ref)        # same later-visited-wins index as the oracle
+
+
+def test_empty_scene_and_empty_batch(va, engine):
+    scene = va.build_scene(engine, np.zeros((0, 3, 3), np.float32))
+    rays = va.make_rays([[0, 0, 0]] * 5, [[1, 0, 0]] * 5)
+    h = scene.trace_closest(rays)
+    assert (h["prim"] == va._lib.VT_MISS).all() and (h["t"] == 0).all()
+    assert (scene.trace_any(rays) == 0).all()
+    scene2 = va.build_scene(engine, TRI)
+    assert len(scene2.trace_closest(rays[:0])) == 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 257, 1000])
+def test_ragged_batch_sizes(va, engine, make_bundle, n):
+    from vistrace_amd import workloads as W
+    b = make_bundle("S1k")
+    scene = upload(va, engine, b)
+    rays = W.sphere_rays(n, 1000 + n, origin=(10.0, 20.0, 30.0))
+    assert_hits_equal(scene.trace_closest(rays), b.oracle(rays))
+
+
+# ---- seeded scenes -------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["S1k", "S10k"])
+def test_scene_parity_with_counters(va, engine, make_bundle, name):
+    from vistrace_amd import workloads as W
+    b = make_bundle(name)
+    scene = upload(va, engine, b)
+    prim = W.primary_rays(128, 64)
+    sph = W.sphere_rays(8192, 5, origin=(-300.0, 250.0, 40.0))
+    win = sph[:2048].copy(); win["tmin"], win["tmax"] = 350.0, 1200.0
+    rays = np.concatenate([prim, sph, win])
+    ref, ref_st = b.oracle(rays, want_stats=True)
+    assert_hits_equal(scene.trace_closest(rays), ref)
+    got, st = stats_on_device(va, scene, rays)
+    assert_hits_equal(got, ref)
+    assert (st["steps"] == ref_st[:, 0]).all() and (st["tests"] == ref_st[:, 1]).all()
+    occ = scene.trace_any(rays)
+    assert (occ == (ref["prim"] != O_MISS)).all()
+    any_ref = b.oracle(rays, any_hit=True)
+    assert (occ == (any_ref["prim"] != O_MISS)).all()
+
+
+O_MISS = 0xFFFFFFFF
+
+
+def test_single_ray_config1(va, engine, make_bundle, O):
+    """BASELINE config 1: S10k, single-ray calls, uniform sphere directions from the centre;
+    parity vs the brute-force intersector (t identical, index in the min-t set)."""
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    scene = upload(va, engine, b)
+    rays = W.sphere_rays(10000, W.SEED + 1)
+    single = np.concatenate([scene.trace_closest(rays[i:i + 1]) for i in range(64)])   # truly one ray per call
+    batch = scene.trace_closest(rays)
+    assert_hits_equal(single, batch[:64])
+    brute = O.trace_brute(b.otris, rays)
+    assert (batch["t"].view(np.uint32) == brute["t"].view(np.uint32)).all()
+    for i in np.nonzero(batch["prim"] != brute["prim"])[0]:
+        _, ids, n = O.min_t_set(b.otris, rays[i:i + 1])
+        assert batch["prim"][i] in ids[:n]
+
+
+def test_backface_cull_terrain(va, engine, make_bundle):
+    from vistrace_amd import workloads as W
+    b = make_bundle("terrain")
+    scene = upload(va, engine, b)
+    down = W.sphere_rays(4096, 21, origin=(0.0, 0.0, 60.0))      # from above and below the heightfield
+    up = W.sphere_rays(4096, 22, origin=(3.0, -4.0, -30.0))
+    rays = np.concatenate([down, up])
+    ref = b.oracle(rays)
+    got = scene.trace_closest(rays)
+    assert_hits_equal(got, ref)
+    n_down, n_up = int((got["prim"][:4096] != O_MISS).sum()), int((got["prim"][4096:] != O_MISS).sum())
+    assert n_down > 0 and n_up > 0 and n_down != n_up            # the cull bit really changes the answer
+
+
+def test_weird_rays(va, engine, make_bundle):
+    """Zero / negative-zero / tiny direction components (safe_inverse clamp), NaN and inf inputs,
+    NaN ranges: whatever the reference algorithm yields, the device yields the same."""
+    from vistrace_amd import workloads as W
+    b = make_bundle("S1k")
+    scene = upload(va, engine, b)
+    base = W.sphere_rays(512, 9, origin=(5.0, 6.0, 7.0))
+    rays = np.concatenate([base] * 8)
+    d = rays["dir"]
+    d[0:512, 0] = 0.0
+    d[512:1024, 1] = -0.0
+    d[1024:1536, 2] = 1e-9
+    d[1536:2048, :2] = 0.0                                       # axis-parallel
+    rays["tmin"][2048:2560] = np.nan
+    rays["tmax"][2560:3072] = np.nan
+    d[3072:3328, 0] = np.nan
+    d[3328:3584, 1] = np.inf
+    rays["org"][3584:3840, 2] = np.nan
+    rays["tmax"][3840:] = 1e-30                                  # nothing in range
+    ref, ref_st = b.oracle(rays, want_stats=True)
+    got, st = stats_on_device(va, scene, rays)
+    assert_hits_equal(got, ref)
+    assert_hits_equal(scene.trace_closest(rays), ref)
+    assert (st["steps"] == ref_st[:, 0]).all() and (st["tests"] == ref_st[:, 1]).all()
+
+
+def test_launch_options_do_not_change_results(va, make_bundle):
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    eng = va.Engine(0)
+    scene = va.Scene(eng, b.host_scene)
+    rays = np.concatenate([W.primary_rays(96, 96), W.sphere_rays(6000, 3, origin=(100.0, 100.0, -200.0))])
+    ref = b.oracle(rays)
+    configs = [dict(persistent=0), dict(persistent=1, fetch_dma=0), dict(persistent=1, fetch_dma=1, lds_entries=2),
+               dict(persistent=1, fetch_dma=1, lds_entries=64), dict(refill_threshold=1, tri_threshold=1, block_rays=64),
+               dict(refill_threshold=64, tri_threshold=64, block_rays=4096), dict(blocks_per_cu=1),
+               dict(fetch_dma=0, lds_entries=1, refill_threshold=3, tri_threshold=7)]
+    for cfg in configs:
+        for k, v in cfg.items():
+            eng.set_option(k, v)
+        assert_hits_equal(scene.trace_closest(rays), ref)
+        assert (scene.trace_any(rays) == (ref["prim"] != O_MISS)).all()
+
+
+def test_hit_attrs_vs_oracle(va, engine, make_bundle, O):
+    """TraceResult core (TraceResult.cpp:45-86, 255-262) on the device: Pos(), uvw, geometric
+    normal, wo within 1e-5 relative; frontFacing and indices exact."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    scene = upload(va, engine, b)
+    rays = np.concatenate([W.primary_rays(64, 64), W.sphere_rays(4096, 8, origin=(-50.0, 10.0, 300.0))])
+    rays["dir"][:100] *= 3.5                                     # un-normalised directions too
+    dev = torch.device("cuda", 0)
+    d_rays = tp.to_device(rays, dev)
+    d_hits = tp.trace_closest(scene, d_rays, len(rays))
+    attrs = tp.to_host(tp.hit_attrs(scene, d_rays, d_hits, len(rays)), va.HIT_ATTRS)
+    hits = tp.to_host(d_hits, va.HIT)
+    ref_hits = b.oracle(rays)
+    assert_hits_equal(hits, ref_hits)
+    ref = O.hit_attrs(b.otris, rays, ref_hits)
+    hit = ref_hits["prim"] != O_MISS
+    assert (attrs["hit"] == hit).all() and (attrs["prim"] == ref_hits["prim"])[hit].all()
+    assert (attrs["t"].view(np.uint32) == ref_hits["t"].view(np.uint32))[hit].all()
+    assert (attrs["front"] == ref["front"])[hit].all()
+    for k in ("pos", "uvw", "ngeo", "wo"):
+        err = np.abs(attrs[k][hit] - ref[k][hit])
+        scale = np.maximum(np.abs(ref[k][hit]).max(axis=1, keepdims=True), 1e-30)
+        assert (err / scale).max() <= REL_TOL, k
+
+
+# ---- BASELINE sizes ----------------------------------------------------------------------------------
+def test_config2_primary_1m_rays_s100k(va, engine, make_bundle):
+    """BASELINE config 2: 1024x1024 pinhole into the 100k-triangle scene, all 1 048 576 rays
+    against the oracle (the oracle finishes this in well under a second on the GPU host)."""
+    from vistrace_amd import workloads as W
+    b = make_bundle("S100k")
+    scene = upload(va, engine, b)
+    rays = W.primary_rays(1024, 1024)
+    assert_hits_equal(scene.trace_closest(rays), b.oracle(rays))
+
+
+def test_full_size_properties_s1m(va, engine, make_bundle):
+    """BASELINE config 3/4 sizes: 16 Mi incoherent rays into the 1M-triangle scene.  The oracle
+    covers a 1 Mi-ray slice; the whole batch is checked through size-independent properties:
+    determinism across launch modes, any-hit <=> closest-hit, t inside [tmin, tmax], the hit
+    point lies on the reported triangle's plane and inside it (barycentrics), misses are clean."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S1M")
+    scene = upload(va, engine, b)
+    dev = torch.device("cuda", 0)
+    side = 4096
+    n = side * side
+    prim = W.primary_rays(side, side)
+    d_prim = tp.to_device(prim, dev)
+    d_h0 = tp.trace_closest(scene, d_prim, n)
+    attrs = tp.to_host(tp.hit_attrs(scene, d_prim, d_h0, n), va.HIT_ATTRS)
+    rays = W.bounce_rays(attrs, W.SEED + 3)
+    del attrs, d_prim, d_h0
+    d_rays = tp.to_device(rays, dev)
+    hits = tp.to_host(tp.trace_closest(scene, d_rays, n), va.HIT)
+    # oracle slice
+    sl = slice(0, 1 << 20)
+    assert_hits_equal(hits[sl], b.oracle(rays[sl]))
+    # determinism across the other launch modes (static one-ray-per-lane kernel, direct fetch)
+    for cfg in (dict(persistent=0), dict(persistent=1, fetch_dma=0)):
+        for k, v in cfg.items():
+            engine.set_option(k, v)
+        again = tp.to_host(tp.trace_closest(scene, d_rays, n), va.HIT)
+        assert (again.view(np.uint8) == hits.view(np.uint8)).all()
+    engine.set_option("persistent", 1); engine.set_option("fetch_dma", 1)
+    # any-hit <=> closest-hit
+    occ = tp.trace_any(scene, d_rays, n).cpu().numpy()
+    hit = hits["prim"] != O_MISS
+    assert (occ == hit).all()
+    assert (hits["t"][~hit] == 0).all() and (hits["u"][~hit] == 0).all()
+    assert hit.mean() > 0.99                                      # closed room
+    h, r = hits[hit], rays[hit]
+    assert (h["t"] >= r["tmin"]).all() and (h["t"] <= r["tmax"]).all()
+    assert (h["u"] >= 0).all() and (h["v"] >= 0).all() and (h["u"] + h["v"] <= 1 + 1e-6).all()
+    assert h["prim"].max() < len(b.tris)
+    # org + t*dir reproduces the barycentric point on the triangle
+    T = b.tris[h["prim"]]
+    w = 1.0 - h["u"].astype(np.float64) - h["v"]
+    pos_tri = (w[:, None] * T["p0"] + h["u"][:, None] * (T["p0"].astype(np.float64) - T["e1"]) +
+               h["v"][:, None] * (T["p0"].astype(np.float64) + T["e2"]))
+    pos_ray = r["org"].astype(np.float64) + h["t"][:, None].astype(np.float64) * r["dir"]
+    err = np.abs(pos_tri - pos_ray).max(axis=1)
+    assert np.percentile(err, 99.9) < 0.05 and err.max() < 2.0    # Source units; fp32 t at ~1e3 scale

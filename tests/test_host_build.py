@@ -1,0 +1,120 @@
+"""Host side of Rebuild (CPU): BVH build (AccelStruct.cpp:763-770 equivalent) and the
+re-pack for the device.  Structural invariants + edge cases; no GPU needed."""
+import numpy as np
+import pytest
+
+
+def check_tree(va, tris, bvh):
+    nodes, pidx = bvh.nodes(), bvh.prim_indices()
+    n = len(tris)
+    if n == 0:
+        assert len(nodes) == 0 and len(pidx) == 0
+        return
+    assert sorted(pidx.tolist()) == list(range(n))            # every triangle exactly once
+    seen = np.zeros(len(nodes), bool)
+    seen[0] = True
+    leaves = 0
+    for i, nd in enumerate(nodes):
+        assert seen[i], "unreachable node"
+        b = nd["bounds"]
+        if nd["prim_count"] == 0:
+            l = int(nd["first"])
+            assert l > i and l % 2 == 1 and l + 1 < len(nodes)   # children adjacent, after the parent, left odd
+            for c in (nodes[l], nodes[l + 1]):
+                cb = c["bounds"]
+                assert (cb[0::2] >= b[0::2]).all() and (cb[1::2] <= b[1::2]).all()
+            seen[l] = seen[l + 1] = True
+        else:
+            leaves += 1
+            first, cnt = int(nd["first"]), int(nd["prim_count"])
+            for idx in pidx[first:first + cnt]:
+                t = tris[idx]
+                p = np.stack([t["p0"], t["p0"] - t["e1"], t["p0"] + t["e2"]])
+                assert (p.min(0) >= b[0::2]).all() and (p.max(0) <= b[1::2]).all()
+    assert len(nodes) == 2 * leaves - 1
+
+
+def check_linearised(hs, bvh, tris):
+    nodes, pidx = bvh.nodes(), bvh.prim_indices()
+    pairs, ltris = hs.pairs(), hs.tris()
+    assert len(ltris) == len(tris)
+    if len(nodes) == 0:
+        assert len(pairs) == 0 and hs.root_leaf_count == 0
+        return
+    if nodes[0]["prim_count"] != 0:
+        assert hs.root_leaf_count == nodes[0]["prim_count"] and len(pairs) == 0
+        assert ltris["prim"].tolist() == pidx.tolist()
+        return
+    assert len(pairs) == (len(nodes) - 1) // 2
+    # walk both trees together: same bounds, same leaf contents, depth-first numbering
+    order = []
+    stack = [(int(nodes[0]["first"]), 0, 1)]
+    max_depth = 0
+    while stack:
+        fc, pi, depth = stack.pop()
+        order.append(pi)
+        max_depth = max(max_depth, depth)
+        for side in (1, 0):
+            nd, ch = nodes[fc + side], pairs[pi]["child"][side]
+            assert (nd["bounds"] == ch["bounds"]).all() and nd["prim_count"] == ch["prim_count"]
+            if nd["prim_count"] == 0:
+                stack.append((int(nd["first"]), int(ch["first"]), depth + 1))
+            else:
+                f, c = int(nd["first"]), int(nd["prim_count"])
+                got = ltris["prim"][int(ch["first"]):int(ch["first"]) + c]
+                assert got.tolist() == pidx[f:f + c].tolist()
+    assert order == list(range(len(pairs)))                   # depth-first, left-first numbering
+    assert hs.max_depth == max_depth
+    # two leaf siblings are contiguous in the leaf-ordered triangle array (the kernel relies on it)
+    for p in pairs:
+        l, r = p["child"]
+        if l["prim_count"] and r["prim_count"]:
+            assert int(r["first"]) == int(l["first"]) + int(l["prim_count"])
+    src = tris[ltris["prim"]]
+    for k in ("p0", "e1", "e2", "n", "flags"):
+        assert (ltris[k] == src[k]).all()
+
+
+@pytest.mark.parametrize("name", ["S1k", "S10k"])
+def test_scene_trees(va, name):
+    from vistrace_amd import workloads as W
+    tris = va.tris_setup(W.make_scene(name))
+    bvh = va.HostBvh(tris)
+    check_tree(va, tris, bvh)
+    check_linearised(va.HostScene(bvh), bvh, tris)
+    counts = bvh.nodes()["prim_count"]
+    assert counts.max() <= 16 and (counts > 1).any()          # leaf collapse produced multi-triangle leaves
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 64, 257])
+def test_small_and_empty(va, n):
+    rng = np.random.default_rng(n)
+    verts = rng.uniform(-10, 10, (n, 3, 3)).astype(np.float32)
+    tris = va.tris_setup(verts)
+    bvh = va.HostBvh(tris)
+    check_tree(va, tris, bvh)
+    hs = va.HostScene(bvh)
+    check_linearised(hs, bvh, tris)
+    if n == 1:
+        assert hs.root_leaf_count == 1
+
+
+def test_degenerate_inputs(va):
+    # all triangles identical (same centroid/Morton code), and a flat scene (zero extent in z)
+    same = np.tile(np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32), (100, 1, 1))
+    for verts in (same, np.concatenate([same, same + np.array([3, 0, 0], np.float32)])):
+        tris = va.tris_setup(verts)
+        bvh = va.HostBvh(tris)
+        check_tree(va, tris, bvh)
+        check_linearised(va.HostScene(bvh), bvh, tris)
+
+
+def test_flags_travel_to_records(va):
+    from vistrace_amd import workloads as W
+    verts, flags = W.make_terrain(8)
+    flags = flags.copy(); flags[::3] = 0
+    tris = va.tris_setup(verts, flags)
+    assert (tris["flags"] == flags).all()
+    hs = va.HostScene(va.HostBvh(tris))
+    lt = hs.tris()
+    assert (lt["flags"] == flags[lt["prim"]]).all()

@@ -1,0 +1,63 @@
+"""Golden vectors (tests/golden/s1k_golden.npz, made by tests/golden/make_golden.py).
+
+CPU part: the oracle must reproduce the committed vectors on the committed tree, agree with
+the brute-force intersector, and the host BVH builder must rebuild the committed tree from
+the committed vertices (deterministic build).  The GPU part lives in test_gpu_parity.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "s1k_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLDEN)
+
+
+def test_oracle_reproduces_golden(O, gold):
+    tris = O.tris_setup(gold["verts"])
+    hits, stats, _, _, _ = O.traverse_batch(gold["nodes"].view(O.NODE), gold["prim_indices"], tris,
+                                            gold["rays"].view(O.RAY), want_stats=True)
+    g = gold["hits"].view(O.HIT)
+    assert (hits["prim"] == g["prim"]).all()
+    for k in ("t", "u", "v"):
+        assert (hits[k].view(np.uint32) == g[k].view(np.uint32)).all()
+    assert (stats == gold["stats"]).all()
+    occ, _, _, _, _ = O.traverse_batch(gold["nodes"].view(O.NODE), gold["prim_indices"], tris,
+                                       gold["rays"].view(O.RAY), any_hit=True)
+    assert ((occ["prim"] != O.MISS).astype(np.uint8) == gold["occluded"]).all()
+
+
+def test_golden_matches_brute_force(O, gold):
+    tris = O.tris_setup(gold["verts"])
+    rays = gold["rays"].view(O.RAY)
+    brute = O.trace_brute(tris, rays)
+    g = gold["hits"].view(O.HIT)
+    assert ((brute["prim"] == O.MISS) == (g["prim"] == O.MISS)).all()
+    assert (brute["t"].view(np.uint32) == g["t"].view(np.uint32)).all()
+    for i in np.nonzero(brute["prim"] != g["prim"])[0]:      # tie-broken index: must be in the min-t set
+        _, ids, n = O.min_t_set(tris, rays[i:i + 1])
+        assert g["prim"][i] in ids[:n]
+    # any-hit <=> closest-hit finds something in the same interval
+    assert ((g["prim"] != O.MISS).astype(np.uint8) == gold["occluded"]).all()
+    assert 0 < int((g["prim"][-256:] != O.MISS).sum()) < 256      # the windowed rays do both
+
+
+def test_builder_rebuilds_golden_tree(va, gold):
+    tris = va.tris_setup(gold["verts"])
+    bvh = va.HostBvh(tris)
+    assert (bvh.nodes().view(np.uint8) == gold["nodes"].view(np.uint8)).all()
+    assert (bvh.prim_indices() == gold["prim_indices"]).all()
+    bvh1 = va.HostBvh(tris, nthreads=1)                          # thread count must not change the tree
+    assert (bvh1.nodes().view(np.uint8) == gold["nodes"].view(np.uint8)).all()
+
+
+def test_product_tri_setup_matches_oracle(va, O, gold):
+    mine = va.tris_setup(gold["verts"])
+    ref = O.tris_setup(gold["verts"])
+    for k in ("p0", "e1", "e2", "n"):
+        assert (mine[k].view(np.uint32) == ref[k].view(np.uint32)).all()
+    assert (mine["prim"] == np.arange(len(mine))).all()

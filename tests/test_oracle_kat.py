@@ -1,0 +1,195 @@
+"""Known-answer tests that pin the CPU oracle (oracle/vt_oracle.c).
+
+The reference holds no tests or vectors for this path, so the oracle is
+pinned analytically: every expected value below is derived by hand from the arithmetic of
+source/objects/Primitives.h:168-215 (triangle test), SURVEY.md 3.2 (bvh v1 walk),
+source/VisTrace.cpp:1495-1517 (CalcRayOrigin) and source/libraries/BSDF.cpp:69-77.
+"""
+import numpy as np
+import pytest
+
+FLT_MAX = np.finfo(np.float32).max
+
+
+def ray(O, org, d, tmin=0.0, tmax=FLT_MAX):
+    r = np.zeros(1, O.RAY)
+    r["org"], r["dir"], r["tmin"], r["tmax"] = org, d, tmin, tmax
+    return r
+
+
+# triangle in the plane z = 0: p0=(0,0,0) p1=(1,0,0) p2=(0,1,0)
+# e1 = p0-p1 = (-1,0,0), e2 = p2-p0 = (0,1,0), n = cross(e1,e2) = (0*0-0*1, 0*0-(-1)*0, -1*1-0*0) = (0,0,-1)
+TRI = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32)
+
+
+def test_tri_setup_fields(O):
+    t = O.tris_setup(TRI)
+    assert t["p0"][0].tolist() == [0, 0, 0]
+    assert t["e1"][0].tolist() == [-1, 0, 0]
+    assert t["e2"][0].tolist() == [0, 1, 0]
+    assert t["n"][0].tolist() == [0, 0, -1]
+
+
+def test_centre_hit_and_barycentrics(O):
+    # ray from (0.25,0.5,1) along -z: nDotDir = 1, c = p0-org = (-.25,-.5,-1), r = cross(dir,c) = (-0.5,0.25,0)
+    # u = dot(r,e2) = 0.25 (weights vertex 1), v = dot(r,e1) = 0.5 (vertex 2), t = dot(n,c) = 1
+    t = O.tris_setup(TRI)
+    h = O.trace_brute(t, ray(O, [0.25, 0.5, 1], [0, 0, -1]))
+    assert h["prim"][0] == 0 and h["t"][0] == 1.0 and h["u"][0] == 0.25 and h["v"][0] == 0.5
+
+
+@pytest.mark.parametrize("x,y,hit", [
+    (0.0, 0.0, True), (1.0, 0.0, True), (0.0, 1.0, True),      # the three vertices (u,v,w == 0 accepted: >= 0)
+    (0.5, 0.0, True), (0.0, 0.5, True), (0.5, 0.5, True),      # edge midpoints
+    (-0.001, 0.5, False), (0.5, -0.001, False), (0.51, 0.51, False),
+])
+def test_edges_vertices_no_epsilon(O, x, y, hit):
+    t = O.tris_setup(TRI)
+    h = O.trace_brute(t, ray(O, [x, y, 1], [0, 0, -1]))
+    assert (h["prim"][0] != O.MISS) == hit
+
+
+def test_backface_cull_flag(O):
+    # from below (dir +z): nDotDir = dot((0,0,-1),(0,0,1)) = -1 -> not > 0 -> kept even when one-sided;
+    # from above (dir -z): nDotDir = +1 > 0 -> culled only with the flag (oneSided && !nocull)
+    two_sided = O.tris_setup(TRI)
+    one_sided = O.tris_setup(TRI, flags=[1])
+    above, below = ray(O, [0.2, 0.2, 1], [0, 0, -1]), ray(O, [0.2, 0.2, -1], [0, 0, 1])
+    assert O.trace_brute(two_sided, above)["prim"][0] == 0
+    assert O.trace_brute(two_sided, below)["prim"][0] == 0
+    assert O.trace_brute(one_sided, above)["prim"][0] == O.MISS
+    assert O.trace_brute(one_sided, below)["prim"][0] == 0
+
+
+def test_parallel_ray_is_nan_miss(O):
+    t = O.tris_setup(TRI)
+    assert O.trace_brute(t, ray(O, [0.2, 0.2, 0.0], [1, 0, 0]))["prim"][0] == O.MISS  # in-plane: 0/0
+    assert O.trace_brute(t, ray(O, [0.2, 0.2, 1.0], [1, 0, 0]))["prim"][0] == O.MISS  # parallel above: x/0
+
+
+@pytest.mark.parametrize("tmin,tmax,hit", [(0, 1.0, True), (1.0, 2.0, True), (0, 0.999, False), (1.001, 5, False)])
+def test_range_is_closed(O, tmin, tmax, hit):
+    t = O.tris_setup(TRI)
+    h = O.trace_brute(t, ray(O, [0.25, 0.25, 1], [0, 0, -1], tmin, tmax))
+    assert (h["prim"][0] != O.MISS) == hit
+
+
+def test_unnormalised_direction_scales_t(O):
+    t = O.tris_setup(TRI)
+    h = O.trace_brute(t, ray(O, [0.25, 0.25, 1], [0, 0, -4]))
+    assert h["t"][0] == 0.25
+
+
+def test_coincident_triangles_later_wins(O):
+    # two identical triangles: equal t; accept rule is t <= tmax, so the later-tested one replaces
+    verts = np.concatenate([TRI, TRI])
+    t = O.tris_setup(verts)
+    h = O.trace_brute(t, ray(O, [0.25, 0.25, 1], [0, 0, -1]))
+    assert h["prim"][0] == 1
+    tmin_hit, ids, n = O.min_t_set(t, ray(O, [0.25, 0.25, 1], [0, 0, -1]))
+    assert n == 2 and sorted(ids.tolist()) == [0, 1] and tmin_hit == 1.0
+    # any-hit stops at the first accepted one
+    assert O.trace_brute(t, ray(O, [0.25, 0.25, 1], [0, 0, -1]), any_hit=True)["prim"][0] == 0
+
+
+def _two_leaf_tree(O, verts):
+    """Hand-built v1 tree: root + two single-triangle leaves (left = tri 0, right = tri 1)."""
+    tris = O.tris_setup(verts)
+    nodes = np.zeros(3, O.NODE)
+
+    def bounds(v):
+        lo, hi = v.min(0), v.max(0)
+        return [lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]]
+    nodes["bounds"][0] = bounds(verts.reshape(-1, 3))
+    nodes["prim_count"][0], nodes["first"][0] = 0, 1
+    nodes["bounds"][1], nodes["prim_count"][1], nodes["first"][1] = bounds(verts[0]), 1, 0
+    nodes["bounds"][2], nodes["prim_count"][2], nodes["first"][2] = bounds(verts[1]), 1, 1
+    return nodes, np.array([0, 1], np.uint32), tris
+
+
+def test_traverse_two_leaves_order_and_counters(O):
+    # left leaf at z=0, right leaf at z=-1 (behind it along -z): both slabs pass with the
+    # initial tmax (both tested before either leaf), left is intersected first (t=1), the right
+    # leaf is still intersected (its slab test used the old tmax) but t=2 > tmax=1 is rejected.
+    far = TRI.copy(); far[:, :, 2] = -1
+    nodes, pidx, tris = _two_leaf_tree(O, np.concatenate([TRI, far]))
+    hits, st, steps, tests, _ = O.traverse_batch(nodes, pidx, tris, ray(O, [0.25, 0.25, 1], [0, 0, -1]), want_stats=True)
+    assert hits["prim"][0] == 0 and hits["t"][0] == 1.0
+    assert st[0].tolist() == [1, 2]          # one loop iteration, two triangle tests
+    # coincident leaves: equal t, the right (later visited) leaf wins the tie
+    nodes, pidx, tris = _two_leaf_tree(O, np.concatenate([TRI, TRI]))
+    hits, _, _, _, _ = O.traverse_batch(nodes, pidx, tris, ray(O, [0.25, 0.25, 1], [0, 0, -1]))
+    assert hits["prim"][0] == 1
+    hits, _, _, _, _ = O.traverse_batch(nodes, pidx, tris, ray(O, [0.25, 0.25, 1], [0, 0, -1]), any_hit=True)
+    assert hits["prim"][0] == 0
+
+
+def test_root_leaf_has_no_slab_test(O):
+    # a root that is a leaf is intersected directly: even a ray whose slab test would fail
+    # (origin outside, pointing away in x) reaches the triangle test; counters: 0 steps
+    tris = O.tris_setup(np.concatenate([TRI, TRI + 5]))
+    nodes = np.zeros(1, O.NODE)
+    nodes["bounds"][0] = [0, 1, 0, 1, 0, 0]      # deliberately too small for triangle 1
+    nodes["prim_count"][0], nodes["first"][0] = 2, 0
+    r = ray(O, [5.25, 5.25, 6], [0, 0, -1])
+    hits, st, _, _, _ = O.traverse_batch(nodes, np.array([0, 1], np.uint32), tris, r, want_stats=True)
+    assert hits["prim"][0] == 1 and hits["t"][0] == 1.0 and st[0].tolist() == [0, 2]
+
+
+def test_safe_inverse_axis_parallel_rays(O):
+    # dir components of exactly 0 / -0 are clamped to +-1/FLT_EPSILON, so axis-parallel rays walk a
+    # grid of boxes without inf*0 NaNs: ray along +x at y=z=0.25 through two triangles facing x
+    a = np.array([[[1, 0, 0], [1, 1, 0], [1, 0, 1]]], np.float32)
+    b = a.copy(); b[:, :, 0] = 2
+    nodes, pidx, tris = _two_leaf_tree(O, np.concatenate([a, b]))
+    for d in ([1, 0.0, 0.0], [1, -0.0, -0.0], [1, 1e-8, -1e-8]):
+        hits, _, _, _, _ = O.traverse_batch(nodes, pidx, tris, ray(O, [0, 0.25, 0.25], d))
+        assert hits["prim"][0] == 0 and abs(hits["t"][0] - 1.0) < 1e-6
+    # from the other side the far triangle (index 1) is the closest
+    hits, _, _, _, _ = O.traverse_batch(nodes, pidx, tris, ray(O, [3, 0.25, 0.25], [-1, 0.0, -0.0]))
+    assert hits["prim"][0] == 1 and hits["t"][0] == 1.0
+
+
+def test_nan_range_misses_after_one_step(O):
+    far = TRI.copy(); far[:, :, 2] = -1
+    nodes, pidx, tris = _two_leaf_tree(O, np.concatenate([TRI, far]))
+    for tmin, tmax in ((np.nan, FLT_MAX), (0.0, np.nan)):
+        hits, st, _, _, _ = O.traverse_batch(nodes, pidx, tris, ray(O, [0.25, 0.25, 1], [0, 0, -1], tmin, tmax), want_stats=True)
+        assert hits["prim"][0] == O.MISS and st[0].tolist() == [1, 0]
+
+
+def test_hit_attrs(O):
+    # TraceResult.cpp: uvw = (u, v, 1-u-v); pos = w*v0 + u*v1 + v*v2; v1 = p0 - e1, v2 = p0 + e2
+    t = O.tris_setup(TRI)
+    r = ray(O, [0.25, 0.5, 1], [0, 0, -2])
+    h = O.trace_brute(t, r)
+    a = O.hit_attrs(t, r, h)[0]
+    assert a["uvw"].tolist() == [0.25, 0.5, 0.25]
+    assert a["pos"].tolist() == [0.25, 0.5, 0.0]
+    assert a["ngeo"].tolist() == [0, 0, -1]            # n / |n|
+    assert a["wo"].tolist() == [0, 0, 1]               # -normalize(dir)
+    assert a["front"] == 0                             # dot(wo, ngeo) = -1 < 0
+
+
+def test_calc_ray_origin_kat(O):
+    # VisTrace.cpp:1495-1517. |pos| >= 1/32: integer offset iOff = int(n*256) on the float bits,
+    # sign flipped for negative pos; |pos| < 1/32: pos + n/65536.
+    pos = np.array([100.0, -100.0, 0.01], np.float32)
+    nrm = np.array([1.0, 1.0, -1.0], np.float32)
+    out = O.calc_ray_origin(pos, nrm)
+    bits = np.array([100.0, -100.0], np.float32).view(np.int32)
+    exp0 = np.array([bits[0] + 256], np.int32).view(np.float32)[0]
+    exp1 = np.array([bits[1] - 256], np.int32).view(np.float32)[0]   # pos<0: -iOff; moves towards +y (less negative)
+    assert out[0] == exp0 and out[1] == exp1
+    assert out[1] > -100.0 and out[0] > 100.0
+    assert out[2] == np.float32(0.01) + np.float32(-1.0) * np.float32(1 / 65536)
+
+
+def test_hemisphere_cos_kat(O):
+    # BSDF.cpp:69-77: z = sqrt(r1), sinTheta = sqrt(1-r1), phi = 2*pi*r2
+    assert O.hemisphere_cos(1.0, 0.0).tolist() == [0.0, 0.0, 1.0]
+    v = O.hemisphere_cos(0.0, 0.0)
+    assert v.tolist() == [1.0, 0.0, 0.0]
+    v = O.hemisphere_cos(0.25, 0.25)      # phi = pi/2
+    assert abs(v[0]) < 1e-7 and abs(v[1] - np.sqrt(np.float32(0.75))) < 1e-7 and v[2] == 0.5
+    assert abs(np.linalg.norm(O.hemisphere_cos(0.3, 0.7)) - 1.0) < 1e-6

@@ -74,6 +74,7 @@ SYMBOLS = {
     "vt_hit_attrs_dev": (C.c_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     "vt_engine_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "vt_engine_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
+    "vt_engine_stream": (_vp, [_vp]),
     "vt_engine_synchronize": (C.c_int, [_vp]),
     "vt_engine_set_timing": (C.c_int, [_vp, C.c_int]),
     "vt_engine_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),

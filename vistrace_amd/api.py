@@ -144,6 +144,11 @@ class Engine:
         check(lib.vt_engine_get_option(self._h, key.encode(), C.byref(v)))
         return v.value
 
+    @property
+    def stream(self) -> int:
+        """hipStream_t of the engine's private stream (host-buffer calls run there)."""
+        return int(lib.vt_engine_stream(self._h) or 0)
+
     def synchronize(self) -> None:
         check(lib.vt_engine_synchronize(self._h))
 

@@ -34,10 +34,12 @@ struct vt_engine {
 
     // launch configuration (vt_engine_set_option)
     int      persistent       = 1;
-    uint32_t lds_entries      = 16;   // stack entries per lane in LDS (rest spills to global)
+    uint32_t lds_entries      = 8;    // stack entries per lane in LDS (rest spills to global)
     uint32_t blocks_per_cu    = 8;    // persistent grid = cu_count * blocks_per_cu
-    uint32_t block_rays       = 1024; // consecutive rays handed to a wave at a time
-    uint32_t refill_threshold = 16;   // idle lanes that trigger a re-fill
+    uint32_t block_rays       = 64;   // consecutive rays handed to a wave at a time
+    uint32_t refill_threshold = 8;    // idle lanes that trigger a re-fill
+    uint32_t tri_threshold    = 4;    // lanes with pending triangles that trigger the TRI branch
+    int      fetch_dma        = 1;    // quad-cooperative global->LDS record fetch (persistent mode)
 
     // per-launch scratch
     uint32_t* d_cursor = nullptr;
@@ -59,8 +61,9 @@ struct vt_engine {
 
 struct vt_scene {
     vt_engine*    engine = nullptr;
-    vt_node_pair* d_pairs = nullptr;
-    vt_tri64*     d_tris = nullptr;
+    char*         d_records = nullptr; // pairs, then (128-B aligned) the leaf-ordered triangles
+    vt_tri64*     d_tris = nullptr;    // = d_records + tri_base * 64
+    uint32_t      tri_base = 0;
     uint32_t*     d_prim_to_slot = nullptr;
     uint32_t      npairs = 0, ntris = 0, max_depth = 0, root_leaf_count = 0;
     uint64_t      bytes = 0;
@@ -94,29 +97,35 @@ int ensure_bytes(void** ptr, size_t* have, size_t need)
 
 struct LaunchPlan {
     bool     persistent;
+    bool     fetch_dma;
     uint32_t grid_blocks;
     uint32_t lds_entries;
     size_t   lds_bytes;
     uint32_t ovf_entries;
 };
 
-int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, LaunchPlan& p)
+int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool stats, LaunchPlan& p)
 {
     // stack entries a ray can need = inner levels below the root pair
     const uint32_t need = s->max_depth;
     p.persistent = e->persistent != 0;
+    p.fetch_dma = p.persistent && e->fetch_dma != 0;
     const uint64_t blocks_for_rays = (n + kBlockThreads - 1) / kBlockThreads;
     if (p.persistent) {
-        p.grid_blocks = uint32_t(std::min<uint64_t>(uint64_t(e->cu_count) * e->blocks_per_cu, blocks_for_rays));
         p.lds_entries = std::min(std::max(e->lds_entries, 1u), std::max(need, 1u));
         p.ovf_entries = need > p.lds_entries ? need - p.lds_entries : 0;
+        // persistent grid = what is resident at once (registers/LDS decide), capped by the option
+        int occ = 0;
+        VT_HIP(trace_blocks_per_cu(any_hit, stats, true, p.fetch_dma, trace_lds_bytes(p.lds_entries, p.fetch_dma), &occ));
+        const uint32_t per_cu = std::max(1u, std::min(e->blocks_per_cu, uint32_t(std::max(occ, 1))));
+        p.grid_blocks = uint32_t(std::min<uint64_t>(uint64_t(e->cu_count) * per_cu, blocks_for_rays));
     } else {
         if (blocks_for_rays > 0x7FFFFFFFull) return fail(VT_ERR_INVALID_ARG, "too many rays for one launch");
         p.grid_blocks = uint32_t(blocks_for_rays);
         p.lds_entries = std::max(need, 1u); // whole stack in LDS, no overflow area
         p.ovf_entries = 0;
     }
-    p.lds_bytes = size_t(p.lds_entries) * 64 * sizeof(uint32_t) * (kBlockThreads / 64);
+    p.lds_bytes = trace_lds_bytes(p.lds_entries, p.fetch_dma);
     if (p.lds_bytes > e->lds_per_block_max)
         return fail(VT_ERR_STACK, "tree depth " + std::to_string(need) + " needs more LDS stack than one block can hold");
     return VT_OK;
@@ -128,7 +137,7 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     vt_engine* e = s->engine;
     if (n == 0) return VT_OK;
     LaunchPlan p;
-    int rc = plan_launch(e, s, n, p);
+    int rc = plan_launch(e, s, n, any_hit, stats, p);
     if (rc != VT_OK) return rc;
 
     const size_t ovf_words = size_t(p.ovf_entries) * p.grid_blocks * kBlockThreads;
@@ -142,8 +151,8 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     }
 
     TraceArgs a{};
-    a.pairs = s->d_pairs;
-    a.tris = s->d_tris;
+    a.records = s->d_records;
+    a.tri_base = s->tri_base;
     a.rays = static_cast<const vt_ray*>(d_rays);
     a.hits = static_cast<vt_hit*>(d_hits);
     a.occluded = static_cast<uint8_t*>(d_occ);
@@ -154,12 +163,20 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     a.npairs = s->npairs;
     a.root_leaf_count = s->root_leaf_count;
     a.lds_entries = p.lds_entries;
-    a.block_rays = std::max(64u, (e->block_rays / 64u) * 64u);
+    // rays handed to a wave at a time: the configured size, but never so large that the
+    // grid's waves cannot all get several blocks (small batches would leave waves idle)
+    {
+        const uint64_t waves = uint64_t(p.grid_blocks) * (kBlockThreads / 64);
+        uint64_t br = std::max<uint64_t>(64, (e->block_rays / 64u) * 64u);
+        const uint64_t fair = (n / (waves * 8) / 64) * 64;
+        a.block_rays = uint32_t(std::max<uint64_t>(64, std::min(br, std::max<uint64_t>(fair, 64))));
+    }
     a.refill_threshold = std::min(std::max(e->refill_threshold, 1u), 64u);
+    a.tri_threshold = std::min(std::max(e->tri_threshold, 1u), 64u);
 
     if (p.persistent) VT_HIP(hipMemsetAsync(e->d_cursor, 0, sizeof(uint32_t), stream));
     if (e->timing) VT_HIP(hipEventRecord(e->ev_start, stream));
-    VT_HIP(launch_trace(a, any_hit, stats, p.persistent, p.grid_blocks, p.lds_bytes, stream));
+    VT_HIP(launch_trace(a, any_hit, stats, p.persistent, p.fetch_dma, p.grid_blocks, p.lds_bytes, stream));
     if (e->timing) { VT_HIP(hipEventRecord(e->ev_stop, stream)); e->ev_valid = true; }
     e->last_blocks = p.grid_blocks; e->last_threads = kBlockThreads; e->last_lds = uint32_t(p.lds_bytes);
     return VT_OK;
@@ -206,6 +223,8 @@ int vt_engine_open(int device, vt_engine** out)
     e->blocks_per_cu = uint32_t(env_long("VT_BLOCKS_PER_CU", e->blocks_per_cu));
     e->block_rays = uint32_t(env_long("VT_BLOCK_RAYS", e->block_rays));
     e->refill_threshold = uint32_t(env_long("VT_REFILL_THRESHOLD", e->refill_threshold));
+    e->tri_threshold = uint32_t(env_long("VT_TRI_THRESHOLD", e->tri_threshold));
+    e->fetch_dma = int(env_long("VT_FETCH_DMA", e->fetch_dma));
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->d_cursor), 256);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_start);
@@ -242,6 +261,8 @@ int vt_engine_set_option(vt_engine* e, const char* key, int64_t value)
     else if (k == "blocks_per_cu" && value >= 1 && value <= 64) e->blocks_per_cu = uint32_t(value);
     else if (k == "block_rays" && value >= 64 && value <= (1 << 24)) e->block_rays = uint32_t(value);
     else if (k == "refill_threshold" && value >= 1 && value <= 64) e->refill_threshold = uint32_t(value);
+    else if (k == "tri_threshold" && value >= 1 && value <= 64) e->tri_threshold = uint32_t(value);
+    else if (k == "fetch_dma") e->fetch_dma = value != 0;
     else return fail(VT_ERR_INVALID_ARG, "vt_engine_set_option: unknown key or value out of range: " + k);
     return VT_OK;
 }
@@ -255,6 +276,8 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
     else if (k == "blocks_per_cu") *value = e->blocks_per_cu;
     else if (k == "block_rays") *value = e->block_rays;
     else if (k == "refill_threshold") *value = e->refill_threshold;
+    else if (k == "tri_threshold") *value = e->tri_threshold;
+    else if (k == "fetch_dma") *value = e->fetch_dma;
     else if (k == "cu_count") *value = e->cu_count;
     else if (k == "device") *value = e->device;
     else return fail(VT_ERR_INVALID_ARG, "vt_engine_get_option: unknown key: " + k);
@@ -286,17 +309,27 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
         prim_to_slot[hs.tris[i].prim] = uint32_t(i);
     }
 
-    auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
-        if (bytes == 0) return hipSuccess;
-        hipError_t err = hipMalloc(dst, bytes);
-        if (err != hipSuccess) return err;
-        s->bytes += bytes;
-        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-    };
-    hipError_t err = up(reinterpret_cast<void**>(&s->d_pairs), hs.pairs.data(), hs.pairs.size() * sizeof(vt_node_pair));
-    if (err == hipSuccess) err = up(reinterpret_cast<void**>(&s->d_tris), hs.tris.data(), hs.tris.size() * sizeof(vt_tri64));
-    if (err == hipSuccess)
-        err = up(reinterpret_cast<void**>(&s->d_prim_to_slot), prim_to_slot.data(), prim_to_slot.size() * sizeof(uint32_t));
+    // one array of 64-B records: pairs first, triangles behind them on a 128-B boundary
+    s->tri_base = (s->npairs + 1u) & ~1u;
+    const size_t pair_bytes = hs.pairs.size() * sizeof(vt_node_pair);
+    const size_t tri_off = size_t(s->tri_base) * 64, tri_bytes = hs.tris.size() * sizeof(vt_tri64);
+    const size_t rec_bytes = tri_off + tri_bytes;
+    if (uint64_t(s->tri_base) + s->ntris >= 0xFFFFFFFFull) { delete s; return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: scene too large"); }
+    hipError_t err = hipSuccess;
+    if (rec_bytes != 0) {
+        err = hipMalloc(reinterpret_cast<void**>(&s->d_records), rec_bytes);
+        if (err == hipSuccess) err = hipMemset(s->d_records, 0, rec_bytes);
+        if (err == hipSuccess && pair_bytes) err = hipMemcpy(s->d_records, hs.pairs.data(), pair_bytes, hipMemcpyHostToDevice);
+        if (err == hipSuccess && tri_bytes) err = hipMemcpy(s->d_records + tri_off, hs.tris.data(), tri_bytes, hipMemcpyHostToDevice);
+        s->d_tris = reinterpret_cast<vt_tri64*>(s->d_records + tri_off);
+        s->bytes += rec_bytes;
+    }
+    if (err == hipSuccess && !prim_to_slot.empty()) {
+        err = hipMalloc(reinterpret_cast<void**>(&s->d_prim_to_slot), prim_to_slot.size() * sizeof(uint32_t));
+        if (err == hipSuccess)
+            err = hipMemcpy(s->d_prim_to_slot, prim_to_slot.data(), prim_to_slot.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        s->bytes += prim_to_slot.size() * sizeof(uint32_t);
+    }
     if (err != hipSuccess) {
         vt_scene_free(s);
         return fail(VT_ERR_HIP, std::string("vt_scene_upload: ") + hipGetErrorString(err));
@@ -310,8 +343,7 @@ void vt_scene_free(vt_scene* s)
     if (!s) return;
     DeviceGuard guard(s->engine->device);
     (void)hipStreamSynchronize(s->engine->stream);
-    if (s->d_pairs) (void)hipFree(s->d_pairs);
-    if (s->d_tris) (void)hipFree(s->d_tris);
+    if (s->d_records) (void)hipFree(s->d_records);
     if (s->d_prim_to_slot) (void)hipFree(s->d_prim_to_slot);
     delete s;
 }
@@ -362,8 +394,7 @@ static int trace_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, 
     vt_engine* e = s->engine;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_trace_dev: hipSetDevice failed");
-    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : e->stream;
-    return launch(s, d_rays, n, d_hits, d_occ, d_stats, any_hit, stats, st);
+    return launch(s, d_rays, n, d_hits, d_occ, d_stats, any_hit, stats, static_cast<hipStream_t>(stream));
 }
 
 int vt_trace_closest_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* stream)
@@ -397,9 +428,11 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
     a.hits = static_cast<const vt_hit*>(d_hits);
     a.attrs = static_cast<vt_hit_attrs*>(d_attrs);
     a.n = n;
-    VT_HIP(launch_hit_attrs(a, stream ? static_cast<hipStream_t>(stream) : e->stream));
+    VT_HIP(launch_hit_attrs(a, static_cast<hipStream_t>(stream)));
     return VT_OK;
 }
+
+void* vt_engine_stream(vt_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
 
 int vt_engine_synchronize(vt_engine* e)
 {

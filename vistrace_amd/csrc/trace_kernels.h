@@ -12,8 +12,7 @@ namespace vt {
 constexpr uint32_t kBlockThreads = 256; // 4 waves of 64
 
 struct TraceArgs {
-    const vt_node_pair* pairs;
-    const vt_tri64*     tris;
+    const void*         records;     // 64-B records: pairs [0, npairs), triangles from tri_base on
     const vt_ray*       rays;
     vt_hit*             hits;        // closest-hit output (or nullptr for any-hit)
     uint8_t*            occluded;    // any-hit output
@@ -22,10 +21,12 @@ struct TraceArgs {
     uint32_t*           block_cursor;// persistent mode: next block of rays to hand out
     uint64_t            nrays;
     uint32_t            npairs;
+    uint32_t            tri_base;    // record index of triangle 0
     uint32_t            root_leaf_count;
     uint32_t            lds_entries; // stack entries per lane kept in LDS
     uint32_t            block_rays;  // rays per block handed to a wave (multiple of 64)
     uint32_t            refill_threshold; // re-fill a wave once this many lanes are idle
+    uint32_t            tri_threshold;    // run the TRI branch once this many lanes wait for it
 };
 
 struct HitAttrsArgs {
@@ -37,8 +38,10 @@ struct HitAttrsArgs {
     uint64_t        n;
 };
 
-hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, uint32_t grid_blocks,
-                        size_t lds_bytes, hipStream_t stream);
+size_t     trace_lds_bytes(uint32_t lds_entries, bool fetch_dma);
+hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, bool fetch_dma,
+                        uint32_t grid_blocks, size_t lds_bytes, hipStream_t stream);
+hipError_t trace_blocks_per_cu(bool any_hit, bool stats, bool persistent, bool fetch_dma, size_t lds_bytes, int* out);
 hipError_t launch_hit_attrs(const HitAttrsArgs& a, hipStream_t stream);
 
 } // namespace vt

@@ -7,15 +7,19 @@
 // order (the tie-broken primitive index depends on it) and with the same fp32 rounding
 // (no FMA contraction, IEEE divide).  What is MI355X-specific is everything around it:
 //
-//  * node pairs and triangles are 64-B records (vt_node_pair / vt_tri64), fetched as four
-//    16-B loads per lane from ONE address stream (a lane is either on a node or on a
-//    triangle, never both);
-//  * the walk is a two-state machine per lane (NODE step / TRI test) so that a wave never
-//    sits in one lane's leaf loop: leaves found by a node step become a pending
-//    [tri_cur, tri_end) range (the two leaf children of a pair are contiguous in the
-//    leaf-ordered triangle array) that is drained one triangle per iteration before the
-//    lane's next node step -- the order of slab tests and triangle tests per ray is
-//    unchanged;
+//  * node pairs and triangles are 64-B records in ONE device array (pairs first, then the
+//    leaf-ordered triangles), so a lane's next fetch is always "record r";
+//  * the walk is a two-state machine per lane (NODE step / TRI test): leaves found by a node
+//    step become a pending [tri_cur, tri_end) range (two leaf siblings are contiguous in the
+//    triangle array) that is drained before the lane's next node step -- the order of slab
+//    tests and triangle tests per ray is unchanged, but a wave never sits in one lane's leaf
+//    loop, and the TRI branch only runs once enough lanes are waiting for it;
+//  * DMA fetch (FETCH_DMA): the four lanes of a quad fetch each other's records together --
+//    for k = 0..3 all four lanes load the four 16-B pieces of quad-lane k's record with one
+//    `global_load_lds_dwordx4`, which lands as one contiguous 64-B line in a wave-private LDS
+//    staging row; every lane then reads its own record back with four ds_read_b128.  The
+//    vector L1 sees ONE 64-B request per record instead of four 16-B requests to four
+//    different lines per lane (the direct form was L1-request bound: profiles/r1);
 //  * the traversal stack lives in LDS as stack[entry][lane] (bank = lane, conflict-free),
 //    `lds_entries` deep, with a per-lane global overflow area for deeper trees;
 //  * persistent waves: a wave pulls blocks of consecutive rays from a global cursor and
@@ -34,7 +38,8 @@ namespace vt {
 
 namespace {
 
-constexpr uint32_t kDone = 0xFFFFFFFFu; // node cursor: nothing left to walk
+constexpr uint32_t kDone    = 0xFFFFFFFFu; // node cursor: nothing left to walk
+constexpr uint32_t kNoFetch = 0xFFFFFFFFu; // record cursor: lane fetches nothing this round
 
 __device__ __forceinline__ uint32_t lane_id()
 {
@@ -47,13 +52,33 @@ __device__ __forceinline__ uint32_t prefix_count(uint64_t mask)
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
 
-// bvh v1 utilities: safe_inverse / robust_min / robust_max
+// value of quad-lane K (0..3) broadcast to the four lanes of every quad (DPP quad_perm)
+template <int K>
+__device__ __forceinline__ uint32_t quad_broadcast(uint32_t v)
+{
+    return uint32_t(__builtin_amdgcn_mov_dpp(int(v), K * 0x55, 0xF, 0xF, true));
+}
+
+// bvh v1 safe_inverse
 __device__ __forceinline__ float safe_inverse(float x)
 {
     return fabsf(x) <= FLT_EPSILON ? copysignf(1.0f / FLT_EPSILON, x) : 1.0f / x;
 }
-__device__ __forceinline__ float robust_max(float a, float b) { return a > b ? a : b; }
-__device__ __forceinline__ float robust_min(float a, float b) { return a < b ? a : b; }
+
+// bvh v1 robust_max(a,b) = a > b ? a : b and robust_min(a,b) = a < b ? a : b, nested as
+//   first  = rmax(e0, rmax(e1, rmax(e2, tmin)))   second = rmin(x0, rmin(x1, rmin(x2, tmax))).
+// With tmin/tmax not NaN (guarded at ray start) every nested call has a non-NaN second
+// operand, for which rmax(a,b) == maxnum(a,b) and rmin(a,b) == minnum(a,b) up to the sign of
+// a zero result (a NaN first operand yields b in both).  Zero signs never change the
+// comparisons first <= second / first_l > first_r, so v_max3/v_min3 give the same decisions.
+__device__ __forceinline__ float slab_first(float e0, float e1, float e2, float tmin)
+{
+    return fmaxf(e0, fmaxf(e1, fmaxf(e2, tmin)));
+}
+__device__ __forceinline__ float slab_second(float x0, float x1, float x2, float tmax)
+{
+    return fminf(x0, fminf(x1, fminf(x2, tmax)));
+}
 
 struct Lane {
     // ray (bvh::Ray, Primitives.h:11-33); tmax shrinks as hits are found
@@ -70,21 +95,30 @@ struct Lane {
     uint32_t steps, tests;
 };
 
+typedef __attribute__((address_space(1))) const void* global_cptr;
+typedef __attribute__((address_space(3))) void*       lds_ptr;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t kStageRow   = 1024 + 16;      // one staging row: 16 quads x 64 B, +16 B so that
+constexpr uint32_t kStageBytes = 4 * kStageRow;  // the four rows start on different banks
+
 } // namespace
 
-template <bool ANY_HIT, bool STATS, bool PERSISTENT>
+template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA>
 __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
 {
-    extern __shared__ uint32_t lds_stack[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
-    uint32_t* const st_lds = lds_stack + size_t(wave) * a.lds_entries * 64 + lane; // entry k at [k*64]
+    uint32_t* const st_lds = lds_dyn + size_t(wave) * a.lds_entries * 64 + lane; // entry k at [k*64]
     const uint32_t gthread = blockIdx.x * kBlockThreads + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlockThreads;
-    uint32_t* const st_ovf = a.overflow + gthread;                                  // entry k at [k*gstride]
+    uint32_t* const st_ovf = a.overflow + gthread;                               // entry k at [k*gstride]
+    // wave-private staging rows behind the stacks of the block's four waves (DMA fetch only)
+    char* const stage = reinterpret_cast<char*>(lds_dyn) + size_t(kBlockThreads / 64) * a.lds_entries * 256 +
+                        size_t(wave) * kStageBytes;
 
-    const float4* const pairs4 = reinterpret_cast<const float4*>(a.pairs);
-    const float4* const tris4  = reinterpret_cast<const float4*>(a.tris);
+    const char* const records = reinterpret_cast<const char*>(a.records);
 
     Lane L;
     uint64_t ray_idx = 0;
@@ -107,6 +141,13 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
             L.node = kDone; L.tri_cur = 0; L.tri_end = a.root_leaf_count;
         } else {
             L.node = a.npairs != 0 ? 0u : kDone; L.tri_cur = 0; L.tri_end = 0;
+        }
+        // A NaN tmin or tmax makes every slab test and every triangle range test of the
+        // reference false: the ray misses after one step (or after testing a leaf root).
+        if (L.tmin != L.tmin || L.tmax != L.tmax) {
+            L.steps = (a.root_leaf_count == 0 && a.npairs != 0) ? 1u : 0u;
+            L.tests = a.root_leaf_count;
+            L.node = kDone; L.tri_cur = 0; L.tri_end = 0;
         }
         ray_idx = idx;
         has_ray = true;
@@ -131,6 +172,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
     if constexpr (!PERSISTENT) {
         const uint64_t idx = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
         if (idx < a.nrays) start_ray(idx);
+        if (has_ray && L.node == kDone && L.tri_cur >= L.tri_end) finish_ray();
     }
 
     for (;;) {
@@ -150,7 +192,10 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                     if (!exhausted) {
                         const uint64_t avail = blk_end - blk_cur;
                         const uint32_t mine = prefix_count(idle);
-                        if (!has_ray && mine < avail) start_ray(blk_cur + mine);
+                        if (!has_ray && mine < avail) {
+                            start_ray(blk_cur + mine);
+                            if (L.node == kDone && L.tri_cur >= L.tri_end) finish_ray(); // empty scene / NaN range
+                        }
                         blk_cur += nidle < avail ? nidle : avail;
                     }
                 }
@@ -160,92 +205,137 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
             if (__ballot(has_ray) == 0) break;
         }
 
-        if (has_ray) {
-            if (L.tri_cur < L.tri_end) {
-                // ---- TRI: TriangleBackfaceCull::intersect, Primitives.h:168-215 ----------
-                const float4* t4 = tris4 + size_t(L.tri_cur) * 4;
-                const float4 q0 = t4[0], q1 = t4[1], q2 = t4[2], q3 = t4[3];
-                ++L.tri_cur;
-                if constexpr (STATS) ++L.tests;
-                const float p0x = q0.x, p0y = q0.y, p0z = q0.z;
-                const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
-                const float e2x = q1.z, e2y = q1.w, e2z = q2.x;
-                const float nx = q2.y, ny = q2.z, nz = q2.w;
-                const uint32_t tprim = __float_as_uint(q3.x), tflags = __float_as_uint(q3.y);
+        // ---- which record does this lane need? ----------------------------------------------
+        const bool want_tri  = has_ray && L.tri_cur < L.tri_end;
+        const bool want_node = has_ray && !want_tri;       // node != kDone is implied (else finished)
+        // the TRI branch runs only when enough lanes wait for it, or nobody can step a node
+        const uint64_t tri_mask = __ballot(want_tri);
+        const bool run_tri = tri_mask != 0 && (uint32_t(__popcll(tri_mask)) >= a.tri_threshold || __ballot(want_node) == 0);
+        const bool do_tri = want_tri && run_tri;
+        const uint32_t rec = do_tri ? a.tri_base + L.tri_cur : (want_node ? L.node : kNoFetch);
 
-                const float nDotDir = (nx * L.dx + ny * L.dy) + nz * L.dz;                 // :173
-                const bool culled = (tflags & VT_TRI_CULL_BACKFACE) && nDotDir > 0.0f;     // :174
-                const float cx = p0x - L.ox, cy = p0y - L.oy, cz = p0z - L.oz;             // :176
-                const float rx = L.dy * cz - L.dz * cy;                                    // :177
-                const float ry = L.dz * cx - L.dx * cz;
-                const float rz = L.dx * cy - L.dy * cx;
-                const float inv_det = 1.0f / nDotDir;                                      // :178
-                const float u = ((rx * e2x + ry * e2y) + rz * e2z) * inv_det;              // :180
-                const float v = ((rx * e1x + ry * e1y) + rz * e1z) * inv_det;              // :181
-                const float w = 1.0f - u - v;                                              // :182
-                const float t = ((nx * cx + ny * cy) + nz * cz) * inv_det;                 // :188
-                if (!culled && u >= 0.0f && v >= 0.0f && w >= 0.0f &&                      // :187
-                    t >= L.tmin && t <= L.tmax) {                                          // :189
-                    L.prim = tprim; L.u = u; L.v = v; L.tmax = t;
-                    if constexpr (ANY_HIT) { L.tri_cur = L.tri_end; L.node = kDone; }
-                }
-            } else {
-                // ---- NODE: one iteration of SingleRayTraverser::traverse ---------------
-                const float4* p4 = pairs4 + size_t(L.node) * 4;
-                const float4 n0 = p4[0], n1 = p4[1], n2 = p4[2], n3 = p4[3];
-                if constexpr (STATS) ++L.steps;
-                const bool ox = __float_as_uint(L.dx) >> 31, oy = __float_as_uint(L.dy) >> 31,
-                           oz = __float_as_uint(L.dz) >> 31; // octant = signbit(dir)
-                // left child: bounds {n0.x n0.y | n0.z n0.w | n1.x n1.y}, count n1.z, first n1.w
-                float e0 = (ox ? n0.y : n0.x) * L.ix + L.sx, x0 = (ox ? n0.x : n0.y) * L.ix + L.sx;
-                float e1 = (oy ? n0.w : n0.z) * L.iy + L.sy, x1 = (oy ? n0.z : n0.w) * L.iy + L.sy;
-                float e2 = (oz ? n1.y : n1.x) * L.iz + L.sz, x2 = (oz ? n1.x : n1.y) * L.iz + L.sz;
-                const float fl = robust_max(e0, robust_max(e1, robust_max(e2, L.tmin)));
-                const float sl = robust_min(x0, robust_min(x1, robust_min(x2, L.tmax)));
-                // right child: bounds {n2.x n2.y | n2.z n2.w | n3.x n3.y}, count n3.z, first n3.w
-                e0 = (ox ? n2.y : n2.x) * L.ix + L.sx; x0 = (ox ? n2.x : n2.y) * L.ix + L.sx;
-                e1 = (oy ? n2.w : n2.z) * L.iy + L.sy; x1 = (oy ? n2.z : n2.w) * L.iy + L.sy;
-                e2 = (oz ? n3.y : n3.x) * L.iz + L.sz; x2 = (oz ? n3.x : n3.y) * L.iz + L.sz;
-                const float fr = robust_max(e0, robust_max(e1, robust_max(e2, L.tmin)));
-                const float sr = robust_min(x0, robust_min(x1, robust_min(x2, L.tmax)));
-
-                const uint32_t lcount = __float_as_uint(n1.z), lfirst = __float_as_uint(n1.w);
-                const uint32_t rcount = __float_as_uint(n3.z), rfirst = __float_as_uint(n3.w);
-                const bool hit_l = fl <= sl, hit_r = fr <= sr;
-                const bool leaf_l = lcount != 0, leaf_r = rcount != 0;
-
-                // leaves that were hit become the pending triangle range, left before right;
-                // two leaf siblings are contiguous in the leaf-ordered triangle array
-                uint32_t tc = 0, te = 0;
-                if (hit_l && leaf_l) { tc = lfirst; te = lfirst + lcount; }
-                if (hit_r && leaf_r) { if (te == 0) tc = rfirst; te = rfirst + rcount; }
-                L.tri_cur = tc; L.tri_end = te;
-
-                const bool go_l = hit_l && !leaf_l, go_r = hit_r && !leaf_r;
-                uint32_t next;
-                if (go_l && go_r) {
-                    // near child first (ties keep left first); push the far child's pair
-                    const bool swap = fl > fr;
-                    next = swap ? rfirst : lfirst;
-                    const uint32_t far = swap ? lfirst : rfirst;
-                    if (L.sp < a.lds_entries) st_lds[L.sp * 64] = far;
-                    else st_ovf[size_t(L.sp - a.lds_entries) * gstride] = far;
-                    ++L.sp;
-                } else if (go_l) {
-                    next = lfirst;
-                } else if (go_r) {
-                    next = rfirst;
-                } else if (L.sp != 0) {
-                    --L.sp;
-                    next = L.sp < a.lds_entries ? st_lds[L.sp * 64]
-                                                : st_ovf[size_t(L.sp - a.lds_entries) * gstride];
-                } else {
-                    next = kDone;
-                }
-                L.node = next;
+        float4 q0, q1, q2, q3;
+        if constexpr (FETCH_DMA) {
+            // quad-cooperative fetch through LDS: row k holds the records of every quad's lane k
+            const uint32_t piece = (lane & 3u) * 16u;
+            const uint32_t r0 = quad_broadcast<0>(rec), r1 = quad_broadcast<1>(rec),
+                           r2 = quad_broadcast<2>(rec), r3 = quad_broadcast<3>(rec);
+            if (r0 != kNoFetch)
+                __builtin_amdgcn_global_load_lds((global_cptr)(records + size_t(r0) * 64 + piece),
+                                                 (lds_ptr)(stage + 0 * kStageRow), 16, 0, 0);
+            if (r1 != kNoFetch)
+                __builtin_amdgcn_global_load_lds((global_cptr)(records + size_t(r1) * 64 + piece),
+                                                 (lds_ptr)(stage + 1 * kStageRow), 16, 0, 0);
+            if (r2 != kNoFetch)
+                __builtin_amdgcn_global_load_lds((global_cptr)(records + size_t(r2) * 64 + piece),
+                                                 (lds_ptr)(stage + 2 * kStageRow), 16, 0, 0);
+            if (r3 != kNoFetch)
+                __builtin_amdgcn_global_load_lds((global_cptr)(records + size_t(r3) * 64 + piece),
+                                                 (lds_ptr)(stage + 3 * kStageRow), 16, 0, 0);
+            // Wait for the DMA rows (vmcnt) and read this lane's 64-B record back.  One asm
+            // statement holds the four ds_read_b128 and their wait, so hipcc can neither split
+            // the reads nor consume a destination early (cdna_hip_programming.md 5.7 item 1).
+            const uint32_t my_rec = uint32_t(uintptr_t((lds_ptr)(stage + (lane & 3u) * kStageRow + (lane >> 2) * 64u)));
+            f32x4 v0, v1, v2, v3;
+            asm volatile("s_waitcnt vmcnt(0)\n\t"
+                         "ds_read_b128 %0, %4\n\t"
+                         "ds_read_b128 %1, %4 offset:16\n\t"
+                         "ds_read_b128 %2, %4 offset:32\n\t"
+                         "ds_read_b128 %3, %4 offset:48\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                         : "v"(my_rec)
+                         : "memory");
+            q0 = make_float4(v0.x, v0.y, v0.z, v0.w); q1 = make_float4(v1.x, v1.y, v1.z, v1.w);
+            q2 = make_float4(v2.x, v2.y, v2.z, v2.w); q3 = make_float4(v3.x, v3.y, v3.z, v3.w);
+        } else {
+            if (rec != kNoFetch) {
+                const float4* g = reinterpret_cast<const float4*>(records + size_t(rec) * 64);
+                q0 = g[0]; q1 = g[1]; q2 = g[2]; q3 = g[3];
             }
-            if (L.node == kDone && L.tri_cur >= L.tri_end) finish_ray();
         }
+
+        if (do_tri) {
+            // ---- TRI: TriangleBackfaceCull::intersect, Primitives.h:168-215 --------------
+            ++L.tri_cur;
+            if constexpr (STATS) ++L.tests;
+            const float p0x = q0.x, p0y = q0.y, p0z = q0.z;
+            const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
+            const float e2x = q1.z, e2y = q1.w, e2z = q2.x;
+            const float nx = q2.y, ny = q2.z, nz = q2.w;
+            const uint32_t tprim = __float_as_uint(q3.x), tflags = __float_as_uint(q3.y);
+
+            const float nDotDir = (nx * L.dx + ny * L.dy) + nz * L.dz;                 // :173
+            const bool culled = (tflags & VT_TRI_CULL_BACKFACE) && nDotDir > 0.0f;     // :174
+            const float cx = p0x - L.ox, cy = p0y - L.oy, cz = p0z - L.oz;             // :176
+            const float rx = L.dy * cz - L.dz * cy;                                    // :177
+            const float ry = L.dz * cx - L.dx * cz;
+            const float rz = L.dx * cy - L.dy * cx;
+            const float inv_det = 1.0f / nDotDir;                                      // :178
+            const float u = ((rx * e2x + ry * e2y) + rz * e2z) * inv_det;              // :180
+            const float v = ((rx * e1x + ry * e1y) + rz * e1z) * inv_det;              // :181
+            const float w = 1.0f - u - v;                                              // :182
+            const float t = ((nx * cx + ny * cy) + nz * cz) * inv_det;                 // :188
+            if (!culled && u >= 0.0f && v >= 0.0f && w >= 0.0f &&                      // :187
+                t >= L.tmin && t <= L.tmax) {                                          // :189
+                L.prim = tprim; L.u = u; L.v = v; L.tmax = t;
+                if constexpr (ANY_HIT) { L.tri_cur = L.tri_end; L.node = kDone; }
+            }
+        } else if (want_node) {
+            // ---- NODE: one iteration of SingleRayTraverser::traverse -------------------
+            const float4 n0 = q0, n1 = q1, n2 = q2, n3 = q3;
+            if constexpr (STATS) ++L.steps;
+            const bool ox = __float_as_uint(L.dx) >> 31, oy = __float_as_uint(L.dy) >> 31,
+                       oz = __float_as_uint(L.dz) >> 31; // octant = signbit(dir)
+            // left child: bounds {n0.x n0.y | n0.z n0.w | n1.x n1.y}, count n1.z, first n1.w
+            float e0 = (ox ? n0.y : n0.x) * L.ix + L.sx, x0 = (ox ? n0.x : n0.y) * L.ix + L.sx;
+            float e1 = (oy ? n0.w : n0.z) * L.iy + L.sy, x1 = (oy ? n0.z : n0.w) * L.iy + L.sy;
+            float e2 = (oz ? n1.y : n1.x) * L.iz + L.sz, x2 = (oz ? n1.x : n1.y) * L.iz + L.sz;
+            const float fl = slab_first(e0, e1, e2, L.tmin);
+            const float sl = slab_second(x0, x1, x2, L.tmax);
+            // right child: bounds {n2.x n2.y | n2.z n2.w | n3.x n3.y}, count n3.z, first n3.w
+            e0 = (ox ? n2.y : n2.x) * L.ix + L.sx; x0 = (ox ? n2.x : n2.y) * L.ix + L.sx;
+            e1 = (oy ? n2.w : n2.z) * L.iy + L.sy; x1 = (oy ? n2.z : n2.w) * L.iy + L.sy;
+            e2 = (oz ? n3.y : n3.x) * L.iz + L.sz; x2 = (oz ? n3.x : n3.y) * L.iz + L.sz;
+            const float fr = slab_first(e0, e1, e2, L.tmin);
+            const float sr = slab_second(x0, x1, x2, L.tmax);
+
+            const uint32_t lcount = __float_as_uint(n1.z), lfirst = __float_as_uint(n1.w);
+            const uint32_t rcount = __float_as_uint(n3.z), rfirst = __float_as_uint(n3.w);
+            const bool hit_l = fl <= sl, hit_r = fr <= sr;
+            const bool leaf_l = lcount != 0, leaf_r = rcount != 0;
+
+            // leaves that were hit become the pending triangle range, left before right;
+            // two leaf siblings are contiguous in the leaf-ordered triangle array
+            uint32_t tc = 0, te = 0;
+            if (hit_l && leaf_l) { tc = lfirst; te = lfirst + lcount; }
+            if (hit_r && leaf_r) { if (te == 0) tc = rfirst; te = rfirst + rcount; }
+            L.tri_cur = tc; L.tri_end = te;
+
+            const bool go_l = hit_l && !leaf_l, go_r = hit_r && !leaf_r;
+            uint32_t next;
+            if (go_l && go_r) {
+                // near child first (ties keep left first); push the far child's pair
+                const bool swap = fl > fr;
+                next = swap ? rfirst : lfirst;
+                const uint32_t far = swap ? lfirst : rfirst;
+                if (L.sp < a.lds_entries) st_lds[L.sp * 64] = far;
+                else st_ovf[size_t(L.sp - a.lds_entries) * gstride] = far;
+                ++L.sp;
+            } else if (go_l) {
+                next = lfirst;
+            } else if (go_r) {
+                next = rfirst;
+            } else if (L.sp != 0) {
+                --L.sp;
+                next = L.sp < a.lds_entries ? st_lds[L.sp * 64]
+                                            : st_ovf[size_t(L.sp - a.lds_entries) * gstride];
+            } else {
+                next = kDone;
+            }
+            L.node = next;
+        }
+        if (has_ray && L.node == kDone && L.tri_cur >= L.tri_end) finish_ray();
     }
 }
 
@@ -282,25 +372,62 @@ __global__ __launch_bounds__(kBlockThreads) void hit_attrs_kernel(HitAttrsArgs a
 }
 
 // ---- launchers ---------------------------------------------------------------------------
-template <bool ANY_HIT, bool STATS, bool PERSISTENT>
+template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA>
 static hipError_t launch_one(const TraceArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((trace_kernel<ANY_HIT, STATS, PERSISTENT>), grid, dim3(kBlockThreads), lds_bytes, stream, a);
+    hipLaunchKernelGGL((trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA>), grid, dim3(kBlockThreads), lds_bytes,
+                       stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, uint32_t grid_blocks,
-                        size_t lds_bytes, hipStream_t stream)
+size_t trace_lds_bytes(uint32_t lds_entries, bool fetch_dma)
 {
-    const dim3 grid(grid_blocks);
-    if (persistent) {
-        if (any_hit) return launch_one<true, false, true>(a, grid, lds_bytes, stream);
-        if (stats)   return launch_one<false, true, true>(a, grid, lds_bytes, stream);
-        return launch_one<false, false, true>(a, grid, lds_bytes, stream);
+    size_t b = size_t(lds_entries) * 64 * sizeof(uint32_t) * (kBlockThreads / 64);
+    if (fetch_dma) b += size_t(kStageBytes) * (kBlockThreads / 64);
+    return b;
+}
+
+namespace {
+
+// one entry per compiled variant: launch it, or ask how many blocks fit on a CU
+template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA>
+hipError_t variant_op(const TraceArgs* a, dim3 grid, size_t lds_bytes, hipStream_t stream, int* blocks_per_cu)
+{
+    if (blocks_per_cu)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            blocks_per_cu, trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA>, int(kBlockThreads), lds_bytes);
+    return launch_one<ANY_HIT, STATS, PERSISTENT, FETCH_DMA>(*a, grid, lds_bytes, stream);
+}
+
+hipError_t dispatch(const TraceArgs* a, bool any_hit, bool stats, bool persistent, bool fetch_dma, dim3 grid,
+                    size_t lds_bytes, hipStream_t stream, int* occ)
+{
+    if (persistent && fetch_dma) {
+        if (any_hit) return variant_op<true, false, true, true>(a, grid, lds_bytes, stream, occ);
+        if (stats)   return variant_op<false, true, true, true>(a, grid, lds_bytes, stream, occ);
+        return variant_op<false, false, true, true>(a, grid, lds_bytes, stream, occ);
     }
-    if (any_hit) return launch_one<true, false, false>(a, grid, lds_bytes, stream);
-    if (stats)   return launch_one<false, true, false>(a, grid, lds_bytes, stream);
-    return launch_one<false, false, false>(a, grid, lds_bytes, stream);
+    if (persistent) {
+        if (any_hit) return variant_op<true, false, true, false>(a, grid, lds_bytes, stream, occ);
+        if (stats)   return variant_op<false, true, true, false>(a, grid, lds_bytes, stream, occ);
+        return variant_op<false, false, true, false>(a, grid, lds_bytes, stream, occ);
+    }
+    if (any_hit) return variant_op<true, false, false, false>(a, grid, lds_bytes, stream, occ);
+    if (stats)   return variant_op<false, true, false, false>(a, grid, lds_bytes, stream, occ);
+    return variant_op<false, false, false, false>(a, grid, lds_bytes, stream, occ);
+}
+
+} // namespace
+
+hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, bool fetch_dma,
+                        uint32_t grid_blocks, size_t lds_bytes, hipStream_t stream)
+{
+    return dispatch(&a, any_hit, stats, persistent, fetch_dma, dim3(grid_blocks), lds_bytes, stream, nullptr);
+}
+
+hipError_t trace_blocks_per_cu(bool any_hit, bool stats, bool persistent, bool fetch_dma, size_t lds_bytes, int* out)
+{
+    return dispatch(nullptr, any_hit, stats, persistent, fetch_dma, dim3(1), lds_bytes, nullptr, out);
 }
 
 hipError_t launch_hit_attrs(const HitAttrsArgs& a, hipStream_t stream)
