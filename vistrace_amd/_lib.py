@@ -89,7 +89,31 @@ class VisTraceError(RuntimeError):
         self.msg = msg
 
 
+def _preload_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1 with the
+    same sonames as /opt/rocm's.  Whichever copy is mapped first serves the whole process,
+    and torch does not initialise on the system copy ("No HIP GPUs are available").  If torch
+    is installed, map ITS runtime first (without importing torch) so that the order in which
+    callers import torch and vistrace_amd does not matter."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def _load() -> C.CDLL:
+    _preload_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
