@@ -1,0 +1,284 @@
+// test_binding.cpp -- drives the Tracing API thunks (vistrace.CreateAccel, AccelStruct:Rebuild,
+// :Traverse, :TraverseBatch, TraceResult getters) through a fake Lua state and checks argument
+// defaults, validation messages (source/objects/AccelStruct.cpp:780-806), return counts and
+// the hit-record getters.  `--cpu` runs the part that needs no GPU.
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+
+#include "AccelStruct.h"
+#include "Binding.h"
+#include "FakeLua.h"
+#include "TraceResult.h"
+
+using namespace vistrace;
+using fakelua::LuaError;
+using fakelua::State;
+namespace LT = GarrysMod::Lua::Type;
+
+static int g_fail = 0, g_run = 0;
+#define CHECK(cond)                                                                      \
+    do {                                                                                 \
+        ++g_run;                                                                         \
+        if (!(cond)) { ++g_fail; std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); } \
+    } while (0)
+
+static std::string error_of(const std::function<void()>& f, int* arg = nullptr)
+{
+    try { f(); } catch (const LuaError& e) { if (arg) *arg = e.arg; return e.what(); }
+    return "";
+}
+static bool contains(const std::string& s, const char* sub) { return s.find(sub) != std::string::npos; }
+
+// floor triangle pair at z = 0 (one-sided world brush), entity quad at z = 5 (two-sided)
+static Triangle make_tri(Vec3 a, Vec3 b, Vec3 c, bool oneSided, size_t material)
+{
+    Triangle t;
+    t.p0 = a; t.p1 = b; t.p2 = c;
+    t.oneSided = oneSided;
+    t.material = material;
+    t.uvs[0] = Vec2{0, 0}; t.uvs[1] = Vec2{1, 0}; t.uvs[2] = Vec2{0, 1};
+    t.alphas[0] = 0.f; t.alphas[1] = 1.f; t.alphas[2] = 0.5f;
+    return t;
+}
+
+struct FakeMeshSource : IEntityMeshSource {
+    int calls = 0;
+    bool AppendEntity(void* ud, Entity& ent, std::vector<Triangle>& tris, std::vector<Material>& mats) override
+    {
+        ++calls;
+        ent.rawEntity = ud;
+        ent.id = 42;
+        mats.push_back(Material{"models/fake", MATFLAG_NONE});
+        tris.push_back(make_tri({0, 0, 5}, {4, 0, 5}, {0, 4, 5}, false, 0));
+        return true;
+    }
+};
+
+static void test_cpu_side()
+{
+    State L;
+    RegisterTracingApi(&L);
+    CHECK(AccelStruct_id >= LT::Count && TraceResult::id >= LT::Count && AccelStruct_id != TraceResult::id);
+    CHECK(L.Top() == 0);
+
+    // Traverse on an accel that was never built -> the reference's message (AccelStruct.cpp:780)
+    {
+        AccelStruct* a = new AccelStruct();
+        L.PushUserType(a, AccelStruct_id);
+        L.PushValue(State::Vec(0, 0, 1));
+        L.PushValue(State::Vec(0, 0, -1));
+        std::string e = error_of([&] { AccelStruct_Traverse(&L); });
+        CHECK(e == "Unable to perform traversal, acceleration structure invalid (use AccelStruct:Rebuild to rebuild it)");
+        L.Pop(L.Top());
+        L.PushUserType(a, AccelStruct_id);
+        CHECK(AccelStruct_gc(&L) == 0);
+        L.Pop(L.Top());
+    }
+    // wrong self type
+    {
+        L.PushNumber(3);
+        std::string e = error_of([&] { AccelStruct_Traverse(&L); });
+        CHECK(contains(e, "AccelStruct expected"));
+        L.Pop(L.Top());
+    }
+    // CreateAccel: first argument must be a table (or nil / nothing)
+    {
+        L.PushNumber(1);
+        std::string e = error_of([&] { vistrace_CreateAccel(&L); });
+        CHECK(contains(e, "table expected"));
+        L.Pop(L.Top());
+    }
+    // CreateAccel: "Build list must only contain entities" (AccelStruct.cpp:575), before any device work
+    {
+        L.PushValue(State::Array({State::Num(7)}));
+        L.PushBool(false);
+        std::string e = error_of([&] { vistrace_CreateAccel(&L); });
+        CHECK(e == "Build list must only contain entities");
+        L.Pop(L.Top());
+    }
+    {
+        CHECK(AccelStruct_tostring(&L) == 1);
+        CHECK(L.stack.back().str == "AccelStruct");
+        L.Pop(L.Top());
+    }
+    // TraceResult hit-record math (TraceResult.cpp:45-86, 255-262) on a hand-checked case
+    {
+        Triangle t = make_tri({0, 0, 0}, {1, 0, 0}, {0, 1, 0}, false, 3);
+        Entity ent; ent.id = 9;
+        TraceResult r(Vec3{0, 0, -2}, 1.0f, -1, -1, t, 5, Vec2{0.25f, 0.5f}, ent);
+        CHECK(r.uvw.x == 0.25f && r.uvw.y == 0.5f && r.uvw.z == 0.25f);
+        CHECK(r.GetPos().x == 0.25f && r.GetPos().y == 0.5f && r.GetPos().z == 0.0f);
+        CHECK(r.geometricNormal.x == 0 && r.geometricNormal.y == 0 && r.geometricNormal.z == -1);   // cross(e1,e2)/|n|
+        CHECK(r.wo.z == 1.0f && r.frontFacing == false);
+        CHECK(r.texUV.x == 0.25f && r.texUV.y == 0.5f);           // w*uv0 + u*uv1 + v*uv2
+        CHECK(r.blendFactor == 0.25f * 0.f + 0.25f * 1.f + 0.5f * 0.5f);
+        CHECK(r.entIdx == 9 && r.submatIdx == 3 && r.distance == 1.0f && r.primitiveIndex == 5);
+    }
+}
+
+static int call_traverse(State& L, AccelStruct* a, std::vector<fakelua::Value> args)
+{
+    L.Pop(L.Top());
+    L.PushUserType(a, AccelStruct_id);
+    for (auto& v : args) L.PushValue(v);
+    return AccelStruct_Traverse(&L);
+}
+
+static void test_gpu_side()
+{
+    State L;
+    RegisterTracingApi(&L);
+    FakeMeshSource src;
+    AccelStruct::SetEntityMeshSource(&src);
+
+    World world;
+    world.materials.push_back(Material{"brush/floor", MATFLAG_NONE});
+    world.materials.push_back(Material{"brush/nocull", MATFLAG_NOCULL});
+    world.entities.push_back(Entity{nullptr, 0});
+    // one-sided floor: n = cross(e1,e2) with e1=p0-p1, e2=p2-p0 -> (0,0,-1); rays going -z have nDotDir > 0 => culled
+    world.triangles.push_back(make_tri({0, 0, 0}, {10, 0, 0}, {0, 10, 0}, true, 0));
+    // same winding, nocull material, shifted in x: never culled
+    world.triangles.push_back(make_tri({20, 0, 0}, {30, 0, 0}, {20, 10, 0}, true, 1));
+    SetWorld(&world);
+
+    // vistrace.CreateAccel({ent}, true)
+    int dummyEntity = 0;
+    L.PushValue(State::Array({State::User(&dummyEntity, LT::Entity)}));
+    L.PushBool(true);
+    CHECK(vistrace_CreateAccel(&L) == 1);
+    CHECK(L.Top() >= 1 && L.GetType(-1) == AccelStruct_id);
+    AccelStruct* accel = L.GetUserType<AccelStruct>(-1, AccelStruct_id);
+    CHECK(accel && accel->IsBuilt() && accel->TriangleCount() == 3 && src.calls == 1);
+    CHECK(accel->GetMaterial(1).flags == MATFLAG_NOCULL);
+
+    // defaults: tMin 0, tMax FLT_MAX, cones -1: hit the entity quad from above
+    CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1)}) == 1);
+    CHECK(L.Top() == 1 && L.GetType(1) == TraceResult::id);
+    {
+        TraceResult* r = L.GetUserType<TraceResult>(1, TraceResult::id);
+        CHECK(r->distance == 3.0f && r->entIdx == 42 && r->primitiveIndex == 2);
+        CHECK(TraceResult_Pos(&L) == 1);
+        ::Vector p = L.GetVector(-1);
+        CHECK(p.x == 1.f && p.y == 1.f && p.z == 5.f);
+        L.Pop();
+        CHECK(TraceResult_Distance(&L) == 1 && L.GetNumber(-1) == 3.0); L.Pop();
+        CHECK(TraceResult_Barycentric(&L) == 1);
+        ::Vector b = L.GetVector(-1);
+        CHECK(b.x == 0.25f && b.y == 0.25f && b.z == 0.5f);
+        L.Pop();
+        CHECK(TraceResult_EntIndex(&L) == 1 && L.GetNumber(-1) == 42); L.Pop();
+        CHECK(TraceResult_GeometricNormal(&L) == 1 && L.GetVector(-1).z == -1.f); L.Pop();
+        CHECK(TraceResult_FrontFacing(&L) == 1 && L.GetBool(-1) == false); L.Pop();
+        CHECK(TraceResult_SubMaterialIndex(&L) == 1 && L.GetNumber(-1) == 3); L.Pop();   // 2 world mats + 0, 1-based
+        CHECK(TraceResult_Incident(&L) == 1 && L.GetVector(-1).z == 1.f); L.Pop();
+        CHECK(TraceResult_TextureUV(&L) == 1); L.Pop();
+        CHECK(TraceResult_gc(&L) == 0);
+        CHECK(L.GetUserType<TraceResult>(1, TraceResult::id) == nullptr);
+    }
+    // un-normalised direction: t scales, Incident is normalised
+    CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -2)}) == 1);
+    { TraceResult* r = L.GetUserType<TraceResult>(1, TraceResult::id); CHECK(r->distance == 1.5f && r->wo.z == 1.f); delete r; }
+    // miss -> 0 results (Lua sees nil), stack cleared
+    CHECK(call_traverse(L, accel, {State::Vec(100, 100, 8), State::Vec(0, 0, 1)}) == 0);
+    CHECK(L.Top() == 0);
+    // one-sided floor seen from above (nDotDir > 0) is culled -> the ray passes the floor and misses;
+    // from below it hits; the nocull-material floor is hit from both sides
+    CHECK(call_traverse(L, accel, {State::Vec(3, 3, 3), State::Vec(0, 0, -1)}) == 0);
+    CHECK(call_traverse(L, accel, {State::Vec(3, 3, -3), State::Vec(0, 0, 1)}) == 1);
+    delete L.GetUserType<TraceResult>(1, TraceResult::id);
+    CHECK(call_traverse(L, accel, {State::Vec(22, 2, 3), State::Vec(0, 0, -1)}) == 1);
+    delete L.GetUserType<TraceResult>(1, TraceResult::id);
+    // tMin / tMax window and nil placeholders
+    CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1), State::Num(0), State::Num(2.5)}) == 0);
+    CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1), State::Nil(), State::Num(3.0)}) == 1);
+    delete L.GetUserType<TraceResult>(1, TraceResult::id);
+    CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1), State::Num(3.5), State::Nil()}) == 0);
+
+    // validation messages and argument numbers (AccelStruct.cpp:802-806)
+    int arg = 0;
+    std::string e = error_of([&] { call_traverse(L, accel, {State::Vec(0, 0, 1), State::Vec(0, 0, -1), State::Num(-1)}); }, &arg);
+    CHECK(contains(e, "tMin cannot be less than 0") && arg == 4);
+    e = error_of([&] { call_traverse(L, accel, {State::Vec(0, 0, 1), State::Vec(0, 0, -1), State::Num(2), State::Num(2)}); }, &arg);
+    CHECK(contains(e, "tMax must be greater than tMin") && arg == 5);
+    e = error_of([&] { call_traverse(L, accel, {State::Vec(0, 0, 1), State::Vec(0, 0, -1), State::Nil(), State::Nil(), State::Num(1), State::Num(0)}); });
+    CHECK(e == "Valid cone width but invalid cone angle passed");
+    e = error_of([&] { call_traverse(L, accel, {State::Vec(0, 0, 1), State::Vec(0, 0, -1), State::Nil(), State::Nil(), State::Num(-1), State::Num(0.1)}); });
+    CHECK(e == "Valid cone angle but invalid cone width passed");
+    e = error_of([&] { call_traverse(L, accel, {State::Num(1), State::Vec(0, 0, -1)}); }, &arg);
+    CHECK(contains(e, "Vector expected") && arg == 2);
+    e = error_of([&] { call_traverse(L, accel, {State::Vec(0, 0, 1), State::Vec(0, 0, -1), State::Str("x")}); }, &arg);
+    CHECK(contains(e, "number expected") && arg == 4);
+
+    // TraverseBatch agrees with Traverse ray by ray
+    {
+        L.Pop(L.Top());
+        L.PushUserType(accel, AccelStruct_id);
+        L.PushValue(State::Array({
+            State::Array({State::Vec(1, 1, 8), State::Vec(0, 0, -1)}),
+            State::Array({State::Vec(100, 100, 8), State::Vec(0, 0, 1)}),
+            State::Array({State::Vec(3, 3, -3), State::Vec(0, 0, 1), State::Num(0), State::Num(10)}),
+            State::Array({State::Vec(3, 3, -3), State::Vec(0, 0, 1), State::Num(0), State::Num(2)}),
+        }));
+        CHECK(AccelStruct_TraverseBatch(&L) == 1);
+        CHECK(L.Top() == 1 && L.GetType(1) == LT::Table);
+        auto& kv = L.stack.back().tab->kv;
+        CHECK(kv.size() == 4);
+        CHECK(kv[0].second.type == TraceResult::id && kv[1].second.type == LT::Bool && kv[2].second.type == TraceResult::id &&
+              kv[3].second.type == LT::Bool);
+        TraceResult* r0 = static_cast<TraceResult*>(*kv[0].second.ud);
+        TraceResult* r2 = static_cast<TraceResult*>(*kv[2].second.ud);
+        CHECK(r0->distance == 3.0f && r0->entIdx == 42 && r2->distance == 3.0f && r2->primitiveIndex == 0);
+        delete r0; delete r2;
+        L.Pop(L.Top());
+    }
+
+    // Rebuild(nil, false): no world, no entities -> empty but valid accel, every trace misses
+    {
+        L.Pop(L.Top());
+        L.PushUserType(accel, AccelStruct_id);
+        L.PushNil();
+        L.PushBool(false);
+        CHECK(AccelStruct_Rebuild(&L) == 0);
+        CHECK(accel->IsBuilt() && accel->TriangleCount() == 0);
+        CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1)}) == 0);
+        // Rebuild({ent}) with the world again
+        L.Pop(L.Top());
+        L.PushUserType(accel, AccelStruct_id);
+        L.PushValue(State::Array({State::User(&dummyEntity, LT::Entity), State::User(&dummyEntity, LT::Entity)}));
+        CHECK(AccelStruct_Rebuild(&L) == 0);
+        CHECK(accel->TriangleCount() == 4 && src.calls == 3);
+        CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1)}) == 1);
+        delete L.GetUserType<TraceResult>(1, TraceResult::id);
+    }
+    // alpha-tested material: not supported on the device yet -> loud error at build, accel left invalid
+    {
+        world.materials.push_back(Material{"brush/fence", MATFLAG_ALPHATEST});
+        world.triangles.push_back(make_tri({40, 0, 0}, {50, 0, 0}, {40, 10, 0}, false, 2));
+        L.Pop(L.Top());
+        L.PushUserType(accel, AccelStruct_id);
+        std::string err = error_of([&] { AccelStruct_Rebuild(&L); });
+        CHECK(contains(err, "alpha-tested"));
+        CHECK(!accel->IsBuilt());
+        err = error_of([&] { call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1)}); });
+        CHECK(contains(err, "acceleration structure invalid"));
+        world.triangles.pop_back();
+    }
+    L.Pop(L.Top());
+    L.PushUserType(accel, AccelStruct_id);
+    CHECK(AccelStruct_gc(&L) == 0);
+    SetWorld(nullptr);
+    AccelStruct::SetEntityMeshSource(nullptr);
+}
+
+int main(int argc, char** argv)
+{
+    const bool cpu_only = argc > 1 && std::strcmp(argv[1], "--cpu") == 0;
+    test_cpu_side();
+    if (!cpu_only) test_gpu_side();
+    std::printf("%s: %d checks, %d failed\n", cpu_only ? "binding (cpu)" : "binding (cpu+gpu)", g_run, g_fail);
+    return g_fail ? 1 : 0;
+}

@@ -1,0 +1,30 @@
+"""Runs tests/cpp/test_binding (fake Lua state driving the Tracing API thunks of
+vistrace_amd/csrc/host).  CPU part: error messages, type checks, TraceResult math.
+GPU part: CreateAccel / Rebuild / Traverse / TraverseBatch / getters end to end."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "_build", "test_binding")
+
+
+def _build():
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+
+
+def test_binding_cpu_side():
+    _build()
+    out = subprocess.run([EXE, "--cpu"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 failed" in out.stdout
+
+
+@pytest.mark.gpu
+def test_binding_end_to_end():
+    _build()
+    out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 failed" in out.stdout

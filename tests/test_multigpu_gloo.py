@@ -1,0 +1,64 @@
+"""world_size-2 CPU test (gloo) of the multi-GPU layer: contiguous ray shards, one gather of
+hit records to the root.  The per-rank tracer here is the CPU oracle (test infrastructure);
+on GPUs the same helpers run over RCCL with the HIP tracer (bench.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_cover_exactly():
+    from vistrace_amd.distributed import shard_bounds, shard_capacity
+    for n in (0, 1, 7, 64, 1000, 1 << 20):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(hi - lo for lo, hi in spans) <= shard_capacity(n, world)
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+def _worker(rank, world, port, n, result_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import vistrace_amd as va
+        from oracle import binding as O
+        from vistrace_amd import workloads as W
+        from vistrace_amd.distributed import trace_sharded
+        tris = va.tris_setup(W.make_scene("S1k"))           # every rank builds its own replica
+        bvh = va.HostBvh(tris)
+        nodes, pidx, otris = bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris)
+        rays = W.sphere_rays(n, 99, origin=(1.0, 2.0, 3.0))
+        rays_t = torch.from_numpy(rays.view(np.uint8).reshape(-1).copy())
+
+        def trace_fn(shard, count):
+            r = shard.numpy().view(O.RAY)
+            assert len(r) == count
+            hits, _, _, _, _ = O.traverse_batch(nodes, pidx, otris, r, nthreads=1)
+            return torch.from_numpy(hits.view(np.uint8).reshape(-1).copy())
+
+        got = trace_sharded(trace_fn, rays_t, n)
+        if rank == 0:
+            full, _, _, _, _ = O.traverse_batch(nodes, pidx, otris, rays, nthreads=1)
+            ok = got is not None and got.numpy().tobytes() == full.tobytes()
+            open(result_path, "w").write("ok" if ok else "mismatch")
+        else:
+            assert got is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1001, 4096])
+def test_two_rank_shard_and_gather(tmp_path, n):
+    result = tmp_path / "result.txt"
+    port = 29500 + (os.getpid() + n) % 2000
+    mp.spawn(_worker, args=(2, port, n, str(result)), nprocs=2, join=True)
+    assert result.read_text() == "ok"

@@ -1,0 +1,229 @@
+// AccelStruct.cpp -- see AccelStruct.h.  Follows source/objects/AccelStruct.cpp:533-838 for
+// argument handling, defaults, error messages and result selection; the BVH build/traverse
+// calls at :763-773 and :818 go through the C ABI (CPU build -> linearise -> upload; GPU trace).
+#include "AccelStruct.h"
+
+#include <cfloat>
+#include <cstring>
+#include <string>
+
+#include "TraceResult.h"
+
+using namespace GarrysMod::Lua;
+
+namespace vistrace {
+
+namespace {
+
+IEntityMeshSource* g_meshSource = nullptr;
+vt_engine* g_engine = nullptr;
+
+// one engine per process, opened on first use (device from VISTRACE_DEVICE, default 0)
+vt_engine* Engine(ILuaBase* LUA)
+{
+    if (!g_engine) {
+        int dev = 0;
+        if (const char* e = std::getenv("VISTRACE_DEVICE")) dev = std::atoi(e);
+        if (vt_engine_open(dev, &g_engine) != VT_OK) {
+            g_engine = nullptr;
+            std::string msg = std::string("VisTrace: cannot open the HIP device: ") + vt_last_error();
+            LUA->ThrowError(msg.c_str());
+        }
+    }
+    return g_engine;
+}
+
+} // namespace
+
+void AccelStruct::SetEntityMeshSource(IEntityMeshSource* src) { g_meshSource = src; }
+
+AccelStruct::AccelStruct() : mAccelBuilt(false), mpScene(nullptr) {}
+
+AccelStruct::~AccelStruct() { ReleaseDevice(); }                       // AccelStruct.cpp:525-531
+
+void AccelStruct::ReleaseDevice()
+{
+    if (mpScene) vt_scene_free(mpScene);
+    mpScene = nullptr;
+}
+
+void AccelStruct::PopulateAccel(ILuaBase* LUA, const World* pWorld)
+{
+    // tear down the previous build (AccelStruct.cpp:537-550)
+    mAccelBuilt = false;
+    ReleaseDevice();
+    mTriangles.clear();
+    mEntities.clear();
+    mMaterials.clear();
+
+    if (pWorld) {                                                       // :552-555
+        mTriangles = pWorld->triangles;
+        mEntities = pWorld->entities;
+        mMaterials = pWorld->materials;
+    }
+
+    // iterate the entity table on top of the stack (:567-758)
+    LUA->PushNil();
+    while (LUA->Next(-2) != 0) {
+        if (!LUA->IsType(-1, Type::Entity)) LUA->ThrowError("Build list must only contain entities");   // :575
+        if (g_meshSource) {
+            Entity ent;
+            std::vector<Triangle> tris;
+            std::vector<Material> mats;
+            void* ud = LUA->GetUserdataRaw(-1, Type::Entity);
+            if (g_meshSource->AppendEntity(ud, ent, tris, mats)) {
+                if (mEntities.size() >= 65535) LUA->ThrowError("Too many entities in build list");       // uint16_t entIdx
+                const size_t matBase = mMaterials.size();
+                const uint16_t entIdx = uint16_t(mEntities.size());
+                for (Triangle& t : tris) { t.material += matBase; t.entIdx = entIdx; }
+                mMaterials.insert(mMaterials.end(), mats.begin(), mats.end());
+                mTriangles.insert(mTriangles.end(), tris.begin(), tris.end());
+                mEntities.push_back(ent);
+            }
+        }
+        LUA->Pop();                                                     // pop value, keep key
+    }
+    LUA->Pop();                                                         // pop entity table (:760)
+
+    // Build BVH (:762-775): CPU PLOC + leaf collapse, re-pack, upload once per Rebuild
+    const uint32_t n = uint32_t(mTriangles.size());
+    std::vector<float> verts(size_t(n) * 9);
+    std::vector<uint8_t> flags(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const Triangle& t = mTriangles[i];
+        const float v[9] = {t.p0.x, t.p0.y, t.p0.z, t.p1.x, t.p1.y, t.p1.z, t.p2.x, t.p2.y, t.p2.z};
+        std::memcpy(&verts[size_t(i) * 9], v, sizeof(v));
+        const uint32_t mflags = t.material < mMaterials.size() ? mMaterials[t.material].flags : 0u;
+        uint8_t f = 0;
+        if (t.oneSided && !(mflags & MATFLAG_NOCULL)) f |= VT_TRI_CULL_BACKFACE;   // Primitives.h:174
+        if (mflags & MATFLAG_ALPHATEST) f |= VT_TRI_ALPHATEST;                     // Primitives.h:196
+        flags[i] = f;
+    }
+    std::vector<vt_tri64> recs(n);
+    vt_bvh* bvh = nullptr;
+    vt_host_scene* hs = nullptr;
+    int rc = vt_tris_setup(verts.data(), flags.data(), n, recs.data());
+    if (rc == VT_OK) rc = vt_bvh_build(recs.data(), n, 0, &bvh);
+    if (rc == VT_OK) rc = vt_scene_linearise(bvh, recs.data(), &hs);
+    vt_engine* eng = nullptr;
+    if (rc == VT_OK) eng = Engine(LUA);
+    if (rc == VT_OK) rc = vt_scene_upload(eng, hs, &mpScene);
+    if (hs) vt_host_scene_free(hs);
+    if (bvh) vt_bvh_free(bvh);
+    if (rc != VT_OK) {
+        mpScene = nullptr;
+        std::string msg = std::string("VisTrace: acceleration structure build failed: ") + vt_last_error();
+        LUA->ThrowError(msg.c_str());
+    }
+    mAccelBuilt = true;
+}
+
+TraceResult* AccelStruct::MakeResult(const vt_ray& ray, const vt_hit& hit, float coneWidth, float coneAngle) const
+{
+    const Triangle& tri = mTriangles[hit.prim];                          // :821
+    static const Entity kNoEntity{};
+    const Entity& ent = tri.entIdx < mEntities.size() ? mEntities[tri.entIdx] : kNoEntity;   // :822
+    return new TraceResult(Vec3{ray.dir[0], ray.dir[1], ray.dir[2]}, hit.t, coneWidth, coneAngle, tri, hit.prim,
+                           Vec2{hit.u, hit.v}, ent);                     // :825-831
+}
+
+int AccelStruct::Traverse(ILuaBase* LUA)
+{
+    if (!mAccelBuilt)
+        LUA->ThrowError("Unable to perform traversal, acceleration structure invalid (use AccelStruct:Rebuild to rebuild it)");
+    int numArgs = LUA->Top();
+
+    LUA->CheckType(2, Type::Vector);
+    LUA->CheckType(3, Type::Vector);
+    Vector origin = LUA->GetVector(2);
+    Vector direction = LUA->GetVector(3);
+
+    float tMin = 0.f;
+    if (numArgs > 3 && !LUA->IsType(4, Type::Nil)) tMin = static_cast<float>(LUA->CheckNumber(4));
+    float tMax = FLT_MAX;
+    if (numArgs > 4 && !LUA->IsType(5, Type::Nil)) tMax = static_cast<float>(LUA->CheckNumber(5));
+    float coneWidth = -1;
+    if (numArgs > 5 && !LUA->IsType(6, Type::Nil)) coneWidth = static_cast<float>(LUA->CheckNumber(6));
+    float coneAngle = -1;
+    if (numArgs > 6 && !LUA->IsType(7, Type::Nil)) coneAngle = static_cast<float>(LUA->CheckNumber(7));
+
+    if (coneWidth >= 0 && coneAngle <= 0.f) LUA->ThrowError("Valid cone width but invalid cone angle passed");
+    if (coneWidth < 0 && coneAngle > 0.f) LUA->ThrowError("Valid cone angle but invalid cone width passed");
+    if (tMin < 0.f) LUA->ArgError(4, "tMin cannot be less than 0");
+    if (tMax <= tMin) LUA->ArgError(5, "tMax must be greater than tMin");
+
+    LUA->Pop(LUA->Top());
+
+    const vt_ray ray{{origin.x, origin.y, origin.z}, {direction.x, direction.y, direction.z}, tMin, tMax};
+    vt_hit hit;
+    if (vt_trace_closest(mpScene, &ray, 1, &hit) != VT_OK) {             // replaces :818
+        std::string msg = std::string("VisTrace: traversal failed: ") + vt_last_error();
+        LUA->ThrowError(msg.c_str());
+    }
+    if (hit.prim != VT_MISS) {
+        LUA->PushUserType_Value(MakeResult(ray, hit, coneWidth, coneAngle), TraceResult::id);
+        return 1;
+    }
+    return 0;
+}
+
+int AccelStruct::TraceClosest(const vt_ray* rays, uint64_t n, vt_hit* hits) const
+{
+    if (!mAccelBuilt) return VT_ERR_INVALID_ARG;
+    return vt_trace_closest(mpScene, rays, n, hits);
+}
+
+int AccelStruct::TraverseBatch(ILuaBase* LUA)
+{
+    if (!mAccelBuilt)
+        LUA->ThrowError("Unable to perform traversal, acceleration structure invalid (use AccelStruct:Rebuild to rebuild it)");
+    LUA->CheckType(2, Type::Table);
+    std::vector<vt_ray> rays;
+    // rays[i] = { origin, direction, tMin?, tMax? } with the defaults and checks of Traverse
+    LUA->PushNil();
+    while (LUA->Next(2) != 0) {
+        LUA->CheckType(-1, Type::Table);
+        const int rt = LUA->Top();
+        vt_ray r{{0, 0, 0}, {0, 0, 0}, 0.f, FLT_MAX};
+        int field = 0;
+        LUA->PushNil();
+        while (LUA->Next(rt) != 0) {
+            ++field;
+            if (field <= 2) {
+                LUA->CheckType(-1, Type::Vector);
+                const Vector v = LUA->GetVector(-1);
+                float* dst = field == 1 ? r.org : r.dir;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z;
+            } else if (field == 3 && !LUA->IsType(-1, Type::Nil)) {
+                r.tmin = static_cast<float>(LUA->CheckNumber(-1));
+            } else if (field == 4 && !LUA->IsType(-1, Type::Nil)) {
+                r.tmax = static_cast<float>(LUA->CheckNumber(-1));
+            }
+            LUA->Pop();
+        }
+        if (field < 2) LUA->ThrowError("Each ray must be a table {origin, direction[, tMin[, tMax]]}");
+        if (r.tmin < 0.f) LUA->ThrowError("tMin cannot be less than 0");
+        if (r.tmax <= r.tmin) LUA->ThrowError("tMax must be greater than tMin");
+        rays.push_back(r);
+        LUA->Pop();
+    }
+    LUA->Pop(LUA->Top());
+
+    std::vector<vt_hit> hits(rays.size());
+    if (vt_trace_closest(mpScene, rays.data(), rays.size(), hits.data()) != VT_OK) {
+        std::string msg = std::string("VisTrace: traversal failed: ") + vt_last_error();
+        LUA->ThrowError(msg.c_str());
+    }
+    LUA->CreateTable();
+    for (size_t i = 0; i < hits.size(); ++i) {
+        LUA->PushNumber(double(i + 1));
+        if (hits[i].prim != VT_MISS) LUA->PushUserType_Value(MakeResult(rays[i], hits[i], -1.f, -1.f), TraceResult::id);
+        else LUA->PushBool(false);
+        LUA->SetTable(-3);
+    }
+    return 1;
+}
+
+const Material& AccelStruct::GetMaterial(size_t i) const { return mMaterials[i]; }     // :840-843
+
+} // namespace vistrace

@@ -1,0 +1,54 @@
+// AccelStruct.h -- host class behind the GLua type `AccelStruct`, same public surface as the
+// reference (source/objects/AccelStruct.h:61-86): PopulateAccel / Traverse / GetMaterial.
+// The CPU BVH objects (mAccel, mpIntersector, mpTraverser) are replaced by a device scene
+// reached through the C ABI of include/vistrace_hip.h; TraverseBatch is the additive entry
+// that lets a script hand over N rays at once.
+#pragma once
+
+#include <memory>
+#include <vector>
+
+#include "LuaShim.h"
+#include "Scene.h"
+#include "vistrace_hip.h"
+
+namespace vistrace {
+
+class TraceResult;
+
+class AccelStruct {
+public:
+    AccelStruct();
+    ~AccelStruct();
+    AccelStruct(const AccelStruct&) = delete;
+    AccelStruct& operator=(const AccelStruct&) = delete;
+
+    // Lua stack on entry: the entity table on top (source/VisTrace.cpp:776-788).  Pops it.
+    void PopulateAccel(GarrysMod::Lua::ILuaBase* LUA, const World* pWorld = nullptr);
+    // accel:Traverse(origin, direction, tMin=0, tMax=FLT_MAX, coneWidth=-1, coneAngle=-1)
+    int Traverse(GarrysMod::Lua::ILuaBase* LUA);
+    // accel:TraverseBatch(rays) -- rays: array of {origin, direction[, tMin[, tMax]]} tables;
+    // returns an array with a TraceResult or false per ray.  New, does not alter Traverse.
+    int TraverseBatch(GarrysMod::Lua::ILuaBase* LUA);
+
+    const Material& GetMaterial(size_t i) const;
+
+    // Non-Lua batch entry for native callers (extensions): closest hits for n rays.
+    int TraceClosest(const vt_ray* rays, uint64_t n, vt_hit* hits) const;
+
+    static void SetEntityMeshSource(IEntityMeshSource* src);   // module-wide hook (see Scene.h)
+    size_t TriangleCount() const { return mTriangles.size(); }
+    bool   IsBuilt() const { return mAccelBuilt; }
+
+private:
+    bool mAccelBuilt;
+    vt_scene* mpScene;                      // device-resident linearised BVH + triangles
+    std::vector<Triangle> mTriangles;
+    std::vector<Entity>   mEntities;
+    std::vector<Material> mMaterials;
+
+    void ReleaseDevice();
+    TraceResult* MakeResult(const vt_ray& ray, const vt_hit& hit, float coneWidth, float coneAngle) const;
+};
+
+} // namespace vistrace
