@@ -112,7 +112,7 @@ def main() -> None:
     d_hits = tp.empty_records(n, HIT, device)
     gather_list = None
     if world > 1 and rank == 0:
-        gather_list = [tp.empty_records(n, HIT, device) for _ in range(world)]
+        gather_list = [tp.empty_records(n, HIT, device) for _ in range(world)]   # receive buffers, reused every step
     t4 = time.time()
     log(f"[bench] ray set-up {t4 - t3:.2f}s")
 
@@ -131,7 +131,7 @@ def main() -> None:
 
     def step():
         tp.trace_closest(scene, d_rays, n, d_hits)
-        if world > 1:
+        if world > 1:   # the single exchange of the path: hit records -> rank 0 (RCCL gather over xGMI)
             dist.gather(d_hits, gather_list, dst=0)
 
     for _ in range(args.warmup):
@@ -161,6 +161,15 @@ def main() -> None:
     k_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
+    traffic = None
+    try:   # HBM-side bytes per launch from the committed rocprofv3 PMC pass of this same command
+        with open(os.path.join(ROOT, "profiles", "r1", "traffic.json")) as f:
+            tj = json.load(f)
+        if tj.get("workload") == f"{args.scene}_{args.kind}{n}":
+            traffic = tj.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+
     result = {
         "metric": "Mrays/s closest-hit, 1M-triangle scene",
         "value": round(value, 2),
@@ -181,7 +190,8 @@ def main() -> None:
             "query": "closest-hit",
             "ray_kind": "cosine-hemisphere bounce (incoherent)" if args.kind == "bounce" else "pinhole primary",
             "parallelism": f"rays sharded x{world}, BVH replicated" + (", RCCL gather of hits to rank 0" if world > 1 else ""),
-            "kernel_mode": "persistent" if engine.get_option("persistent") else "static",
+            "kernel_mode": ("persistent" + ("+lds-dma-fetch" if engine.get_option("fetch_dma") else "")) if engine.get_option("persistent") else "static",
+            "launch_options": {k: engine.get_option(k) for k in ("lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold")},
             "launch": engine.launch_info(),
         },
         "roofline": {
@@ -190,8 +200,10 @@ def main() -> None:
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
-            "kernel": "vt::trace_kernel<false,false,true>" if engine.get_option("persistent") else "vt::trace_kernel<false,false,false>",
+            "traffic": traffic,
+            "kernel": "vt::trace_kernel<false,false,%s,%s>" % (
+                "true" if engine.get_option("persistent") else "false",
+                "true" if engine.get_option("persistent") and engine.get_option("fetch_dma") else "false"),
             "kernel_ms": round(k_ms, 4),
             "alg_bytes_per_ray": round(alg_bytes / n, 1),
             "steps_per_ray": round(tot_steps / n, 2),

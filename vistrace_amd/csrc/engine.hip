@@ -109,7 +109,9 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool 
     // stack entries a ray can need = inner levels below the root pair
     const uint32_t need = s->max_depth;
     p.persistent = e->persistent != 0;
-    p.fetch_dma = p.persistent && e->fetch_dma != 0;
+    // the DMA-fetch kernel addresses records as base + 32-bit byte offset: scenes below 4 GiB
+    const uint64_t rec_bytes = (uint64_t(s->tri_base) + s->ntris) * 64;
+    p.fetch_dma = p.persistent && e->fetch_dma != 0 && rec_bytes < (uint64_t(1) << 32);
     const uint64_t blocks_for_rays = (n + kBlockThreads - 1) / kBlockThreads;
     if (p.persistent) {
         p.lds_entries = std::min(std::max(e->lds_entries, 1u), std::max(need, 1u));

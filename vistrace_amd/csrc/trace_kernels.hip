@@ -71,13 +71,30 @@ __device__ __forceinline__ float safe_inverse(float x)
 // operand, for which rmax(a,b) == maxnum(a,b) and rmin(a,b) == minnum(a,b) up to the sign of
 // a zero result (a NaN first operand yields b in both).  Zero signs never change the
 // comparisons first <= second / first_l > first_r, so v_max3/v_min3 give the same decisions.
+// v_max3_f32 / v_min3_f32 written out so hipcc does not put a canonicalising v_max in front of
+// every use of tmin/tmax: all NaNs that can reach these (inf - inf, 0 * inf) are quiet, and
+// for quiet NaNs the instruction returns the non-NaN operand(s), like maxnum/minnum.
 __device__ __forceinline__ float slab_first(float e0, float e1, float e2, float tmin)
 {
-    return fmaxf(e0, fmaxf(e1, fmaxf(e2, tmin)));
+    float m, r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(e2), "v"(tmin));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(e0), "v"(e1), "v"(m));
+    return r;
 }
 __device__ __forceinline__ float slab_second(float x0, float x1, float x2, float tmax)
 {
-    return fminf(x0, fminf(x1, fminf(x2, tmax)));
+    float m, r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(x2), "v"(tmax));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x0), "v"(x1), "v"(m));
+    return r;
+}
+
+// lane-wise select with the mask in an SGPR pair: mask bit set -> if_set, else if_clear
+__device__ __forceinline__ float sel(uint64_t mask, float if_set, float if_clear)
+{
+    float r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
 }
 
 struct Lane {
@@ -98,6 +115,8 @@ struct Lane {
 typedef __attribute__((address_space(1))) const void* global_cptr;
 typedef __attribute__((address_space(3))) void*       lds_ptr;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kStageRow   = 1024 + 16;      // one staging row: 16 quads x 64 B, +16 B so that
 constexpr uint32_t kStageBytes = 4 * kStageRow;  // the four rows start on different banks
@@ -119,6 +138,8 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                         size_t(wave) * kStageBytes;
 
     const char* const records = reinterpret_cast<const char*>(a.records);
+    // LDS byte address of this lane's 64-B slot: row (lane & 3), quad (lane >> 2)
+    const uint32_t my_rec = uint32_t(uintptr_t((lds_ptr)(stage + (lane & 3u) * kStageRow + (lane >> 2) * 64u)));
 
     Lane L;
     uint64_t ray_idx = 0;
@@ -214,28 +235,31 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
         const bool do_tri = want_tri && run_tri;
         const uint32_t rec = do_tri ? a.tri_base + L.tri_cur : (want_node ? L.node : kNoFetch);
 
-        float4 q0, q1, q2, q3;
+        float4 q0, q1, q2, q3;   // the record, direct fetch
         if constexpr (FETCH_DMA) {
-            // quad-cooperative fetch through LDS: row k holds the records of every quad's lane k
+            // quad-cooperative fetch through LDS: row k receives the records of every quad's lane k.
+            // Addresses are base + 32-bit byte offset (the engine uses this kernel below 4 GiB).
             const uint32_t piece = (lane & 3u) * 16u;
             const uint32_t r0 = quad_broadcast<0>(rec), r1 = quad_broadcast<1>(rec),
                            r2 = quad_broadcast<2>(rec), r3 = quad_broadcast<3>(rec);
             if (r0 != kNoFetch)
-                __builtin_amdgcn_global_load_lds((global_cptr)(records + size_t(r0) * 64 + piece),
+                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r0 << 6) | piece)),
                                                  (lds_ptr)(stage + 0 * kStageRow), 16, 0, 0);
             if (r1 != kNoFetch)
-                __builtin_amdgcn_global_load_lds((global_cptr)(records + size_t(r1) * 64 + piece),
+                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r1 << 6) | piece)),
                                                  (lds_ptr)(stage + 1 * kStageRow), 16, 0, 0);
             if (r2 != kNoFetch)
-                __builtin_amdgcn_global_load_lds((global_cptr)(records + size_t(r2) * 64 + piece),
+                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r2 << 6) | piece)),
                                                  (lds_ptr)(stage + 2 * kStageRow), 16, 0, 0);
             if (r3 != kNoFetch)
-                __builtin_amdgcn_global_load_lds((global_cptr)(records + size_t(r3) * 64 + piece),
+                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r3 << 6) | piece)),
                                                  (lds_ptr)(stage + 3 * kStageRow), 16, 0, 0);
-            // Wait for the DMA rows (vmcnt) and read this lane's 64-B record back.  One asm
-            // statement holds the four ds_read_b128 and their wait, so hipcc can neither split
-            // the reads nor consume a destination early (cdna_hip_programming.md 5.7 item 1).
-            const uint32_t my_rec = uint32_t(uintptr_t((lds_ptr)(stage + (lane & 3u) * kStageRow + (lane >> 2) * 64u)));
+            // Wait for the DMA rows, then read this lane's 64-B record back with four ds_read_b128
+            // (conflict-free with the padded rows).  One asm statement holds the reads and their
+            // waits, so hipcc can neither split the reads nor consume a destination early
+            // (cdna_hip_programming.md 5.7 item 1).  Octant-ordered ds_read2_b32 reads would save
+            // the twelve selects of a NODE step but are 4-way bank conflicted (64-B slot stride,
+            // 32 banks for 4-byte reads) and made the LDS the bottleneck: profiles/r1/notes.md.
             f32x4 v0, v1, v2, v3;
             asm volatile("s_waitcnt vmcnt(0)\n\t"
                          "ds_read_b128 %0, %4\n\t"
@@ -283,25 +307,32 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
             }
         } else if (want_node) {
             // ---- NODE: one iteration of SingleRayTraverser::traverse -------------------
-            const float4 n0 = q0, n1 = q1, n2 = q2, n3 = q3;
             if constexpr (STATS) ++L.steps;
-            const bool ox = __float_as_uint(L.dx) >> 31, oy = __float_as_uint(L.dy) >> 31,
-                       oz = __float_as_uint(L.dz) >> 31; // octant = signbit(dir)
-            // left child: bounds {n0.x n0.y | n0.z n0.w | n1.x n1.y}, count n1.z, first n1.w
-            float e0 = (ox ? n0.y : n0.x) * L.ix + L.sx, x0 = (ox ? n0.x : n0.y) * L.ix + L.sx;
-            float e1 = (oy ? n0.w : n0.z) * L.iy + L.sy, x1 = (oy ? n0.z : n0.w) * L.iy + L.sy;
-            float e2 = (oz ? n1.y : n1.x) * L.iz + L.sz, x2 = (oz ? n1.x : n1.y) * L.iz + L.sz;
-            const float fl = slab_first(e0, e1, e2, L.tmin);
-            const float sl = slab_second(x0, x1, x2, L.tmax);
-            // right child: bounds {n2.x n2.y | n2.z n2.w | n3.x n3.y}, count n3.z, first n3.w
-            e0 = (ox ? n2.y : n2.x) * L.ix + L.sx; x0 = (ox ? n2.x : n2.y) * L.ix + L.sx;
-            e1 = (oy ? n2.w : n2.z) * L.iy + L.sy; x1 = (oy ? n2.z : n2.w) * L.iy + L.sy;
-            e2 = (oz ? n3.y : n3.x) * L.iz + L.sz; x2 = (oz ? n3.x : n3.y) * L.iz + L.sz;
-            const float fr = slab_first(e0, e1, e2, L.tmin);
-            const float sr = slab_second(x0, x1, x2, L.tmax);
+            // bounds[2a + octant[a]] (entry side) and bounds[2a + 1 - octant[a]] (exit side) of
+            // the left and the right child; counts and first indices
+            float lnx, lfx, lny, lfy, lnz, lfz, rnx, rfx, rny, rfy, rnz, rfz;
+            uint32_t lcount, lfirst, rcount, rfirst;
+            {
+                // octant = signbit(dir).  The selects are written as v_cndmask with an SGPR-pair
+                // mask: the VCC form hipcc often picks issues ~4x slower on gfx950 (measured,
+                // scripts/ubench_valu.hip: 16 vs 4.2 cycles per wave-instruction).
+                const uint64_t mx = __ballot(__float_as_uint(L.dx) >> 31), my = __ballot(__float_as_uint(L.dy) >> 31),
+                               mz = __ballot(__float_as_uint(L.dz) >> 31);
+                // left: bounds {q0.x q0.y | q0.z q0.w | q1.x q1.y}; right: {q2.x q2.y | q2.z q2.w | q3.x q3.y}
+                lnx = sel(mx, q0.y, q0.x); lfx = sel(mx, q0.x, q0.y);
+                lny = sel(my, q0.w, q0.z); lfy = sel(my, q0.z, q0.w);
+                lnz = sel(mz, q1.y, q1.x); lfz = sel(mz, q1.x, q1.y);
+                rnx = sel(mx, q2.y, q2.x); rfx = sel(mx, q2.x, q2.y);
+                rny = sel(my, q2.w, q2.z); rfy = sel(my, q2.z, q2.w);
+                rnz = sel(mz, q3.y, q3.x); rfz = sel(mz, q3.x, q3.y);
+                lcount = __float_as_uint(q1.z); lfirst = __float_as_uint(q1.w);
+                rcount = __float_as_uint(q3.z); rfirst = __float_as_uint(q3.w);
+            }
+            const float fl = slab_first(lnx * L.ix + L.sx, lny * L.iy + L.sy, lnz * L.iz + L.sz, L.tmin);
+            const float sl = slab_second(lfx * L.ix + L.sx, lfy * L.iy + L.sy, lfz * L.iz + L.sz, L.tmax);
+            const float fr = slab_first(rnx * L.ix + L.sx, rny * L.iy + L.sy, rnz * L.iz + L.sz, L.tmin);
+            const float sr = slab_second(rfx * L.ix + L.sx, rfy * L.iy + L.sy, rfz * L.iz + L.sz, L.tmax);
 
-            const uint32_t lcount = __float_as_uint(n1.z), lfirst = __float_as_uint(n1.w);
-            const uint32_t rcount = __float_as_uint(n3.z), rfirst = __float_as_uint(n3.w);
             const bool hit_l = fl <= sl, hit_r = fr <= sr;
             const bool leaf_l = lcount != 0, leaf_r = rcount != 0;
 
