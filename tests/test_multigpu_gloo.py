@@ -56,6 +56,50 @@ def _worker(rank, world, port, n, result_path):
         dist.destroy_process_group()
 
 
+def _worker_weak(rank, world, port, n, result_path):
+    """bench.py's N > 1 step: every rank traces ITS OWN batch in chunks, async gather to rank 0."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import vistrace_amd as va
+        from oracle import binding as O
+        from vistrace_amd import workloads as W
+        from vistrace_amd.distributed import chunk_bounds, pipelined_trace_gather
+        tris = va.tris_setup(W.make_scene("S1k"))
+        bvh = va.HostBvh(tris, nthreads=1)
+        nodes, pidx, otris = bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris)
+
+        def rays_of(r):
+            return W.sphere_rays(n, 500 + r, origin=(10.0 * r, -5.0, 2.0))
+        rays = rays_of(rank)
+        hits_local = torch.zeros(n * 16, dtype=torch.uint8)
+        recv = [torch.zeros(n * 16, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+
+        def trace_chunk(lo, hi):
+            h, _, _, _, _ = O.traverse_batch(nodes, pidx, otris, rays[lo:hi], nthreads=1)
+            hits_local[lo * 16: hi * 16] = torch.from_numpy(h.view(np.uint8).reshape(-1).copy())
+
+        for _ in range(2):   # buffers are reused across steps
+            pipelined_trace_gather(trace_chunk, n, hits_local, recv, nchunks=3)
+        assert chunk_bounds(n, 3)[0][0] == 0 and chunk_bounds(n, 3)[-1][1] == n
+        if rank == 0:
+            ok = True
+            for r in range(world):
+                full, _, _, _, _ = O.traverse_batch(nodes, pidx, otris, rays_of(r), nthreads=1)
+                ok = ok and recv[r].numpy().tobytes() == full.tobytes()
+            open(result_path, "w").write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_weak_scaling_step(tmp_path):
+    result = tmp_path / "result.txt"
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker_weak, args=(2, port, 1000, str(result)), nprocs=2, join=True)
+    assert result.read_text() == "ok"
+
+
 @pytest.mark.parametrize("n", [1001, 4096])
 def test_two_rank_shard_and_gather(tmp_path, n):
     result = tmp_path / "result.txt"

@@ -138,8 +138,10 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                         size_t(wave) * kStageBytes;
 
     const char* const records = reinterpret_cast<const char*>(a.records);
-    // LDS byte address of this lane's 64-B slot: row (lane & 3), quad (lane >> 2)
-    const uint32_t my_rec = uint32_t(uintptr_t((lds_ptr)(stage + (lane & 3u) * kStageRow + (lane >> 2) * 64u)));
+    // LDS byte address of the wave's staging rows, made provably wave-uniform (it becomes M0 of the
+    // DMA loads), and of this lane's 64-B slot: row (lane & 3), quad (lane >> 2)
+    const uint32_t stage_lds = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t((lds_ptr)stage)));
+    const uint32_t my_rec = stage_lds + (lane & 3u) * kStageRow + (lane >> 2) * 64u;
 
     Lane L;
     uint64_t ray_idx = 0;
@@ -244,16 +246,16 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                            r2 = quad_broadcast<2>(rec), r3 = quad_broadcast<3>(rec);
             if (r0 != kNoFetch)
                 __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r0 << 6) | piece)),
-                                                 (lds_ptr)(stage + 0 * kStageRow), 16, 0, 0);
+                                                 (lds_ptr)(uintptr_t)(stage_lds + 0u * kStageRow), 16, 0, 0);
             if (r1 != kNoFetch)
                 __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r1 << 6) | piece)),
-                                                 (lds_ptr)(stage + 1 * kStageRow), 16, 0, 0);
+                                                 (lds_ptr)(uintptr_t)(stage_lds + 1u * kStageRow), 16, 0, 0);
             if (r2 != kNoFetch)
                 __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r2 << 6) | piece)),
-                                                 (lds_ptr)(stage + 2 * kStageRow), 16, 0, 0);
+                                                 (lds_ptr)(uintptr_t)(stage_lds + 2u * kStageRow), 16, 0, 0);
             if (r3 != kNoFetch)
                 __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r3 << 6) | piece)),
-                                                 (lds_ptr)(stage + 3 * kStageRow), 16, 0, 0);
+                                                 (lds_ptr)(uintptr_t)(stage_lds + 3u * kStageRow), 16, 0, 0);
             // Wait for the DMA rows, then read this lane's 64-B record back with four ds_read_b128
             // (conflict-free with the padded rows).  One asm statement holds the reads and their
             // waits, so hipcc can neither split the reads nor consume a destination early

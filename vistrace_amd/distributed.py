@@ -62,3 +62,35 @@ def trace_sharded(trace_fn: Callable[[torch.Tensor, int], torch.Tensor], rays: t
     lo, hi = shard_bounds(n_total, world, rank)
     local = trace_fn(rays[lo * ray_bytes: hi * ray_bytes], hi - lo)
     return gather_records(local, hi - lo, n_total, record_bytes, dst)
+
+
+def chunk_bounds(n: int, nchunks: int, align: int = 64) -> List[Tuple[int, int]]:
+    """Split [0, n) into <= nchunks contiguous pieces whose starts are multiples of `align`."""
+    nchunks = max(1, min(nchunks, max(1, n // align)))
+    per = ((n + nchunks - 1) // nchunks + align - 1) // align * align
+    out = []
+    lo = 0
+    while lo < n:
+        out.append((lo, min(n, lo + per)))
+        lo += per
+    return out
+
+
+def pipelined_trace_gather(trace_chunk: Callable[[int, int], None], n: int, hits_local: torch.Tensor,
+                           recv_bufs: Optional[List[torch.Tensor]], nchunks: int = 4, record_bytes: int = HIT_BYTES,
+                           dst: int = 0) -> None:
+    """Weak-scaling step: every rank traces its own n rays in chunks and the hit records of chunk c
+    travel to `dst` (async gather) while chunk c+1 is being traced.
+
+    trace_chunk(lo, hi) enqueues the trace of rays [lo, hi) into hits_local (bytes [lo*rb, hi*rb)).
+    recv_bufs: on dst, one n*record_bytes uint8 tensor per rank (reused across steps); None elsewhere.
+    Returns after every gather has completed with respect to the current stream."""
+    rank = dist.get_rank()
+    works = []
+    for lo, hi in chunk_bounds(n, nchunks):
+        trace_chunk(lo, hi)
+        send = hits_local[lo * record_bytes: hi * record_bytes]
+        recv = [b[lo * record_bytes: hi * record_bytes] for b in recv_bufs] if rank == dst else None
+        works.append(dist.gather(send, recv, dst=dst, async_op=True))
+    for w in works:
+        w.wait()
