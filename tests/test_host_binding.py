@@ -28,3 +28,13 @@ def test_binding_end_to_end():
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 failed" in out.stdout
+
+
+def test_host_code_under_asan_ubsan():
+    """Triangle set-up, PLOC build, leaf collapse and linearise under ASan + UBSan (CPU only)."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "sanitize"], stdout=subprocess.DEVNULL)
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "test_host_sanitize")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", OMP_NUM_THREADS="3")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 failed" in out.stdout
