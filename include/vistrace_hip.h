@@ -80,6 +80,15 @@ typedef struct vt_hit_attrs {
     float wo[3];    uint32_t hit;   /* wo :56 ; hit = 1, or 0 for a miss (all zero) */
 } vt_hit_attrs;
 
+/* Per-triangle side table for the rest of the TraceResult constructor (original triangle
+ * order): uvs/alphas of the three vertices (source/objects/Primitives.h:65-66), the owning
+ * entity's id (Entity::id, source/objects/AccelStruct.h:36) and the material index. 48 B. */
+typedef struct vt_tri_attribs { float uv[3][2]; float alpha[3]; uint32_t ent_id; uint32_t material; uint32_t pad; } vt_tri_attribs;
+
+/* texUV, blendFactor, entIdx, submatIdx of a hit (source/objects/TraceResult.cpp:73-78). 32 B.
+ * A miss yields zeros with ent_id = material = VT_MISS. */
+typedef struct vt_hit_shade { float tex_uv[2]; float blend; uint32_t ent_id; uint32_t material; uint32_t pad[3]; } vt_hit_shade;
+
 typedef struct vt_bvh        vt_bvh;        /* host: v1-layout tree                 */
 typedef struct vt_host_scene vt_host_scene; /* host: linearised pairs + tri records */
 typedef struct vt_engine     vt_engine;     /* one HIP device + stream              */
@@ -156,6 +165,11 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value);
 void* vt_engine_stream(vt_engine* e);
 /* Wait for everything enqueued on the engine's own stream. */
 int vt_engine_synchronize(vt_engine* e);
+
+/* Optional per-triangle side table (n must equal the scene's triangle count); copied to the device. */
+int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_t n);
+/* entIdx / texUV / blendFactor / submatIdx per hit (needs vt_scene_set_tri_attribs). d_out: n x vt_hit_shade. */
+int vt_hit_shade_dev(vt_scene* s, const void* d_hits, uint64_t n, void* d_out, void* stream);
 
 /* When enabled, every trace launch is bracketed by HIP events on its stream;
  * vt_engine_last_kernel_ms synchronises on the last pair and returns its time. */

@@ -53,6 +53,7 @@ def lib() -> C.CDLL:
         L.vto_traverse_batch.argtypes = [vp, vp, vp, vp, u64, C.c_int, vp, vp, vp, C.c_int]
         L.vto_traverse_batch.restype = C.c_int
         L.vto_hit_attrs.argtypes = [vp, vp, C.c_float, C.c_float, vp]
+        L.vto_hit_shade.argtypes = [C.c_float, C.c_float, vp, vp, vp, vp]
         L.vto_calc_ray_origin.argtypes = [vp, vp, vp]
         L.vto_hemisphere_cos.argtypes = [C.c_float, C.c_float, vp]
         _lib = L
@@ -121,6 +122,16 @@ def hit_attrs(tris: np.ndarray, rays: np.ndarray, hits: np.ndarray) -> np.ndarra
         L.vto_hit_attrs(tris[int(hits["prim"][i]):].ctypes.data, rays["dir"][i].ctypes.data, float(hits["u"][i]),
                         float(hits["v"][i]), out[i:i + 1].ctypes.data)
     return out
+
+
+def hit_shade(u: float, v: float, uvs, alphas):
+    """(texUV[2], blendFactor) per TraceResult.cpp:70,73-74."""
+    uvs = np.ascontiguousarray(uvs, np.float32).reshape(6)
+    alphas = np.ascontiguousarray(alphas, np.float32).reshape(3)
+    tex = np.zeros(2, np.float32)
+    blend = C.c_float(0)
+    lib().vto_hit_shade(float(u), float(v), uvs.ctypes.data, alphas.ctypes.data, tex.ctypes.data, C.addressof(blend))
+    return tex, np.float32(blend.value)
 
 
 def calc_ray_origin(pos, normal) -> np.ndarray:

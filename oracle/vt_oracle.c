@@ -313,6 +313,15 @@ void vto_hit_attrs(const vto_tri* tri, const float dir[3], float u, float v, vto
     out->front = dot3(out->wo, out->ngeo) >= 0.0f ? 1u : 0u;           /* :85 */
 }
 
+/* ---- TraceResult.cpp:70,73-74 -------------------------------------------------------*/
+void vto_hit_shade(float u, float v, const float uvs[6], const float alphas[3], float tex_uv[2], float* blend)
+{
+    const float w = 1.0f - u - v;                                            /* :70 uvw.z */
+    *blend = (w * alphas[0] + u * alphas[1]) + v * alphas[2];                /* :73 */
+    tex_uv[0] = (w * uvs[0] + u * uvs[2]) + v * uvs[4];                      /* :74 (glm vec2: per component) */
+    tex_uv[1] = (w * uvs[1] + u * uvs[3]) + v * uvs[5];
+}
+
 /* ---- VisTrace.cpp:1495-1517 ------------------------------------------------*/
 void vto_calc_ray_origin(const float pos[3], const float normal[3], float out[3])
 {

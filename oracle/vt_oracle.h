@@ -107,6 +107,9 @@ int vto_traverse_batch(const vto_node* nodes, const uint32_t* prim_indices,
 /* TraceResult.cpp:45-86 + GetPos :255-262 for hit {prim,u,v} of ray dir */
 void vto_hit_attrs(const vto_tri* tri, const float dir[3], float u, float v, vto_attrs* out);
 
+/* texUV and blendFactor of a hit: TraceResult.cpp:70,73-74 (uvs[3][2], alphas[3] of the triangle) */
+void vto_hit_shade(float u, float v, const float uvs[6], const float alphas[3], float tex_uv[2], float* blend);
+
 /* vistrace.CalcRayOrigin, VisTrace.cpp:1495-1517 */
 void vto_calc_ray_origin(const float pos[3], const float normal[3], float out[3]);
 

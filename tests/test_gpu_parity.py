@@ -288,3 +288,41 @@ def test_full_size_properties_s1m(va, engine, make_bundle):
     pos_ray = r["org"].astype(np.float64) + h["t"][:, None].astype(np.float64) * r["dir"]
     err = np.abs(pos_tri - pos_ray).max(axis=1)
     assert np.percentile(err, 99.9) < 0.05 and err.max() < 2.0    # Source units; fp32 t at ~1e3 scale
+
+
+def test_hit_shade_vs_oracle(va, engine, make_bundle, O):
+    """texUV / blendFactor / entIdx / submatIdx (TraceResult.cpp:70,73-78) from the per-triangle
+    side table: floats bit-identical to the oracle, ids exact, misses flagged."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S1k")
+    scene = upload(va, engine, b)
+    rng = np.random.default_rng(3)
+    n_tri = len(b.tris)
+    attribs = np.zeros(n_tri, va.TRI_ATTRIBS)
+    attribs["uv"] = rng.uniform(-2, 2, (n_tri, 3, 2)).astype(np.float32)
+    attribs["alpha"] = rng.uniform(0, 1, (n_tri, 3)).astype(np.float32)
+    attribs["ent_id"] = rng.integers(0, 65535, n_tri)
+    attribs["material"] = rng.integers(0, 100, n_tri)
+    scene.set_tri_attribs(attribs)
+    rays = np.concatenate([W.sphere_rays(3000, 17, origin=(0.0, 0.0, 0.0)), va.make_rays([[0, 0, 0]] * 8, [[1, 0, 0]] * 8, 0.0, 1e-3)])
+    dev = torch.device("cuda", 0)
+    d_rays = tp.to_device(rays, dev)
+    d_hits = tp.trace_closest(scene, d_rays, len(rays))
+    d_out = tp.empty_records(len(rays), va.HIT_SHADE, dev)
+    scene.hit_shade_dev(d_hits.data_ptr(), len(rays), d_out.data_ptr(), tp.current_stream_handle(dev))
+    out = tp.to_host(d_out, va.HIT_SHADE)
+    hits = tp.to_host(d_hits, va.HIT)
+    hit = hits["prim"] != O_MISS
+    assert hit[:3000].all() and not hit[3000:].any()
+    assert (out["ent_id"][~hit] == O_MISS).all() and (out["material"][~hit] == O_MISS).all() and (out["blend"][~hit] == 0).all()
+    assert (out["ent_id"][hit] == attribs["ent_id"][hits["prim"][hit]]).all()
+    assert (out["material"][hit] == attribs["material"][hits["prim"][hit]]).all()
+    for i in np.nonzero(hit)[0][:500]:
+        a = attribs[hits["prim"][i]]
+        tex, blend = O.hit_shade(hits["u"][i], hits["v"][i], a["uv"], a["alpha"])
+        assert (out["tex_uv"][i].view(np.uint32) == tex.view(np.uint32)).all()
+        assert np.float32(out["blend"][i]).view(np.uint32) == blend.view(np.uint32)
+    with pytest.raises(va._lib.VisTraceError):
+        scene.set_tri_attribs(attribs[:-1])

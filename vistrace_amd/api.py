@@ -14,7 +14,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from ._lib import (BVH_NODE, HIT, HIT_ATTRS, NODE_PAIR, RAY, RAY_STATS, TRI64, check, lib, ptr)
+from ._lib import (BVH_NODE, HIT, HIT_ATTRS, HIT_SHADE, NODE_PAIR, RAY, RAY_STATS, TRI64, TRI_ATTRIBS, check, lib, ptr)
 
 FLT_MAX = float(np.finfo(np.float32).max)
 
@@ -216,6 +216,15 @@ class Scene:
     def hit_attrs_dev(self, d_rays: int, d_hits: int, n: int, d_attrs: int, stream: int = 0) -> None:
         check(lib.vt_hit_attrs_dev(self._h, d_rays, d_hits, n, d_attrs, stream or None))
 
+    def set_tri_attribs(self, attribs: np.ndarray) -> None:
+        """Per-triangle uvs / alphas / entity id / material (original order) for hit_shade_dev."""
+        assert attribs.dtype == TRI_ATTRIBS
+        attribs = np.ascontiguousarray(attribs)
+        check(lib.vt_scene_set_tri_attribs(self._h, ptr(attribs) if len(attribs) else None, len(attribs)))
+
+    def hit_shade_dev(self, d_hits: int, n: int, d_out: int, stream: int = 0) -> None:
+        check(lib.vt_hit_shade_dev(self._h, d_hits, n, d_out, stream or None))
+
 
 def build_scene(engine: Engine, verts: np.ndarray, flags: Optional[np.ndarray] = None, nthreads: int = 0) -> Scene:
     """verts (n,3,3) -> setup -> PLOC build -> linearise -> upload."""
@@ -224,4 +233,5 @@ def build_scene(engine: Engine, verts: np.ndarray, flags: Optional[np.ndarray] =
 
 
 __all__ = ["Engine", "Scene", "HostBvh", "HostScene", "tris_setup", "build_scene", "make_rays", "device_count",
-           "RAY", "HIT", "TRI64", "BVH_NODE", "NODE_PAIR", "RAY_STATS", "HIT_ATTRS", "FLT_MAX", "_lib"]
+           "RAY", "HIT", "TRI64", "BVH_NODE", "NODE_PAIR", "RAY_STATS", "HIT_ATTRS", "TRI_ATTRIBS", "HIT_SHADE",
+           "FLT_MAX", "_lib"]

@@ -65,6 +65,7 @@ struct vt_scene {
     vt_tri64*     d_tris = nullptr;    // = d_records + tri_base * 64
     uint32_t      tri_base = 0;
     uint32_t*     d_prim_to_slot = nullptr;
+    vt_tri_attribs* d_attribs = nullptr;   // optional side table, original triangle order
     uint32_t      npairs = 0, ntris = 0, max_depth = 0, root_leaf_count = 0;
     uint64_t      bytes = 0;
 };
@@ -347,6 +348,7 @@ void vt_scene_free(vt_scene* s)
     (void)hipStreamSynchronize(s->engine->stream);
     if (s->d_records) (void)hipFree(s->d_records);
     if (s->d_prim_to_slot) (void)hipFree(s->d_prim_to_slot);
+    if (s->d_attribs) (void)hipFree(s->d_attribs);
     delete s;
 }
 
@@ -435,6 +437,40 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
 }
 
 void* vt_engine_stream(vt_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
+
+int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_t n)
+{
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_tri_attribs: scene is NULL");
+    if (n != s->ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_tri_attribs: n differs from the scene's triangle count");
+    if (n != 0 && !attribs) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_tri_attribs: attribs is NULL");
+    DeviceGuard guard(s->engine->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_set_tri_attribs: hipSetDevice failed");
+    if (n == 0) return VT_OK;
+    const size_t bytes = size_t(n) * sizeof(vt_tri_attribs);
+    if (!s->d_attribs) {
+        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_attribs), bytes));
+        s->bytes += bytes;
+    }
+    VT_HIP(hipMemcpy(s->d_attribs, attribs, bytes, hipMemcpyHostToDevice));
+    return VT_OK;
+}
+
+int vt_hit_shade_dev(vt_scene* s, const void* d_hits, uint64_t n, void* d_out, void* stream)
+{
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_hit_shade_dev: scene is NULL");
+    if (n == 0) return VT_OK;
+    if (!d_hits || !d_out) return fail(VT_ERR_INVALID_ARG, "vt_hit_shade_dev: NULL device buffer");
+    if (!s->d_attribs) return fail(VT_ERR_INVALID_ARG, "vt_hit_shade_dev: call vt_scene_set_tri_attribs first");
+    DeviceGuard guard(s->engine->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_hit_shade_dev: hipSetDevice failed");
+    HitShadeArgs a{};
+    a.attribs = s->d_attribs;
+    a.hits = static_cast<const vt_hit*>(d_hits);
+    a.out = static_cast<vt_hit_shade*>(d_out);
+    a.n = n;
+    VT_HIP(launch_hit_shade(a, static_cast<hipStream_t>(stream)));
+    return VT_OK;
+}
 
 int vt_engine_synchronize(vt_engine* e)
 {

@@ -38,10 +38,18 @@ struct HitAttrsArgs {
     uint64_t        n;
 };
 
+struct HitShadeArgs {
+    const vt_tri_attribs* attribs;   // original triangle order
+    const vt_hit*         hits;
+    vt_hit_shade*         out;
+    uint64_t              n;
+};
+
 size_t     trace_lds_bytes(uint32_t lds_entries, bool fetch_dma);
 hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, bool fetch_dma,
                         uint32_t grid_blocks, size_t lds_bytes, hipStream_t stream);
 hipError_t trace_blocks_per_cu(bool any_hit, bool stats, bool persistent, bool fetch_dma, size_t lds_bytes, int* out);
 hipError_t launch_hit_attrs(const HitAttrsArgs& a, hipStream_t stream);
+hipError_t launch_hit_shade(const HitShadeArgs& a, hipStream_t stream);
 
 } // namespace vt

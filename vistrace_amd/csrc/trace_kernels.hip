@@ -404,6 +404,27 @@ __global__ __launch_bounds__(kBlockThreads) void hit_attrs_kernel(HitAttrsArgs a
     a.attrs[i] = o;
 }
 
+// ---- rest of the TraceResult constructor: TraceResult.cpp:73-78 ---------------------------------
+__global__ __launch_bounds__(kBlockThreads) void hit_shade_kernel(HitShadeArgs a)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
+    if (i >= a.n) return;
+    const vt_hit h = a.hits[i];
+    vt_hit_shade o{};
+    if (h.prim == VT_MISS) {
+        o.ent_id = VT_MISS; o.material = VT_MISS;
+    } else {
+        const vt_tri_attribs A = a.attribs[h.prim];
+        const float w = 1.0f - h.u - h.v;                                               // uvw = (u, v, 1-u-v) :70
+        o.blend = (w * A.alpha[0] + h.u * A.alpha[1]) + h.v * A.alpha[2];               // :73
+        o.tex_uv[0] = (w * A.uv[0][0] + h.u * A.uv[1][0]) + h.v * A.uv[2][0];           // :74
+        o.tex_uv[1] = (w * A.uv[0][1] + h.u * A.uv[1][1]) + h.v * A.uv[2][1];
+        o.ent_id = A.ent_id;                                                            // :76
+        o.material = A.material;                                                        // :78
+    }
+    a.out[i] = o;
+}
+
 // ---- launchers ---------------------------------------------------------------------------
 template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA>
 static hipError_t launch_one(const TraceArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
@@ -468,6 +489,14 @@ hipError_t launch_hit_attrs(const HitAttrsArgs& a, hipStream_t stream)
     if (a.n == 0) return hipSuccess;
     const uint64_t blocks = (a.n + kBlockThreads - 1) / kBlockThreads;
     hipLaunchKernelGGL(hit_attrs_kernel, dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_hit_shade(const HitShadeArgs& a, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    const uint64_t blocks = (a.n + kBlockThreads - 1) / kBlockThreads;
+    hipLaunchKernelGGL(hit_shade_kernel, dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -13,6 +13,8 @@ static_assert(sizeof(vt_bvh_node) == 32, "vt_bvh_node must be 32 bytes");
 static_assert(sizeof(vt_node_pair) == 64, "vt_node_pair must be 64 bytes");
 static_assert(sizeof(vt_tri64) == 64, "vt_tri64 must be 64 bytes");
 static_assert(sizeof(vt_hit_attrs) == 64, "vt_hit_attrs must be 64 bytes");
+static_assert(sizeof(vt_tri_attribs) == 48, "vt_tri_attribs must be 48 bytes");
+static_assert(sizeof(vt_hit_shade) == 32, "vt_hit_shade must be 32 bytes");
 
 namespace vt {
 
