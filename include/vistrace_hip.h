@@ -14,6 +14,11 @@
  * All calls are synchronous unless the name ends in `_dev` (device pointers,
  * enqueued on the given HIP stream, no host sync).  There is NO CPU fallback:
  * if no HIP device is usable the call fails with VT_ERR_HIP.
+ *
+ * Threading: like the reference (GMod Lua is single-threaded) an engine and
+ * its scenes serve ONE caller at a time.  Launches of one engine share per-launch scratch
+ * (ray cursor, stack overflow area), so enqueue them on one stream, or synchronise between
+ * streams; different engines (devices) are independent.
  */
 #ifndef VISTRACE_HIP_H
 #define VISTRACE_HIP_H
