@@ -206,7 +206,7 @@ def main() -> None:
             "query": "closest-hit",
             "ray_kind": "cosine-hemisphere bounce (incoherent)" if args.kind == "bounce" else "pinhole primary",
             "parallelism": f"rays sharded x{world}, BVH replicated" + (f", RCCL gather of hits to rank 0 ({args.chunks} chunks, overlapped)" if world > 1 else ""),
-            "kernel_mode": ("persistent" + ("+lds-dma-fetch" if engine.get_option("fetch_dma") else "")) if engine.get_option("persistent") else "static",
+            "kernel_mode": ("persistent" + ("+lds-dma-fetch" if engine.get_option("last_fetch_dma") else "")) if engine.get_option("last_persistent") else "static",
             "launch_options": {k: engine.get_option(k) for k in ("lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold")},
             "launch": engine.launch_info(),
         },
@@ -218,8 +218,8 @@ def main() -> None:
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
             "kernel": "vt::trace_kernel<false,false,%s,%s>" % (
-                "true" if engine.get_option("persistent") else "false",
-                "true" if engine.get_option("persistent") and engine.get_option("fetch_dma") else "false"),
+                "true" if engine.get_option("last_persistent") else "false",
+                "true" if engine.get_option("last_fetch_dma") else "false"),
             "kernel_ms": round(k_ms, 4),
             "alg_bytes_per_ray": round(alg_bytes / n, 1),
             "steps_per_ray": round(tot_steps / n, 2),

@@ -161,9 +161,10 @@ int vt_trace_stats_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits
 int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64_t n,
                      void* d_attrs, void* stream);
 
-/* Launch configuration. Keys: "persistent" (0/1), "lds_entries" (stack entries per lane
+/* Launch configuration. Keys: "persistent" (0 = one ray per lane, 1 = persistent waves, 2 = auto
+ * by batch size, the default), "auto_static_factor", "lds_entries" (stack entries per lane
  * kept in LDS), "blocks_per_cu", "block_rays" (rays handed to a wave at a time),
- * "refill_threshold" (idle lanes that trigger a re-fill); read-only: "cu_count", "device".
+ * "refill_threshold" (idle lanes that trigger a re-fill); read-only: "cu_count", "device", "last_persistent", "last_fetch_dma" (what the last launch used).
  * Results never depend on these, only speed does. */
 int vt_engine_set_option(vt_engine* e, const char* key, int64_t value);
 int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value);

@@ -67,11 +67,16 @@ def main():
     d_hits = tp.empty_records(n, HIT, device)
     d_occ = torch.empty(n, dtype=torch.uint8, device=device)
     engine.set_timing(True)
-    variants = args.opt or ["persistent=1"]
+    variants = args.opt or ["persistent=2"]
+    keys = ["persistent", "fetch_dma", "lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold",
+            "auto_static_factor", "static_overflow_mb", "coherent_detect"]
+    defaults = {k: engine.get_option(k) for k in keys}
     times = {v: [] for v in variants}
     ref = None
     for r in range(args.rounds + 1):
         for v in variants:
+            for k, val in defaults.items():      # every variant starts from the defaults
+                engine.set_option(k, val)
             for kv in v.split(","):
                 k, val = kv.split("=")
                 engine.set_option(k, int(val))

@@ -33,8 +33,11 @@ struct vt_engine {
     size_t      lds_per_block_max = 0;
 
     // launch configuration (vt_engine_set_option)
-    int      persistent       = 1;
-    uint32_t lds_entries      = 8;    // stack entries per lane in LDS (rest spills to global)
+    int      persistent       = 2;    // 0 static (one ray per lane), 1 persistent waves, 2 auto by batch size
+    uint32_t coherent_detect  = 1;    // persistent DMA kernel: per-wave coherence probe (see trace_kernels.hip)
+    uint32_t static_overflow_mb = 256; // static kernel: largest per-lane stack overflow area (else full LDS stack)
+    uint32_t auto_static_factor = 2;  // auto: static when n <= factor * (CUs * 8 blocks * 256 lanes)
+    uint32_t lds_entries      = 10;   // stack entries per lane in LDS (rest spills to global)
     uint32_t blocks_per_cu    = 8;    // persistent grid = cu_count * blocks_per_cu
     uint32_t block_rays       = 64;   // consecutive rays handed to a wave at a time
     uint32_t refill_threshold = 8;    // idle lanes that trigger a re-fill
@@ -57,6 +60,7 @@ struct vt_engine {
 
     // last launch geometry
     uint32_t last_blocks = 0, last_threads = 0, last_lds = 0;
+    int      last_persistent = 0, last_dma = 0;
 };
 
 struct vt_scene {
@@ -109,7 +113,10 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool 
 {
     // stack entries a ray can need = inner levels below the root pair
     const uint32_t need = s->max_depth;
-    p.persistent = e->persistent != 0;
+    // persistent = 2 (default): small batches (a few rays per resident lane) finish sooner with one
+    // ray per lane -- no block cursor, no re-fill, and no end-of-queue tail across the whole grid
+    p.persistent = e->persistent == 1 ||
+                   (e->persistent == 2 && n > uint64_t(e->auto_static_factor) * e->cu_count * 8 * kBlockThreads);
     // the DMA-fetch kernel addresses records as base + 32-bit byte offset: scenes below 4 GiB
     const uint64_t rec_bytes = (uint64_t(s->tri_base) + s->ntris) * 64;
     p.fetch_dma = p.persistent && e->fetch_dma != 0 && rec_bytes < (uint64_t(1) << 32);
@@ -125,8 +132,14 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool 
     } else {
         if (blocks_for_rays > 0x7FFFFFFFull) return fail(VT_ERR_INVALID_ARG, "too many rays for one launch");
         p.grid_blocks = uint32_t(blocks_for_rays);
-        p.lds_entries = std::max(need, 1u); // whole stack in LDS, no overflow area
-        p.ovf_entries = 0;
+        // one ray per lane: short LDS stack + per-lane overflow while the overflow area stays small
+        // (<= 256 MiB), else the whole stack in LDS
+        p.lds_entries = std::min(std::max(e->lds_entries, 1u), std::max(need, 1u));
+        p.ovf_entries = need > p.lds_entries ? need - p.lds_entries : 0;
+        if (uint64_t(p.ovf_entries) * blocks_for_rays * kBlockThreads * sizeof(uint32_t) > (uint64_t(e->static_overflow_mb) << 20)) {
+            p.lds_entries = std::max(need, 1u);
+            p.ovf_entries = 0;
+        }
     }
     p.lds_bytes = trace_lds_bytes(p.lds_entries, p.fetch_dma);
     if (p.lds_bytes > e->lds_per_block_max)
@@ -176,12 +189,14 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     }
     a.refill_threshold = std::min(std::max(e->refill_threshold, 1u), 64u);
     a.tri_threshold = std::min(std::max(e->tri_threshold, 1u), 64u);
+    a.coherent_detect = e->coherent_detect;
 
     if (p.persistent) VT_HIP(hipMemsetAsync(e->d_cursor, 0, sizeof(uint32_t), stream));
     if (e->timing) VT_HIP(hipEventRecord(e->ev_start, stream));
     VT_HIP(launch_trace(a, any_hit, stats, p.persistent, p.fetch_dma, p.grid_blocks, p.lds_bytes, stream));
     if (e->timing) { VT_HIP(hipEventRecord(e->ev_stop, stream)); e->ev_valid = true; }
     e->last_blocks = p.grid_blocks; e->last_threads = kBlockThreads; e->last_lds = uint32_t(p.lds_bytes);
+    e->last_persistent = p.persistent; e->last_dma = p.fetch_dma;
     return VT_OK;
 }
 
@@ -259,7 +274,10 @@ int vt_engine_set_option(vt_engine* e, const char* key, int64_t value)
 {
     if (!e || !key) return fail(VT_ERR_INVALID_ARG, "vt_engine_set_option: NULL");
     const std::string k(key);
-    if (k == "persistent") e->persistent = value != 0;
+    if (k == "persistent" && value >= 0 && value <= 2) e->persistent = int(value);
+    else if (k == "auto_static_factor" && value >= 0 && value <= 1024) e->auto_static_factor = uint32_t(value);
+    else if (k == "coherent_detect") e->coherent_detect = value != 0;
+    else if (k == "static_overflow_mb" && value >= 0 && value <= 65536) e->static_overflow_mb = uint32_t(value);
     else if (k == "lds_entries" && value >= 1 && value <= 4096) e->lds_entries = uint32_t(value);
     else if (k == "blocks_per_cu" && value >= 1 && value <= 64) e->blocks_per_cu = uint32_t(value);
     else if (k == "block_rays" && value >= 64 && value <= (1 << 24)) e->block_rays = uint32_t(value);
@@ -279,9 +297,14 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
     else if (k == "blocks_per_cu") *value = e->blocks_per_cu;
     else if (k == "block_rays") *value = e->block_rays;
     else if (k == "refill_threshold") *value = e->refill_threshold;
+    else if (k == "auto_static_factor") *value = e->auto_static_factor;
+    else if (k == "static_overflow_mb") *value = e->static_overflow_mb;
+    else if (k == "coherent_detect") *value = e->coherent_detect;
     else if (k == "tri_threshold") *value = e->tri_threshold;
     else if (k == "fetch_dma") *value = e->fetch_dma;
     else if (k == "cu_count") *value = e->cu_count;
+    else if (k == "last_persistent") *value = e->last_persistent;
+    else if (k == "last_fetch_dma") *value = e->last_dma;
     else if (k == "device") *value = e->device;
     else return fail(VT_ERR_INVALID_ARG, "vt_engine_get_option: unknown key: " + k);
     return VT_OK;

@@ -27,6 +27,7 @@ struct TraceArgs {
     uint32_t            block_rays;  // rays per block handed to a wave (multiple of 64)
     uint32_t            refill_threshold; // re-fill a wave once this many lanes are idle
     uint32_t            tri_threshold;    // run the TRI branch once this many lanes wait for it
+    uint32_t            coherent_detect;  // DMA kernel: per-wave octant probe -> direct fetch, whole-wave re-fill
 };
 
 struct HitAttrsArgs {

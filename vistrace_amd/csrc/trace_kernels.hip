@@ -150,6 +150,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
     // wave-uniform block cursor (PERSISTENT)
     uint64_t blk_cur = 0, blk_end = 0;
     bool exhausted = false;
+    bool coherent = false;   // wave-uniform: this wave's rays share a direction octant
 
     auto start_ray = [&](uint64_t idx) {
         const float4* r4 = reinterpret_cast<const float4*>(a.rays + idx);
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
             const uint64_t idle = __ballot(!has_ray);
             if (idle != 0 && !exhausted) {
                 const uint32_t nidle = __popcll(idle);
-                if (nidle >= a.refill_threshold || idle == ~0ull) {
+                // a coherent wave (see below) is only re-filled as a whole, so it stays coherent
+                if ((nidle >= a.refill_threshold && !coherent) || idle == ~0ull) {
                     if (blk_cur == blk_end) { // acquire the next block of consecutive rays
                         uint32_t b = 0;
                         if (lane == 0) b = atomicAdd(a.block_cursor, 1u);
@@ -220,6 +222,22 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                             if (L.node == kDone && L.tri_cur >= L.tri_end) finish_ray(); // empty scene / NaN range
                         }
                         blk_cur += nidle < avail ? nidle : avail;
+                        if constexpr (FETCH_DMA) {
+                            // Coherence probe when a wave starts from empty: if all of its rays share one
+                            // direction octant (camera-like packets) the lanes walk the tree together --
+                            // fetch records directly (neighbouring lanes hit the same L1 lines) and never
+                            // mix new rays into the wave until it has drained.
+                            if (idle == ~0ull) {
+                                const uint64_t act = __ballot(has_ray);
+                                const uint64_t ax = __ballot(has_ray && (__float_as_uint(L.dx) >> 31)),
+                                               ay = __ballot(has_ray && (__float_as_uint(L.dy) >> 31)),
+                                               az = __ballot(has_ray && (__float_as_uint(L.dz) >> 31));
+                                coherent = a.coherent_detect != 0 && (ax == 0 || ax == act) && (ay == 0 || ay == act) &&
+                                           (az == 0 || az == act);
+                            } else {
+                                coherent = false;
+                            }
+                        }
                     }
                 }
             }
@@ -237,8 +255,18 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
         const bool do_tri = want_tri && run_tri;
         const uint32_t rec = do_tri ? a.tri_base + L.tri_cur : (want_node ? L.node : kNoFetch);
 
-        float4 q0, q1, q2, q3;   // the record, direct fetch
+        float4 q0, q1, q2, q3;   // the record
+        bool fetched = false;
         if constexpr (FETCH_DMA) {
+            if (coherent) {      // wave-uniform
+                if (rec != kNoFetch) {
+                    const float4* g = reinterpret_cast<const float4*>(records + (size_t(rec) << 6));
+                    q0 = g[0]; q1 = g[1]; q2 = g[2]; q3 = g[3];
+                }
+                fetched = true;
+            }
+        }
+        if (FETCH_DMA && !fetched) {
             // quad-cooperative fetch through LDS: row k receives the records of every quad's lane k.
             // Addresses are base + 32-bit byte offset (the engine uses this kernel below 4 GiB).
             const uint32_t piece = (lane & 3u) * 16u;
@@ -274,7 +302,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                          : "memory");
             q0 = make_float4(v0.x, v0.y, v0.z, v0.w); q1 = make_float4(v1.x, v1.y, v1.z, v1.w);
             q2 = make_float4(v2.x, v2.y, v2.z, v2.w); q3 = make_float4(v3.x, v3.y, v3.z, v3.w);
-        } else {
+        } else if (!fetched) {
             if (rec != kNoFetch) {
                 const float4* g = reinterpret_cast<const float4*>(records + size_t(rec) * 64);
                 q0 = g[0]; q1 = g[1]; q2 = g[2]; q3 = g[3];
