@@ -52,6 +52,7 @@ def main() -> None:
     ap.add_argument("--kind", default="bounce", choices=["bounce", "primary"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--gen", default="device", choices=["device", "host"], help="where the synthetic rays are generated")
     ap.add_argument("--chunks", type=int, default=4, help="N > 1: trace/gather pipeline depth per step")
     ap.add_argument("--mode", default=None, choices=[None, "persistent", "static"])
     args = ap.parse_args()
@@ -83,7 +84,7 @@ def main() -> None:
     verts = W.make_scene(args.scene)
     tris = va.tris_setup(verts)
     t1 = time.time()
-    bvh = va.HostBvh(tris, nthreads=max(1, (os.cpu_count() or 8) // max(1, world)))   # ranks build side by side
+    bvh = va.HostBvh(tris, nthreads=max(1, len(os.sched_getaffinity(0)) // max(1, world)) if world > 1 else 0)   # ranks build side by side
     t2 = time.time()
     host_scene = va.HostScene(bvh)
     engine = va.Engine(local_rank)
@@ -99,18 +100,32 @@ def main() -> None:
     n = side * side
     cams = W.camera_positions(args.scene)
     cam = cams[rank % len(cams)]
-    prim_rays = W.primary_rays(side, side, pos=cam)
-    d_prim = tp.to_device(prim_rays, device)
+    stream0 = tp.current_stream_handle(device)
+    rays_host = None
+    if args.gen == "host":
+        prim_rays = W.primary_rays(side, side, pos=cam)
+        d_prim = tp.to_device(prim_rays, device)
+    else:   # rays are generated on the device (vt_gen_primary_dev / vt_gen_bounce_dev)
+        d_prim = tp.empty_records(n, RAY, device)
+        engine.gen_primary_dev(side, side, d_prim.data_ptr(), pos=tuple(float(x) for x in cam), stream=stream0)
     if args.kind == "primary":
-        d_rays, rays_host = d_prim, prim_rays
+        d_rays = d_prim
+        if args.gen == "host":
+            rays_host = prim_rays
     else:
         d_hits0 = tp.trace_closest(scene, d_prim, n)
-        attrs = tp.to_host(tp.hit_attrs(scene, d_prim, d_hits0, n), HIT_ATTRS)
-        miss = int((attrs["hit"] == 0).sum())
-        rays_host = W.bounce_rays(attrs, W.SEED + 3 + 1000 * rank)
-        d_rays = tp.to_device(rays_host, device)
-        del attrs, d_hits0, d_prim
-        log(f"[bench] bounce rays: {n} from {side}x{side} primary hits ({miss} primary misses re-filled)")
+        d_attrs = tp.hit_attrs(scene, d_prim, d_hits0, n)
+        miss = n - int(d_attrs.view(torch.int32).view(n, 16)[:, 15].sum().item())
+        seed = W.SEED + 3 + 1000 * rank
+        if args.gen == "host":
+            rays_host = W.bounce_rays(tp.to_host(d_attrs, HIT_ATTRS), seed)
+            d_rays = tp.to_device(rays_host, device)
+        else:
+            d_rays = tp.empty_records(n, RAY, device)
+            engine.gen_bounce_dev(d_attrs.data_ptr(), n, seed, d_rays.data_ptr(), stream=stream0)
+        del d_attrs, d_hits0, d_prim
+        log(f"[bench] bounce rays: {n} from {side}x{side} primary hits ({miss} primary misses"
+            f"{' re-filled' if args.gen == 'host' else ' -> null rays'}), generated on the {args.gen}")
     d_hits = tp.empty_records(n, HIT, device)
     gather_list = None
     if world > 1 and rank == 0:
@@ -198,7 +213,7 @@ def main() -> None:
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic (seeded; rays generated on the %s)" % args.gen,
         "config": {
             "workload": f"{args.scene}_{args.kind}{n}",
             "scene_triangles": int(len(tris)),
@@ -230,6 +245,8 @@ def main() -> None:
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) -------------------
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import binding as O
+        if rays_host is None:
+            rays_host = tp.to_host(d_rays, RAY)
         nodes = bvh.nodes().view(O.NODE)
         pidx = bvh.prim_indices()
         otris = O.tris_from_tri64(tris)

@@ -94,6 +94,9 @@ typedef struct vt_tri_attribs { float uv[3][2]; float alpha[3]; uint32_t ent_id;
  * A miss yields zeros with ent_id = material = VT_MISS. */
 typedef struct vt_hit_shade { float tex_uv[2]; float blend; uint32_t ent_id; uint32_t material; uint32_t pad[3]; } vt_hit_shade;
 
+/* Pinhole camera of the synthetic workloads (pixel-centre rays, row-major, top row first). */
+typedef struct vt_camera { float pos[3]; float forward[3]; float up[3]; float vfov_deg; uint32_t width; uint32_t height; } vt_camera;
+
 typedef struct vt_bvh        vt_bvh;        /* host: v1-layout tree                 */
 typedef struct vt_host_scene vt_host_scene; /* host: linearised pairs + tri records */
 typedef struct vt_engine     vt_engine;     /* one HIP device + stream              */
@@ -176,6 +179,15 @@ int vt_engine_synchronize(vt_engine* e);
 int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_t n);
 /* entIdx / texUV / blendFactor / submatIdx per hit (needs vt_scene_set_tri_attribs). d_out: n x vt_hit_shade. */
 int vt_hit_shade_dev(vt_scene* s, const void* d_hits, uint64_t n, void* d_out, void* stream);
+
+/* Device-side ray generation for wavefront-style callers; nothing is traced.
+ * vt_gen_primary_dev: width*height normalised pinhole rays, range [0, FLT_MAX].
+ * vt_gen_bounce_dev : one ray per hit record: origin = vistrace.CalcRayOrigin(Pos, Ng facing wo)
+ *   (source/VisTrace.cpp:1495-1517), direction = cosine hemisphere about that normal with the mapping of
+ *   hemisphere_cos (source/libraries/BSDF.cpp:69-77) and counter-based splitmix64 samples (seed, 2i / 2i+1);
+ *   a missed record yields a null ray (tmax = 1e-30) so that the batch keeps its size and order. */
+int vt_gen_primary_dev(vt_engine* e, const vt_camera* cam, void* d_rays, void* stream);
+int vt_gen_bounce_dev(vt_engine* e, const void* d_attrs, uint64_t n, uint64_t seed, void* d_rays, void* stream);
 
 /* When enabled, every trace launch is bracketed by HIP events on its stream;
  * vt_engine_last_kernel_ms synchronises on the last pair and returns its time. */

@@ -36,6 +36,7 @@ HIT_ATTRS = np.dtype([("pos", "<f4", 3), ("t", "<f4"), ("ngeo", "<f4", 3), ("pri
                       ("uvw", "<f4", 3), ("front", "<u4"), ("wo", "<f4", 3), ("hit", "<u4")])
 TRI_ATTRIBS = np.dtype([("uv", "<f4", (3, 2)), ("alpha", "<f4", 3), ("ent_id", "<u4"), ("material", "<u4"), ("pad", "<u4")])
 HIT_SHADE = np.dtype([("tex_uv", "<f4", 2), ("blend", "<f4"), ("ent_id", "<u4"), ("material", "<u4"), ("pad", "<u4", 3)])
+CAMERA = np.dtype([("pos", "<f4", 3), ("forward", "<f4", 3), ("up", "<f4", 3), ("vfov_deg", "<f4"), ("width", "<u4"), ("height", "<u4")])
 assert TRI_ATTRIBS.itemsize == 48 and HIT_SHADE.itemsize == 32
 assert RAY.itemsize == 32 and HIT.itemsize == 16 and BVH_NODE.itemsize == 32
 assert NODE_PAIR.itemsize == 64 and TRI64.itemsize == 64 and HIT_ATTRS.itemsize == 64
@@ -77,6 +78,8 @@ SYMBOLS = {
     "vt_hit_attrs_dev": (C.c_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     "vt_scene_set_tri_attribs": (C.c_int, [_vp, _vp, _u32]),
     "vt_hit_shade_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
+    "vt_gen_primary_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "vt_gen_bounce_dev": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "vt_engine_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "vt_engine_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "vt_engine_stream": (_vp, [_vp]),

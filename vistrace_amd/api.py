@@ -160,6 +160,18 @@ class Engine:
         check(lib.vt_engine_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def gen_primary_dev(self, width: int, height: int, d_rays: int, pos=(0.0, 0.0, 0.0), forward=(1.0, 0.0, 0.0),
+                        up=(0.0, 0.0, 1.0), vfov_deg: float = 60.0, stream: int = 0) -> None:
+        """width*height pinhole rays written to device memory (same camera model as workloads.primary_rays)."""
+        cam = np.zeros(1, _lib.CAMERA)
+        cam["pos"], cam["forward"], cam["up"], cam["vfov_deg"] = pos, forward, up, vfov_deg
+        cam["width"], cam["height"] = width, height
+        check(lib.vt_gen_primary_dev(self._h, ptr(cam), d_rays, stream or None))
+
+    def gen_bounce_dev(self, d_attrs: int, n: int, seed: int, d_rays: int, stream: int = 0) -> None:
+        """One cosine-hemisphere bounce ray per vt_hit_attrs record (same construction as workloads.bounce_rays)."""
+        check(lib.vt_gen_bounce_dev(self._h, d_attrs, n, seed & 0xFFFFFFFFFFFFFFFF, d_rays, stream or None))
+
     def launch_info(self) -> dict:
         b, t, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(lib.vt_engine_launch_info(self._h, C.byref(b), C.byref(t), C.byref(l)))

@@ -495,6 +495,29 @@ int vt_hit_shade_dev(vt_scene* s, const void* d_hits, uint64_t n, void* d_out, v
     return VT_OK;
 }
 
+int vt_gen_primary_dev(vt_engine* e, const vt_camera* cam, void* d_rays, void* stream)
+{
+    if (!e || !cam || !d_rays) return fail(VT_ERR_INVALID_ARG, "vt_gen_primary_dev: NULL argument");
+    if (uint64_t(cam->width) * cam->height > 0x7FFFFFFFull * kBlockThreads) return fail(VT_ERR_INVALID_ARG, "vt_gen_primary_dev: image too large");
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_gen_primary_dev: hipSetDevice failed");
+    GenPrimaryArgs a{*cam, static_cast<vt_ray*>(d_rays)};
+    VT_HIP(launch_gen_primary(a, static_cast<hipStream_t>(stream)));
+    return VT_OK;
+}
+
+int vt_gen_bounce_dev(vt_engine* e, const void* d_attrs, uint64_t n, uint64_t seed, void* d_rays, void* stream)
+{
+    if (!e) return fail(VT_ERR_INVALID_ARG, "vt_gen_bounce_dev: engine is NULL");
+    if (n == 0) return VT_OK;
+    if (!d_attrs || !d_rays) return fail(VT_ERR_INVALID_ARG, "vt_gen_bounce_dev: NULL device buffer");
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_gen_bounce_dev: hipSetDevice failed");
+    GenBounceArgs a{static_cast<const vt_hit_attrs*>(d_attrs), static_cast<vt_ray*>(d_rays), n, seed};
+    VT_HIP(launch_gen_bounce(a, static_cast<hipStream_t>(stream)));
+    return VT_OK;
+}
+
 int vt_engine_synchronize(vt_engine* e)
 {
     if (!e) return fail(VT_ERR_INVALID_ARG, "vt_engine_synchronize: NULL");

@@ -46,6 +46,11 @@ struct HitShadeArgs {
     uint64_t              n;
 };
 
+struct GenPrimaryArgs { vt_camera cam; vt_ray* rays; };
+struct GenBounceArgs { const vt_hit_attrs* attrs; vt_ray* rays; uint64_t n; uint64_t seed; };
+hipError_t launch_gen_primary(const GenPrimaryArgs& a, hipStream_t stream);
+hipError_t launch_gen_bounce(const GenBounceArgs& a, hipStream_t stream);
+
 size_t     trace_lds_bytes(uint32_t lds_entries, bool fetch_dma);
 hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, bool fetch_dma,
                         uint32_t grid_blocks, size_t lds_bytes, hipStream_t stream);

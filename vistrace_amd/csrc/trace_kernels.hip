@@ -453,6 +453,79 @@ __global__ __launch_bounds__(kBlockThreads) void hit_shade_kernel(HitShadeArgs a
     a.out[i] = o;
 }
 
+// ---- device-side ray generation (harness for wavefront callers) ----
+__global__ __launch_bounds__(kBlockThreads) void gen_primary_kernel(GenPrimaryArgs a)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
+    const uint32_t w = a.cam.width, h = a.cam.height;
+    if (i >= uint64_t(w) * h) return;
+    const uint32_t px = uint32_t(i % w), py = uint32_t(i / w);
+    // double precision set-up, rounded once to fp32 (as the host generator does)
+    double f[3] = {a.cam.forward[0], a.cam.forward[1], a.cam.forward[2]};
+    double up[3] = {a.cam.up[0], a.cam.up[1], a.cam.up[2]};
+    double fl = sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+    f[0] /= fl; f[1] /= fl; f[2] /= fl;
+    double r[3] = {f[1] * up[2] - f[2] * up[1], f[2] * up[0] - f[0] * up[2], f[0] * up[1] - f[1] * up[0]};
+    double rl = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    r[0] /= rl; r[1] /= rl; r[2] /= rl;
+    const double u[3] = {r[1] * f[2] - r[2] * f[1], r[2] * f[0] - r[0] * f[2], r[0] * f[1] - r[1] * f[0]};
+    const double th = tan(double(a.cam.vfov_deg) * 3.14159265358979323846 / 180.0 / 2.0);
+    const double sx = ((double(px) + 0.5) / w * 2.0 - 1.0) * th * (double(w) / h);
+    const double sy = (1.0 - (double(py) + 0.5) / h * 2.0) * th;
+    double d[3] = {f[0] + sx * r[0] + sy * u[0], f[1] + sx * r[1] + sy * u[1], f[2] + sx * r[2] + sy * u[2]};
+    const double dl = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    vt_ray ray;
+    for (int k = 0; k < 3; ++k) { ray.org[k] = a.cam.pos[k]; ray.dir[k] = float(d[k] / dl); }
+    ray.tmin = 0.f; ray.tmax = FLT_MAX;
+    a.rays[i] = ray;
+}
+
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t index)
+{
+    uint64_t z = seed + (index + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void gen_bounce_kernel(GenBounceArgs a)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
+    if (i >= a.n) return;
+    const vt_hit_attrs A = a.attrs[i];
+    vt_ray ray{};
+    if (A.hit == 0) {   // null ray: keeps batch size and order, cannot hit anything
+        ray.dir[0] = 1.f; ray.tmin = 0.f; ray.tmax = 1e-30f;
+        a.rays[i] = ray;
+        return;
+    }
+    // geometric normal flipped towards wo (the side the ray arrived from)
+    float n[3];
+    for (int k = 0; k < 3; ++k) n[k] = A.front ? A.ngeo[k] : -A.ngeo[k];
+    // vistrace.CalcRayOrigin, VisTrace.cpp:1495-1517
+    const float origin = 1.f / 32.f, fScale = 1.f / 65536.f, iScale = 256.f;
+    for (int k = 0; k < 3; ++k) {
+        const int32_t iOff = int32_t(n[k] * iScale);
+        const int32_t bits = int32_t(__float_as_uint(A.pos[k])) + (A.pos[k] < 0.f ? -iOff : iOff);
+        const float iPos = __uint_as_float(uint32_t(bits));
+        ray.org[k] = fabsf(A.pos[k]) < origin ? A.pos[k] + n[k] * fScale : iPos;
+    }
+    // hemisphere_cos, BSDF.cpp:69-77, samples = top 24 bits of splitmix64 outputs 2i and 2i+1
+    const float r1 = float(splitmix64_at(a.seed, 2 * i) >> 40) * (1.0f / 16777216.0f);
+    const float r2 = float(splitmix64_at(a.seed, 2 * i + 1) >> 40) * (1.0f / 16777216.0f);
+    const float z = sqrtf(r1), sinTheta = sqrtf(1.f - r1), phi = 2.f * 3.14159265358979323846f * r2;
+    const float lx = sinTheta * cosf(phi), ly = sinTheta * sinf(phi);
+    // orthonormal basis around n (Duff et al. 2017), as vistrace_amd/workloads.py::_onb
+    const float sign = n[2] >= 0.f ? 1.f : -1.f;
+    const float aa = -1.f / (sign + n[2]);
+    const float b = n[0] * n[1] * aa;
+    const float b1[3] = {1.f + sign * n[0] * n[0] * aa, sign * b, -sign * n[0]};
+    const float b2[3] = {b, sign + n[1] * n[1] * aa, -n[1]};
+    for (int k = 0; k < 3; ++k) ray.dir[k] = (b1[k] * lx + b2[k] * ly) + n[k] * z;
+    ray.tmin = 0.f; ray.tmax = FLT_MAX;
+    a.rays[i] = ray;
+}
+
 // ---- launchers ---------------------------------------------------------------------------
 template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA>
 static hipError_t launch_one(const TraceArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
@@ -517,6 +590,23 @@ hipError_t launch_hit_attrs(const HitAttrsArgs& a, hipStream_t stream)
     if (a.n == 0) return hipSuccess;
     const uint64_t blocks = (a.n + kBlockThreads - 1) / kBlockThreads;
     hipLaunchKernelGGL(hit_attrs_kernel, dim3(uint32_t(blocks)), dim3(kBlockThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_primary(const GenPrimaryArgs& a, hipStream_t stream)
+{
+    const uint64_t n = uint64_t(a.cam.width) * a.cam.height;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gen_primary_kernel, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0,
+                       stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_bounce(const GenBounceArgs& a, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gen_bounce_kernel, dim3(uint32_t((a.n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0,
+                       stream, a);
     return hipGetLastError();
 }
 
