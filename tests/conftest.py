@@ -69,6 +69,11 @@ def make_bundle(va, O):
     return _make
 
 
-@pytest.fixture(scope="session")
-def engine(va):
-    return va.Engine(0)
+@pytest.fixture(scope="session", params=["persistent", "static"])
+def engine(va, request):
+    """Every GPU parity test runs against both kernels: persistent waves (LDS-DMA fetch, lane re-fill,
+    coherence probe) and the one-ray-per-lane kernel that the default auto mode picks for small batches."""
+    eng = va.Engine(0)
+    eng.set_option("persistent", 1 if request.param == "persistent" else 0)
+    eng.set_option("static_overflow_mb", 2048)
+    return eng

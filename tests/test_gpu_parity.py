@@ -189,7 +189,8 @@ def test_launch_options_do_not_change_results(va, make_bundle):
     scene = va.Scene(eng, b.host_scene)
     rays = np.concatenate([W.primary_rays(96, 96), W.sphere_rays(6000, 3, origin=(100.0, 100.0, -200.0))])
     ref = b.oracle(rays)
-    configs = [dict(persistent=0), dict(persistent=1, fetch_dma=0), dict(persistent=1, fetch_dma=1, lds_entries=2),
+    configs = [dict(persistent=0), dict(persistent=2), dict(persistent=2, auto_static_factor=0), dict(persistent=1, coherent_detect=0),
+               dict(persistent=0, static_overflow_mb=0), dict(persistent=1, fetch_dma=0), dict(persistent=1, fetch_dma=1, lds_entries=2),
                dict(persistent=1, fetch_dma=1, lds_entries=64), dict(refill_threshold=1, tri_threshold=1, block_rays=64),
                dict(refill_threshold=64, tri_threshold=64, block_rays=4096), dict(blocks_per_cu=1),
                dict(fetch_dma=0, lds_entries=1, refill_threshold=3, tri_threshold=7)]
@@ -264,12 +265,14 @@ def test_full_size_properties_s1m(va, engine, make_bundle):
     sl = slice(0, 1 << 20)
     assert_hits_equal(hits[sl], b.oracle(rays[sl]))
     # determinism across the other launch modes (static one-ray-per-lane kernel, direct fetch)
-    for cfg in (dict(persistent=0), dict(persistent=1, fetch_dma=0)):
+    saved = {k: engine.get_option(k) for k in ("persistent", "fetch_dma", "coherent_detect")}
+    for cfg in (dict(persistent=0), dict(persistent=1, fetch_dma=0), dict(persistent=1, fetch_dma=1, coherent_detect=0)):
         for k, v in cfg.items():
             engine.set_option(k, v)
         again = tp.to_host(tp.trace_closest(scene, d_rays, n), va.HIT)
         assert (again.view(np.uint8) == hits.view(np.uint8)).all()
-    engine.set_option("persistent", 1); engine.set_option("fetch_dma", 1)
+    for k, v in saved.items():
+        engine.set_option(k, v)
     # any-hit <=> closest-hit
     occ = tp.trace_any(scene, d_rays, n).cpu().numpy()
     hit = hits["prim"] != O_MISS
@@ -404,3 +407,17 @@ def test_device_ray_generation_matches_host(va, engine, make_bundle):
     assert (nb["tmax"][::7] == np.float32(1e-30)).all() and (nb["tmax"][1::7] == got_b["tmax"][1::7]).all()
     assert (scene.trace_closest(nb)["prim"][::7] == O_MISS).all()
     assert_hits_equal(scene.trace_closest(got_b), b.oracle(got_b))
+
+
+def test_auto_mode_picks_kernel_by_batch_size(va, make_bundle):
+    from vistrace_amd import workloads as W
+    b = make_bundle("S1k")
+    eng = va.Engine(0)                                   # defaults: persistent = 2 (auto)
+    scene = va.Scene(eng, b.host_scene)
+    assert eng.get_option("persistent") == 2
+    small = W.sphere_rays(5000, 1)
+    assert_hits_equal(scene.trace_closest(small), b.oracle(small))
+    assert eng.get_option("last_persistent") == 0        # a few rays per resident lane -> one ray per lane
+    eng.set_option("auto_static_factor", 0)
+    assert_hits_equal(scene.trace_closest(small), b.oracle(small))
+    assert eng.get_option("last_persistent") == 1 and eng.get_option("last_fetch_dma") == 1

@@ -339,7 +339,8 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
     s->tri_base = (s->npairs + 1u) & ~1u;
     const size_t pair_bytes = hs.pairs.size() * sizeof(vt_node_pair);
     const size_t tri_off = size_t(s->tri_base) * 64, tri_bytes = hs.tris.size() * sizeof(vt_tri64);
-    const size_t rec_bytes = tri_off + tri_bytes;
+    // never empty: idle lanes of the DMA-fetch kernel read record 0, so it must exist (zeros for an empty scene)
+    const size_t rec_bytes = std::max<size_t>(tri_off + tri_bytes, 128);
     if (uint64_t(s->tri_base) + s->ntris >= 0xFFFFFFFFull) { delete s; return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: scene too large"); }
     hipError_t err = hipSuccess;
     if (rec_bytes != 0) {

@@ -24,7 +24,13 @@
 //    `lds_entries` deep, with a per-lane global overflow area for deeper trees;
 //  * persistent waves: a wave pulls blocks of consecutive rays from a global cursor and
 //    re-fills idle lanes (ballot + mbcnt prefix) once enough of them have retired, so
-//    divergent ray lengths do not leave lanes empty.
+//    divergent ray lengths do not leave lanes empty;
+//  * coherence probe: a wave that starts from empty with all rays in one direction octant
+//    (camera-like packets) fetches records directly and is only re-filled as a whole;
+//  * PERSISTENT=false: one ray per lane, no cursor and no re-fill -- what the engine's auto mode
+//    launches for small batches (no end-of-queue tail across the grid).
+// Measured issue costs behind the instruction choices (selects with SGPR-pair masks, v_max3/
+// v_min3, branch-free DMA): scripts/ubench_valu.hip, profiles/r1/notes.md.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -253,13 +259,15 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
         const uint64_t tri_mask = __ballot(want_tri);
         const bool run_tri = tri_mask != 0 && (uint32_t(__popcll(tri_mask)) >= a.tri_threshold || __ballot(want_node) == 0);
         const bool do_tri = want_tri && run_tri;
-        const uint32_t rec = do_tri ? a.tri_base + L.tri_cur : (want_node ? L.node : kNoFetch);
+        // idle lanes (no ray, or waiting for the TRI branch) fetch record 0 in the DMA form: an always-valid
+        // address keeps the four DMA loads branch-free; the direct form skips them instead
+        const uint32_t rec = do_tri ? a.tri_base + L.tri_cur : (want_node ? L.node : (FETCH_DMA ? 0u : kNoFetch));
 
         float4 q0, q1, q2, q3;   // the record
         bool fetched = false;
         if constexpr (FETCH_DMA) {
             if (coherent) {      // wave-uniform
-                if (rec != kNoFetch) {
+                if (do_tri || want_node) {
                     const float4* g = reinterpret_cast<const float4*>(records + (size_t(rec) << 6));
                     q0 = g[0]; q1 = g[1]; q2 = g[2]; q3 = g[3];
                 }
@@ -272,18 +280,14 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
             const uint32_t piece = (lane & 3u) * 16u;
             const uint32_t r0 = quad_broadcast<0>(rec), r1 = quad_broadcast<1>(rec),
                            r2 = quad_broadcast<2>(rec), r3 = quad_broadcast<3>(rec);
-            if (r0 != kNoFetch)
-                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r0 << 6) | piece)),
-                                                 (lds_ptr)(uintptr_t)(stage_lds + 0u * kStageRow), 16, 0, 0);
-            if (r1 != kNoFetch)
-                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r1 << 6) | piece)),
-                                                 (lds_ptr)(uintptr_t)(stage_lds + 1u * kStageRow), 16, 0, 0);
-            if (r2 != kNoFetch)
-                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r2 << 6) | piece)),
-                                                 (lds_ptr)(uintptr_t)(stage_lds + 2u * kStageRow), 16, 0, 0);
-            if (r3 != kNoFetch)
-                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r3 << 6) | piece)),
-                                                 (lds_ptr)(uintptr_t)(stage_lds + 3u * kStageRow), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r0 << 6) | piece)),
+                                             (lds_ptr)(uintptr_t)(stage_lds + 0u * kStageRow), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r1 << 6) | piece)),
+                                             (lds_ptr)(uintptr_t)(stage_lds + 1u * kStageRow), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r2 << 6) | piece)),
+                                             (lds_ptr)(uintptr_t)(stage_lds + 2u * kStageRow), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r3 << 6) | piece)),
+                                             (lds_ptr)(uintptr_t)(stage_lds + 3u * kStageRow), 16, 0, 0);
             // Wait for the DMA rows, then read this lane's 64-B record back with four ds_read_b128
             // (conflict-free with the padded rows).  One asm statement holds the reads and their
             // waits, so hipcc can neither split the reads nor consume a destination early
