@@ -52,6 +52,11 @@ struct vt_engine {
     // staging for the host-pointer entry points
     void*  d_rays = nullptr;  size_t d_rays_bytes = 0;
     void*  d_out  = nullptr;  size_t d_out_bytes = 0;
+    // single-ray / tiny-batch path: pinned, device-mapped host memory the kernel reads and writes in
+    // place (no copy calls: one launch + one stream sync per Traverse)
+    static constexpr uint32_t kTinyRays = 256;
+    vt_ray* h_tiny_rays = nullptr;  void* d_tiny_rays = nullptr;
+    char*   h_tiny_out  = nullptr;  void* d_tiny_out  = nullptr;
 
     // timing
     int        timing = 0;
@@ -245,6 +250,10 @@ int vt_engine_open(int device, vt_engine** out)
     e->fetch_dma = int(env_long("VT_FETCH_DMA", e->fetch_dma));
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->d_cursor), 256);
+    if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&e->h_tiny_rays), vt_engine::kTinyRays * sizeof(vt_ray), hipHostMallocMapped);
+    if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&e->h_tiny_out), vt_engine::kTinyRays * sizeof(vt_hit), hipHostMallocMapped);
+    if (err == hipSuccess) err = hipHostGetDevicePointer(&e->d_tiny_rays, e->h_tiny_rays, 0);
+    if (err == hipSuccess) err = hipHostGetDevicePointer(&e->d_tiny_out, e->h_tiny_out, 0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_start);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_stop);
     if (err != hipSuccess) {
@@ -264,6 +273,8 @@ void vt_engine_close(vt_engine* e)
     if (e->d_overflow) (void)hipFree(e->d_overflow);
     if (e->d_rays) (void)hipFree(e->d_rays);
     if (e->d_out) (void)hipFree(e->d_out);
+    if (e->h_tiny_rays) (void)hipHostFree(e->h_tiny_rays);
+    if (e->h_tiny_out) (void)hipHostFree(e->h_tiny_out);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -386,6 +397,16 @@ static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, si
     vt_engine* e = s->engine;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_trace: hipSetDevice failed");
+    if (n <= vt_engine::kTinyRays) {
+        // what AccelStruct:Traverse does per call: the kernel works directly on pinned host memory
+        std::memcpy(e->h_tiny_rays, rays, n * sizeof(vt_ray));
+        int rc = launch(s, e->d_tiny_rays, n, any_hit ? nullptr : e->d_tiny_out, any_hit ? e->d_tiny_out : nullptr, nullptr,
+                        any_hit, false, e->stream);
+        if (rc != VT_OK) return rc;
+        VT_HIP(hipStreamSynchronize(e->stream));
+        std::memcpy(out, e->h_tiny_out, n * out_elem);
+        return VT_OK;
+    }
     const uint64_t chunk = uint64_t(1) << 24; // 16 Mi rays = 512 MiB of rays per staging pass
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = std::min(chunk, n - off);
