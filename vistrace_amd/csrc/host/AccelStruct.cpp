@@ -131,22 +131,21 @@ int AccelStruct::Traverse(ILuaBase* LUA)
 {
     if (!mAccelBuilt)
         LUA->ThrowError("Unable to perform traversal, acceleration structure invalid (use AccelStruct:Rebuild to rebuild it)");
-    int numArgs = LUA->Top();
+    const int numArgs = LUA->Top();
 
+    // (origin, direction) are mandatory Vectors; the four numbers are optional and nil keeps the default
     LUA->CheckType(2, Type::Vector);
     LUA->CheckType(3, Type::Vector);
-    Vector origin = LUA->GetVector(2);
-    Vector direction = LUA->GetVector(3);
+    const Vector origin = LUA->GetVector(2), direction = LUA->GetVector(3);
+    auto optional_number = [&](int pos, float dflt) {
+        return (numArgs >= pos && !LUA->IsType(pos, Type::Nil)) ? static_cast<float>(LUA->CheckNumber(pos)) : dflt;
+    };
+    const float tMin = optional_number(4, 0.f);            // AccelStruct.cpp:790-791
+    const float tMax = optional_number(5, FLT_MAX);        // :793-794
+    const float coneWidth = optional_number(6, -1.f);      // :796-797 (negative: mip 0 only)
+    const float coneAngle = optional_number(7, -1.f);      // :799-800
 
-    float tMin = 0.f;
-    if (numArgs > 3 && !LUA->IsType(4, Type::Nil)) tMin = static_cast<float>(LUA->CheckNumber(4));
-    float tMax = FLT_MAX;
-    if (numArgs > 4 && !LUA->IsType(5, Type::Nil)) tMax = static_cast<float>(LUA->CheckNumber(5));
-    float coneWidth = -1;
-    if (numArgs > 5 && !LUA->IsType(6, Type::Nil)) coneWidth = static_cast<float>(LUA->CheckNumber(6));
-    float coneAngle = -1;
-    if (numArgs > 6 && !LUA->IsType(7, Type::Nil)) coneAngle = static_cast<float>(LUA->CheckNumber(7));
-
+    // same checks, order and messages as :802-806
     if (coneWidth >= 0 && coneAngle <= 0.f) LUA->ThrowError("Valid cone width but invalid cone angle passed");
     if (coneWidth < 0 && coneAngle > 0.f) LUA->ThrowError("Valid cone angle but invalid cone width passed");
     if (tMin < 0.f) LUA->ArgError(4, "tMin cannot be less than 0");

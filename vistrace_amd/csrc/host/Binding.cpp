@@ -26,23 +26,34 @@ LUA_FUNCTION(AccelStruct_gc)                                           // VisTra
     return 0;
 }
 
-LUA_FUNCTION(vistrace_CreateAccel)                                     // VisTrace.cpp:770-792
+// Both CreateAccel(ents, traceWorld) and accel:Rebuild(ents, traceWorld) accept nothing / nil / a table
+// for `ents` and leave exactly [self,] table on the stack for PopulateAccel (VisTrace.cpp:776-788, 806-815).
+// `tablePos` is where the table argument sits (1 for CreateAccel, 2 for Rebuild); `onBadType` runs before
+// the type error is raised (the error does not unwind C++ frames in the real module).
+template <class Cleanup>
+static void NormaliseEntityListArg(ILuaBase* LUA, int tablePos, Cleanup onBadType)
 {
-    bool traceWorld = true;
-    if (LUA->IsType(2, Type::Bool)) traceWorld = LUA->GetBool(2);
-
-    AccelStruct* pAccelStruct = new AccelStruct();
-    if (LUA->Top() == 0) LUA->CreateTable();
-    else if (LUA->IsType(1, Type::Nil)) {
-        LUA->Pop(LUA->Top());
+    if (LUA->Top() < tablePos) {
+        LUA->CreateTable();
+    } else if (LUA->IsType(tablePos, Type::Nil)) {
+        LUA->Pop(LUA->Top() - (tablePos - 1));
         LUA->CreateTable();
     } else {
-        if (!LUA->IsType(1, Type::Table)) {
-            delete pAccelStruct;                    // throwing will not destruct it
-            LUA->CheckType(1, Type::Table);         // formatted type error
+        if (!LUA->IsType(tablePos, Type::Table)) {
+            onBadType();
+            LUA->CheckType(tablePos, Type::Table);   // raises the formatted type error
         }
-        LUA->Pop(LUA->Top() - 1);                   // leave only the table
+        LUA->Pop(LUA->Top() - tablePos);
     }
+}
+
+static bool TraceWorldArg(ILuaBase* LUA, int pos) { return LUA->IsType(pos, Type::Bool) ? LUA->GetBool(pos) : true; }
+
+LUA_FUNCTION(vistrace_CreateAccel)                                     // VisTrace.cpp:770-792
+{
+    const bool traceWorld = TraceWorldArg(LUA, 2);
+    AccelStruct* pAccelStruct = new AccelStruct();
+    NormaliseEntityListArg(LUA, 1, [&] { delete pAccelStruct; });
     try {
         pAccelStruct->PopulateAccel(LUA, traceWorld ? g_pWorld : nullptr);
     } catch (...) {                                 // test doubles throw instead of longjmp: do not leak
@@ -56,17 +67,9 @@ LUA_FUNCTION(vistrace_CreateAccel)                                     // VisTra
 LUA_FUNCTION(AccelStruct_Rebuild)                                      // VisTrace.cpp:798-818
 {
     LUA->CheckType(1, AccelStruct_id);
-    bool traceWorld = true;
-    if (LUA->IsType(3, Type::Bool)) traceWorld = LUA->GetBool(3);
+    const bool traceWorld = TraceWorldArg(LUA, 3);
     AccelStruct* pAccelStruct = LUA->GetUserType<AccelStruct>(1, AccelStruct_id);
-    if (LUA->Top() == 1) LUA->CreateTable();
-    else if (LUA->IsType(2, Type::Nil)) {
-        LUA->Pop(LUA->Top());
-        LUA->CreateTable();
-    } else {
-        LUA->CheckType(2, Type::Table);
-        LUA->Pop(LUA->Top() - 2);                   // leave self and the table
-    }
+    NormaliseEntityListArg(LUA, 2, [] {});
     pAccelStruct->PopulateAccel(LUA, traceWorld ? g_pWorld : nullptr);
     return 0;
 }
