@@ -200,12 +200,17 @@ static inline int leaf_isect(const vto_node* leaf, const uint32_t* prim_indices,
     return 0;
 }
 
+/* diagnostics for stack sizing (tests/scripts only): per-call maximum stack depth and push count */
+static _Thread_local uint32_t g_last_max_sp, g_last_pushes;
+void vto_last_stack_use(uint32_t* max_sp, uint32_t* pushes) { *max_sp = g_last_max_sp; *pushes = g_last_pushes; }
+
 int vto_traverse(const vto_node* nodes, const uint32_t* prim_indices,
                  const vto_tri* tris, const vto_ray* ray, int any_hit,
                  vto_hit* best, vto_stats* stats)
 {
     uint64_t steps = 0, tests = 0;
     int found = 0;
+    g_last_max_sp = 0; g_last_pushes = 0;
     float tmax = ray->tmax;            /* traverse() takes the ray by value */
     best->prim = VTO_MISS; best->t = 0.f; best->u = 0.f; best->v = 0.f;
 
@@ -249,6 +254,8 @@ int vto_traverse(const vto_node* nodes, const uint32_t* prim_indices,
                     if (fl > fr) { const vto_node* tmp = left; left = right; right = tmp; }
                     if (sp >= VTO_STACK_CAP) { fprintf(stderr, "vt_oracle: stack overflow\n"); abort(); }
                     stack[sp++] = right->first;     /* far inner node's first-child index */
+                    ++g_last_pushes;
+                    if ((uint32_t)sp > g_last_max_sp) g_last_max_sp = (uint32_t)sp;
                 }
                 left = &nodes[left->first];
             } else if (right) {

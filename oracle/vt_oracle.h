@@ -96,6 +96,9 @@ int vto_traverse(const vto_node* nodes, const uint32_t* prim_indices,
                  const vto_tri* tris, const vto_ray* ray, int any_hit,
                  vto_hit* hit, vto_stats* stats);
 
+/* Stack use of the calling thread's last vto_traverse (diagnostic for stack sizing). */
+void vto_last_stack_use(uint32_t* max_sp, uint32_t* pushes);
+
 /* OpenMP loop over rays around vto_traverse: schedule(dynamic,4096).
  * per_ray_stats (2*nrays uint32: steps,tests) and total may be NULL.
  * nthreads <= 0 -> omp default. Returns the thread count used. */
