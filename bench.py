@@ -53,7 +53,9 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--gen", default="device", choices=["device", "host"], help="where the synthetic rays are generated")
-    ap.add_argument("--chunks", type=int, default=4, help="N > 1: trace/gather pipeline depth per step")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (one GPU per rank); gloo = test mode: ranks may share a GPU, hits gathered via host")
+    ap.add_argument("--chunks", type=int, default=2, help="N > 1: chunks per batch in the trace/gather pipeline")
     ap.add_argument("--mode", default=None, choices=[None, "persistent", "static"])
     args = ap.parse_args()
 
@@ -62,7 +64,7 @@ def main() -> None:
 
     import vistrace_amd as va
     from vistrace_amd import torch_plumbing as tp
-    from vistrace_amd.distributed import pipelined_trace_gather
+    from vistrace_amd.distributed import HitGatherPipeline
     from vistrace_amd import workloads as W
     from vistrace_amd._lib import HIT, HIT_ATTRS, RAY, RAY_STATS
 
@@ -74,10 +76,15 @@ def main() -> None:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the traversal has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, ndev)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     # ---- scene: CPU build once, upload once (Rebuild) -----------------------------------
     t0 = time.time()
@@ -87,7 +94,7 @@ def main() -> None:
     bvh = va.HostBvh(tris, nthreads=max(1, len(os.sched_getaffinity(0)) // max(1, world)) if world > 1 else 0)   # ranks build side by side
     t2 = time.time()
     host_scene = va.HostScene(bvh)
-    engine = va.Engine(local_rank)
+    engine = va.Engine(dev_index)
     if args.mode is not None:
         engine.set_option("persistent", 1 if args.mode == "persistent" else 0)
     scene = va.Scene(engine, host_scene)
@@ -127,9 +134,7 @@ def main() -> None:
         log(f"[bench] bounce rays: {n} from {side}x{side} primary hits ({miss} primary misses"
             f"{' re-filled' if args.gen == 'host' else ' -> null rays'}), generated on the {args.gen}")
     d_hits = tp.empty_records(n, HIT, device)
-    gather_list = None
-    if world > 1 and rank == 0:
-        gather_list = [tp.empty_records(n, HIT, device) for _ in range(world)]   # receive buffers, reused every step
+    pipe = HitGatherPipeline(n, device, nchunks=args.chunks, via_host=args.backend == "gloo") if world > 1 else None
     t4 = time.time()
     log(f"[bench] ray set-up {t4 - t3:.2f}s")
 
@@ -148,16 +153,16 @@ def main() -> None:
 
     stream = tp.current_stream_handle(device)
 
-    def trace_chunk(lo, hi):
-        scene.trace_closest_dev(d_rays.data_ptr() + lo * RAY.itemsize, hi - lo, d_hits.data_ptr() + lo * HIT.itemsize, stream)
+    def trace_chunk(hits_buf, lo, hi):
+        scene.trace_closest_dev(d_rays.data_ptr() + lo * RAY.itemsize, hi - lo, hits_buf.data_ptr() + lo * HIT.itemsize, stream)
 
     def step():
         if world == 1:
             tp.trace_closest(scene, d_rays, n, d_hits)
         else:
-            # the single exchange of the path: hit records -> rank 0 (RCCL gather over xGMI), chunked so
-            # that the gather of chunk c overlaps the trace of chunk c+1
-            pipelined_trace_gather(trace_chunk, n, d_hits, gather_list, nchunks=args.chunks)
+            # the single exchange of the path: hit records -> rank 0 (RCCL gather over xGMI).  Chunked and
+            # double-buffered: the gather of one chunk/batch overlaps the tracing of the next
+            pipe.submit(trace_chunk)
 
     # dominant-kernel time for the roofline: whole-batch launches bracketed by HIP events
     pre_ms = []
@@ -166,6 +171,8 @@ def main() -> None:
         pre_ms.append(engine.last_kernel_ms())
     for _ in range(args.warmup):
         step()
+    if pipe is not None:
+        pipe.drain()
     kernel_ms = []
     torch.cuda.synchronize(device)
     if world > 1:
@@ -176,13 +183,15 @@ def main() -> None:
         step()
         if world == 1:
             kernel_ms.append(engine.last_kernel_ms())  # HIP events on the launch stream
+    if pipe is not None:
+        pipe.drain()                                   # every hit record has reached rank 0
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     engine.set_timing(False)
@@ -220,7 +229,7 @@ def main() -> None:
             "rays_per_gpu": n,
             "query": "closest-hit",
             "ray_kind": "cosine-hemisphere bounce (incoherent)" if args.kind == "bounce" else "pinhole primary",
-            "parallelism": f"rays sharded x{world}, BVH replicated" + (f", RCCL gather of hits to rank 0 ({args.chunks} chunks, overlapped)" if world > 1 else ""),
+            "parallelism": f"rays sharded x{world}, BVH replicated" + (f", RCCL gather of hits to rank 0 ({args.chunks} chunks per batch, double-buffered, overlapped with tracing)" if world > 1 else ""),
             "kernel_mode": ("persistent" + ("+lds-dma-fetch" if engine.get_option("last_fetch_dma") else "")) if engine.get_option("last_persistent") else "static",
             "launch_options": {k: engine.get_option(k) for k in ("lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold")},
             "launch": engine.launch_info(),

@@ -65,7 +65,7 @@ def _worker_weak(rank, world, port, n, result_path):
         import vistrace_amd as va
         from oracle import binding as O
         from vistrace_amd import workloads as W
-        from vistrace_amd.distributed import chunk_bounds, pipelined_trace_gather
+        from vistrace_amd.distributed import HitGatherPipeline, chunk_bounds, pipelined_trace_gather
         tris = va.tris_setup(W.make_scene("S1k"))
         bvh = va.HostBvh(tris, nthreads=1)
         nodes, pidx, otris = bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris)
@@ -83,8 +83,23 @@ def _worker_weak(rank, world, port, n, result_path):
         for _ in range(2):   # buffers are reused across steps
             pipelined_trace_gather(trace_chunk, n, hits_local, recv, nchunks=3)
         assert chunk_bounds(n, 3)[0][0] == 0 and chunk_bounds(n, 3)[-1][1] == n
+        # the double-buffered pipeline bench.py uses: three batches, results of the last two checked
+        pipe = HitGatherPipeline(n, torch.device("cpu"), nchunks=2)
+        batch_rays = [W.sphere_rays(n, 900 + 10 * k + rank, origin=(1.0 * k, 2.0, 3.0)) for k in range(3)]
+        used = []
+        for k in range(3):
+            def tc(buf, lo, hi, k=k):
+                h, _, _, _, _ = O.traverse_batch(nodes, pidx, otris, batch_rays[k][lo:hi], nthreads=1)
+                buf[lo * 16: hi * 16] = torch.from_numpy(h.view(np.uint8).reshape(-1).copy())
+            used.append(pipe.submit(tc))
+        pipe.drain()
+        assert used == [0, 1, 0]
         if rank == 0:
             ok = True
+            for k in (1, 2):
+                for r in range(world):
+                    full, _, _, _, _ = O.traverse_batch(nodes, pidx, otris, W.sphere_rays(n, 900 + 10 * k + r, origin=(1.0 * k, 2.0, 3.0)), nthreads=1)
+                    ok = ok and pipe.recv[used[k]][r].numpy().tobytes() == full.tobytes()
             for r in range(world):
                 full, _, _, _, _ = O.traverse_batch(nodes, pidx, otris, rays_of(r), nthreads=1)
                 ok = ok and recv[r].numpy().tobytes() == full.tobytes()

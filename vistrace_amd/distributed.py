@@ -78,19 +78,75 @@ def chunk_bounds(n: int, nchunks: int, align: int = 64) -> List[Tuple[int, int]]
 
 def pipelined_trace_gather(trace_chunk: Callable[[int, int], None], n: int, hits_local: torch.Tensor,
                            recv_bufs: Optional[List[torch.Tensor]], nchunks: int = 4, record_bytes: int = HIT_BYTES,
-                           dst: int = 0) -> None:
+                           dst: int = 0, via_host: bool = False) -> None:
     """Weak-scaling step: every rank traces its own n rays in chunks and the hit records of chunk c
     travel to `dst` (async gather) while chunk c+1 is being traced.
 
     trace_chunk(lo, hi) enqueues the trace of rays [lo, hi) into hits_local (bytes [lo*rb, hi*rb)).
     recv_bufs: on dst, one n*record_bytes uint8 tensor per rank (reused across steps); None elsewhere.
+    via_host=True stages every chunk through host memory (for backends without device-tensor gather,
+    e.g. gloo when two ranks share one GPU in a test); the RCCL path gathers device tensors directly.
     Returns after every gather has completed with respect to the current stream."""
     rank = dist.get_rank()
     works = []
     for lo, hi in chunk_bounds(n, nchunks):
         trace_chunk(lo, hi)
         send = hits_local[lo * record_bytes: hi * record_bytes]
+        if via_host:
+            host_recv = [torch.empty(send.numel(), dtype=torch.uint8) for _ in recv_bufs] if rank == dst else None
+            dist.gather(send.cpu(), host_recv, dst=dst)
+            if rank == dst:
+                for b, h in zip(recv_bufs, host_recv):
+                    b[lo * record_bytes: hi * record_bytes].copy_(h)
+            continue
         recv = [b[lo * record_bytes: hi * record_bytes] for b in recv_bufs] if rank == dst else None
         works.append(dist.gather(send, recv, dst=dst, async_op=True))
     for w in works:
         w.wait()
+
+
+class HitGatherPipeline:
+    """Double-buffered form of pipelined_trace_gather for a stream of batches (bench.py's N > 1 loop).
+
+    Batch b traces into hits[b % 2] and gathers into recv[b % 2]; the gathers of batch b are only waited
+    for when buffer b % 2 is needed again (batch b + 2) or at drain(), so the xGMI transfer of one batch
+    overlaps the tracing of the next.  Results on the root: recv[b % 2][rank] after drain()/next reuse."""
+
+    def __init__(self, n: int, device, nchunks: int = 2, record_bytes: int = HIT_BYTES, dst: int = 0,
+                 via_host: bool = False):
+        self.n, self.nchunks, self.rb, self.dst, self.via_host = n, nchunks, record_bytes, dst, via_host
+        world, rank = dist.get_world_size(), dist.get_rank()
+        self.hits = [torch.empty(n * record_bytes, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = [[torch.empty(n * record_bytes, dtype=torch.uint8, device=device) for _ in range(world)]
+                     if rank == dst else None for _ in range(2)]
+        self.pending: List[List] = [[], []]
+        self.batch = 0
+
+    def submit(self, trace_chunk: Callable[[torch.Tensor, int, int], None]) -> int:
+        """trace_chunk(hits_buffer, lo, hi) enqueues the trace of rays [lo, hi) of the current batch.
+        Returns the buffer index the batch uses."""
+        b = self.batch % 2
+        for w in self.pending[b]:
+            w.wait()
+        self.pending[b] = []
+        rank = dist.get_rank()
+        for lo, hi in chunk_bounds(self.n, self.nchunks):
+            trace_chunk(self.hits[b], lo, hi)
+            send = self.hits[b][lo * self.rb: hi * self.rb]
+            if self.via_host:
+                host_recv = [torch.empty(send.numel(), dtype=torch.uint8) for _ in self.recv[b]] if rank == self.dst else None
+                dist.gather(send.cpu(), host_recv, dst=self.dst)
+                if rank == self.dst:
+                    for buf, h in zip(self.recv[b], host_recv):
+                        buf[lo * self.rb: hi * self.rb].copy_(h)
+                continue
+            recv = [buf[lo * self.rb: hi * self.rb] for buf in self.recv[b]] if rank == self.dst else None
+            self.pending[b].append(dist.gather(send, recv, dst=self.dst, async_op=True))
+        self.batch += 1
+        return b
+
+    def drain(self) -> None:
+        for p in self.pending:
+            for w in p:
+                w.wait()
+        self.pending = [[], []]
