@@ -55,6 +55,23 @@ def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "s1k_golden.npz")
     np.savez_compressed(out, verts=verts, nodes=nodes, prim_indices=pidx, rays=rays, hits=hits, stats=stats,
                         occluded=(any_hits["prim"] != O.MISS).astype(np.uint8))
+    # ---- second fixture: one-sided heightfield (cull flag set), rays from above and below, windows ----
+    tverts, tflags = W.make_terrain(16)
+    ttris = va.tris_setup(tverts, tflags)
+    tbvh = va.HostBvh(ttris)
+    tnodes, tpidx, totris = tbvh.nodes(), tbvh.prim_indices(), O.tris_from_tri64(ttris)
+    trays = np.concatenate([W.sphere_rays(1024, W.SEED + 21, origin=(0.0, 0.0, 60.0)),
+                            W.sphere_rays(1024, W.SEED + 22, origin=(3.0, -4.0, -30.0))])
+    twin = trays[:256].copy()
+    twin["tmin"], twin["tmax"] = 30.0, 70.0
+    trays = np.concatenate([trays, twin])
+    thits, tstats, _, _, _ = O.traverse_batch(tnodes.view(O.NODE), tpidx, totris, trays, want_stats=True)
+    tbrute = O.trace_brute(totris, trays)
+    assert (tbrute["t"].view(np.uint32) == thits["t"].view(np.uint32)).all()
+    assert ((tbrute["prim"] == O.MISS) == (thits["prim"] == O.MISS)).all()
+    tout = os.path.join(os.path.dirname(os.path.abspath(__file__)), "terrain_golden.npz")
+    np.savez_compressed(tout, verts=tverts, flags=tflags, nodes=tnodes, prim_indices=tpidx, rays=trays, hits=thits, stats=tstats)
+    print(f"wrote {tout}: {len(trays)} rays, {int((thits['prim'] != O.MISS).sum())} hits, {os.path.getsize(tout) / 1024:.0f} KiB")
     print(f"wrote {out}: {len(rays)} rays, {int((hits['prim'] != O.MISS).sum())} hits, {ties} tie-broken indices, "
           f"{os.path.getsize(out) / 1024:.0f} KiB")
 

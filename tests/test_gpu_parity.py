@@ -49,6 +49,15 @@ def test_golden_vectors(va, engine):
     assert (st["steps"] == gold["stats"][:, 0]).all() and (st["tests"] == gold["stats"][:, 1]).all()
 
 
+def test_terrain_golden_vectors(va, engine):
+    gold = np.load(os.path.join(os.path.dirname(GOLDEN), "terrain_golden.npz"))
+    scene = va.Scene(engine, va.HostScene(va.HostBvh(va.tris_setup(gold["verts"], gold["flags"]))))
+    rays = gold["rays"].view(va.RAY)
+    assert_hits_equal(scene.trace_closest(rays), gold["hits"].view(va.HIT))
+    _, st = stats_on_device(va, scene, rays)
+    assert (st["steps"] == gold["stats"][:, 0]).all() and (st["tests"] == gold["stats"][:, 1]).all()
+
+
 # ---- analytic known answers, on the device ---------------------------------------------------------
 TRI = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32)
 
@@ -421,3 +430,31 @@ def test_auto_mode_picks_kernel_by_batch_size(va, make_bundle):
     eng.set_option("auto_static_factor", 0)
     assert_hits_equal(scene.trace_closest(small), b.oracle(small))
     assert eng.get_option("last_persistent") == 1 and eng.get_option("last_fetch_dma") == 1
+
+
+def test_config4_shadow_rays_any_hit(va, engine, make_bundle):
+    """BASELINE config 4 (any-hit shadow rays, tMax early-out) at 16 Mi rays on S1M: occluded <=> the
+    closest-hit kernel finds a hit in the same interval; oracle any-hit on a 256 Ki slice."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S1M")
+    scene = upload(va, engine, b)
+    dev = torch.device("cuda", 0)
+    side = 2048
+    n0 = side * side
+    d_prim = tp.empty_records(n0, va.RAY, dev)
+    engine.gen_primary_dev(side, side, d_prim.data_ptr(), stream=tp.current_stream_handle(dev))
+    d_h = tp.trace_closest(scene, d_prim, n0)
+    attrs = tp.to_host(tp.hit_attrs(scene, d_prim, d_h, n0), va.HIT_ATTRS)
+    rays = W.shadow_rays(attrs, W.light_positions("S1M"), W.SEED + 4, per_hit=4)      # 16 Mi rays
+    n = len(rays)
+    d_rays = tp.to_device(rays, dev)
+    occ = tp.trace_any(scene, d_rays, n).cpu().numpy()
+    hits = tp.to_host(tp.trace_closest(scene, d_rays, n), va.HIT)
+    assert (occ == (hits["prim"] != O_MISS)).all()
+    assert 0.05 < occ.mean() < 0.95                      # lights are both visible and hidden
+    sl = slice(0, 1 << 18)
+    ref = b.oracle(rays[sl], any_hit=True)
+    assert (occ[sl] == (ref["prim"] != O_MISS)).all()
+    assert (hits["t"][hits["prim"] != O_MISS] <= rays["tmax"][hits["prim"] != O_MISS]).all()

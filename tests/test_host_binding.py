@@ -38,3 +38,23 @@ def test_host_code_under_asan_ubsan():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 failed" in out.stdout
+
+
+def test_plain_c_example_builds_and_fails_loudly_without_gpu():
+    """examples/trace_batch.c compiles as C11 against the header; without a device it reports
+    VT_ERR_HIP (exit 2) instead of falling back to anything."""
+    import torch
+    _build()
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "trace_batch")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; covered by test_plain_c_example_on_gpu")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "no HIP device" in out.stderr + out.stdout or "hipGetDeviceCount" in out.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_example_on_gpu():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "_build", "trace_batch")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr

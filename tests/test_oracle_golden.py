@@ -61,3 +61,21 @@ def test_product_tri_setup_matches_oracle(va, O, gold):
     for k in ("p0", "e1", "e2", "n"):
         assert (mine[k].view(np.uint32) == ref[k].view(np.uint32)).all()
     assert (mine["prim"] == np.arange(len(mine))).all()
+
+
+TERRAIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "terrain_golden.npz")
+
+
+def test_terrain_golden_cull_flags(va, O):
+    """One-sided heightfield (VT_TRI_CULL_BACKFACE on every triangle): oracle and builder vs the fixture."""
+    g = np.load(TERRAIN)
+    tris = O.tris_setup(g["verts"], g["flags"])
+    hits, stats, _, _, _ = O.traverse_batch(g["nodes"].view(O.NODE), g["prim_indices"], tris, g["rays"].view(O.RAY), want_stats=True)
+    ref = g["hits"].view(O.HIT)
+    assert (hits["prim"] == ref["prim"]).all() and (stats == g["stats"]).all()
+    for k in ("t", "u", "v"):
+        assert (hits[k].view(np.uint32) == ref[k].view(np.uint32)).all()
+    n_above = int((ref["prim"][:1024] != O.MISS).sum()); n_below = int((ref["prim"][1024:2048] != O.MISS).sum())
+    assert n_above != n_below and n_above > 0 and n_below > 0        # the cull bit changes the answer
+    bvh = va.HostBvh(va.tris_setup(g["verts"], g["flags"]))
+    assert (bvh.nodes().view(np.uint8) == g["nodes"].view(np.uint8)).all()
