@@ -52,6 +52,8 @@ def main() -> None:
     ap.add_argument("--kind", default="bounce", choices=["bounce", "primary"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--builder", default="ploc", choices=["ploc", "sah"],
+                    help="ploc = the reference's build pipeline (default); sah = opt-in binned SAH (not the headline)")
     ap.add_argument("--gen", default="device", choices=["device", "host"], help="where the synthetic rays are generated")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (one GPU per rank); gloo = test mode: ranks may share a GPU, hits gathered via host")
@@ -91,7 +93,7 @@ def main() -> None:
     verts = W.make_scene(args.scene)
     tris = va.tris_setup(verts)
     t1 = time.time()
-    bvh = va.HostBvh(tris, nthreads=max(1, len(os.sched_getaffinity(0)) // max(1, world)) if world > 1 else 0)   # ranks build side by side
+    bvh = va.HostBvh(tris, nthreads=max(1, len(os.sched_getaffinity(0)) // max(1, world)) if world > 1 else 0, builder=args.builder)   # ranks build side by side
     t2 = time.time()
     host_scene = va.HostScene(bvh)
     engine = va.Engine(dev_index)
@@ -226,6 +228,7 @@ def main() -> None:
         "config": {
             "workload": f"{args.scene}_{args.kind}{n}",
             "scene_triangles": int(len(tris)),
+            "bvh_builder": "PLOC r=14 + SAH leaf collapse (reference pipeline)" if args.builder == "ploc" else "binned SAH (opt-in)",
             "rays_per_gpu": n,
             "query": "closest-hit",
             "ray_kind": "cosine-hemisphere bounce (incoherent)" if args.kind == "bounce" else "pinhole primary",

@@ -117,6 +117,11 @@ int vt_tris_setup(const float* verts, const uint8_t* flags, uint32_t n, vt_tri64
  * radius 14), SAH leaf collapse.  tris in ORIGINAL order.  n == 0 gives an empty
  * tree (every trace misses).  nthreads <= 0: OpenMP default. */
 int             vt_bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, vt_bvh** out);
+/* Same, with the builder named.  VT_BUILDER_PLOC is the reference's pipeline (what vt_bvh_build uses);
+ * VT_BUILDER_BINNED_SAH is an opt-in top-down binned-SAH build (slower Rebuild, fewer traversal steps per
+ * ray; identical t,u,v -- only tie-broken indices can differ, as between any two trees). */
+enum vt_builder { VT_BUILDER_PLOC = 0, VT_BUILDER_BINNED_SAH = 1 };
+int             vt_bvh_build_ex(const vt_tri64* tris, uint32_t n, int nthreads, int builder, vt_bvh** out);
 void            vt_bvh_free(vt_bvh* bvh);
 uint32_t        vt_bvh_node_count(const vt_bvh* bvh);
 uint32_t        vt_bvh_prim_count(const vt_bvh* bvh);

@@ -458,3 +458,16 @@ def test_config4_shadow_rays_any_hit(va, engine, make_bundle):
     ref = b.oracle(rays[sl], any_hit=True)
     assert (occ[sl] == (ref["prim"] != O_MISS)).all()
     assert (hits["t"][hits["prim"] != O_MISS] <= rays["tmax"][hits["prim"] != O_MISS]).all()
+
+
+def test_sah_tree_on_device(va, engine, O):
+    """The kernels are tree-agnostic: on the opt-in binned-SAH tree the device still equals the oracle."""
+    from vistrace_amd import workloads as W
+    tris = va.tris_setup(W.make_scene("S10k"))
+    bvh = va.HostBvh(tris, builder="sah")
+    scene = va.Scene(engine, va.HostScene(bvh))
+    rays = np.concatenate([W.primary_rays(96, 64), W.sphere_rays(6000, 12, origin=(-200.0, 30.0, 10.0))])
+    ref, ref_st, _, _, _ = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris), rays, want_stats=True)
+    got, st = stats_on_device(va, scene, rays)
+    assert_hits_equal(got, ref)
+    assert (st["steps"] == ref_st[:, 0]).all() and (st["tests"] == ref_st[:, 1]).all()

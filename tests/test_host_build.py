@@ -118,3 +118,27 @@ def test_flags_travel_to_records(va):
     hs = va.HostScene(va.HostBvh(tris))
     lt = hs.tris()
     assert (lt["flags"] == flags[lt["prim"]]).all()
+
+
+@pytest.mark.parametrize("name", ["S1k", "S10k"])
+def test_optional_sah_builder(va, O, name):
+    """Opt-in binned-SAH builder: same structural invariants, deterministic, and the oracle finds the
+    same t,u,v on it as on the default PLOC tree (only tie-broken indices may differ)."""
+    from vistrace_amd import workloads as W
+    tris = va.tris_setup(W.make_scene(name))
+    sah = va.HostBvh(tris, builder="sah")
+    check_tree(va, tris, sah)
+    check_linearised(va.HostScene(sah), sah, tris)
+    again = va.HostBvh(tris, nthreads=1, builder="sah")
+    assert (again.nodes().view(np.uint8) == sah.nodes().view(np.uint8)).all()
+    ploc = va.HostBvh(tris)
+    rays = np.concatenate([W.primary_rays(48, 48), W.sphere_rays(2000, 4, origin=(100.0, -50.0, 20.0))])
+    ot = O.tris_from_tri64(tris)
+    a, _, _, _, _ = O.traverse_batch(sah.nodes().view(O.NODE), sah.prim_indices(), ot, rays)
+    b, _, _, _, _ = O.traverse_batch(ploc.nodes().view(O.NODE), ploc.prim_indices(), ot, rays)
+    for k in ("t", "u", "v"):
+        same = a["prim"] == b["prim"]
+        assert (a[k][same].view(np.uint32) == b[k][same].view(np.uint32)).all()
+    assert (a["t"].view(np.uint32) == b["t"].view(np.uint32)).all()
+    with pytest.raises(KeyError):
+        va.HostBvh(tris, builder="nope")

@@ -51,6 +51,7 @@ SYMBOLS = {
     "vt_abi_version": (C.c_int, []),
     "vt_tris_setup": (C.c_int, [_vp, _vp, _u32, _vp]),
     "vt_bvh_build": (C.c_int, [_vp, _u32, C.c_int, _pp]),
+    "vt_bvh_build_ex": (C.c_int, [_vp, _u32, C.c_int, C.c_int, _pp]),
     "vt_bvh_free": (None, [_vp]),
     "vt_bvh_node_count": (_u32, [_vp]),
     "vt_bvh_prim_count": (_u32, [_vp]),

@@ -55,11 +55,15 @@ def tris_setup(verts: np.ndarray, flags: Optional[np.ndarray] = None) -> np.ndar
 class HostBvh:
     """v1-layout tree (bvh::Bvh<float>): nodes[0] = root, siblings adjacent."""
 
-    def __init__(self, tris: np.ndarray, nthreads: int = 0):
+    BUILDERS = {"ploc": 0, "sah": 1}
+
+    def __init__(self, tris: np.ndarray, nthreads: int = 0, builder: str = "ploc"):
+        """builder: "ploc" = the reference's pipeline (PLOC + leaf collapse), "sah" = opt-in binned SAH."""
         assert tris.dtype == TRI64
         self._tris = np.ascontiguousarray(tris)
         h = C.c_void_p()
-        check(lib.vt_bvh_build(ptr(self._tris) if len(self._tris) else None, len(self._tris), nthreads, C.byref(h)))
+        check(lib.vt_bvh_build_ex(ptr(self._tris) if len(self._tris) else None, len(self._tris), nthreads,
+                                  self.BUILDERS[builder], C.byref(h)))
         self._h = h
 
     def __del__(self):

@@ -15,6 +15,7 @@
 #include "vt_internal.h"
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -183,7 +184,135 @@ void collapse_leaves(std::vector<vt_bvh_node>& nodes, std::vector<uint32_t>& pri
 
 } // namespace
 
-int bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out)
+namespace {
+
+// ---- optional builder: top-down binned SAH (Wald 2007) --------------------------------------------
+// NOT the reference's pipeline (that is PLOC + leaf collapse above, the default): an opt-in for hosts
+// that prefer a slower Rebuild and a cheaper Traverse.  Same v1 node layout, same traversal, same hits
+// (t,u,v; the tie-broken index may differ as with any other tree).  Deterministic for any thread count.
+int build_binned_sah(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out)
+{
+    constexpr int kBins = 16;
+    constexpr uint32_t kMaxLeaf = 4;
+    std::vector<Box> boxes(n);
+    std::vector<float> centers(size_t(n) * 3);
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t i = 0; i < int64_t(n); ++i) tri_box_center(tris[i], boxes[i], &centers[size_t(i) * 3]);
+
+    std::vector<uint32_t> idx(n);
+    for (uint32_t i = 0; i < n; ++i) idx[i] = i;
+    std::vector<vt_bvh_node> nodes;
+    nodes.reserve(size_t(2) * n);
+    nodes.emplace_back();
+    struct Task { uint32_t node, begin, end; };
+    std::vector<Task> stack{{0u, 0u, n}};
+    const Box empty{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+
+    while (!stack.empty()) {
+        const Task t = stack.back();
+        stack.pop_back();
+        const uint32_t count = t.end - t.begin;
+        // node bounds and centroid bounds
+        Box nb = empty, cb = empty;
+        for (uint32_t i = t.begin; i < t.end; ++i) {
+            nb = box_union(nb, boxes[idx[i]]);
+            const float* c = &centers[size_t(idx[i]) * 3];
+            for (int k = 0; k < 3; ++k) { cb.lo[k] = c[k] < cb.lo[k] ? c[k] : cb.lo[k]; cb.hi[k] = c[k] > cb.hi[k] ? c[k] : cb.hi[k]; }
+        }
+        set_node_box(nodes[t.node], nb);
+        auto make_leaf = [&]() { nodes[t.node].prim_count = count; nodes[t.node].first = t.begin; };
+        if (count <= 1) { make_leaf(); continue; }
+
+        // best binned split over the three axes: cost = A_l * N_l + A_r * N_r
+        float best_cost = FLT_MAX;
+        int best_axis = -1, best_bin = 0;
+        for (int axis = 0; axis < 3; ++axis) {
+            const float extent = cb.hi[axis] - cb.lo[axis];
+            if (!(extent > 0.0f)) continue;
+            const float scale = float(kBins) / extent;
+            Box bin_box[kBins];
+            uint32_t bin_n[kBins] = {0};
+            for (int b = 0; b < kBins; ++b) bin_box[b] = empty;
+            if (count > 65536 && nthreads > 1) {
+#pragma omp parallel num_threads(nthreads)
+                {
+                    Box lb[kBins];
+                    uint32_t ln[kBins] = {0};
+                    for (int b = 0; b < kBins; ++b) lb[b] = empty;
+#pragma omp for schedule(static) nowait
+                    for (int64_t i = t.begin; i < int64_t(t.end); ++i) {
+                        int b = int((centers[size_t(idx[i]) * 3 + axis] - cb.lo[axis]) * scale);
+                        b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                        lb[b] = box_union(lb[b], boxes[idx[i]]);
+                        ++ln[b];
+                    }
+#pragma omp critical
+                    for (int b = 0; b < kBins; ++b) { bin_box[b] = box_union(bin_box[b], lb[b]); bin_n[b] += ln[b]; }
+                }
+            } else {
+                for (uint32_t i = t.begin; i < t.end; ++i) {
+                    int b = int((centers[size_t(idx[i]) * 3 + axis] - cb.lo[axis]) * scale);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    bin_box[b] = box_union(bin_box[b], boxes[idx[i]]);
+                    ++bin_n[b];
+                }
+            }
+            float right_area[kBins];
+            uint32_t right_n[kBins];
+            Box acc = empty;
+            uint32_t cnt = 0;
+            for (int b = kBins - 1; b > 0; --b) {
+                acc = box_union(acc, bin_box[b]);
+                cnt += bin_n[b];
+                right_area[b] = cnt ? half_area(acc) : 0.0f;
+                right_n[b] = cnt;
+            }
+            acc = empty;
+            cnt = 0;
+            for (int b = 0; b < kBins - 1; ++b) {
+                acc = box_union(acc, bin_box[b]);
+                cnt += bin_n[b];
+                if (cnt == 0 || right_n[b + 1] == 0) continue;
+                const float cost = half_area(acc) * float(cnt) + right_area[b + 1] * float(right_n[b + 1]);
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+            }
+        }
+        const float leaf_cost = half_area(nb) * (float(count) - kTraversalCost);
+        uint32_t mid;
+        if (best_axis < 0 || (count <= kMaxLeaf && best_cost >= leaf_cost)) {
+            if (count <= kMaxLeaf) { make_leaf(); continue; }
+            mid = t.begin + count / 2;                  // coincident centroids: split by index
+        } else {
+            const float scale = float(kBins) / (cb.hi[best_axis] - cb.lo[best_axis]);
+            const float lo = cb.lo[best_axis];
+            uint32_t* first = idx.data() + t.begin;
+            uint32_t* last = idx.data() + t.end;
+            uint32_t* m = std::stable_partition(first, last, [&](uint32_t p) {
+                int b = int((centers[size_t(p) * 3 + best_axis] - lo) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                return b <= best_bin;
+            });
+            mid = uint32_t(m - idx.data());
+            if (mid == t.begin || mid == t.end) mid = t.begin + count / 2;
+        }
+        const uint32_t fc = uint32_t(nodes.size());
+        nodes.emplace_back();
+        nodes.emplace_back();
+        nodes[t.node].prim_count = 0;
+        nodes[t.node].first = fc;
+        stack.push_back({fc + 1, mid, t.end});
+        stack.push_back({fc, t.begin, mid});
+    }
+    out.nodes.swap(nodes);
+    out.prim_indices.swap(idx);
+    return VT_OK;
+}
+
+int build_ploc(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out);
+
+} // namespace
+
+int bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, int builder, Bvh& out)
 {
     out.nodes.clear();
     out.prim_indices.clear();
@@ -195,6 +324,15 @@ int bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out)
 #else
     nthreads = 1;
 #endif
+    if (builder == VT_BUILDER_PLOC) return build_ploc(tris, n, nthreads, out);
+    if (builder == VT_BUILDER_BINNED_SAH) return build_binned_sah(tris, n, nthreads, out);
+    return fail(VT_ERR_INVALID_ARG, "vt_bvh_build_ex: unknown builder");
+}
+
+namespace {
+
+int build_ploc(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out)
+{
 
     // 1. boxes, centres, scene box
     std::vector<Box> boxes(n);
@@ -301,5 +439,7 @@ int bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out)
     out.prim_indices.swap(order);
     return VT_OK;
 }
+
+} // namespace
 
 } // namespace vt

@@ -41,11 +41,16 @@ int vt_tris_setup(const float* verts, const uint8_t* flags, uint32_t n, vt_tri64
 
 int vt_bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, vt_bvh** out)
 {
+    return vt_bvh_build_ex(tris, n, nthreads, VT_BUILDER_PLOC, out);
+}
+
+int vt_bvh_build_ex(const vt_tri64* tris, uint32_t n, int nthreads, int builder, vt_bvh** out)
+{
     if (!out) return fail(VT_ERR_INVALID_ARG, "vt_bvh_build: out is NULL");
     *out = nullptr;
     try {
         vt_bvh* b = new vt_bvh();
-        int rc = bvh_build(tris, n, nthreads, b->bvh);
+        int rc = bvh_build(tris, n, nthreads, builder, b->bvh);
         if (rc != VT_OK) { delete b; return rc; }
         *out = b;
         return VT_OK;

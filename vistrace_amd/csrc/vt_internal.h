@@ -32,7 +32,7 @@ struct HostScene {
     uint32_t root_leaf_count = 0;      // != 0: the root itself is a leaf over tris[0..count)
 };
 
-int  bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out);
+int  bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, int builder, Bvh& out);
 int  scene_linearise(const Bvh& bvh, const vt_tri64* tris, HostScene& out);
 void tri_setup(const float p0[3], const float p1[3], const float p2[3], uint32_t prim,
                uint32_t flags, vt_tri64& out);
