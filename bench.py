@@ -207,7 +207,7 @@ def main() -> None:
     try:   # HBM-side bytes per launch from the committed rocprofv3 PMC pass of this same command
         with open(os.path.join(ROOT, "profiles", "r1", "traffic.json")) as f:
             tj = json.load(f)
-        if tj.get("workload") == f"{args.scene}_{args.kind}{n}":
+        if tj.get("workload") == f"{args.scene}_{args.kind}{n}" and args.builder == "ploc":
             traffic = tj.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
