@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvistrace_hip.so")
+LIB_PATH = os.environ.get("VISTRACE_HIP_LIB") or os.path.join(_HERE, "lib", "libvistrace_hip.so")   # override: A/B of builds
 
 VT_OK = 0
 VT_ERR_INVALID_ARG = 1

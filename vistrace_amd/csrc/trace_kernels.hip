@@ -393,8 +393,9 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                 next = rfirst;
             } else if (L.sp != 0) {
                 --L.sp;
-                next = L.sp < a.lds_entries ? st_lds[L.sp * 64]
-                                            : st_ovf[size_t(L.sp - a.lds_entries) * gstride];
+                // two separate loads on purpose: a pointer select would turn this into a flat_load
+                if (L.sp < a.lds_entries) next = st_lds[L.sp * 64];
+                else next = st_ovf[size_t(L.sp - a.lds_entries) * gstride];
             } else {
                 next = kDone;
             }
