@@ -128,6 +128,11 @@ uint32_t        vt_bvh_prim_count(const vt_bvh* bvh);
 const vt_bvh_node* vt_bvh_nodes(const vt_bvh* bvh);
 const uint32_t* vt_bvh_prim_indices(const vt_bvh* bvh);
 
+/* Refit: keep the topology, recompute every node's bounds bottom-up from
+ * moved triangles (same count, same order).  Cheaper than a Rebuild when entities only deform; the
+ * tree gets looser as they move far, results stay exact for the tree as refitted. */
+int             vt_bvh_refit(vt_bvh* bvh, const vt_tri64* tris);
+
 /* Re-pack for the device (replaces `new Intersector(mAccel, mTriangles.data())` /
  * `new Traverser(mAccel)`, source/objects/AccelStruct.cpp:772-773): sibling pairs
  * in depth-first order, triangles pre-shuffled into leaf order. */
@@ -179,6 +184,16 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value);
 void* vt_engine_stream(vt_engine* e);
 /* Wait for everything enqueued on the engine's own stream. */
 int vt_engine_synchronize(vt_engine* e);
+
+/* Device-side refit of an uploaded scene: new vertices (n x 9 floats, host memory, original triangle
+ * order; n = the scene's triangle count; flags may be NULL = unchanged) -> triangle records and all
+ * pair bounds are recomputed in place on the device, level by level from the leaves up.  Produces
+ * exactly the records vt_tris_setup + vt_bvh_refit + vt_scene_linearise would. */
+int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32_t n);
+
+/* Copy the device-resident records back (pairs: vt_host_scene_pair_count entries, tris: leaf order);
+ * either pointer may be NULL.  For inspection and tests. */
+int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_out);
 
 /* Optional per-triangle side table (n must equal the scene's triangle count); copied to the device. */
 int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_t n);

@@ -471,3 +471,32 @@ def test_sah_tree_on_device(va, engine, O):
     got, st = stats_on_device(va, scene, rays)
     assert_hits_equal(got, ref)
     assert (st["steps"] == ref_st[:, 0]).all() and (st["tests"] == ref_st[:, 1]).all()
+
+
+def test_device_refit_matches_host_refit(va, engine, O):
+    """vt_scene_refit (device, level by level) produces exactly the records of the host path
+    (vt_tris_setup + vt_bvh_refit + vt_scene_linearise), and tracing the refitted scene equals the
+    oracle on the refitted tree and the brute-force intersector on the moved triangles."""
+    from vistrace_amd import workloads as W
+    verts = W.make_scene("S10k")
+    tris = va.tris_setup(verts)
+    bvh = va.HostBvh(tris)
+    scene = va.Scene(engine, va.HostScene(bvh))
+    rng = np.random.default_rng(1)
+    moved = (verts + rng.normal(scale=5.0, size=(len(verts), 1, 3)) + rng.normal(scale=0.5, size=verts.shape)).astype(np.float32)
+    scene.refit(moved)
+    mtris = va.tris_setup(moved)
+    bvh.refit(mtris)
+    ref_hs = va.HostScene(bvh)
+    pairs, dtris = scene.read_records()
+    assert (dtris.view(np.uint8) == ref_hs.tris().view(np.uint8)).all()
+    assert (pairs.view(np.uint8) == ref_hs.pairs().view(np.uint8)).all()
+    rays = np.concatenate([W.primary_rays(64, 64), W.sphere_rays(4000, 31, origin=(50.0, 60.0, -70.0))])
+    otris = O.tris_from_tri64(mtris)
+    ref, _, _, _, _ = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays)
+    got = scene.trace_closest(rays)
+    assert_hits_equal(got, ref)
+    brute = O.trace_brute(otris, rays)
+    assert (brute["t"].view(np.uint32) == got["t"].view(np.uint32)).all()
+    with pytest.raises(va._lib.VisTraceError):
+        scene.refit(moved[:-1])

@@ -142,3 +142,22 @@ def test_optional_sah_builder(va, O, name):
     assert (a["t"].view(np.uint32) == b["t"].view(np.uint32)).all()
     with pytest.raises(KeyError):
         va.HostBvh(tris, builder="nope")
+
+
+def test_host_refit_keeps_topology_and_bounds_the_moved_triangles(va):
+    from vistrace_amd import workloads as W
+    verts = W.make_scene("S1k")
+    tris = va.tris_setup(verts)
+    bvh = va.HostBvh(tris)
+    before = bvh.nodes()
+    rng = np.random.default_rng(0)
+    moved = (verts + rng.normal(scale=3.0, size=verts.shape)).astype(np.float32)
+    mtris = va.tris_setup(moved)
+    bvh.refit(mtris)
+    after = bvh.nodes()
+    assert (after["prim_count"] == before["prim_count"]).all() and (after["first"] == before["first"]).all()
+    assert not (after["bounds"] == before["bounds"]).all()
+    check_tree(va, mtris, bvh)                       # every node still bounds its children / triangles
+    check_linearised(va.HostScene(bvh), bvh, mtris)
+    bvh.refit(tris)                                  # moving back restores the original bounds exactly
+    assert (bvh.nodes().view(np.uint8) == before.view(np.uint8)).all()

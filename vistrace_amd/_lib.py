@@ -52,6 +52,7 @@ SYMBOLS = {
     "vt_tris_setup": (C.c_int, [_vp, _vp, _u32, _vp]),
     "vt_bvh_build": (C.c_int, [_vp, _u32, C.c_int, _pp]),
     "vt_bvh_build_ex": (C.c_int, [_vp, _u32, C.c_int, C.c_int, _pp]),
+    "vt_bvh_refit": (C.c_int, [_vp, _vp]),
     "vt_bvh_free": (None, [_vp]),
     "vt_bvh_node_count": (_u32, [_vp]),
     "vt_bvh_prim_count": (_u32, [_vp]),
@@ -77,6 +78,8 @@ SYMBOLS = {
     "vt_trace_any_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
     "vt_trace_stats_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "vt_hit_attrs_dev": (C.c_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    "vt_scene_refit": (C.c_int, [_vp, _vp, _vp, _u32]),
+    "vt_scene_read_records": (C.c_int, [_vp, _vp, _vp]),
     "vt_scene_set_tri_attribs": (C.c_int, [_vp, _vp, _u32]),
     "vt_hit_shade_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
     "vt_gen_primary_dev": (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -75,6 +75,12 @@ class HostBvh:
     def tris(self) -> np.ndarray:
         return self._tris
 
+    def refit(self, tris: np.ndarray) -> None:
+        """Keep the topology, recompute all bounds from moved triangles (same count and order)."""
+        assert tris.dtype == TRI64 and len(tris) == len(self._tris)
+        self._tris = np.ascontiguousarray(tris)
+        check(lib.vt_bvh_refit(self._h, ptr(self._tris) if len(self._tris) else None))
+
     def nodes(self) -> np.ndarray:
         return _copy_from(lib.vt_bvh_nodes(self._h), lib.vt_bvh_node_count(self._h), BVH_NODE)
 
@@ -231,6 +237,19 @@ class Scene:
 
     def hit_attrs_dev(self, d_rays: int, d_hits: int, n: int, d_attrs: int, stream: int = 0) -> None:
         check(lib.vt_hit_attrs_dev(self._h, d_rays, d_hits, n, d_attrs, stream or None))
+
+    def refit(self, verts: np.ndarray, flags: Optional[np.ndarray] = None) -> None:
+        """Device-side refit in place: (n,3,3) vertices in original triangle order, same topology."""
+        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
+        fl = np.ascontiguousarray(flags, dtype=np.uint8) if flags is not None else None
+        check(lib.vt_scene_refit(self._h, ptr(verts) if len(verts) else None, ptr(fl) if fl is not None else None, len(verts)))
+
+    def read_records(self):
+        """(pairs, tris) as they currently are on the device."""
+        pairs = np.zeros(self.host_scene.pair_count, dtype=NODE_PAIR)
+        tris = np.zeros(self.host_scene.tri_count, dtype=TRI64)
+        check(lib.vt_scene_read_records(self._h, ptr(pairs) if len(pairs) else None, ptr(tris) if len(tris) else None))
+        return pairs, tris
 
     def set_tri_attribs(self, attribs: np.ndarray) -> None:
         """Per-triangle uvs / alphas / entity id / material (original order) for hit_shade_dev."""

@@ -329,6 +329,31 @@ int bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, int builder, Bvh& 
     return fail(VT_ERR_INVALID_ARG, "vt_bvh_build_ex: unknown builder");
 }
 
+// Refit: same topology, bounds recomputed bottom-up.  Parents precede children in `nodes`, so a
+// descending index sweep visits children first.
+int bvh_refit(Bvh& bvh, const vt_tri64* tris)
+{
+    if (bvh.nodes.empty()) return VT_OK;
+    if (!tris) return fail(VT_ERR_INVALID_ARG, "vt_bvh_refit: tris is NULL");
+    for (size_t k = bvh.nodes.size(); k-- > 0;) {
+        vt_bvh_node& nd = bvh.nodes[k];
+        Box b;
+        if (nd.prim_count != 0) {
+            float c[3];
+            tri_box_center(tris[bvh.prim_indices[nd.first]], b, c);
+            for (uint32_t q = 1; q < nd.prim_count; ++q) {
+                Box t;
+                tri_box_center(tris[bvh.prim_indices[nd.first + q]], t, c);
+                b = box_union(b, t);
+            }
+        } else {
+            b = box_union(node_box(bvh.nodes[nd.first]), node_box(bvh.nodes[nd.first + 1]));
+        }
+        set_node_box(nd, b);
+    }
+    return VT_OK;
+}
+
 namespace {
 
 int build_ploc(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out)

@@ -75,6 +75,9 @@ struct vt_scene {
     uint32_t      tri_base = 0;
     uint32_t*     d_prim_to_slot = nullptr;
     vt_tri_attribs* d_attribs = nullptr;   // optional side table, original triangle order
+    // refit: pair indices sorted by depth (deepest level first) and where each level starts
+    uint32_t*     d_level_pairs = nullptr;
+    std::vector<uint32_t> level_begin;     // level_begin[k] .. level_begin[k+1]) = k-th deepest level
     uint32_t      npairs = 0, ntris = 0, max_depth = 0, root_leaf_count = 0;
     uint64_t      bytes = 0;
 };
@@ -368,6 +371,20 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
             err = hipMemcpy(s->d_prim_to_slot, prim_to_slot.data(), prim_to_slot.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         s->bytes += prim_to_slot.size() * sizeof(uint32_t);
     }
+    if (err == hipSuccess && !hs.pairs.empty()) {
+        // pairs grouped by depth, deepest first (counting sort), for the level-wise refit
+        std::vector<uint32_t> count(hs.max_depth + 2, 0);
+        for (uint32_t d : hs.pair_depth) ++count[d];
+        s->level_begin.assign(1, 0);
+        std::vector<uint32_t> start(hs.max_depth + 2, 0);
+        uint32_t acc = 0;
+        for (uint32_t d = hs.max_depth; d >= 1; --d) { start[d] = acc; acc += count[d]; s->level_begin.push_back(acc); }
+        std::vector<uint32_t> order(hs.pairs.size());
+        for (uint32_t p = 0; p < hs.pairs.size(); ++p) order[start[hs.pair_depth[p]]++] = p;
+        err = hipMalloc(reinterpret_cast<void**>(&s->d_level_pairs), order.size() * sizeof(uint32_t));
+        if (err == hipSuccess) err = hipMemcpy(s->d_level_pairs, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        s->bytes += order.size() * sizeof(uint32_t);
+    }
     if (err != hipSuccess) {
         vt_scene_free(s);
         return fail(VT_ERR_HIP, std::string("vt_scene_upload: ") + hipGetErrorString(err));
@@ -384,6 +401,7 @@ void vt_scene_free(vt_scene* s)
     if (s->d_records) (void)hipFree(s->d_records);
     if (s->d_prim_to_slot) (void)hipFree(s->d_prim_to_slot);
     if (s->d_attribs) (void)hipFree(s->d_attribs);
+    if (s->d_level_pairs) (void)hipFree(s->d_level_pairs);
     delete s;
 }
 
@@ -482,6 +500,46 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
 }
 
 void* vt_engine_stream(vt_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
+
+int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32_t n)
+{
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: scene is NULL");
+    if (n != s->ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: n differs from the scene's triangle count");
+    if (n == 0) return VT_OK;
+    if (!verts) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: verts is NULL");
+    if (flags)
+        for (uint32_t i = 0; i < n; ++i)
+            if (flags[i] & VT_TRI_ALPHATEST) return fail(VT_ERR_UNSUPPORTED, "vt_scene_refit: alpha-tested triangles are not supported");
+    vt_engine* e = s->engine;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_refit: hipSetDevice failed");
+    int rc = ensure_bytes(&e->d_rays, &e->d_rays_bytes, size_t(n) * 9 * sizeof(float));
+    if (rc == VT_OK && flags) rc = ensure_bytes(&e->d_out, &e->d_out_bytes, n);
+    if (rc != VT_OK) return rc;
+    VT_HIP(hipMemcpyAsync(e->d_rays, verts, size_t(n) * 9 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    if (flags) VT_HIP(hipMemcpyAsync(e->d_out, flags, n, hipMemcpyHostToDevice, e->stream));
+    RefitTrisArgs ta{static_cast<const float*>(e->d_rays), flags ? static_cast<const uint8_t*>(e->d_out) : nullptr,
+                     s->d_prim_to_slot, s->d_tris, n};
+    VT_HIP(launch_refit_tris(ta, e->stream));
+    for (size_t k = 0; k + 1 < s->level_begin.size(); ++k) {   // deepest level first
+        RefitLevelArgs la{reinterpret_cast<vt_node_pair*>(s->d_records), s->d_tris, s->d_level_pairs + s->level_begin[k],
+                          s->level_begin[k + 1] - s->level_begin[k]};
+        VT_HIP(launch_refit_level(la, e->stream));
+    }
+    VT_HIP(hipStreamSynchronize(e->stream));
+    return VT_OK;
+}
+
+int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_out)
+{
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_read_records: scene is NULL");
+    DeviceGuard guard(s->engine->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_read_records: hipSetDevice failed");
+    VT_HIP(hipStreamSynchronize(s->engine->stream));
+    if (pairs_out && s->npairs) VT_HIP(hipMemcpy(pairs_out, s->d_records, size_t(s->npairs) * sizeof(vt_node_pair), hipMemcpyDeviceToHost));
+    if (tris_out && s->ntris) VT_HIP(hipMemcpy(tris_out, s->d_tris, size_t(s->ntris) * sizeof(vt_tri64), hipMemcpyDeviceToHost));
+    return VT_OK;
+}
 
 int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_t n)
 {

@@ -61,6 +61,12 @@ int vt_bvh_build_ex(const vt_tri64* tris, uint32_t n, int nthreads, int builder,
     }
 }
 
+int vt_bvh_refit(vt_bvh* bvh, const vt_tri64* tris)
+{
+    if (!bvh) return fail(VT_ERR_INVALID_ARG, "vt_bvh_refit: bvh is NULL");
+    return bvh_refit(bvh->bvh, tris);
+}
+
 void vt_bvh_free(vt_bvh* bvh) { delete bvh; }
 uint32_t vt_bvh_node_count(const vt_bvh* b) { return b ? uint32_t(b->bvh.nodes.size()) : 0; }
 uint32_t vt_bvh_prim_count(const vt_bvh* b) { return b ? uint32_t(b->bvh.prim_indices.size()) : 0; }

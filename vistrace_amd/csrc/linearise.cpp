@@ -61,6 +61,7 @@ int scene_linearise(const Bvh& bvh, const vt_tri64* tris, HostScene& out)
 
     const size_t npairs = (nodes.size() - 1) / 2;
     out.pairs.resize(npairs);
+    out.pair_depth.resize(npairs);
     // Depth-first, left-first numbering.  A pair's index is assigned when it is popped,
     // so the whole left subtree is numbered (and laid out) before the right one; the
     // parent's child record is patched with the index at that moment.
@@ -75,6 +76,7 @@ int scene_linearise(const Bvh& bvh, const vt_tri64* tris, HostScene& out)
         if (me >= npairs) return fail(VT_ERR_INVALID_ARG, "vt_scene_linearise: malformed tree");
         if (it.parent != 0xFFFFFFFFu) out.pairs[it.parent].child[it.side].first = me;
         if (it.depth > out.max_depth) out.max_depth = it.depth;
+        out.pair_depth[me] = it.depth;
         vt_node_pair& P = out.pairs[me];
         for (int side = 0; side < 2; ++side) {
             const vt_bvh_node& c = nodes[it.fc + side];

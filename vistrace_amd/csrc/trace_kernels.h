@@ -51,6 +51,11 @@ struct GenBounceArgs { const vt_hit_attrs* attrs; vt_ray* rays; uint64_t n; uint
 hipError_t launch_gen_primary(const GenPrimaryArgs& a, hipStream_t stream);
 hipError_t launch_gen_bounce(const GenBounceArgs& a, hipStream_t stream);
 
+struct RefitTrisArgs { const float* verts; const uint8_t* flags; const uint32_t* prim_to_slot; vt_tri64* tris; uint32_t n; };
+struct RefitLevelArgs { vt_node_pair* pairs; const vt_tri64* tris; const uint32_t* level_pairs; uint32_t count; };
+hipError_t launch_refit_tris(const RefitTrisArgs& a, hipStream_t stream);
+hipError_t launch_refit_level(const RefitLevelArgs& a, hipStream_t stream);
+
 size_t     trace_lds_bytes(uint32_t lds_entries, bool fetch_dma);
 hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, bool fetch_dma,
                         uint32_t grid_blocks, size_t lds_bytes, hipStream_t stream);

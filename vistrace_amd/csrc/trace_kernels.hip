@@ -531,6 +531,66 @@ __global__ __launch_bounds__(kBlockThreads) void gen_bounce_kernel(GenBounceArgs
     a.rays[i] = ray;
 }
 
+// ---- refit: triangle records and pair bounds recomputed in place ----------
+__global__ __launch_bounds__(kBlockThreads) void refit_tris_kernel(RefitTrisArgs a)
+{
+    const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
+    if (i >= a.n) return;
+    const float* v = a.verts + size_t(i) * 9;
+    const uint32_t slot = a.prim_to_slot[i];
+    vt_tri64 t;
+    for (int k = 0; k < 3; ++k) {                      // Primitives.h:82
+        t.p0[k] = v[k];
+        t.e1[k] = v[k] - v[3 + k];
+        t.e2[k] = v[6 + k] - v[k];
+    }
+    t.n[0] = t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1];    // Primitives.h:93
+    t.n[1] = t.e1[2] * t.e2[0] - t.e1[0] * t.e2[2];
+    t.n[2] = t.e1[0] * t.e2[1] - t.e1[1] * t.e2[0];
+    t.prim = i;
+    t.flags = a.flags ? uint32_t(a.flags[i]) : a.tris[slot].flags;
+    t.pad[0] = t.pad[1] = 0;
+    a.tris[slot] = t;
+}
+
+__device__ __forceinline__ void box_of_child(const vt_node_pair* pairs, const vt_tri64* tris, const vt_bvh_node& c, float* b)
+{
+    float lo[3], hi[3];
+    if (c.prim_count != 0) {                           // leaf: Triangle::bounding_box(), Primitives.h:107-113
+        for (int k = 0; k < 3; ++k) { lo[k] = FLT_MAX; hi[k] = -FLT_MAX; }
+        for (uint32_t q = 0; q < c.prim_count; ++q) {
+            const vt_tri64& t = tris[c.first + q];
+            for (int k = 0; k < 3; ++k) {
+                const float p0 = t.p0[k], p1 = t.p0[k] - t.e1[k], p2 = t.p0[k] + t.e2[k];
+                float l = p0, h = p0;
+                l = p1 < l ? p1 : l; h = p1 > h ? p1 : h;
+                l = p2 < l ? p2 : l; h = p2 > h ? p2 : h;
+                lo[k] = l < lo[k] ? l : lo[k]; hi[k] = h > hi[k] ? h : hi[k];
+            }
+        }
+    } else {                                           // inner: union of its two (already refitted) children
+        const vt_node_pair& p = pairs[c.first];
+        for (int k = 0; k < 3; ++k) {
+            const float l0 = p.child[0].bounds[2 * k], l1 = p.child[1].bounds[2 * k];
+            const float h0 = p.child[0].bounds[2 * k + 1], h1 = p.child[1].bounds[2 * k + 1];
+            lo[k] = l0 < l1 ? l0 : l1; hi[k] = h0 > h1 ? h0 : h1;
+        }
+    }
+    for (int k = 0; k < 3; ++k) { b[2 * k] = lo[k]; b[2 * k + 1] = hi[k]; }
+}
+
+// one thread per (pair, child) of one tree level; levels run deepest first
+__global__ __launch_bounds__(kBlockThreads) void refit_level_kernel(RefitLevelArgs a)
+{
+    const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
+    if (i >= a.count * 2) return;
+    vt_node_pair& p = a.pairs[a.level_pairs[i >> 1]];
+    vt_bvh_node& c = p.child[i & 1];
+    float b[6];
+    box_of_child(a.pairs, a.tris, c, b);
+    for (int k = 0; k < 6; ++k) c.bounds[k] = b[k];
+}
+
 // ---- launchers ---------------------------------------------------------------------------
 template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA>
 static hipError_t launch_one(const TraceArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
@@ -611,6 +671,21 @@ hipError_t launch_gen_bounce(const GenBounceArgs& a, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
     hipLaunchKernelGGL(gen_bounce_kernel, dim3(uint32_t((a.n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0,
+                       stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_refit_tris(const RefitTrisArgs& a, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(refit_tris_kernel, dim3((a.n + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_refit_level(const RefitLevelArgs& a, hipStream_t stream)
+{
+    if (a.count == 0) return hipSuccess;
+    hipLaunchKernelGGL(refit_level_kernel, dim3((a.count * 2 + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0,
                        stream, a);
     return hipGetLastError();
 }

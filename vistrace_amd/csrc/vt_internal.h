@@ -28,12 +28,14 @@ struct Bvh {
 struct HostScene {
     std::vector<vt_node_pair> pairs;   // depth-first order; pairs[0] = the root's children
     std::vector<vt_tri64>     tris;    // leaf order
+    std::vector<uint32_t>     pair_depth; // depth of every pair (root's pair = 1), for level-wise refit
     uint32_t max_depth       = 0;      // deepest inner level = stack entries a ray can need
     uint32_t root_leaf_count = 0;      // != 0: the root itself is a leaf over tris[0..count)
 };
 
 int  bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, int builder, Bvh& out);
 int  scene_linearise(const Bvh& bvh, const vt_tri64* tris, HostScene& out);
+int  bvh_refit(Bvh& bvh, const vt_tri64* tris);
 void tri_setup(const float p0[3], const float p1[3], const float p2[3], uint32_t prim,
                uint32_t flags, vt_tri64& out);
 
