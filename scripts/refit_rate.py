@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Time a device-side refit of S1M against a full CPU Rebuild (build + linearise + upload)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import vistrace_amd as va
+from vistrace_amd import workloads as W
+
+eng = va.Engine(0)
+verts = W.make_scene("S1M")
+t0 = time.perf_counter(); tris = va.tris_setup(verts); bvh = va.HostBvh(tris); hs = va.HostScene(bvh); scene = va.Scene(eng, hs); t1 = time.perf_counter()
+print(f"full Rebuild (setup + PLOC + collapse + linearise + upload): {(t1 - t0) * 1e3:.0f} ms")
+moved = (verts + np.float32(0.25)).astype(np.float32)
+scene.refit(moved)
+t0 = time.perf_counter()
+for _ in range(5):
+    scene.refit(moved)
+t1 = time.perf_counter()
+print(f"vt_scene_refit (H2D of 36 MB vertices + {hs.max_depth} level launches): {(t1 - t0) / 5 * 1e3:.1f} ms")
