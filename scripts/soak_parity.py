@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Long randomized parity soak on the GPU: many seeded triangle soups (degenerate / duplicate triangles, cull
+flags, extreme scales) x random rays (windows, zero components), device vs oracle bit for bit incl. counters,
+for the persistent, static and auto kernels.  Usage: python scripts/soak_parity.py [first_seed] [count]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import vistrace_amd as va
+from oracle import binding as O
+from vistrace_amd import torch_plumbing as tp
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+eng = va.Engine(0)
+dev = torch.device("cuda", 0)
+bad = 0
+t0 = time.time()
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 20000))
+    spread = 10.0 ** rng.uniform(0, 3)
+    centre = rng.uniform(-spread, spread, (n, 1, 3))
+    scale = 10.0 ** rng.uniform(-4, 2, (n, 1, 1))
+    verts = (centre + rng.normal(size=(n, 3, 3)) * scale).astype(np.float32)
+    if n > 40:
+        verts[::17, 1] = verts[::17, 0]
+        verts[3::29] = verts[2::29][: len(verts[3::29])]
+    flags = (rng.random(n) < rng.random()).astype(np.uint8)
+    tris = va.tris_setup(verts, flags)
+    bvh = va.HostBvh(tris, builder="sah" if seed % 5 == 0 else "ploc")
+    scene = va.Scene(eng, va.HostScene(bvh))
+    m = int(rng.integers(1, 30000))
+    org = rng.uniform(-2 * spread, 2 * spread, (m, 3)).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32) * np.float32(10.0 ** rng.uniform(-3, 3))
+    k = m // 3
+    d[:k] = (centre[rng.integers(0, n, k), 0] - org[:k]).astype(np.float32)
+    d[::37, rng.integers(0, 3)] = 0.0
+    tmin = np.where(rng.random(m) < 0.3, rng.uniform(0, spread, m), 0.0).astype(np.float32)
+    tmax = np.where(rng.random(m) < 0.3, tmin + rng.uniform(1e-3, 4 * spread, m), np.finfo(np.float32).max).astype(np.float32)
+    rays = va.make_rays(org, d, tmin, tmax)
+    ref, ref_st, _, _, _ = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris), rays, want_stats=True)
+    for mode in (1, 0, 2):
+        eng.set_option("persistent", mode)
+        d_rays = tp.to_device(rays, dev)
+        d_hits, d_stats = tp.trace_stats(scene, d_rays, m)
+        torch.cuda.synchronize()
+        got, st = tp.to_host(d_hits, va.HIT), tp.to_host(d_stats, va.RAY_STATS)
+        ok = (got.view(np.uint8) == ref.view(np.uint8)).all() and (st["steps"] == ref_st[:, 0]).all() and (st["tests"] == ref_st[:, 1]).all()
+        ok = ok and (scene.trace_closest(rays).view(np.uint8) == ref.view(np.uint8)).all()
+        ok = ok and (scene.trace_any(rays) == (ref["prim"] != O.MISS)).all()
+        if not ok:
+            bad += 1
+            print(f"MISMATCH seed {seed} mode {mode} n {n} m {m}", flush=True)
+print(f"soak: seeds {first}..{first + count - 1}, {bad} mismatches, {time.time() - t0:.0f}s")
+sys.exit(1 if bad else 0)
