@@ -93,7 +93,8 @@ def main() -> None:
     verts = W.make_scene(args.scene)
     tris = va.tris_setup(verts)
     t1 = time.time()
-    bvh = va.HostBvh(tris, nthreads=max(1, len(os.sched_getaffinity(0)) // max(1, world)) if world > 1 else 0, builder=args.builder)   # ranks build side by side
+    host_threads = max(1, len(os.sched_getaffinity(0)) // max(1, world))   # explicit: launchers may export OMP_NUM_THREADS=1
+    bvh = va.HostBvh(tris, nthreads=host_threads, builder=args.builder)   # ranks build side by side   # ranks build side by side
     t2 = time.time()
     host_scene = va.HostScene(bvh)
     engine = va.Engine(dev_index)
@@ -265,12 +266,13 @@ def main() -> None:
         otris = O.tris_from_tri64(tris)
         pilot = min(n, 1 << 15)
         tp0 = time.perf_counter()
-        O.traverse_batch(nodes, pidx, otris, rays_host[:pilot])
+        O.traverse_batch(nodes, pidx, otris, rays_host[:pilot], nthreads=host_threads)
         rate = pilot / (time.perf_counter() - tp0)
         sample = int(min(n, max(pilot, rate * args.cpu_seconds)))
         sample = max(4096, (sample // 4096) * 4096) if n >= 4096 else n
         tc0 = time.perf_counter()
-        ref, ref_stats, s_steps, s_tests, threads = O.traverse_batch(nodes, pidx, otris, rays_host[:sample], want_stats=True)
+        ref, ref_stats, s_steps, s_tests, threads = O.traverse_batch(nodes, pidx, otris, rays_host[:sample], want_stats=True,
+                                                                    nthreads=host_threads)
         cpu_s = time.perf_counter() - tc0
         gpu = tp.to_host(d_hits[: sample * HIT.itemsize], HIT)
         same_prim = bool((gpu["prim"] == ref["prim"]).all())
