@@ -264,15 +264,21 @@ def main() -> None:
         nodes = bvh.nodes().view(O.NODE)
         pidx = bvh.prim_indices()
         otris = O.tris_from_tri64(tris)
-        pilot = min(n, 1 << 15)
-        tp0 = time.perf_counter()
-        O.traverse_batch(nodes, pidx, otris, rays_host[:pilot], nthreads=host_threads)
-        rate = pilot / (time.perf_counter() - tp0)
+        pilot = min(n, 1 << 17)
+        # the CPU gets its best thread count: all logical CPUs or one per physical core (SMT often hurts this walk)
+        rate, cpu_threads = 0.0, host_threads
+        for cand in sorted({host_threads, max(1, host_threads // 2)}, reverse=True):
+            O.traverse_batch(nodes, pidx, otris, rays_host[:pilot], nthreads=cand)           # warm-up
+            tp0 = time.perf_counter()
+            O.traverse_batch(nodes, pidx, otris, rays_host[:pilot], nthreads=cand)
+            r = pilot / (time.perf_counter() - tp0)
+            if r > rate:
+                rate, cpu_threads = r, cand
         sample = int(min(n, max(pilot, rate * args.cpu_seconds)))
         sample = max(4096, (sample // 4096) * 4096) if n >= 4096 else n
         tc0 = time.perf_counter()
         ref, ref_stats, s_steps, s_tests, threads = O.traverse_batch(nodes, pidx, otris, rays_host[:sample], want_stats=True,
-                                                                    nthreads=host_threads)
+                                                                    nthreads=cpu_threads)
         cpu_s = time.perf_counter() - tc0
         gpu = tp.to_host(d_hits[: sample * HIT.itemsize], HIT)
         same_prim = bool((gpu["prim"] == ref["prim"]).all())
