@@ -174,10 +174,18 @@ int vt_trace_stats_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits
 int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64_t n,
                      void* d_attrs, void* stream);
 
-/* Launch configuration. Keys: "persistent" (0 = one ray per lane, 1 = persistent waves, 2 = auto
- * by batch size, the default), "auto_static_factor", "lds_entries" (stack entries per lane
- * kept in LDS), "blocks_per_cu", "block_rays" (rays handed to a wave at a time),
- * "refill_threshold" (idle lanes that trigger a re-fill); read-only: "cu_count", "device", "last_persistent", "last_fetch_dma" (what the last launch used).
+/* Launch configuration (also readable from VT_* environment variables at vt_engine_open).  Keys:
+ *   "persistent"         0 = one ray per lane, 1 = persistent waves, 2 = auto by batch size (default)
+ *   "auto_static_factor" auto: one ray per lane when n <= factor x (CUs x 8 x 256) rays (default 2)
+ *   "fetch_dma"          persistent kernel: quad-cooperative global->LDS record fetch (default 1)
+ *   "coherent_detect"    persistent kernel: per-wave octant probe -> direct fetch + whole-wave re-fill (1)
+ *   "lds_entries"        stack entries per lane kept in LDS, the rest spills to global memory (10)
+ *   "blocks_per_cu"      cap on resident 256-thread blocks per CU (8; the occupancy query decides below it)
+ *   "block_rays"         consecutive rays handed to a wave at a time (64)
+ *   "refill_threshold"   idle lanes that trigger a re-fill (8);  "tri_threshold": waiting lanes that
+ *                        trigger the triangle branch (4);  "static_overflow_mb": overflow-area cap of the
+ *                        one-ray-per-lane kernel (256)
+ * Read-only: "cu_count", "device", "last_persistent", "last_fetch_dma" (what the last launch used).
  * Results never depend on these, only speed does. */
 int vt_engine_set_option(vt_engine* e, const char* key, int64_t value);
 int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value);
