@@ -245,7 +245,7 @@ def main() -> None:
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
-            "traffic_source": "profiles/r1/traffic.json: FETCH_SIZE x2 + WRITE_SIZE of a separate rocprofv3 --pmc pass of this command" if traffic else None,
+            "traffic_source": "profiles/r1/traffic.json: FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass of this command (factor calibrated: profiles/r1/calib_fetch.txt)" if traffic else None,
             "kernel": "vt::trace_kernel<false,false,%s,%s>" % (
                 "true" if engine.get_option("last_persistent") else "false",
                 "true" if engine.get_option("last_fetch_dma") else "false"),

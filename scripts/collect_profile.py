@@ -5,9 +5,11 @@
 
 Writes kernel_stats.csv (rocprofv3 --kernel-trace --stats), pmc_summary.txt (one line per
 counter: last dispatch = one timed step of the bench workload), bench_line.json (the JSON line
-bench.py printed under the profiler) and traffic.json (HBM-side bytes per launch:
-FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024; the x2 is the gfx950 FETCH_SIZE correction of
-MI355X_MICROARCH.md "HBM": requests are tallied at 64 B but move 128 B).
+bench.py printed under the profiler) and traffic.json (fabric-side bytes per launch:
+FETCH_SIZE x 1024 + WRITE_SIZE x 1024.  The gfx950 x2 correction of MI355X_MICROARCH.md "HBM" applies to wide
+streaming reads (128-B requests tallied at 64 B); this kernel fetches random 64-B records with 64-B requests,
+and scripts/calib_fetch.hip measures FETCH_SIZE x 1024 / true bytes = 1.000 for exactly that pattern
+(profiles/r1/calib_fetch.txt), so no doubling is applied).
 """
 import glob
 import json
@@ -38,10 +40,11 @@ if "FETCH_SIZE" in vals:
         "workload": line.get("config", {}).get("workload"),
         "kernel": line.get("roofline", {}).get("kernel"),
         "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
-        "hbm_bytes_per_launch": int(fetch_kb * 1024 * 2 + write_kb * 1024),
-        "note": "per launch of the dominant kernel (last dispatch of the PMC pass); FETCH_SIZE doubled per the gfx950 "
-                "correction; these are L2-miss (fabric-side) bytes: the 104 MB scene is Infinity-Cache resident, so "
-                "true HBM traffic is lower still",
+        "hbm_bytes_per_launch": int(fetch_kb * 1024 + write_kb * 1024),
+        "note": "per launch of the dominant kernel (last dispatch of the PMC pass); FETCH_SIZE x 1024 + WRITE_SIZE x 1024, "
+                "calibrated for this access pattern (64-B random records: factor 1.000, profiles/r1/calib_fetch.txt); "
+                "these are L2-miss (fabric-side) bytes: the 104 MB scene is Infinity-Cache resident, so true HBM "
+                "traffic is lower still",
     }
     json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(out)
