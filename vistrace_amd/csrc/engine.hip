@@ -199,7 +199,8 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     a.tri_threshold = std::min(std::max(e->tri_threshold, 1u), 64u);
     a.coherent_detect = e->coherent_detect;
 
-    if (p.persistent) VT_HIP(hipMemsetAsync(e->d_cursor, 0, sizeof(uint32_t), stream));
+    // the first block of every wave is static (block w -> wave w); the cursor hands out the rest
+    if (p.persistent) VT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_cursor), int(p.grid_blocks * (kBlockThreads / 64)), 1, stream));
     if (e->timing) VT_HIP(hipEventRecord(e->ev_start, stream));
     VT_HIP(launch_trace(a, any_hit, stats, p.persistent, p.fetch_dma, p.grid_blocks, p.lds_bytes, stream));
     if (e->timing) { VT_HIP(hipEventRecord(e->ev_stop, stream)); e->ev_valid = true; }

@@ -157,6 +157,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
     uint64_t blk_cur = 0, blk_end = 0;
     bool exhausted = false;
     bool coherent = false;   // wave-uniform: this wave's rays share a direction octant
+    bool first_block = true; // wave-uniform: the first block of rays is assigned statically
 
     auto start_ray = [&](uint64_t idx) {
         const float4* r4 = reinterpret_cast<const float4*>(a.rays + idx);
@@ -214,7 +215,12 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                 if ((nidle >= a.refill_threshold && !coherent) || idle == ~0ull) {
                     if (blk_cur == blk_end) { // acquire the next block of consecutive rays
                         uint32_t b = 0;
-                        if (lane == 0) b = atomicAdd(a.block_cursor, 1u);
+                        if (first_block) {            // block w goes to wave w without touching the cursor,
+                            b = blockIdx.x * (kBlockThreads / 64) + wave;   // which the host starts at #waves
+                            first_block = false;
+                        } else if (lane == 0) {
+                            b = atomicAdd(a.block_cursor, 1u);
+                        }
                         b = __builtin_amdgcn_readfirstlane(b);
                         blk_cur = uint64_t(b) * a.block_rays;
                         blk_end = blk_cur + a.block_rays < a.nrays ? blk_cur + a.block_rays : a.nrays;
