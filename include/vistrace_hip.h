@@ -199,6 +199,22 @@ int vt_engine_synchronize(vt_engine* e);
  * exactly the records vt_tris_setup + vt_bvh_refit + vt_scene_linearise would. */
 int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32_t n);
 
+/* Device-side skinning + refit (the per-frame half of AccelStruct::Rebuild for animated entities,
+ * source/objects/AccelStruct.cpp:34-102 SkinTriangle/TransformToBone, call site :749).
+ * vt_skin_vertex = one vertex's Triangle::weights / boneIds / numBones (source/objects/Primitives.h:68-70). */
+typedef struct vt_skin_vertex { float weight[3]; int8_t bone[3]; uint8_t num_bones; } vt_skin_vertex;
+/* Once per build: the mesh triangles in bind pose (n x 9 floats, original order; n = the scene's triangle
+ * count), their 3 x n skin vertices, and for every triangle the index of its entity's first matrix in the
+ * arrays later given to vt_scene_skin_refit (boneIds are relative to it).  Static triangles use one bone
+ * of weight 1 and an identity matrix pair.  Host pointers; the data stays on the device. */
+int vt_scene_set_skin(vt_scene* s, const float* bind_verts, const vt_skin_vertex* skin, const uint32_t* matrix_base,
+                      uint32_t n);
+/* Per frame: bones[i] (Entity:GetBoneMatrix, AccelStruct.cpp:655-667) and binds[i] (the model's bind
+ * matrices, :668) as nmat glm::mat4 (16 floats, column-major) each; only these 128 x nmat bytes cross the
+ * bus.  Every vertex is moved by TransformToBone, the triangle records are rebuilt (Primitives.h:82,93) and
+ * all pair bounds refitted, exactly as vt_scene_refit would from the skinned vertices. */
+int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uint32_t nmat);
+
 /* Copy the device-resident records back (pairs: vt_host_scene_pair_count entries, tris: leaf order);
  * either pointer may be NULL.  For inspection and tests. */
 int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_out);

@@ -20,6 +20,7 @@ RAY = np.dtype([("org", "<f4", 3), ("dir", "<f4", 3), ("tmin", "<f4"), ("tmax", 
 TRI = np.dtype([("p0", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3), ("n", "<f4", 3), ("flags", "<u4")])
 NODE = np.dtype([("bounds", "<f4", 6), ("prim_count", "<u4"), ("first", "<u4")])
 HIT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+SKIN_VERTEX = np.dtype([("weight", "<f4", 3), ("bone", "i1", 3), ("num_bones", "u1")])
 ATTRS = np.dtype([("pos", "<f4", 3), ("uvw", "<f4", 3), ("ngeo", "<f4", 3), ("wo", "<f4", 3), ("front", "<u4")])
 
 
@@ -56,6 +57,8 @@ def lib() -> C.CDLL:
         L.vto_hit_shade.argtypes = [C.c_float, C.c_float, vp, vp, vp, vp]
         L.vto_calc_ray_origin.argtypes = [vp, vp, vp]
         L.vto_hemisphere_cos.argtypes = [C.c_float, C.c_float, vp]
+        L.vto_skin_matrices.argtypes = [vp, vp, u32, vp]
+        L.vto_skin_verts.argtypes = [vp, vp, vp, u32, vp, vp]
         _lib = L
     return _lib
 
@@ -145,4 +148,27 @@ def calc_ray_origin(pos, normal) -> np.ndarray:
 def hemisphere_cos(r1: float, r2: float) -> np.ndarray:
     out = np.zeros(3, np.float32)
     lib().vto_hemisphere_cos(float(r1), float(r2), out.ctypes.data)
+    return out
+
+
+def skin_matrices(bones: np.ndarray, binds: np.ndarray) -> np.ndarray:
+    """bones[i] * binds[i] (glm mat4, column-major 16 floats each), AccelStruct.cpp:44."""
+    bones = np.ascontiguousarray(bones, np.float32).reshape(-1, 16)
+    binds = np.ascontiguousarray(binds, np.float32).reshape(-1, 16)
+    assert bones.shape == binds.shape
+    out = np.zeros_like(bones)
+    lib().vto_skin_matrices(bones.ctypes.data, binds.ctypes.data, bones.shape[0], out.ctypes.data)
+    return out
+
+
+def skin_verts(bind_verts: np.ndarray, skin: np.ndarray, matrix_base: np.ndarray, mats: np.ndarray) -> np.ndarray:
+    """SkinTriangle (AccelStruct.cpp:66-102) positions for every triangle: n x 9 floats."""
+    bind_verts = np.ascontiguousarray(bind_verts, np.float32).reshape(-1, 9)
+    n = bind_verts.shape[0]
+    skin = np.ascontiguousarray(skin, SKIN_VERTEX).reshape(n * 3)
+    matrix_base = np.ascontiguousarray(matrix_base, np.uint32).reshape(n)
+    mats = np.ascontiguousarray(mats, np.float32).reshape(-1, 16)
+    out = np.zeros((n, 9), np.float32)
+    lib().vto_skin_verts(bind_verts.ctypes.data, skin.ctypes.data, matrix_base.ctypes.data, n, mats.ctypes.data,
+                         out.ctypes.data)
     return out

@@ -357,3 +357,56 @@ void vto_hemisphere_cos(float r1, float r2, float out[3])
     out[1] = sinTheta * sinf(phi);
     out[2] = z;
 }
+
+/* ---- AccelStruct.cpp:34-102: skinning -----------------------------------------
+ * glm (un-vendored, version unpinned) supplies mat4*mat4, mat4*vec4 and vec4*scalar; the
+ * scalar forms restated here are glm's generic (non-SIMD) ones:
+ *   mat4*mat4: Result[c] = A[0]*B[c][0] + A[1]*B[c][1] + A[2]*B[c][2] + A[3]*B[c][3], left to right
+ *   mat4*vec4: (m[0]*v.x + m[1]*v.y) + (m[2]*v.z + m[3]*v.w)                                    */
+void vto_skin_matrices(const float* bones, const float* binds, uint32_t nmat, float* out)
+{
+    for (uint32_t i = 0; i < nmat; ++i) {
+        const float* A = bones + (size_t)i * 16;
+        const float* B = binds + (size_t)i * 16;
+        float* R = out + (size_t)i * 16;
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) {
+                float acc = A[0 * 4 + r] * B[c * 4 + 0];
+                acc = acc + A[1 * 4 + r] * B[c * 4 + 1];
+                acc = acc + A[2 * 4 + r] * B[c * 4 + 2];
+                acc = acc + A[3 * 4 + r] * B[c * 4 + 3];
+                R[c * 4 + r] = acc;
+            }
+    }
+}
+
+/* TransformToBone :35-47 with angleOnly = false: vertex = (vec, 1), final = sum_i (M_i * vertex) * w_i */
+static void vto_transform_to_bone(const float v[3], const vto_skin_vertex* sv, const float* mats, float out[3])
+{
+    float fin[4] = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t i = 0; i < sv->num_bones; ++i) {
+        const float* M = mats + (size_t)(int)sv->bone[i] * 16;
+        for (int r = 0; r < 4; ++r) {
+            const float a0 = M[0 * 4 + r] * v[0] + M[1 * 4 + r] * v[1];
+            const float a1 = M[2 * 4 + r] * v[2] + M[3 * 4 + r] * 1.f;
+            fin[r] = fin[r] + (a0 + a1) * sv->weight[i];
+        }
+    }
+    out[0] = fin[0]; out[1] = fin[1]; out[2] = fin[2];
+}
+
+void vto_skin_verts(const float* bind_verts, const vto_skin_vertex* skin, const uint32_t* matrix_base,
+                    uint32_t n, const float* mats, float* out_verts)
+{
+    for (uint32_t t = 0; t < n; ++t) {
+        const float* b = bind_verts + (size_t)t * 9;
+        float pos[3][3];
+        for (int k = 0; k < 3; ++k) {                 /* Triangle ctor :82, then SkinTriangle :68-72 */
+            const float p0 = b[k], e1 = b[k] - b[3 + k], e2 = b[6 + k] - b[k];
+            pos[0][k] = p0; pos[1][k] = p0 - e1; pos[2][k] = p0 + e2;
+        }
+        const float* mats_t = mats + (size_t)matrix_base[t] * 16;
+        for (int vi = 0; vi < 3; ++vi)
+            vto_transform_to_bone(pos[vi], &skin[(size_t)t * 3 + vi], mats_t, out_verts + (size_t)t * 9 + vi * 3);
+    }
+}

@@ -119,6 +119,20 @@ void vto_calc_ray_origin(const float pos[3], const float normal[3], float out[3]
 /* hemisphere_cos, BSDF.cpp:69-77 (r1, r2 are the two sampler floats, in call order) */
 void vto_hemisphere_cos(float r1, float r2, float out[3]);
 
+/* ---- skinning on Rebuild, source/objects/AccelStruct.cpp:34-102 ----------------
+ * One vertex's Triangle::weights / boneIds / numBones (Primitives.h:68-70). 16 B. */
+typedef struct vto_skin_vertex { float weight[3]; int8_t bone[3]; uint8_t num_bones; } vto_skin_vertex;
+
+/* out[i] = bones[i] * binds[i] (the product TransformToBone forms per vertex and bone, :44);
+ * glm::mat4 layout: 16 floats, column-major. */
+void vto_skin_matrices(const float* bones, const float* binds, uint32_t nmat, float* out);
+
+/* SkinTriangle :66-102 for n triangles: bind_verts n x 9 (the mesh's p0,p1,p2); the three
+ * positions are re-derived through the stored p0/e1/e2 (:68-72), each is moved by
+ * TransformToBone (:35-47) with the matrices mats[matrix_base[t] + bone], out_verts n x 9. */
+void vto_skin_verts(const float* bind_verts, const vto_skin_vertex* skin, const uint32_t* matrix_base,
+                    uint32_t n, const float* mats, float* out_verts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -500,3 +500,37 @@ def test_device_refit_matches_host_refit(va, engine, O):
     assert (brute["t"].view(np.uint32) == got["t"].view(np.uint32)).all()
     with pytest.raises(va._lib.VisTraceError):
         scene.refit(moved[:-1])
+
+
+def test_device_skin_refit_matches_host_pipeline(va, engine, O):
+    """vt_scene_skin_refit (matrices -> skinned vertices -> records -> level-wise refit, all on the device)
+    equals the oracle's SkinTriangle restatement pushed through the host path (vt_tris_setup + vt_bvh_refit +
+    vt_scene_linearise) bit for bit, frame after frame, and tracing the posed scene equals the oracle."""
+    from vistrace_amd import workloads as W
+    verts = W.make_scene("S10k")
+    n = len(verts)
+    tris = va.tris_setup(verts)
+    bvh = va.HostBvh(tris)
+    scene = va.Scene(engine, va.HostScene(bvh))
+    with pytest.raises(va._lib.VisTraceError):
+        scene.skin_refit(np.eye(4, dtype=np.float32).reshape(1, 16), np.eye(4, dtype=np.float32).reshape(1, 16))
+    skin, base, nmat = W.skinned_rig(n)
+    scene.set_skin(verts, skin, base)
+    rays = np.concatenate([W.primary_rays(64, 64), W.sphere_rays(4000, 37, origin=(40.0, -60.0, 70.0))])
+    for frame in range(3):
+        bones, binds = W.rig_pose(nmat, frame)
+        scene.skin_refit(bones, binds)
+        posed = O.skin_verts(verts.reshape(n, 9), skin, base, O.skin_matrices(bones, binds)).reshape(n, 3, 3)
+        mtris = va.tris_setup(posed)
+        bvh.refit(mtris)
+        ref_hs = va.HostScene(bvh)
+        pairs, dtris = scene.read_records()
+        assert (dtris.view(np.uint8) == ref_hs.tris().view(np.uint8)).all()
+        assert (pairs.view(np.uint8) == ref_hs.pairs().view(np.uint8)).all()
+        otris = O.tris_from_tri64(mtris)
+        ref, _, _, _, _ = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays)
+        assert_hits_equal(scene.trace_closest(rays), ref)
+    bad = skin.copy()
+    bad["num_bones"][0, 0] = 4
+    with pytest.raises(va._lib.VisTraceError):
+        scene.set_skin(verts, bad, base)

@@ -193,3 +193,75 @@ def test_hemisphere_cos_kat(O):
     v = O.hemisphere_cos(0.25, 0.25)      # phi = pi/2
     assert abs(v[0]) < 1e-7 and abs(v[1] - np.sqrt(np.float32(0.75))) < 1e-7 and v[2] == 0.5
     assert abs(np.linalg.norm(O.hemisphere_cos(0.3, 0.7)) - 1.0) < 1e-6
+
+
+# ---- skinning on Rebuild: AccelStruct.cpp:34-102 ------------------------------------------------------------
+def _cm(M):
+    return np.ascontiguousarray(np.asarray(M, np.float32).T.reshape(16))
+
+
+def _skin1(O, n, bone=0, weight=1.0):
+    sv = np.zeros((n, 3), O.SKIN_VERTEX)
+    sv["weight"][:, :, 0] = weight
+    sv["bone"][:, :, 0] = bone
+    sv["num_bones"] = 1
+    return sv
+
+
+def test_skin_identity_and_roundtrip(O):
+    """Identity bone x bind: the vertices come back through the p0 - (p0 - p1) round trip of SkinTriangle :68-72."""
+    rng = np.random.default_rng(3)
+    v = rng.normal(scale=100, size=(50, 9)).astype(np.float32)
+    I = np.eye(4, dtype=np.float32)
+    mats = O.skin_matrices(_cm(I)[None], _cm(I)[None])
+    assert (mats == _cm(I)).all()
+    out = O.skin_verts(v, _skin1(O, 50), np.zeros(50, np.uint32), mats)
+    p0, p1, p2 = v[:, 0:3], v[:, 3:6], v[:, 6:9]
+    exp = np.concatenate([p0, p0 - (p0 - p1), p0 + (p2 - p0)], axis=1)
+    assert (out.view(np.uint32) == exp.view(np.uint32)).all()
+
+
+def test_skin_exact_cases(O):
+    """Exactly representable transforms: quarter turn about z plus a shift; bone*bind that cancels; a 50/50
+    blend of two opposite shifts; zero bones -> origin (final starts at 0, :42)."""
+    v = np.array([[1, 2, 3, 5, 2, 3, 1, 6, 3]], np.float32)
+    Rz = np.array([[0, -1, 0, 10], [1, 0, 0, 20], [0, 0, 1, 30], [0, 0, 0, 1]], np.float32)
+    I = np.eye(4, dtype=np.float32)
+    out = O.skin_verts(v, _skin1(O, 1), np.zeros(1, np.uint32), O.skin_matrices(_cm(Rz)[None], _cm(I)[None]))
+    assert out.tolist() == [[8, 21, 33, 8, 25, 33, 4, 21, 33]]
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = [4, -8, 16]
+    Tinv = np.eye(4, dtype=np.float32); Tinv[:3, 3] = [-4, 8, -16]
+    out = O.skin_verts(v, _skin1(O, 1), np.zeros(1, np.uint32), O.skin_matrices(_cm(T)[None], _cm(Tinv)[None]))
+    assert out.tolist() == v.tolist()
+    sv = np.zeros((1, 3), O.SKIN_VERTEX)
+    sv["weight"][:, :, :2] = 0.5
+    sv["bone"][:, :, 1] = 1
+    sv["num_bones"] = 2
+    mats = O.skin_matrices(np.stack([_cm(T), _cm(Tinv)]), np.stack([_cm(I), _cm(I)]))
+    assert O.skin_verts(v, sv, np.zeros(1, np.uint32), mats).tolist() == v.tolist()
+    sv["num_bones"] = 0
+    assert O.skin_verts(v, sv, np.zeros(1, np.uint32), mats).tolist() == [[0] * 9]
+    # matrix_base selects the entity's block of matrices
+    mats2 = np.concatenate([mats, O.skin_matrices(_cm(Rz)[None], _cm(I)[None])])
+    out = O.skin_verts(v, _skin1(O, 1), np.array([2], np.uint32), mats2)
+    assert out.tolist() == [[8, 21, 33, 8, 25, 33, 4, 21, 33]]
+
+
+def test_skin_matches_float64_model(O):
+    from vistrace_amd import workloads as W
+    rng = np.random.default_rng(5)
+    n = 300
+    v = rng.normal(scale=60, size=(n, 9)).astype(np.float32)
+    skin, base, nmat = W.skinned_rig(n, nents=3, bones_per_ent=5)
+    bones, binds = W.rig_pose(nmat, frame=2)
+    mats = O.skin_matrices(bones, binds)
+    M64 = bones.reshape(nmat, 4, 4).transpose(0, 2, 1).astype(np.float64) @ binds.reshape(nmat, 4, 4).transpose(0, 2, 1).astype(np.float64)
+    assert np.allclose(mats.reshape(nmat, 4, 4).transpose(0, 2, 1), M64, rtol=1e-5, atol=1e-4)
+    out = O.skin_verts(v, skin, base, mats).reshape(n, 3, 3)
+    exp = np.zeros((n, 3, 3))
+    for t in range(n):
+        for vi in range(3):
+            p = np.append(v[t, vi * 3:vi * 3 + 3].astype(np.float64), 1.0)
+            for q in range(skin["num_bones"][t, vi]):
+                exp[t, vi] += (M64[base[t] + skin["bone"][t, vi, q]] @ p)[:3] * skin["weight"][t, vi, q]
+    assert np.allclose(out, exp, rtol=1e-4, atol=2e-3)

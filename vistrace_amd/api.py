@@ -14,7 +14,8 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from ._lib import (BVH_NODE, HIT, HIT_ATTRS, HIT_SHADE, NODE_PAIR, RAY, RAY_STATS, TRI64, TRI_ATTRIBS, check, lib, ptr)
+from ._lib import (BVH_NODE, HIT, HIT_ATTRS, HIT_SHADE, NODE_PAIR, RAY, RAY_STATS, SKIN_VERTEX, TRI64, TRI_ATTRIBS, check, lib,
+                   ptr)
 
 FLT_MAX = float(np.finfo(np.float32).max)
 
@@ -244,6 +245,23 @@ class Scene:
         fl = np.ascontiguousarray(flags, dtype=np.uint8) if flags is not None else None
         check(lib.vt_scene_refit(self._h, ptr(verts) if len(verts) else None, ptr(fl) if fl is not None else None, len(verts)))
 
+    def set_skin(self, bind_verts: np.ndarray, skin: np.ndarray, matrix_base: np.ndarray) -> None:
+        """Bind-pose triangles (n,3,3), their (n,3) SKIN_VERTEX records and each triangle's first-matrix index."""
+        bind_verts = np.ascontiguousarray(bind_verts, np.float32).reshape(-1, 9)
+        n = len(bind_verts)
+        skin = np.ascontiguousarray(skin, SKIN_VERTEX).reshape(n * 3)
+        matrix_base = np.ascontiguousarray(matrix_base, np.uint32).reshape(n)
+        check(lib.vt_scene_set_skin(self._h, ptr(bind_verts) if n else None, ptr(skin) if n else None,
+                                    ptr(matrix_base) if n else None, n))
+
+    def skin_refit(self, bones: np.ndarray, binds: np.ndarray) -> None:
+        """Per frame: bone and bind matrices (nmat, 16) column-major -> skin, rebuild records, refit, on the device."""
+        bones = np.ascontiguousarray(bones, np.float32).reshape(-1, 16)
+        binds = np.ascontiguousarray(binds, np.float32).reshape(-1, 16)
+        if bones.shape != binds.shape:
+            raise ValueError("bones and binds must have the same shape")
+        check(lib.vt_scene_skin_refit(self._h, ptr(bones) if len(bones) else None, ptr(binds) if len(binds) else None, len(bones)))
+
     def read_records(self):
         """(pairs, tris) as they currently are on the device."""
         pairs = np.zeros(self.host_scene.pair_count, dtype=NODE_PAIR)
@@ -268,5 +286,5 @@ def build_scene(engine: Engine, verts: np.ndarray, flags: Optional[np.ndarray] =
 
 
 __all__ = ["Engine", "Scene", "HostBvh", "HostScene", "tris_setup", "build_scene", "make_rays", "device_count",
-           "RAY", "HIT", "TRI64", "BVH_NODE", "NODE_PAIR", "RAY_STATS", "HIT_ATTRS", "TRI_ATTRIBS", "HIT_SHADE",
+           "RAY", "HIT", "TRI64", "BVH_NODE", "NODE_PAIR", "RAY_STATS", "HIT_ATTRS", "TRI_ATTRIBS", "HIT_SHADE", "SKIN_VERTEX",
            "FLT_MAX", "_lib"]

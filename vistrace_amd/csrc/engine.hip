@@ -78,6 +78,12 @@ struct vt_scene {
     // refit: pair indices sorted by depth (deepest level first) and where each level starts
     uint32_t*     d_level_pairs = nullptr;
     std::vector<uint32_t> level_begin;     // level_begin[k] .. level_begin[k+1]) = k-th deepest level
+    // skinning inputs (vt_scene_set_skin) and the per-frame matrix table
+    float*          d_bind_verts = nullptr;
+    vt_skin_vertex* d_skin = nullptr;
+    uint32_t*       d_matrix_base = nullptr;
+    float*          d_skin_mats = nullptr;   // 3 x mats_cap matrices: bones | binds | products
+    uint32_t        mats_cap = 0;
     uint32_t      npairs = 0, ntris = 0, max_depth = 0, root_leaf_count = 0;
     uint64_t      bytes = 0;
 };
@@ -403,6 +409,10 @@ void vt_scene_free(vt_scene* s)
     if (s->d_prim_to_slot) (void)hipFree(s->d_prim_to_slot);
     if (s->d_attribs) (void)hipFree(s->d_attribs);
     if (s->d_level_pairs) (void)hipFree(s->d_level_pairs);
+    if (s->d_bind_verts) (void)hipFree(s->d_bind_verts);
+    if (s->d_skin) (void)hipFree(s->d_skin);
+    if (s->d_matrix_base) (void)hipFree(s->d_matrix_base);
+    if (s->d_skin_mats) (void)hipFree(s->d_skin_mats);
     delete s;
 }
 
@@ -502,6 +512,19 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
 
 void* vt_engine_stream(vt_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
 
+// all pair bounds from the (already rewritten) triangle records, deepest level first; waits for the result
+static int refit_levels(vt_scene* s)
+{
+    vt_engine* e = s->engine;
+    for (size_t k = 0; k + 1 < s->level_begin.size(); ++k) {
+        RefitLevelArgs la{reinterpret_cast<vt_node_pair*>(s->d_records), s->d_tris, s->d_level_pairs + s->level_begin[k],
+                          s->level_begin[k + 1] - s->level_begin[k]};
+        VT_HIP(launch_refit_level(la, e->stream));
+    }
+    VT_HIP(hipStreamSynchronize(e->stream));
+    return VT_OK;
+}
+
 int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32_t n)
 {
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: scene is NULL");
@@ -522,13 +545,60 @@ int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32
     RefitTrisArgs ta{static_cast<const float*>(e->d_rays), flags ? static_cast<const uint8_t*>(e->d_out) : nullptr,
                      s->d_prim_to_slot, s->d_tris, n};
     VT_HIP(launch_refit_tris(ta, e->stream));
-    for (size_t k = 0; k + 1 < s->level_begin.size(); ++k) {   // deepest level first
-        RefitLevelArgs la{reinterpret_cast<vt_node_pair*>(s->d_records), s->d_tris, s->d_level_pairs + s->level_begin[k],
-                          s->level_begin[k + 1] - s->level_begin[k]};
-        VT_HIP(launch_refit_level(la, e->stream));
+    return refit_levels(s);
+}
+
+int vt_scene_set_skin(vt_scene* s, const float* bind_verts, const vt_skin_vertex* skin, const uint32_t* matrix_base, uint32_t n)
+{
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_skin: scene is NULL");
+    if (n != s->ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_skin: n differs from the scene's triangle count");
+    if (n == 0) return VT_OK;
+    if (!bind_verts || !skin || !matrix_base) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_skin: NULL argument");
+    for (size_t i = 0; i < size_t(n) * 3; ++i) {
+        if (skin[i].num_bones > 3) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_skin: a vertex has more than 3 bones");
+        for (uint32_t q = 0; q < skin[i].num_bones; ++q)
+            if (skin[i].bone[q] < 0) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_skin: negative bone id");
     }
+    vt_engine* e = s->engine;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_set_skin: hipSetDevice failed");
+    const size_t vb = size_t(n) * 9 * sizeof(float), sb = size_t(n) * 3 * sizeof(vt_skin_vertex), mb = size_t(n) * sizeof(uint32_t);
+    if (!s->d_bind_verts) {
+        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_bind_verts), vb));
+        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_skin), sb));
+        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_matrix_base), mb));
+        s->bytes += vb + sb + mb;
+    }
+    VT_HIP(hipMemcpyAsync(s->d_bind_verts, bind_verts, vb, hipMemcpyHostToDevice, e->stream));
+    VT_HIP(hipMemcpyAsync(s->d_skin, skin, sb, hipMemcpyHostToDevice, e->stream));
+    VT_HIP(hipMemcpyAsync(s->d_matrix_base, matrix_base, mb, hipMemcpyHostToDevice, e->stream));
     VT_HIP(hipStreamSynchronize(e->stream));
     return VT_OK;
+}
+
+int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uint32_t nmat)
+{
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: scene is NULL");
+    if (s->ntris == 0) return VT_OK;
+    if (!s->d_bind_verts) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: no skin data (call vt_scene_set_skin first)");
+    if (nmat == 0 || !bones || !binds) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: no matrices");
+    vt_engine* e = s->engine;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_skin_refit: hipSetDevice failed");
+    if (nmat > s->mats_cap) {
+        if (s->d_skin_mats) { VT_HIP(hipFree(s->d_skin_mats)); s->d_skin_mats = nullptr; s->mats_cap = 0; }
+        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_skin_mats), size_t(nmat) * 3 * 64));
+        s->mats_cap = nmat;
+    }
+    float* d_bones = s->d_skin_mats;
+    float* d_binds = d_bones + size_t(s->mats_cap) * 16;
+    float* d_prod = d_binds + size_t(s->mats_cap) * 16;
+    VT_HIP(hipMemcpyAsync(d_bones, bones, size_t(nmat) * 64, hipMemcpyHostToDevice, e->stream));
+    VT_HIP(hipMemcpyAsync(d_binds, binds, size_t(nmat) * 64, hipMemcpyHostToDevice, e->stream));
+    VT_HIP(launch_skin_matrices(SkinMatricesArgs{d_bones, d_binds, d_prod, nmat}, e->stream));
+    SkinTrisArgs ta{s->d_bind_verts, s->d_skin, s->d_matrix_base, d_prod, s->d_prim_to_slot, s->d_tris, s->ntris, nmat};
+    VT_HIP(launch_skin_tris(ta, e->stream));
+    return refit_levels(s);
 }
 
 int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_out)

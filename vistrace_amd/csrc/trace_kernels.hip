@@ -538,25 +538,82 @@ __global__ __launch_bounds__(kBlockThreads) void gen_bounce_kernel(GenBounceArgs
 }
 
 // ---- refit: triangle records and pair bounds recomputed in place ----------
-__global__ __launch_bounds__(kBlockThreads) void refit_tris_kernel(RefitTrisArgs a)
+// triangle record from three vertices: Triangle ctor Primitives.h:82 + ComputeNormalAndLoD :93
+__device__ __forceinline__ void store_tri_record(const float* v, uint32_t prim, uint32_t flags, vt_tri64* dst)
 {
-    const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
-    if (i >= a.n) return;
-    const float* v = a.verts + size_t(i) * 9;
-    const uint32_t slot = a.prim_to_slot[i];
     vt_tri64 t;
-    for (int k = 0; k < 3; ++k) {                      // Primitives.h:82
+    for (int k = 0; k < 3; ++k) {
         t.p0[k] = v[k];
         t.e1[k] = v[k] - v[3 + k];
         t.e2[k] = v[6 + k] - v[k];
     }
-    t.n[0] = t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1];    // Primitives.h:93
+    t.n[0] = t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1];
     t.n[1] = t.e1[2] * t.e2[0] - t.e1[0] * t.e2[2];
     t.n[2] = t.e1[0] * t.e2[1] - t.e1[1] * t.e2[0];
-    t.prim = i;
-    t.flags = a.flags ? uint32_t(a.flags[i]) : a.tris[slot].flags;
+    t.prim = prim;
+    t.flags = flags;
     t.pad[0] = t.pad[1] = 0;
-    a.tris[slot] = t;
+    *dst = t;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void refit_tris_kernel(RefitTrisArgs a)
+{
+    const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
+    if (i >= a.n) return;
+    const float* src = a.verts + size_t(i) * 9;
+    float v[9];
+    for (int k = 0; k < 9; ++k) v[k] = src[k];
+    const uint32_t slot = a.prim_to_slot[i];
+    store_tri_record(v, i, a.flags ? uint32_t(a.flags[i]) : a.tris[slot].flags, &a.tris[slot]);
+}
+
+// bones[i] * binds[i], the product TransformToBone forms per vertex and bone (AccelStruct.cpp:44);
+// glm mat4 * mat4: Result[c] = A[0]*B[c][0] + A[1]*B[c][1] + A[2]*B[c][2] + A[3]*B[c][3].  One thread per element.
+__global__ __launch_bounds__(kBlockThreads) void skin_matrices_kernel(SkinMatricesArgs a)
+{
+    const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
+    if (i >= a.nmat * 16u) return;
+    const uint32_t m = i >> 4, c = (i >> 2) & 3u, r = i & 3u;
+    const float* A = a.bones + size_t(m) * 16;
+    const float* B = a.binds + size_t(m) * 16;
+    float acc = A[r] * B[c * 4];
+    acc = acc + A[4 + r] * B[c * 4 + 1];
+    acc = acc + A[8 + r] * B[c * 4 + 2];
+    acc = acc + A[12 + r] * B[c * 4 + 3];
+    a.mats[i] = acc;
+}
+
+// SkinTriangle (AccelStruct.cpp:66-102), positions only: one thread per triangle; the three vertices are
+// re-derived through p0/e1/e2 (:68-72), moved by TransformToBone (:35-47; glm mat4 * vec4 =
+// (m0*x + m1*y) + (m2*z + m3*w), then * weight, accumulated from 0) and the record rebuilt in its leaf slot.
+__global__ __launch_bounds__(kBlockThreads) void skin_tris_kernel(SkinTrisArgs a)
+{
+    const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
+    if (i >= a.n) return;
+    const float* b = a.bind_verts + size_t(i) * 9;
+    float pos[9], v[9];
+    for (int k = 0; k < 3; ++k) {
+        const float p0 = b[k], e1 = b[k] - b[3 + k], e2 = b[6 + k] - b[k];
+        pos[k] = p0; pos[3 + k] = p0 - e1; pos[6 + k] = p0 + e2;
+    }
+    const uint32_t base = a.matrix_base[i];
+    for (int vi = 0; vi < 3; ++vi) {
+        const vt_skin_vertex sv = a.skin[size_t(i) * 3 + vi];
+        float fin[3] = {0.f, 0.f, 0.f};
+        for (uint32_t q = 0; q < sv.num_bones && q < 3u; ++q) {
+            uint32_t mi = base + uint32_t(int(sv.bone[q]));
+            mi = mi < a.nmat ? mi : 0u;                            // out-of-range bone id: stay inside the table
+            const float* M = a.mats + size_t(mi) * 16;
+            for (int r = 0; r < 3; ++r) {
+                const float a0 = M[r] * pos[vi * 3] + M[4 + r] * pos[vi * 3 + 1];
+                const float a1 = M[8 + r] * pos[vi * 3 + 2] + M[12 + r] * 1.f;
+                fin[r] = fin[r] + (a0 + a1) * sv.weight[q];
+            }
+        }
+        v[vi * 3] = fin[0]; v[vi * 3 + 1] = fin[1]; v[vi * 3 + 2] = fin[2];
+    }
+    const uint32_t slot = a.prim_to_slot[i];
+    store_tri_record(v, i, a.tris[slot].flags, &a.tris[slot]);
 }
 
 __device__ __forceinline__ void box_of_child(const vt_node_pair* pairs, const vt_tri64* tris, const vt_bvh_node& c, float* b)
@@ -685,6 +742,21 @@ hipError_t launch_refit_tris(const RefitTrisArgs& a, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
     hipLaunchKernelGGL(refit_tris_kernel, dim3((a.n + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_skin_matrices(const SkinMatricesArgs& a, hipStream_t stream)
+{
+    if (a.nmat == 0) return hipSuccess;
+    hipLaunchKernelGGL(skin_matrices_kernel, dim3((a.nmat * 16u + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0,
+                       stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_skin_tris(const SkinTrisArgs& a, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(skin_tris_kernel, dim3((a.n + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -244,3 +244,40 @@ def shadow_rays(attrs: np.ndarray, lights: np.ndarray, seed: int, per_hit: int =
     dist = np.sqrt((to * to).sum(1, dtype=np.float32)).astype(np.float32)
     d = (to / dist[:, None]).astype(np.float32)
     return _pack(org, d, 0.0, (dist * np.float32(1.0 - 1e-4)).astype(np.float32))
+
+
+def skinned_rig(ntris: int, nents: int = 8, bones_per_ent: int = 12, seed: int = SEED + 9):
+    """Synthetic skinning inputs for ntris triangles (seeded): triangles are dealt to `nents` entities in
+    contiguous runs, every vertex gets 1-3 bones of its entity with weights summing to ~1.
+    Returns (skin (ntris,3) SKIN_VERTEX-compatible structured array, matrix_base (ntris,) u32, nmat)."""
+    rng = np.random.default_rng(seed)
+    skin = np.zeros((ntris, 3), np.dtype([("weight", "<f4", 3), ("bone", "i1", 3), ("num_bones", "u1")]))
+    ent = (np.arange(ntris, dtype=np.uint64) * nents // max(ntris, 1)).astype(np.uint32)
+    nb = rng.integers(1, 4, size=(ntris, 3))
+    w = rng.random((ntris, 3, 3)).astype(np.float32) + np.float32(0.05)
+    w *= (np.arange(3)[None, None, :] < nb[:, :, None])
+    w = (w / w.sum(axis=2, keepdims=True)).astype(np.float32)
+    skin["weight"] = w
+    skin["bone"] = rng.integers(0, bones_per_ent, size=(ntris, 3, 3)).astype(np.int8)
+    skin["num_bones"] = nb.astype(np.uint8)
+    return skin, (ent * np.uint32(bones_per_ent)).astype(np.uint32), nents * bones_per_ent
+
+
+def rig_pose(nmat: int, frame: int, seed: int = SEED + 10):
+    """(bones, binds) as (nmat,16) column-major float32: binds are fixed seeded affine matrices, bones are
+    small frame-dependent rotations + translations composed with the inverse bind (so the pose stays near
+    the bind pose, as an animated model does)."""
+    rng = np.random.default_rng(seed)
+    def affine(r, ang, shift):
+        axis = r.normal(size=(nmat, 3)); axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+        a = r.normal(scale=ang, size=nmat)
+        K = np.zeros((nmat, 3, 3)); K[:, 0, 1] = -axis[:, 2]; K[:, 0, 2] = axis[:, 1]; K[:, 1, 0] = axis[:, 2]
+        K[:, 1, 2] = -axis[:, 0]; K[:, 2, 0] = -axis[:, 1]; K[:, 2, 1] = axis[:, 0]
+        R = np.eye(3)[None] + np.sin(a)[:, None, None] * K + (1 - np.cos(a))[:, None, None] * (K @ K)
+        M = np.tile(np.eye(4), (nmat, 1, 1)); M[:, :3, :3] = R; M[:, :3, 3] = r.normal(scale=shift, size=(nmat, 3))
+        return M
+    bind = affine(rng, 0.6, 40.0)
+    move = affine(np.random.default_rng(seed + 1 + frame), 0.08, 6.0)
+    bone = move @ np.linalg.inv(bind)
+    cm = lambda M: np.ascontiguousarray(np.transpose(M, (0, 2, 1)).reshape(nmat, 16), np.float32)   # column-major
+    return cm(bone), cm(bind)
