@@ -233,6 +233,18 @@ int vt_hit_shade_dev(vt_scene* s, const void* d_hits, uint64_t n, void* d_out, v
 int vt_gen_primary_dev(vt_engine* e, const vt_camera* cam, void* d_rays, void* stream);
 int vt_gen_bounce_dev(vt_engine* e, const void* d_attrs, uint64_t n, uint64_t seed, void* d_rays, void* stream);
 
+/* Device-resident bounce loop (wavefront queue of live paths).  Starting from n rays
+ * (d_rays, left untouched), `depth` times: trace the live paths' rays (closest hit), write the hits to row d of
+ * d_hits (depth x n vt_hit, row-major, indexed by path = index of the starting ray; a path that has already
+ * ended reads VT_MISS/0/0/0), and give every path that hit something its next ray -- exactly
+ * vt_gen_bounce_dev(vt_hit_attrs_dev(...), seed + d) with the path index as the sample counter.  Paths that miss
+ * leave the queue, which is compacted in path order, so the result does not depend on scheduling and equals the
+ * uncompacted composition of the three calls.  live_out (host, depth entries, may be NULL): paths traced at each
+ * depth.  Only the live-path count crosses the bus (4 B per depth); the call returns with the last depth's work
+ * still in flight on `stream`. */
+int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t depth, uint64_t seed, void* d_hits,
+                       uint64_t* live_out, void* stream);
+
 /* When enabled, every trace launch is bracketed by HIP events on its stream;
  * vt_engine_last_kernel_ms synchronises on the last pair and returns its time. */
 int vt_engine_set_timing(vt_engine* e, int enabled);

@@ -534,3 +534,45 @@ def test_device_skin_refit_matches_host_pipeline(va, engine, O):
     bad["num_bones"][0, 0] = 4
     with pytest.raises(va._lib.VisTraceError):
         scene.set_skin(verts, bad, base)
+
+
+@pytest.mark.parametrize("name", ["terrain", "S10k"])
+def test_bounce_loop_matches_composition_and_oracle(va, engine, make_bundle, name):
+    """vt_bounce_loop_dev (compacted queue of live paths) row by row against (a) the uncompacted composition
+    trace -> vt_hit_attrs_dev -> vt_gen_bounce_dev(seed + d) over all n paths and (b) the oracle's traversal of
+    each depth's rays; live counts = hits of the previous depth."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle(name)
+    scene = upload(va, engine, b)
+    dev = torch.device("cuda", 0)
+    n, depth, seed = 20001, 5, 4242
+    start = W.sphere_rays(n, 77, origin=(3.0, -4.0, 60.0) if name == "terrain" else (15.0, 25.0, -35.0))
+    d_start = tp.to_device(start, dev)
+    d_rows, live = tp.bounce_loop(scene, d_start, n, depth, seed)
+    torch.cuda.synchronize()
+    rows = tp.to_host(d_rows, va.HIT).reshape(depth, n)
+    assert (tp.to_host(d_start, va.RAY).view(np.uint8) == start.view(np.uint8)).all()      # input untouched
+    d_rays = d_start
+    expect_live = n
+    for d in range(depth):
+        assert live[d] == expect_live
+        rays = tp.to_host(d_rays, va.RAY)
+        d_hits = tp.trace_closest(scene, d_rays, n)
+        hits = tp.to_host(d_hits, va.HIT)
+        assert_hits_equal(hits, b.oracle(rays))
+        assert_hits_equal(rows[d], hits)
+        expect_live = int((hits["prim"] != O_MISS).sum())
+        d_attrs = tp.hit_attrs(scene, d_rays, d_hits, n)
+        d_next = tp.empty_records(n, va.RAY, dev)
+        engine.gen_bounce_dev(d_attrs.data_ptr(), n, seed + d, d_next.data_ptr(), stream=tp.current_stream_handle(dev))
+        d_rays = d_next
+    if name == "terrain":
+        assert live[1] < n and live[-1] < live[1]          # an open scene: paths leave the queue
+    # depth 1 = a plain trace; depth 0 and n 0 are no-ops
+    d_one, live1 = tp.bounce_loop(scene, d_start, n, 1, seed)
+    torch.cuda.synchronize()
+    assert_hits_equal(tp.to_host(d_one, va.HIT), rows[0])
+    assert live1 == [n]
+    assert scene.bounce_loop_dev(d_start.data_ptr(), 0, 3, seed, d_rows.data_ptr()) == [0, 0, 0]

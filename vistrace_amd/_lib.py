@@ -87,6 +87,7 @@ SYMBOLS = {
     "vt_hit_shade_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
     "vt_gen_primary_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
     "vt_gen_bounce_dev": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
+    "vt_bounce_loop_dev": (C.c_int, [_vp, _vp, _u64, _u32, _u64, _vp, _vp, _vp]),
     "vt_engine_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "vt_engine_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "vt_engine_stream": (_vp, [_vp]),

@@ -230,6 +230,13 @@ class Scene:
     def trace_closest_dev(self, d_rays: int, n: int, d_hits: int, stream: int = 0) -> None:
         check(lib.vt_trace_closest_dev(self._h, d_rays, n, d_hits, stream or None))
 
+    def bounce_loop_dev(self, d_rays: int, n: int, depth: int, seed: int, d_hits: int, stream: int = 0) -> list:
+        """Device-resident bounce loop: depth x n hit records (row d = hits of bounce d, indexed by path).
+        Returns the number of live paths traced at each depth."""
+        live = (C.c_uint64 * max(depth, 1))()
+        check(lib.vt_bounce_loop_dev(self._h, d_rays, n, depth, seed & 0xFFFFFFFFFFFFFFFF, d_hits, live, stream or None))
+        return [int(x) for x in live[:depth]]
+
     def trace_any_dev(self, d_rays: int, n: int, d_occ: int, stream: int = 0) -> None:
         check(lib.vt_trace_any_dev(self._h, d_rays, n, d_occ, stream or None))
 

@@ -52,6 +52,9 @@ struct vt_engine {
     // staging for the host-pointer entry points
     void*  d_rays = nullptr;  size_t d_rays_bytes = 0;
     void*  d_out  = nullptr;  size_t d_out_bytes = 0;
+    // bounce loop: two ray queues, two path-id queues, the queue's hit records, block offsets, live counter
+    void*  d_loop = nullptr;  size_t d_loop_bytes = 0;
+    uint32_t* h_live = nullptr;           // pinned read-back of the live-path count
     // single-ray / tiny-batch path: pinned, device-mapped host memory the kernel reads and writes in
     // place (no copy calls: one launch + one stream sync per Traverse)
     static constexpr uint32_t kTinyRays = 256;
@@ -283,6 +286,8 @@ void vt_engine_close(vt_engine* e)
     if (e->d_overflow) (void)hipFree(e->d_overflow);
     if (e->d_rays) (void)hipFree(e->d_rays);
     if (e->d_out) (void)hipFree(e->d_out);
+    if (e->d_loop) (void)hipFree(e->d_loop);
+    if (e->h_live) (void)hipHostFree(e->h_live);
     if (e->h_tiny_rays) (void)hipHostFree(e->h_tiny_rays);
     if (e->h_tiny_out) (void)hipHostFree(e->h_tiny_out);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
@@ -507,6 +512,59 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
     a.attrs = static_cast<vt_hit_attrs*>(d_attrs);
     a.n = n;
     VT_HIP(launch_hit_attrs(a, static_cast<hipStream_t>(stream)));
+    return VT_OK;
+}
+
+int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t depth, uint64_t seed, void* d_hits,
+                       uint64_t* live_out, void* stream_)
+{
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_bounce_loop_dev: scene is NULL");
+    if (n == 0 || depth == 0) return VT_OK;
+    if (!d_rays || !d_hits) return fail(VT_ERR_INVALID_ARG, "vt_bounce_loop_dev: NULL device buffer");
+    if (n >= (uint64_t(1) << 32)) return fail(VT_ERR_INVALID_ARG, "vt_bounce_loop_dev: more than 2^32-1 paths");
+    vt_engine* e = s->engine;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_bounce_loop_dev: hipSetDevice failed");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const uint64_t nblocks = (n + kBlockThreads - 1) / kBlockThreads;
+    auto al = [](uint64_t b) { return (b + 255) & ~uint64_t(255); };
+    const uint64_t ray_b = al(n * sizeof(vt_ray)), id_b = al(n * 4), hit_b = al(n * sizeof(vt_hit)), off_b = al(nblocks * 4);
+    int rc = ensure_bytes(&e->d_loop, &e->d_loop_bytes, 2 * ray_b + 2 * id_b + hit_b + off_b + 256);
+    if (rc != VT_OK) return rc;
+    if (!e->h_live) VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_live), 64));
+    char* base = static_cast<char*>(e->d_loop);
+    vt_ray* R[2] = {reinterpret_cast<vt_ray*>(base), reinterpret_cast<vt_ray*>(base + ray_b)};
+    uint32_t* I[2] = {reinterpret_cast<uint32_t*>(base + 2 * ray_b), reinterpret_cast<uint32_t*>(base + 2 * ray_b + id_b)};
+    vt_hit* hits_scratch = reinterpret_cast<vt_hit*>(base + 2 * ray_b + 2 * id_b);
+    uint32_t* offsets = reinterpret_cast<uint32_t*>(base + 2 * ray_b + 2 * id_b + hit_b);
+    uint32_t* d_live = reinterpret_cast<uint32_t*>(base + 2 * ray_b + 2 * id_b + hit_b + off_b);
+    vt_hit* H = static_cast<vt_hit*>(d_hits);
+
+    uint64_t m = n;
+    const vt_ray* rays_q = static_cast<const vt_ray*>(d_rays);
+    const uint32_t* ids_q = nullptr;
+    if (live_out) live_out[0] = n;
+    for (uint32_t d = 0; d < depth; ++d) {
+        vt_hit* row = H + uint64_t(d) * n;
+        if (m < n) VT_HIP(launch_fill_miss(row, n, stream));            // paths that ended earlier read as misses
+        const bool last = d + 1 == depth;
+        if (m != 0) {
+            vt_hit* hits_q = d == 0 ? row : hits_scratch;               // depth 0: queue order = path order
+            rc = launch(s, rays_q, m, hits_q, nullptr, nullptr, false, false, stream);
+            if (rc != VT_OK) return rc;
+            QueueArgs qa{s->d_tris, s->d_prim_to_slot, rays_q, hits_q, ids_q, m, d == 0 ? nullptr : row,
+                         last ? nullptr : R[d & 1], last ? nullptr : I[d & 1], offsets, seed + d};
+            VT_HIP(launch_queue_step(qa, d_live, stream));
+            if (!last) {
+                VT_HIP(hipMemcpyAsync(e->h_live, d_live, 4, hipMemcpyDeviceToHost, stream));
+                VT_HIP(hipStreamSynchronize(stream));
+                m = *e->h_live;
+                rays_q = R[d & 1];
+                ids_q = I[d & 1];
+            }
+        }
+        if (live_out && !last) live_out[d + 1] = m;
+    }
     return VT_OK;
 }
 

@@ -51,6 +51,18 @@ struct GenBounceArgs { const vt_hit_attrs* attrs; vt_ray* rays; uint64_t n; uint
 hipError_t launch_gen_primary(const GenPrimaryArgs& a, hipStream_t stream);
 hipError_t launch_gen_bounce(const GenBounceArgs& a, hipStream_t stream);
 
+// one depth of the bounce loop: m queue entries (rays_q[j], hits_q[j], path id ids_q[j] or j when NULL)
+struct QueueArgs {
+    const vt_tri64* tris; const uint32_t* prim_to_slot;
+    const vt_ray* rays_q; const vt_hit* hits_q; const uint32_t* ids_q; uint64_t m;
+    vt_hit* hits_out;          // this depth's row of the result (indexed by path), or NULL when hits_q already is it
+    vt_ray* rays_next; uint32_t* ids_next;   // next queue, or NULL at the last depth
+    uint32_t* block_offsets;   // scratch: one entry per 256 queue entries
+    uint64_t seed;
+};
+hipError_t launch_queue_step(const QueueArgs& a, uint32_t* live_out, hipStream_t stream);
+hipError_t launch_fill_miss(vt_hit* hits, uint64_t n, hipStream_t stream);
+
 struct RefitTrisArgs { const float* verts; const uint8_t* flags; const uint32_t* prim_to_slot; vt_tri64* tris; uint32_t n; };
 struct RefitLevelArgs { vt_node_pair* pairs; const vt_tri64* tris; const uint32_t* level_pairs; uint32_t count; };
 hipError_t launch_refit_tris(const RefitTrisArgs& a, hipStream_t stream);

@@ -412,34 +412,36 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
 }
 
 // ---- TraceResult batch core: TraceResult.cpp:45-86, 255-262 -----------------------------
+__device__ __forceinline__ vt_hit_attrs make_hit_attrs(const vt_tri64& T, const vt_ray& r, const vt_hit& h)
+{
+    vt_hit_attrs o;
+    // AccelStruct.cpp:826 glm::normalize(dir); TraceResult.cpp:56 wo = -direction
+    const float d2 = (r.dir[0] * r.dir[0] + r.dir[1] * r.dir[1]) + r.dir[2] * r.dir[2];
+    const float inv = 1.0f / sqrtf(d2);
+    o.wo[0] = -(r.dir[0] * inv); o.wo[1] = -(r.dir[1] * inv); o.wo[2] = -(r.dir[2] * inv);
+    const float w = 1.0f - h.u - h.v;                               // TraceResult.cpp:70
+    o.uvw[0] = h.u; o.uvw[1] = h.v; o.uvw[2] = w;
+    const float len = sqrtf((T.n[0] * T.n[0] + T.n[1] * T.n[1]) + T.n[2] * T.n[2]);
+    for (int k = 0; k < 3; ++k) {
+        o.ngeo[k] = T.n[k] / len;                                   // Primitives.h:100
+        const float v0 = T.p0[k], v1 = T.p0[k] - T.e1[k], v2 = T.p0[k] + T.e2[k];
+        o.pos[k] = (w * v0 + h.u * v1) + h.v * v2;                  // TraceResult.cpp:258
+    }
+    o.t = h.t;
+    o.prim = h.prim;
+    o.front = ((o.wo[0] * o.ngeo[0] + o.wo[1] * o.ngeo[1]) + o.wo[2] * o.ngeo[2]) >= 0.0f ? 1u : 0u; // :85
+    o.hit = 1;
+    return o;
+}
+
 __global__ __launch_bounds__(kBlockThreads) void hit_attrs_kernel(HitAttrsArgs a)
 {
     const uint64_t i = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
     if (i >= a.n) return;
     const vt_hit h = a.hits[i];
     vt_hit_attrs o;
-    if (h.prim == VT_MISS) {
-        o = vt_hit_attrs{};
-    } else {
-        const vt_tri64 T = a.tris[a.prim_to_slot[h.prim]];
-        const vt_ray r = a.rays[i];
-        // AccelStruct.cpp:826 glm::normalize(dir); TraceResult.cpp:56 wo = -direction
-        const float d2 = (r.dir[0] * r.dir[0] + r.dir[1] * r.dir[1]) + r.dir[2] * r.dir[2];
-        const float inv = 1.0f / sqrtf(d2);
-        o.wo[0] = -(r.dir[0] * inv); o.wo[1] = -(r.dir[1] * inv); o.wo[2] = -(r.dir[2] * inv);
-        const float w = 1.0f - h.u - h.v;                               // TraceResult.cpp:70
-        o.uvw[0] = h.u; o.uvw[1] = h.v; o.uvw[2] = w;
-        const float len = sqrtf((T.n[0] * T.n[0] + T.n[1] * T.n[1]) + T.n[2] * T.n[2]);
-        for (int k = 0; k < 3; ++k) {
-            o.ngeo[k] = T.n[k] / len;                                   // Primitives.h:100
-            const float v0 = T.p0[k], v1 = T.p0[k] - T.e1[k], v2 = T.p0[k] + T.e2[k];
-            o.pos[k] = (w * v0 + h.u * v1) + h.v * v2;                  // TraceResult.cpp:258
-        }
-        o.t = h.t;
-        o.prim = h.prim;
-        o.front = ((o.wo[0] * o.ngeo[0] + o.wo[1] * o.ngeo[1]) + o.wo[2] * o.ngeo[2]) >= 0.0f ? 1u : 0u; // :85
-        o.hit = 1;
-    }
+    if (h.prim == VT_MISS) o = vt_hit_attrs{};
+    else o = make_hit_attrs(a.tris[a.prim_to_slot[h.prim]], a.rays[i], h);
     a.attrs[i] = o;
 }
 
@@ -499,17 +501,10 @@ __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t index)
     return z ^ (z >> 31);
 }
 
-__global__ __launch_bounds__(kBlockThreads) void gen_bounce_kernel(GenBounceArgs a)
+// one bounce ray from a hit record; i = the counter of the path (its index in the batch)
+__device__ __forceinline__ vt_ray make_bounce_ray(const vt_hit_attrs& A, uint64_t seed, uint64_t i)
 {
-    const uint64_t i = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
-    if (i >= a.n) return;
-    const vt_hit_attrs A = a.attrs[i];
     vt_ray ray{};
-    if (A.hit == 0) {   // null ray: keeps batch size and order, cannot hit anything
-        ray.dir[0] = 1.f; ray.tmin = 0.f; ray.tmax = 1e-30f;
-        a.rays[i] = ray;
-        return;
-    }
     // geometric normal flipped towards wo (the side the ray arrived from)
     float n[3];
     for (int k = 0; k < 3; ++k) n[k] = A.front ? A.ngeo[k] : -A.ngeo[k];
@@ -522,8 +517,8 @@ __global__ __launch_bounds__(kBlockThreads) void gen_bounce_kernel(GenBounceArgs
         ray.org[k] = fabsf(A.pos[k]) < origin ? A.pos[k] + n[k] * fScale : iPos;
     }
     // hemisphere_cos, BSDF.cpp:69-77, samples = top 24 bits of splitmix64 outputs 2i and 2i+1
-    const float r1 = float(splitmix64_at(a.seed, 2 * i) >> 40) * (1.0f / 16777216.0f);
-    const float r2 = float(splitmix64_at(a.seed, 2 * i + 1) >> 40) * (1.0f / 16777216.0f);
+    const float r1 = float(splitmix64_at(seed, 2 * i) >> 40) * (1.0f / 16777216.0f);
+    const float r2 = float(splitmix64_at(seed, 2 * i + 1) >> 40) * (1.0f / 16777216.0f);
     const float z = sqrtf(r1), sinTheta = sqrtf(1.f - r1), phi = 2.f * 3.14159265358979323846f * r2;
     const float lx = sinTheta * cosf(phi), ly = sinTheta * sinf(phi);
     // orthonormal basis around n (Duff et al. 2017), as vistrace_amd/workloads.py::_onb
@@ -534,7 +529,84 @@ __global__ __launch_bounds__(kBlockThreads) void gen_bounce_kernel(GenBounceArgs
     const float b2[3] = {b, sign + n[1] * n[1] * aa, -n[1]};
     for (int k = 0; k < 3; ++k) ray.dir[k] = (b1[k] * lx + b2[k] * ly) + n[k] * z;
     ray.tmin = 0.f; ray.tmax = FLT_MAX;
-    a.rays[i] = ray;
+    return ray;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void gen_bounce_kernel(GenBounceArgs a)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
+    if (i >= a.n) return;
+    const vt_hit_attrs A = a.attrs[i];
+    if (A.hit == 0) {   // null ray: keeps batch size and order, cannot hit anything
+        vt_ray ray{};
+        ray.dir[0] = 1.f; ray.tmin = 0.f; ray.tmax = 1e-30f;
+        a.rays[i] = ray;
+        return;
+    }
+    a.rays[i] = make_bounce_ray(A, a.seed, i);
+}
+
+// ---- device-resident bounce loop: queue of live paths, compacted in path order ----
+// step 1: hits per 256-entry block of the queue
+__global__ __launch_bounds__(kBlockThreads) void queue_count_kernel(QueueArgs a)
+{
+    __shared__ uint32_t wave_count[kBlockThreads / 64];
+    const uint64_t j = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
+    const bool live = j < a.m && a.hits_q[j].prim != VT_MISS;
+    const uint64_t mask = __ballot(live);
+    if ((threadIdx.x & 63u) == 0) wave_count[threadIdx.x >> 6] = uint32_t(__popcll(mask));
+    __syncthreads();
+    if (threadIdx.x == 0) a.block_offsets[blockIdx.x] = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+}
+
+// step 2: exclusive scan of the block counts in place (one block; nblocks <= 2^24), total -> *live_out
+__global__ __launch_bounds__(1024) void queue_scan_kernel(uint32_t* counts, uint32_t nblocks, uint32_t* live_out)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nblocks + 1023u) / 1024u;
+    const uint32_t lo = min(threadIdx.x * per, nblocks), hi = min(lo + per, nblocks);
+    uint32_t sum = 0;
+    for (uint32_t k = lo; k < hi; ++k) sum += counts[k];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {                    // Hillis-Steele inclusive scan of the partials
+        const uint32_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = counts[k]; counts[k] = run; run += c; }
+    if (threadIdx.x == 1023u) *live_out = part[1023];
+}
+
+// step 3: scatter this depth's hits to their paths; every hit emits its bounce ray and path id to the next queue
+__global__ __launch_bounds__(kBlockThreads) void queue_emit_kernel(QueueArgs a)
+{
+    __shared__ uint32_t wave_count[kBlockThreads / 64];
+    const uint64_t j = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
+    const bool valid = j < a.m;
+    vt_hit h{VT_MISS, 0.f, 0.f, 0.f};
+    if (valid) h = a.hits_q[j];
+    const uint32_t path = valid ? (a.ids_q ? a.ids_q[j] : uint32_t(j)) : 0u;
+    if (valid && a.hits_out) a.hits_out[path] = h;
+    const bool live = valid && h.prim != VT_MISS;
+    const uint64_t mask = __ballot(live);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_count[wave] = uint32_t(__popcll(mask));
+    __syncthreads();
+    if (!a.rays_next || !live) return;
+    uint32_t dst = a.block_offsets[blockIdx.x] + uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1)));
+    for (uint32_t w = 0; w < wave; ++w) dst += wave_count[w];
+    const vt_hit_attrs A = make_hit_attrs(a.tris[a.prim_to_slot[h.prim]], a.rays_q[j], h);
+    a.rays_next[dst] = make_bounce_ray(A, a.seed, path);
+    a.ids_next[dst] = path;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void fill_miss_kernel(vt_hit* hits, uint64_t n)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
+    if (i < n) hits[i] = vt_hit{VT_MISS, 0.f, 0.f, 0.f};
 }
 
 // ---- refit: triangle records and pair bounds recomputed in place ----------
@@ -735,6 +807,26 @@ hipError_t launch_gen_bounce(const GenBounceArgs& a, hipStream_t stream)
     if (a.n == 0) return hipSuccess;
     hipLaunchKernelGGL(gen_bounce_kernel, dim3(uint32_t((a.n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0,
                        stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_queue_step(const QueueArgs& a, uint32_t* live_out, hipStream_t stream)
+{
+    if (a.m == 0) return hipSuccess;
+    const uint32_t blocks = uint32_t((a.m + kBlockThreads - 1) / kBlockThreads);
+    if (a.rays_next) {
+        hipLaunchKernelGGL(queue_count_kernel, dim3(blocks), dim3(kBlockThreads), 0, stream, a);
+        hipLaunchKernelGGL(queue_scan_kernel, dim3(1), dim3(1024), 0, stream, a.block_offsets, blocks, live_out);
+    }
+    hipLaunchKernelGGL(queue_emit_kernel, dim3(blocks), dim3(kBlockThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_miss(vt_hit* hits, uint64_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_miss_kernel, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
+                       hits, n);
     return hipGetLastError();
 }
 

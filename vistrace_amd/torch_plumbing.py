@@ -57,5 +57,12 @@ def hit_attrs(scene, d_rays: torch.Tensor, d_hits: torch.Tensor, n: int) -> torc
     return d_attrs
 
 
+def bounce_loop(scene, d_rays: torch.Tensor, n: int, depth: int, seed: int):
+    """(d_hits as a (depth*n*16)-byte tensor, live-path counts per depth); see vt_bounce_loop_dev."""
+    d_hits = empty_records(n * depth, HIT, d_rays.device)
+    live = scene.bounce_loop_dev(d_rays.data_ptr(), n, depth, seed, d_hits.data_ptr(), current_stream_handle(d_rays.device))
+    return d_hits, live
+
+
 __all__ = ["to_device", "to_host", "empty_records", "current_stream_handle", "trace_closest", "trace_any",
-           "trace_stats", "hit_attrs", "RAY", "HIT"]
+           "trace_stats", "hit_attrs", "bounce_loop", "RAY", "HIT"]
