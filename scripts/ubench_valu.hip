@@ -57,6 +57,31 @@ KERNEL(k_mov, "", X_MOV)
 KERNEL(k_and, "", X_AND)
 KERNEL(k_lshladd, "", X_LSHLADD)
 
+// same loop with only part of the wave enabled in EXEC: does the SIMD skip 16-lane groups that are all off?
+#define KERNEL_MASKED(NAME, COND, X)                                                                             \
+    __global__ __launch_bounds__(256) void NAME(float* out, int iters, float seed)                               \
+    {                                                                                                            \
+        float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,           \
+              a6 = a0 + 6, a7 = a0 + 7;                                                                          \
+        float c = 1.0001f;                                                                                       \
+        const unsigned l = threadIdx.x & 63u;                                                                    \
+        if (COND) {                                                                                              \
+            for (int i = 0; i < iters; ++i) {                                                                    \
+                asm volatile(OP8(X) OP8(X) OP8(X) OP8(X) OP8(X) OP8(X) OP8(X) OP8(X)                             \
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)    \
+                             : "v"(c)                                                                            \
+                             : "vcc", "s20", "s21");                                                             \
+            }                                                                                                    \
+        }                                                                                                        \
+        out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                             \
+    }
+KERNEL_MASKED(k_max_lo16, l < 16u, X_MAX)
+KERNEL_MASKED(k_max_lo32, l < 32u, X_MAX)
+KERNEL_MASKED(k_max_8scattered, (l & 7u) == 0u, X_MAX)
+KERNEL_MASKED(k_mul_lo16, l < 16u, X_MUL)
+KERNEL_MASKED(k_mul_lo32, l < 32u, X_MUL)
+KERNEL_MASKED(k_rcp_lo16, l < 16u, X_RCP)
+
 typedef void (*kern_t)(float*, int, float);
 
 void run(const char* name, kern_t kf, int cus)
@@ -104,5 +129,11 @@ int main()
     run("v_mov_b32", k_mov, cus);
     run("v_and_b32", k_and, cus);
     run("v_lshl_add_u32", k_lshladd, cus);
+    run("v_max_f32 lanes 0-15", k_max_lo16, cus);
+    run("v_max_f32 lanes 0-31", k_max_lo32, cus);
+    run("v_max_f32 8 scattered", k_max_8scattered, cus);
+    run("v_mul_f32 lanes 0-15", k_mul_lo16, cus);
+    run("v_mul_f32 lanes 0-31", k_mul_lo32, cus);
+    run("v_rcp_f32 lanes 0-15", k_rcp_lo16, cus);
     return 0;
 }
