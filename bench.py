@@ -57,6 +57,8 @@ def main() -> None:
     ap.add_argument("--gen", default="device", choices=["device", "host"], help="where the synthetic rays are generated")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (one GPU per rank); gloo = test mode: ranks may share a GPU, hits gathered via host")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="dev: run the N > 1 control flow (process group, gather pipeline, barriers) even with one rank")
     ap.add_argument("--chunks", type=int, default=1,
                     help="N > 1: launches per batch in the trace/gather pipeline (1 = whole batch per launch: every extra "
                          "launch costs ~0.27 ms of ramp-up and end-of-queue tail; batches are double-buffered either way)")
@@ -84,7 +86,10 @@ def main() -> None:
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, ndev)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
+        if args.force_dist and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -139,7 +144,7 @@ def main() -> None:
         log(f"[bench] bounce rays: {n} from {side}x{side} primary hits ({miss} primary misses"
             f"{' re-filled' if args.gen == 'host' else ' -> null rays'}), generated on the {args.gen}")
     d_hits = tp.empty_records(n, HIT, device)
-    pipe = HitGatherPipeline(n, device, nchunks=args.chunks, via_host=args.backend == "gloo") if world > 1 else None
+    pipe = HitGatherPipeline(n, device, nchunks=args.chunks, via_host=args.backend == "gloo") if dist_on else None
     t4 = time.time()
     log(f"[bench] ray set-up {t4 - t3:.2f}s")
 
@@ -162,7 +167,7 @@ def main() -> None:
         scene.trace_closest_dev(d_rays.data_ptr() + lo * RAY.itemsize, hi - lo, hits_buf.data_ptr() + lo * HIT.itemsize, stream)
 
     def step():
-        if world == 1:
+        if not dist_on:
             tp.trace_closest(scene, d_rays, n, d_hits)
         else:
             # the single exchange of the path: hit records -> rank 0 (RCCL gather over xGMI).  Chunked and
@@ -180,22 +185,22 @@ def main() -> None:
         pipe.drain()
     kernel_ms = []
     torch.cuda.synchronize(device)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize(device)
     start = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if world == 1:
+        if not dist_on:
             kernel_ms.append(engine.last_kernel_ms())  # HIP events on the launch stream
     if pipe is not None:
         pipe.drain()                                   # every hit record has reached rank 0
     torch.cuda.synchronize(device)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - start
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -309,7 +314,7 @@ def main() -> None:
             log("[bench] PARITY FAILURE on the sample")
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
