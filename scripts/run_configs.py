@@ -2,8 +2,8 @@
 """Measure the BASELINE.json configs 2-5 on one GPU (dev/reporting tool; bench.py is the contract).
 
 Prints one JSON line per config: rays, kernel ms (HIP events), Mrays/s, steps/tests per ray,
-algorithmic GB/s.  Config 5 (S10M, 128 Mi primary rays = 128 camera tiles) is traced tile by
-tile on ONE device here; the 8-GPU form shards the tiles across ranks (bench.py --gpus 8).
+algorithmic GB/s.  Config 5 (S10M, 128 Mi primary rays = 128 camera tiles): ONE rank's contiguous shard
+(16 tiles = 16 Mi rays) in one launch here; the 8-GPU form shards the tiles across ranks.
 """
 import argparse
 import json
@@ -19,7 +19,7 @@ import numpy as np  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="2,3,4,5")
-    ap.add_argument("--tiles", type=int, default=8, help="camera tiles of config 5 to trace (128 = full)")
+    ap.add_argument("--tiles", type=int, default=16, help="camera tiles of config 5 in one launch (16 = one of 8 ranks' shard)")
     args = ap.parse_args()
     import torch
     import vistrace_amd as va
@@ -91,21 +91,20 @@ def main():
             print(json.dumps(measure(4, "S1M", d, n, any_hit=True)), flush=True)
             del d
         elif cfg == "5":
+            # one rank's contiguous shard of the 128-tile ray array (N/G with G = 8 -> 16 tiles), one launch
             cams = W.camera_positions("S10M")
-            res = []
+            tile = 1024 * 1024
+            d_rays = tp.empty_records(args.tiles * tile, va.RAY, dev)
             for t in range(args.tiles):
                 fwd = cams[(t + 1) % len(cams)] - cams[t] if t else np.array([1.0, 0, 0])
-                rays = W.primary_rays(1024, 1024, pos=cams[t], forward=fwd if np.linalg.norm(fwd) > 0 else (1, 0, 0))
-                res.append(measure(5, "S10M", tp.to_device(rays, dev), len(rays), reps=2))
-            agg = dict(res[0])
-            agg["rays"] = sum(r["rays"] for r in res)
-            agg["kernel_ms"] = round(sum(r["kernel_ms"] for r in res), 3)
-            agg["mrays_s"] = round(agg["rays"] / agg["kernel_ms"] / 1e3, 1)
-            agg["steps_per_ray"] = round(float(np.mean([r["steps_per_ray"] for r in res])), 2)
-            agg["tests_per_ray"] = round(float(np.mean([r["tests_per_ray"] for r in res])), 2)
-            agg["alg_gb_s"] = round(float(np.mean([r["alg_gb_s"] for r in res])), 1)
-            agg["tiles"] = args.tiles
-            print(json.dumps(agg), flush=True)
+                if np.linalg.norm(fwd) == 0:
+                    fwd = np.array([1.0, 0, 0])
+                engine.gen_primary_dev(1024, 1024, d_rays.data_ptr() + t * tile * va.RAY.itemsize, pos=tuple(cams[t]),
+                                       forward=tuple(fwd), stream=tp.current_stream_handle(dev))
+            torch.cuda.synchronize()
+            r = measure(5, "S10M", d_rays, args.tiles * tile, reps=3)
+            r["tiles"] = args.tiles
+            print(json.dumps(r), flush=True)
 
 
 if __name__ == "__main__":
