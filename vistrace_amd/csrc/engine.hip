@@ -175,8 +175,8 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
 
     const size_t ovf_words = size_t(p.ovf_entries) * p.grid_blocks * kBlockThreads;
     if (ovf_words > e->overflow_words) {
-        // grow (rare: first launch on a deeper tree); must not race with in-flight launches
-        VT_HIP(hipStreamSynchronize(stream));
+        // grow (rare: first launch on a deeper tree); must not race with in-flight launches on any stream
+        VT_HIP(hipDeviceSynchronize());
         if (e->d_overflow) VT_HIP(hipFree(e->d_overflow));
         e->d_overflow = nullptr; e->overflow_words = 0;
         VT_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_overflow), ovf_words * sizeof(uint32_t)));
