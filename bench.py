@@ -59,6 +59,10 @@ def main() -> None:
                     help="nccl = RCCL (one GPU per rank); gloo = test mode: ranks may share a GPU, hits gathered via host")
     ap.add_argument("--force-dist", action="store_true",
                     help="dev: run the N > 1 control flow (process group, gather pipeline, barriers) even with one rank")
+    ap.add_argument("--reserve-cus", type=int, default=32,
+                    help="N > 1: CUs (one per shader engine of every XCD) on which the persistent trace grid leaves room "
+                         "for the RCCL gather's kernels, so that the transfer of batch b overlaps the trace of batch b+1; "
+                         "0 = off (the gather then only starts when the resident grid drains)")
     ap.add_argument("--chunks", type=int, default=1,
                     help="N > 1: launches per batch in the trace/gather pipeline (1 = whole batch per launch: every extra "
                          "launch costs ~0.27 ms of ramp-up and end-of-queue tail; batches are double-buffered either way)")
@@ -160,6 +164,11 @@ def main() -> None:
 
     # ---- timed region -------------------------------------------------------------------
     engine.set_timing(True)
+    if dist_on and args.reserve_cus > 0:
+        # the gather of batch b runs while batch b+1 is traced: its kernels need somewhere to run
+        engine.set_option("reserved_cus", args.reserve_cus)
+        log(f"[bench] {engine.get_option('reserved_cus')} CUs keep room for the collective "
+            f"({engine.get_option('reserved_limit')} trace blocks each instead of {engine.launch_info()['blocks'] // max(1, engine.get_option('cu_count'))})")
 
     stream = tp.current_stream_handle(device)
 
@@ -240,9 +249,9 @@ def main() -> None:
             "rays_per_gpu": n,
             "query": "closest-hit",
             "ray_kind": "cosine-hemisphere bounce (incoherent)" if args.kind == "bounce" else "pinhole primary",
-            "parallelism": f"rays sharded x{world}, BVH replicated" + (f", RCCL gather of hits to rank 0 ({args.chunks} chunks per batch, double-buffered, overlapped with tracing)" if world > 1 else ""),
+            "parallelism": f"rays sharded x{world}, BVH replicated" + (f", RCCL gather of hits to rank 0 ({args.chunks} chunks per batch, double-buffered, overlapped with tracing; {engine.get_option('reserved_cus')} CUs keep room for its kernels)" if world > 1 else ""),
             "kernel_mode": ("persistent" + ("+lds-dma-fetch" if engine.get_option("last_fetch_dma") else "")) if engine.get_option("last_persistent") else "static",
-            "launch_options": {k: engine.get_option(k) for k in ("lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold")},
+            "launch_options": {k: engine.get_option(k) for k in ("lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold", "reserved_cus", "reserved_limit")},
             "launch": engine.launch_info(),
         },
         "roofline": {

@@ -185,6 +185,15 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
  *   "refill_threshold"   idle lanes that trigger a re-fill (8);  "tri_threshold": waiting lanes that
  *                        trigger the triangle branch (4);  "static_overflow_mb": overflow-area cap of the
  *                        one-ray-per-lane kernel (256)
+ *   "reserved_cus"       CUs on which the persistent grid leaves room (0 = off): set it when another stream runs
+ *                        kernels that must make progress during a trace (e.g. the RCCL gather of the previous
+ *                        batch).  A resident persistent grid holds every CU's LDS and registers until its last
+ *                        ray, so such kernels would otherwise only start when the trace ends.  The CUs are
+ *                        chosen one per shader engine of every XCD in turn (the dispatcher binds a workgroup to
+ *                        an XCD/SE before it looks for a CU, so 32 = one per SE is the useful value on MI355X);
+ *   "reserved_limit"     blocks of the grid a reserved CU still keeps (2: measured to leave room for one
+ *                        256-thread workgroup with the footprint of RCCL's kernel, 280 VGPRs + 20 KB LDS --
+ *                        3 does not; 0 = keep the CU empty).  Later arrivals on a full reserved CU exit at once.
  * Read-only: "cu_count", "device", "last_persistent", "last_fetch_dma" (what the last launch used).
  * Results never depend on these, only speed does. */
 int vt_engine_set_option(vt_engine* e, const char* key, int64_t value);

@@ -576,3 +576,29 @@ def test_bounce_loop_matches_composition_and_oracle(va, engine, make_bundle, nam
     assert_hits_equal(tp.to_host(d_one, va.HIT), rows[0])
     assert live1 == [n]
     assert scene.bounce_loop_dev(d_start.data_ptr(), 0, 3, seed, d_rows.data_ptr()) == [0, 0, 0]
+
+
+def test_reserved_cus_do_not_change_results(va, make_bundle):
+    """Engine option reserved_cus (persistent grid leaves room on some CUs for a concurrent collective):
+    blocks that leave take no rays with them -- results, any-hit flags and counters stay exact."""
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    eng = va.Engine(0)
+    eng.set_option("persistent", 1)
+    scene = va.Scene(eng, b.host_scene)
+    rays = np.concatenate([W.primary_rays(256, 256), W.sphere_rays(70000, 9, origin=(20.0, -10.0, 35.0))])
+    ref = b.oracle(rays)
+    for want, limit in ((32, 2), (32, 0), (7, 1), (128, 2)):
+        eng.set_option("reserved_limit", limit)
+        eng.set_option("reserved_cus", want)
+        got = eng.get_option("reserved_cus")
+        assert 0 < got <= want and eng.get_option("reserved_limit") == limit
+        assert_hits_equal(scene.trace_closest(rays), ref)
+        assert (scene.trace_any(rays) == (ref["prim"] != O_MISS)).all()
+        hits, st = stats_on_device(va, scene, rays[:5000])
+        assert_hits_equal(hits, ref[:5000])
+    eng.set_option("reserved_cus", 0)
+    assert eng.get_option("reserved_cus") == 0
+    assert_hits_equal(scene.trace_closest(rays), ref)
+    with pytest.raises(va._lib.VisTraceError):
+        eng.set_option("reserved_cus", 100000)

@@ -43,6 +43,9 @@ struct vt_engine {
     uint32_t refill_threshold = 8;    // idle lanes that trigger a re-fill
     uint32_t tri_threshold    = 4;    // lanes with pending triangles that trigger the TRI branch
     int      fetch_dma        = 1;    // quad-cooperative global->LDS record fetch (persistent mode)
+    uint32_t reserved_cus     = 0;    // CUs on which the persistent grid leaves room (for a concurrent collective's kernels)
+    uint32_t reserved_limit   = 2;    // blocks of the grid a reserved CU still keeps
+    uint32_t* d_reserved      = nullptr; // 1024-bit set of the reserved CUs' __smid() values, then 1024 per-CU counters
 
     // per-launch scratch
     uint32_t* d_cursor = nullptr;
@@ -145,7 +148,10 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool 
         int occ = 0;
         VT_HIP(trace_blocks_per_cu(any_hit, stats, true, p.fetch_dma, trace_lds_bytes(p.lds_entries, p.fetch_dma), &occ));
         const uint32_t per_cu = std::max(1u, std::min(e->blocks_per_cu, uint32_t(std::max(occ, 1))));
-        p.grid_blocks = uint32_t(std::min<uint64_t>(uint64_t(e->cu_count) * per_cu, blocks_for_rays));
+        // with reserved CUs the blocks that land there leave at once; surplus blocks make up for the ones the
+        // dispatcher keeps sending to the emptied CUs while the grid is still being placed
+        const uint64_t surplus = e->reserved_cus && e->d_reserved ? uint64_t(4) * e->reserved_cus * per_cu : 0;
+        p.grid_blocks = uint32_t(std::min<uint64_t>(uint64_t(e->cu_count) * per_cu + surplus, blocks_for_rays + surplus));
     } else {
         if (blocks_for_rays > 0x7FFFFFFFull) return fail(VT_ERR_INVALID_ARG, "too many rays for one launch");
         p.grid_blocks = uint32_t(blocks_for_rays);
@@ -207,14 +213,66 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     a.refill_threshold = std::min(std::max(e->refill_threshold, 1u), 64u);
     a.tri_threshold = std::min(std::max(e->tri_threshold, 1u), 64u);
     a.coherent_detect = e->coherent_detect;
+    a.reserved_cus = p.persistent && e->reserved_cus ? e->d_reserved : nullptr;
+    a.cu_slots = e->d_reserved ? e->d_reserved + 32 : nullptr;
+    a.reserved_limit = e->reserved_limit;
 
     // the first block of every wave is static (block w -> wave w); the cursor hands out the rest
-    if (p.persistent) VT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_cursor), int(p.grid_blocks * (kBlockThreads / 64)), 1, stream));
+    if (a.reserved_cus) VT_HIP(hipMemsetAsync(a.cu_slots, 0, 4096, stream));
+    if (p.persistent)
+        VT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_cursor),
+                                 a.reserved_cus ? 0 : int(p.grid_blocks * (kBlockThreads / 64)), 1, stream));
     if (e->timing) VT_HIP(hipEventRecord(e->ev_start, stream));
     VT_HIP(launch_trace(a, any_hit, stats, p.persistent, p.fetch_dma, p.grid_blocks, p.lds_bytes, stream));
     if (e->timing) { VT_HIP(hipEventRecord(e->ev_stop, stream)); e->ev_valid = true; }
     e->last_blocks = p.grid_blocks; e->last_threads = kBlockThreads; e->last_lds = uint32_t(p.lds_bytes);
     e->last_persistent = p.persistent; e->last_dma = p.fetch_dma;
+    return VT_OK;
+}
+
+// Pick `want` CUs, spread over the XCDs, that the persistent grid will leave empty.  The CUs are named by
+// __smid() (xcc, se, cu): a probe launch records which values exist on this part (harvested CUs differ
+// from device to device), the choice goes to the device as a 1024-bit set.  Returns the number reserved
+// in e->reserved_cus (0 switches the feature off).
+int reserve_cus(vt_engine* e, uint32_t want)
+{
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "reserved_cus: hipSetDevice failed");
+    VT_HIP(hipDeviceSynchronize());                       // no launch may be reading the set while it changes
+    e->reserved_cus = 0;
+    if (want == 0) return VT_OK;
+    if (!e->d_reserved) VT_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_reserved), 128 + 4096));
+    uint32_t seen[32] = {};
+    for (int round = 0; round < 4; ++round) {             // 2 probe blocks fit a CU: a few rounds reach all of them
+        VT_HIP(hipMemsetAsync(e->d_reserved, 0, 128, e->stream));
+        VT_HIP(launch_cu_probe(e->d_reserved, uint32_t(e->cu_count) * 4u, e->stream));
+        uint32_t got[32];
+        VT_HIP(hipMemcpyAsync(got, e->d_reserved, 128, hipMemcpyDeviceToHost, e->stream));
+        VT_HIP(hipStreamSynchronize(e->stream));
+        for (int w = 0; w < 32; ++w) seen[w] |= got[w];
+    }
+    // one list per shader engine of every XCD (id = xcc[9:6] se[5:4] cu[3:0]); take the last CU of each list
+    // in turn: a first pass gives every (XCD, SE) one reserved CU, further passes a second one, ...
+    std::vector<std::vector<uint32_t>> per_se(64);
+    for (uint32_t id = 0; id < 1024; ++id)
+        if ((seen[id >> 5] >> (id & 31u)) & 1u) per_se[id >> 4].push_back(id);
+    uint32_t chosen[32] = {};
+    uint32_t n = 0;
+    for (bool any = true; any && n < want;) {
+        any = false;
+        for (auto& v : per_se) {
+            if (v.size() > 1 && n < want) {               // never the last CU of a shader engine
+                const uint32_t id = v.back();
+                v.pop_back();
+                chosen[id >> 5] |= 1u << (id & 31u);
+                ++n;
+                any = true;
+            }
+        }
+    }
+    VT_HIP(hipMemcpyAsync(e->d_reserved, chosen, 128, hipMemcpyHostToDevice, e->stream));
+    VT_HIP(hipStreamSynchronize(e->stream));
+    e->reserved_cus = n;
     return VT_OK;
 }
 
@@ -287,6 +345,7 @@ void vt_engine_close(vt_engine* e)
     if (e->d_rays) (void)hipFree(e->d_rays);
     if (e->d_out) (void)hipFree(e->d_out);
     if (e->d_loop) (void)hipFree(e->d_loop);
+    if (e->d_reserved) (void)hipFree(e->d_reserved);
     if (e->h_live) (void)hipHostFree(e->h_live);
     if (e->h_tiny_rays) (void)hipHostFree(e->h_tiny_rays);
     if (e->h_tiny_out) (void)hipHostFree(e->h_tiny_out);
@@ -310,6 +369,8 @@ int vt_engine_set_option(vt_engine* e, const char* key, int64_t value)
     else if (k == "refill_threshold" && value >= 1 && value <= 64) e->refill_threshold = uint32_t(value);
     else if (k == "tri_threshold" && value >= 1 && value <= 64) e->tri_threshold = uint32_t(value);
     else if (k == "fetch_dma") e->fetch_dma = value != 0;
+    else if (k == "reserved_cus" && value >= 0 && value <= e->cu_count / 2) return reserve_cus(e, uint32_t(value));
+    else if (k == "reserved_limit" && value >= 0 && value <= 64) e->reserved_limit = uint32_t(value);
     else return fail(VT_ERR_INVALID_ARG, "vt_engine_set_option: unknown key or value out of range: " + k);
     return VT_OK;
 }
@@ -328,6 +389,8 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
     else if (k == "coherent_detect") *value = e->coherent_detect;
     else if (k == "tri_threshold") *value = e->tri_threshold;
     else if (k == "fetch_dma") *value = e->fetch_dma;
+    else if (k == "reserved_cus") *value = e->reserved_cus;
+    else if (k == "reserved_limit") *value = e->reserved_limit;
     else if (k == "cu_count") *value = e->cu_count;
     else if (k == "last_persistent") *value = e->last_persistent;
     else if (k == "last_fetch_dma") *value = e->last_dma;

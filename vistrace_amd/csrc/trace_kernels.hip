@@ -149,6 +149,23 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
     const uint32_t stage_lds = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t((lds_ptr)stage)));
     const uint32_t my_rec = stage_lds + (lane & 3u) * kStageRow + (lane >> 2) * 64u;
 
+    if constexpr (PERSISTENT) {
+        // Software CU reservation (engine option "reserved_cus"): a reserved CU keeps only `reserved_limit` blocks
+        // of this grid, later arrivals leave at once, so that registers and LDS stay free there for the kernels
+        // of a concurrent collective -- a resident persistent grid otherwise fills every CU until its last ray
+        // and such kernels only start when the trace ends (scripts/overlap_probe.py, profiles/r1/notes.md).
+        if (a.reserved_cus != nullptr) {
+            const uint32_t id = __smid() & 1023u;        // xcc[9:6] se[5:4] cu[3:0]: the same for the whole block
+            if ((a.reserved_cus[id >> 5] >> (id & 31u)) & 1u) {
+                uint32_t* const flag = lds_dyn + size_t(kBlockThreads / 64) * a.lds_entries * 64 +
+                                       (FETCH_DMA ? size_t(kBlockThreads / 64) * kStageBytes / 4 : 0);
+                if (threadIdx.x == 0) *flag = atomicAdd(&a.cu_slots[id], 1u) >= a.reserved_limit ? 1u : 0u;
+                __syncthreads();
+                if (*flag != 0) return;
+            }
+        }
+    }
+
     Lane L;
     uint64_t ray_idx = 0;
     bool has_ray = false;
@@ -157,7 +174,9 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
     uint64_t blk_cur = 0, blk_end = 0;
     bool exhausted = false;
     bool coherent = false;   // wave-uniform: this wave's rays share a direction octant
-    bool first_block = true; // wave-uniform: the first block of rays is assigned statically
+    // wave-uniform: the first block of rays is assigned statically (not with reserved CUs: a block that
+    // leaves must not take rays with it, so the cursor hands out everything)
+    bool first_block = a.reserved_cus == nullptr;
 
     auto start_ray = [&](uint64_t idx) {
         const float4* r4 = reinterpret_cast<const float4*>(a.rays + idx);
@@ -739,7 +758,7 @@ size_t trace_lds_bytes(uint32_t lds_entries, bool fetch_dma)
 {
     size_t b = size_t(lds_entries) * 64 * sizeof(uint32_t) * (kBlockThreads / 64);
     if (fetch_dma) b += size_t(kStageBytes) * (kBlockThreads / 64);
-    return b;
+    return b + 16;   // one word behind the stacks/staging rows: the stay-or-leave flag of a reserved CU
 }
 
 namespace {
@@ -783,6 +802,25 @@ hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persi
 hipError_t trace_blocks_per_cu(bool any_hit, bool stats, bool persistent, bool fetch_dma, size_t lds_bytes, int* out)
 {
     return dispatch(nullptr, any_hit, stats, persistent, fetch_dma, dim3(1), lds_bytes, nullptr, out);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void cu_probe_kernel(uint32_t* seen)
+{
+    extern __shared__ uint32_t probe_lds[];              // a large LDS footprint spreads the blocks over the CUs
+    probe_lds[threadIdx.x] = threadIdx.x;
+    const long long t0 = wall_clock64();                 // 100 MHz
+    while (wall_clock64() - t0 < 2000) probe_lds[threadIdx.x] += 1u;
+    if (threadIdx.x == 0 && probe_lds[0] != 0xFFFFFFFFu) {
+        const uint32_t id = __smid() & 1023u;
+        atomicOr(&seen[id >> 5], 1u << (id & 31u));
+    }
+}
+
+hipError_t launch_cu_probe(uint32_t* seen, uint32_t blocks, hipStream_t stream)
+{
+    const int lds = 60 * 1024;
+    hipLaunchKernelGGL(cu_probe_kernel, dim3(blocks), dim3(kBlockThreads), lds, stream, seen);
+    return hipGetLastError();
 }
 
 hipError_t launch_hit_attrs(const HitAttrsArgs& a, hipStream_t stream)
