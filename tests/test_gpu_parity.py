@@ -602,3 +602,26 @@ def test_reserved_cus_do_not_change_results(va, make_bundle):
     assert_hits_equal(scene.trace_closest(rays), ref)
     with pytest.raises(va._lib.VisTraceError):
         eng.set_option("reserved_cus", 100000)
+
+
+def test_host_buffer_pipeline_ragged(va, engine, make_bundle):
+    """vt_trace_closest / vt_trace_any with caller (pageable) buffers above the pipelining threshold and a ragged
+    last chunk: identical to the device-resident path, and to the oracle on a sample."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    scene = upload(va, engine, b)
+    n = 3 * (1 << 20) + 12345
+    rays = W.sphere_rays(n, 123, origin=(-40.0, 10.0, 25.0))
+    got = scene.trace_closest(rays)
+    occ = scene.trace_any(rays)
+    dev = torch.device("cuda", 0)
+    d_rays = tp.to_device(rays, dev)
+    ref = tp.to_host(tp.trace_closest(scene, d_rays, n), va.HIT)
+    assert_hits_equal(got, ref)
+    assert (occ == (ref["prim"] != O_MISS)).all()
+    idx = np.concatenate([np.arange(0, 5000), np.arange((1 << 20) - 2500, (1 << 20) + 2500), np.arange(n - 5000, n)])
+    assert_hits_equal(got[idx], b.oracle(rays[idx]))
+    again = scene.trace_closest(rays[: 2 * (1 << 20) + 1])          # a second call re-uses the staging buffers
+    assert_hits_equal(again, ref[: 2 * (1 << 20) + 1])

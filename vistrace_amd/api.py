@@ -212,10 +212,11 @@ class Scene:
         return lib.vt_scene_device_bytes(self._h)
 
     # host-buffer entry points ------------------------------------------------------------
-    def trace_closest(self, rays: np.ndarray) -> np.ndarray:
+    def trace_closest(self, rays: np.ndarray, out: Optional[np.ndarray] = None) -> np.ndarray:
         assert rays.dtype == RAY
         rays = np.ascontiguousarray(rays)
-        hits = np.zeros(len(rays), dtype=HIT)
+        hits = np.zeros(len(rays), dtype=HIT) if out is None else out
+        assert hits.dtype == HIT and len(hits) == len(rays) and hits.flags.c_contiguous
         check(lib.vt_trace_closest(self._h, ptr(rays), len(rays), ptr(hits)))
         return hits
 

@@ -55,6 +55,13 @@ struct vt_engine {
     // staging for the host-pointer entry points
     void*  d_rays = nullptr;  size_t d_rays_bytes = 0;
     void*  d_out  = nullptr;  size_t d_out_bytes = 0;
+    // large host batches: pinned double buffers + copy streams, so that H2D, trace and D2H of successive
+    // chunks overlap (pageable hipMemcpyAsync serialises on the host)
+    static constexpr uint64_t kHostChunk = uint64_t(1) << 20;   // rays per pipelined chunk
+    char* h_stage_in[2]  = {nullptr, nullptr};
+    char* h_stage_out[2] = {nullptr, nullptr};
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     // bounce loop: two ray queues, two path-id queues, the queue's hit records, block offsets, live counter
     void*  d_loop = nullptr;  size_t d_loop_bytes = 0;
     uint32_t* h_live = nullptr;           // pinned read-back of the live-path count
@@ -347,6 +354,15 @@ void vt_engine_close(vt_engine* e)
     if (e->d_loop) (void)hipFree(e->d_loop);
     if (e->d_reserved) (void)hipFree(e->d_reserved);
     if (e->h_live) (void)hipHostFree(e->h_live);
+    for (int k = 0; k < 2; ++k) {
+        if (e->h_stage_in[k]) (void)hipHostFree(e->h_stage_in[k]);
+        if (e->h_stage_out[k]) (void)hipHostFree(e->h_stage_out[k]);
+        if (e->ev_in[k]) (void)hipEventDestroy(e->ev_in[k]);
+        if (e->ev_k[k]) (void)hipEventDestroy(e->ev_k[k]);
+        if (e->ev_out[k]) (void)hipEventDestroy(e->ev_out[k]);
+    }
+    if (e->s_in) (void)hipStreamDestroy(e->s_in);
+    if (e->s_out) (void)hipStreamDestroy(e->s_out);
     if (e->h_tiny_rays) (void)hipHostFree(e->h_tiny_rays);
     if (e->h_tiny_out) (void)hipHostFree(e->h_tiny_out);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
@@ -504,20 +520,66 @@ static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, si
         std::memcpy(out, e->h_tiny_out, n * out_elem);
         return VT_OK;
     }
-    const uint64_t chunk = uint64_t(1) << 24; // 16 Mi rays = 512 MiB of rays per staging pass
-    for (uint64_t off = 0; off < n; off += chunk) {
-        const uint64_t m = std::min(chunk, n - off);
-        int rc = ensure_bytes(&e->d_rays, &e->d_rays_bytes, m * sizeof(vt_ray));
-        if (rc == VT_OK) rc = ensure_bytes(&e->d_out, &e->d_out_bytes, m * out_elem);
+    const uint64_t C = vt_engine::kHostChunk;
+    if (n <= 2 * C) {   // small batch: one copy each way around one launch
+        int rc = ensure_bytes(&e->d_rays, &e->d_rays_bytes, n * sizeof(vt_ray));
+        if (rc == VT_OK) rc = ensure_bytes(&e->d_out, &e->d_out_bytes, n * out_elem);
         if (rc != VT_OK) return rc;
-        VT_HIP(hipMemcpyAsync(e->d_rays, rays + off, m * sizeof(vt_ray), hipMemcpyHostToDevice, e->stream));
-        rc = launch(s, e->d_rays, m, any_hit ? nullptr : e->d_out, any_hit ? e->d_out : nullptr, nullptr, any_hit, false,
-                    e->stream);
+        VT_HIP(hipMemcpyAsync(e->d_rays, rays, n * sizeof(vt_ray), hipMemcpyHostToDevice, e->stream));
+        rc = launch(s, e->d_rays, n, any_hit ? nullptr : e->d_out, any_hit ? e->d_out : nullptr, nullptr, any_hit, false, e->stream);
         if (rc != VT_OK) return rc;
-        VT_HIP(hipMemcpyAsync(static_cast<char*>(out) + off * out_elem, e->d_out, m * out_elem, hipMemcpyDeviceToHost,
-                              e->stream));
+        VT_HIP(hipMemcpyAsync(out, e->d_out, n * out_elem, hipMemcpyDeviceToHost, e->stream));
         VT_HIP(hipStreamSynchronize(e->stream));
+        return VT_OK;
     }
+
+    // Large batch: chunks of C rays flow through pinned double buffers -- while chunk c is traced, chunk c+1 is
+    // staged and uploaded and chunk c-1 comes back and is copied out to the caller's (pageable) memory.
+    if (!e->s_in) {
+        VT_HIP(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
+        VT_HIP(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage_in[k]), C * sizeof(vt_ray)));
+            VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage_out[k]), C * sizeof(vt_hit)));
+            VT_HIP(hipEventCreateWithFlags(&e->ev_in[k], hipEventDisableTiming));
+            VT_HIP(hipEventCreateWithFlags(&e->ev_k[k], hipEventDisableTiming));
+            VT_HIP(hipEventCreateWithFlags(&e->ev_out[k], hipEventDisableTiming));
+        }
+    }
+    int rc = ensure_bytes(&e->d_rays, &e->d_rays_bytes, 2 * C * sizeof(vt_ray));
+    if (rc == VT_OK) rc = ensure_bytes(&e->d_out, &e->d_out_bytes, 2 * C * sizeof(vt_hit));
+    if (rc != VT_OK) return rc;
+    VT_HIP(hipStreamSynchronize(e->stream));                 // earlier work on the engine's stream owns the staging buffers
+    const uint64_t nchunks = (n + C - 1) / C;
+    auto drain = [&](uint64_t c) -> int {                    // chunk c's results: pinned -> caller
+        const int b = int(c & 1);
+        const uint64_t m = std::min(C, n - c * C);
+        VT_HIP(hipEventSynchronize(e->ev_out[b]));
+        parallel_copy(static_cast<char*>(out) + c * C * out_elem, e->h_stage_out[b], m * out_elem);
+        return VT_OK;
+    };
+    for (uint64_t c = 0; c < nchunks; ++c) {
+        const int b = int(c & 1);
+        const uint64_t m = std::min(C, n - c * C);
+        char* d_in = static_cast<char*>(e->d_rays) + size_t(b) * C * sizeof(vt_ray);
+        char* d_res = static_cast<char*>(e->d_out) + size_t(b) * C * sizeof(vt_hit);
+        if (c >= 2) VT_HIP(hipEventSynchronize(e->ev_in[b]));            // pinned input buffer b is free again
+        parallel_copy(e->h_stage_in[b], rays + c * C, m * sizeof(vt_ray));
+        if (c >= 2) VT_HIP(hipStreamWaitEvent(e->s_in, e->ev_k[b], 0));   // chunk c-2 has read device buffer b
+        VT_HIP(hipMemcpyAsync(d_in, e->h_stage_in[b], m * sizeof(vt_ray), hipMemcpyHostToDevice, e->s_in));
+        VT_HIP(hipEventRecord(e->ev_in[b], e->s_in));
+        VT_HIP(hipStreamWaitEvent(e->stream, e->ev_in[b], 0));
+        if (c >= 2) VT_HIP(hipStreamWaitEvent(e->stream, e->ev_out[b], 0)); // chunk c-2's results have left device buffer b
+        rc = launch(s, d_in, m, any_hit ? nullptr : d_res, any_hit ? d_res : nullptr, nullptr, any_hit, false, e->stream);
+        if (rc != VT_OK) return rc;
+        VT_HIP(hipEventRecord(e->ev_k[b], e->stream));
+        VT_HIP(hipStreamWaitEvent(e->s_out, e->ev_k[b], 0));
+        VT_HIP(hipMemcpyAsync(e->h_stage_out[b], d_res, m * out_elem, hipMemcpyDeviceToHost, e->s_out));
+        VT_HIP(hipEventRecord(e->ev_out[b], e->s_out));
+        if (c >= 1 && (rc = drain(c - 1)) != VT_OK) return rc;
+    }
+    if ((rc = drain(nchunks - 1)) != VT_OK) return rc;
+    VT_HIP(hipStreamSynchronize(e->stream));
     return VT_OK;
 }
 

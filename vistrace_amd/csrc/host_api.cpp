@@ -4,6 +4,10 @@
 // engine.hip and fails loudly there when no device is present.
 #include "vt_internal.h"
 
+#include <omp.h>
+
+#include <algorithm>
+#include <cstring>
 #include <exception>
 #include <new>
 
@@ -17,6 +21,18 @@ int fail(int code, const std::string& msg)
 {
     g_last_error = msg;
     return code;
+}
+
+void parallel_copy(void* dst, const void* src, size_t bytes)
+{
+    const long long piece = 1 << 20;
+    const long long pieces = (static_cast<long long>(bytes) + piece - 1) / piece;
+    const int threads = int(std::max<long long>(1, std::min<long long>({8, pieces, omp_get_max_threads()})));
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long long k = 0; k < pieces; ++k) {
+        const size_t off = size_t(k) * size_t(piece);
+        std::memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, std::min(size_t(piece), bytes - off));
+    }
 }
 
 } // namespace vt

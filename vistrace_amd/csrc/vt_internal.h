@@ -39,6 +39,9 @@ int  bvh_refit(Bvh& bvh, const vt_tri64* tris);
 void tri_setup(const float p0[3], const float p1[3], const float p2[3], uint32_t prim,
                uint32_t flags, vt_tri64& out);
 
+// memcpy split over a few host threads (staging copies of the host-buffer entry points)
+void parallel_copy(void* dst, const void* src, size_t bytes);
+
 void set_error(const std::string& msg);
 int  fail(int code, const std::string& msg);
 
