@@ -296,6 +296,10 @@ def main() -> None:
         ref, ref_stats, s_steps, s_tests, threads = O.traverse_batch(nodes, pidx, otris, rays_host[:sample], want_stats=True,
                                                                     nthreads=cpu_threads)
         cpu_s = time.perf_counter() - tc0
+        # one host thread: the closest analogue of what a GLua script gets today (one ray per call, serial)
+        t10 = time.perf_counter()
+        O.traverse_batch(nodes, pidx, otris, rays_host[:pilot], nthreads=1)
+        one_thread = pilot / (time.perf_counter() - t10) / 1e6
         gpu = tp.to_host(d_hits[: sample * HIT.itemsize], HIT)
         same_prim = bool((gpu["prim"] == ref["prim"]).all())
         same_tuv = all(bool((gpu[k].view(np.uint32) == ref[k].view(np.uint32)).all()) for k in ("t", "u", "v"))
@@ -316,6 +320,7 @@ def main() -> None:
             "kind": "port",
             "sample": f"first {sample} rays of the same batch, same tree, OpenMP schedule(dynamic,4096), {cpu_s:.1f}s",
             "cpu": cpu_model,
+            "one_thread_value": round(one_thread, 4),
         }
         result["parity_sample"] = {"rays": sample, "prim_bit_exact": same_prim, "tuv_bit_exact": same_tuv,
                                    "counters_equal": same_stats}

@@ -82,6 +82,27 @@ KERNEL_MASKED(k_mul_lo16, l < 16u, X_MUL)
 KERNEL_MASKED(k_mul_lo32, l < 32u, X_MUL)
 KERNEL_MASKED(k_rcp_lo16, l < 16u, X_RCP)
 
+// scalar ALU: eight independent s_add_u32 / s_and_b64 chains
+#define KERNEL_SALU(NAME, BODY, ...)                                                                             \
+    __global__ __launch_bounds__(256) void NAME(float* out, int iters, float seed)                               \
+    {                                                                                                            \
+        for (int i = 0; i < iters; ++i) {                                                                        \
+            asm volatile(BODY BODY BODY BODY BODY BODY BODY BODY ::: __VA_ARGS__);                                \
+        }                                                                                                        \
+        out[blockIdx.x * 256 + threadIdx.x] = seed;                                                              \
+    }
+KERNEL_SALU(k_sadd, "s_add_u32 s20, s20, 1\ns_add_u32 s21, s21, 1\ns_add_u32 s22, s22, 1\ns_add_u32 s23, s23, 1\n"
+                    "s_add_u32 s24, s24, 1\ns_add_u32 s25, s25, 1\ns_add_u32 s26, s26, 1\ns_add_u32 s27, s27, 1\n",
+            "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "scc")
+KERNEL_SALU(k_sand64, "s_and_b64 s[20:21], s[20:21], exec\ns_and_b64 s[22:23], s[22:23], exec\ns_and_b64 s[24:25], s[24:25], exec\n"
+                      "s_and_b64 s[26:27], s[26:27], exec\ns_and_b64 s[28:29], s[28:29], exec\ns_and_b64 s[30:31], s[30:31], exec\n"
+                      "s_and_b64 s[32:33], s[32:33], exec\ns_and_b64 s[34:35], s[34:35], exec\n",
+            "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "scc")
+// a VALU stream and a SALU stream interleaved 1:1 in one wave: do they overlap across waves?
+KERNEL_SALU(k_mix, "v_mul_f32 v10, v10, v11\ns_add_u32 s20, s20, 1\nv_mul_f32 v12, v12, v11\ns_add_u32 s21, s21, 1\n"
+                   "v_mul_f32 v13, v13, v11\ns_add_u32 s22, s22, 1\nv_mul_f32 v14, v14, v11\ns_add_u32 s23, s23, 1\n",
+            "s20", "s21", "s22", "s23", "scc", "v10", "v11", "v12", "v13", "v14")
+
 typedef void (*kern_t)(float*, int, float);
 
 void run(const char* name, kern_t kf, int cus)
@@ -129,6 +150,9 @@ int main()
     run("v_mov_b32", k_mov, cus);
     run("v_and_b32", k_and, cus);
     run("v_lshl_add_u32", k_lshladd, cus);
+    run("s_add_u32", k_sadd, cus);
+    run("s_and_b64", k_sand64, cus);
+    run("v_mul + s_add pairs (per pair/2)", k_mix, cus);
     run("v_max_f32 lanes 0-15", k_max_lo16, cus);
     run("v_max_f32 lanes 0-31", k_max_lo32, cus);
     run("v_max_f32 8 scattered", k_max_8scattered, cus);
