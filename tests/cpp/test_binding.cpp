@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -274,8 +275,58 @@ static void test_gpu_side()
     AccelStruct::SetEntityMeshSource(nullptr);
 }
 
+// BASELINE config 1 through the binding: single-ray accel:Traverse calls (10 k-triangle world mesh, 10 k seeded
+// rays), the way a GLua script issues them; prints microseconds per call, TraceResult construction included.
+static void bench_single_calls()
+{
+    State L;
+    RegisterTracingApi(&L);
+    World world;
+    world.materials.push_back(Material{"brush/floor", MATFLAG_NONE});
+    world.entities.push_back(Entity{nullptr, 0});
+    const int k = 71;                                           // 71 x 71 x 2 = 10 082 triangles
+    auto height = [](int i, int j) { return 6.0f * float((i * 7 + j * 13) % 11) / 11.0f; };
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) {
+            const float x0 = float(i) * 4 - 142, x1 = x0 + 4, y0 = float(j) * 4 - 142, y1 = y0 + 4;
+            world.triangles.push_back(make_tri({x0, y0, height(i, j)}, {x1, y0, height(i + 1, j)}, {x0, y1, height(i, j + 1)}, false, 0));
+            world.triangles.push_back(make_tri({x1, y0, height(i + 1, j)}, {x1, y1, height(i + 1, j + 1)}, {x0, y1, height(i, j + 1)}, false, 0));
+        }
+    SetWorld(&world);
+    L.PushValue(State::Array({}));
+    L.PushBool(true);
+    CHECK(vistrace_CreateAccel(&L) == 1);
+    AccelStruct* accel = L.GetUserType<AccelStruct>(-1, AccelStruct_id);
+    CHECK(accel && accel->IsBuilt() && accel->TriangleCount() == size_t(2 * k * k));
+    uint64_t rng = 0x5EEDull;
+    auto next = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return float(rng >> 40) / 16777216.0f; };
+    const int calls = 10000;
+    int hits = 0;
+    for (int pass = 0; pass < 2; ++pass) {                      // pass 0 warms up
+        hits = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int c = 0; c < calls; ++c) {
+            const float dx = next() * 2 - 1, dy = next() * 2 - 1, dz = -(0.2f + next());
+            const int got = call_traverse(L, accel, {State::Vec(next() * 40 - 20, next() * 40 - 20, 60), State::Vec(dx, dy, dz)});
+            if (got == 1) { ++hits; delete L.GetUserType<TraceResult>(1, TraceResult::id); }
+        }
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / calls;
+        if (pass) std::printf("config 1 through the binding: %d accel:Traverse calls, %d hits, %.1f us per call\n", calls, hits, us);
+    }
+    CHECK(hits > calls / 2);
+    L.Pop(L.Top());
+    L.PushUserType(accel, AccelStruct_id);
+    CHECK(AccelStruct_gc(&L) == 0);
+    SetWorld(nullptr);
+}
+
 int main(int argc, char** argv)
 {
+    if (argc > 1 && std::strcmp(argv[1], "--bench") == 0) {
+        bench_single_calls();
+        std::printf("binding (bench): %d checks, %d failed\n", g_run, g_fail);
+        return g_fail ? 1 : 0;
+    }
     const bool cpu_only = argc > 1 && std::strcmp(argv[1], "--cpu") == 0;
     test_cpu_side();
     if (!cpu_only) test_gpu_side();

@@ -30,6 +30,14 @@ def test_binding_end_to_end():
     assert "0 failed" in out.stdout
 
 
+@pytest.mark.gpu
+def test_binding_single_call_config1():
+    """BASELINE config 1 through the binding: 10 k single-ray accel:Traverse calls on a 10 k-triangle world."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([EXE, "--bench"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "us per call" in out.stdout and "0 failed" in out.stdout, out.stdout + out.stderr
+
+
 def test_host_code_under_asan_ubsan():
     """Triangle set-up, PLOC build, leaf collapse and linearise under ASan + UBSan (CPU only)."""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "sanitize"], stdout=subprocess.DEVNULL)
