@@ -185,6 +185,8 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
  *   "refill_threshold"   idle lanes that trigger a re-fill (8);  "tri_threshold": waiting lanes that
  *                        trigger the triangle branch (4);  "static_overflow_mb": overflow-area cap of the
  *                        one-ray-per-lane kernel (256)
+ *   "spin_wait"          host batches of <= 256 rays: watch the pinned result slots change instead of waiting on
+ *                        the stream (default 1; saves ~5 us of the ~24 us single-ray call)
  *   "reserved_cus"       CUs on which the persistent grid leaves room (0 = off): set it when another stream runs
  *                        kernels that must make progress during a trace (e.g. the RCCL gather of the previous
  *                        batch).  A resident persistent grid holds every CU's LDS and registers until its last

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -43,6 +45,7 @@ struct vt_engine {
     uint32_t refill_threshold = 8;    // idle lanes that trigger a re-fill
     uint32_t tri_threshold    = 4;    // lanes with pending triangles that trigger the TRI branch
     int      fetch_dma        = 1;    // quad-cooperative global->LDS record fetch (persistent mode)
+    int      spin_wait        = 1;    // tiny host batches: watch the pinned result slots instead of a stream sync
     uint32_t reserved_cus     = 0;    // CUs on which the persistent grid leaves room (for a concurrent collective's kernels)
     uint32_t reserved_limit   = 2;    // blocks of the grid a reserved CU still keeps
     uint32_t* d_reserved      = nullptr; // 1024-bit set of the reserved CUs' __smid() values, then 1024 per-CU counters
@@ -385,6 +388,7 @@ int vt_engine_set_option(vt_engine* e, const char* key, int64_t value)
     else if (k == "refill_threshold" && value >= 1 && value <= 64) e->refill_threshold = uint32_t(value);
     else if (k == "tri_threshold" && value >= 1 && value <= 64) e->tri_threshold = uint32_t(value);
     else if (k == "fetch_dma") e->fetch_dma = value != 0;
+    else if (k == "spin_wait") e->spin_wait = value != 0;
     else if (k == "reserved_cus" && value >= 0 && value <= e->cu_count / 2) return reserve_cus(e, uint32_t(value));
     else if (k == "reserved_limit" && value >= 0 && value <= 64) e->reserved_limit = uint32_t(value);
     else return fail(VT_ERR_INVALID_ARG, "vt_engine_set_option: unknown key or value out of range: " + k);
@@ -405,6 +409,7 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
     else if (k == "coherent_detect") *value = e->coherent_detect;
     else if (k == "tri_threshold") *value = e->tri_threshold;
     else if (k == "fetch_dma") *value = e->fetch_dma;
+    else if (k == "spin_wait") *value = e->spin_wait;
     else if (k == "reserved_cus") *value = e->reserved_cus;
     else if (k == "reserved_limit") *value = e->reserved_limit;
     else if (k == "cu_count") *value = e->cu_count;
@@ -511,12 +516,35 @@ static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, si
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_trace: hipSetDevice failed");
     if (n <= vt_engine::kTinyRays) {
-        // what AccelStruct:Traverse does per call: the kernel works directly on pinned host memory
+        // what AccelStruct:Traverse does per call: the kernel works directly on pinned host memory.  The result
+        // slots are pre-set to a value the kernel never writes and the host watches them change (each record is
+        // one 16-B store, each any-hit flag one byte): that is a PCIe write away from the last ray's finish, while
+        // hipStreamSynchronize adds the queue's completion signalling (~10 us per call).  If nothing arrives
+        // within a few milliseconds (a fault, a debugger) the ordinary wait takes over and reports the error.
         std::memcpy(e->h_tiny_rays, rays, n * sizeof(vt_ray));
+        const uint32_t kPendingPrim = 0xFFFFFFFEu;               // not VT_MISS and never a triangle index
+        volatile uint32_t* const slots32 = reinterpret_cast<volatile uint32_t*>(e->h_tiny_out);
+        volatile uint8_t* const slots8 = reinterpret_cast<volatile uint8_t*>(e->h_tiny_out);
+        for (uint64_t i = 0; i < n; ++i) {
+            if (any_hit) slots8[i] = 0xFFu; else slots32[i * 4] = kPendingPrim;
+        }
         int rc = launch(s, e->d_tiny_rays, n, any_hit ? nullptr : e->d_tiny_out, any_hit ? e->d_tiny_out : nullptr, nullptr,
                         any_hit, false, e->stream);
         if (rc != VT_OK) return rc;
-        VT_HIP(hipStreamSynchronize(e->stream));
+        bool arrived = false;
+        if (e->spin_wait) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (uint32_t spins = 0; !arrived; ++spins) {
+                arrived = true;
+                for (uint64_t i = 0; i < n && arrived; ++i)
+                    arrived = any_hit ? slots8[i] != 0xFFu : slots32[i * 4] != kPendingPrim;
+                if (!arrived && (spins & 1023u) == 1023u &&
+                    std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5))
+                    break;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!arrived) VT_HIP(hipStreamSynchronize(e->stream));
         std::memcpy(out, e->h_tiny_out, n * out_elem);
         return VT_OK;
     }
