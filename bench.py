@@ -105,7 +105,7 @@ def main() -> None:
     tris = va.tris_setup(verts)
     t1 = time.time()
     host_threads = max(1, len(os.sched_getaffinity(0)) // max(1, world))   # explicit: launchers may export OMP_NUM_THREADS=1
-    bvh = va.HostBvh(tris, nthreads=host_threads, builder=args.builder)   # ranks build side by side
+    bvh = va.HostBvh(tris, nthreads=min(16, host_threads), builder=args.builder)   # ranks build side by side
     t2 = time.time()
     host_scene = va.HostScene(bvh)
     engine = va.Engine(dev_index)

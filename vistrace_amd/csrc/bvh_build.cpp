@@ -320,7 +320,10 @@ int bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, int builder, Bvh& 
     if (n > 0x7FFFFFFFu) return fail(VT_ERR_INVALID_ARG, "vt_bvh_build: more than 2^31-1 triangles");
     if (!tris) return fail(VT_ERR_INVALID_ARG, "vt_bvh_build: tris is NULL");
 #ifdef _OPENMP
-    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    // default: up to 16 threads.  The PLOC rounds are many short parallel regions; measured on a 2 x 64-core
+    // host (scripts/build_rate.py, 1 M triangles): 1 thread 0.60 s, 16 threads 0.20 s, 128 threads 0.52 s,
+    // 256 threads 3.4 s -- more threads only add fork/join and cross-socket traffic.
+    if (nthreads <= 0) nthreads = std::min(omp_get_max_threads(), 16);
 #else
     nthreads = 1;
 #endif

@@ -100,6 +100,7 @@ struct vt_scene {
     uint32_t*       d_matrix_base = nullptr;
     float*          d_skin_mats = nullptr;   // 3 x mats_cap matrices: bones | binds | products
     uint32_t        mats_cap = 0;
+    hipGraphExec_t  refit_graph = nullptr;   // the level-by-level refit launches, captured once (launch-bound: ~30 tiny kernels)
     uint32_t      npairs = 0, ntris = 0, max_depth = 0, root_leaf_count = 0;
     uint64_t      bytes = 0;
 };
@@ -498,6 +499,7 @@ void vt_scene_free(vt_scene* s)
     if (s->d_prim_to_slot) (void)hipFree(s->d_prim_to_slot);
     if (s->d_attribs) (void)hipFree(s->d_attribs);
     if (s->d_level_pairs) (void)hipFree(s->d_level_pairs);
+    if (s->refit_graph) (void)hipGraphExecDestroy(s->refit_graph);
     if (s->d_bind_verts) (void)hipFree(s->d_bind_verts);
     if (s->d_skin) (void)hipFree(s->d_skin);
     if (s->d_matrix_base) (void)hipFree(s->d_matrix_base);
@@ -727,10 +729,34 @@ void* vt_engine_stream(vt_engine* e) { return e ? static_cast<void*>(e->stream) 
 static int refit_levels(vt_scene* s)
 {
     vt_engine* e = s->engine;
-    for (size_t k = 0; k + 1 < s->level_begin.size(); ++k) {
-        RefitLevelArgs la{reinterpret_cast<vt_node_pair*>(s->d_records), s->d_tris, s->d_level_pairs + s->level_begin[k],
-                          s->level_begin[k + 1] - s->level_begin[k]};
-        VT_HIP(launch_refit_level(la, e->stream));
+    const size_t levels = s->level_begin.empty() ? 0 : s->level_begin.size() - 1;
+    auto enqueue = [&]() -> int {
+        for (size_t k = 0; k < levels; ++k) {
+            RefitLevelArgs la{reinterpret_cast<vt_node_pair*>(s->d_records), s->d_tris, s->d_level_pairs + s->level_begin[k],
+                              s->level_begin[k + 1] - s->level_begin[k]};
+            VT_HIP(launch_refit_level(la, e->stream));
+        }
+        return VT_OK;
+    };
+    // One launch per tree level, most of them a handful of threads: launch-bound.  The sequence only depends on
+    // the scene's topology, so it is captured into a hipGraph on first use and replayed afterwards.
+    if (!s->refit_graph && levels > 4) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int rc = enqueue();
+            const hipError_t end = hipStreamEndCapture(e->stream, &graph);
+            if (rc == VT_OK && end == hipSuccess && graph &&
+                hipGraphInstantiate(&s->refit_graph, graph, nullptr, nullptr, 0) != hipSuccess)
+                s->refit_graph = nullptr;
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        (void)hipGetLastError();                        // a failed capture falls back to plain launches below
+    }
+    if (s->refit_graph) {
+        VT_HIP(hipGraphLaunch(s->refit_graph, e->stream));
+    } else {
+        const int rc = enqueue();
+        if (rc != VT_OK) return rc;
     }
     VT_HIP(hipStreamSynchronize(e->stream));
     return VT_OK;
