@@ -49,6 +49,15 @@ for seed in range(first, first + count):
         ok = (got.view(np.uint8) == ref.view(np.uint8)).all() and (st["steps"] == ref_st[:, 0]).all() and (st["tests"] == ref_st[:, 1]).all()
         ok = ok and (scene.trace_closest(rays).view(np.uint8) == ref.view(np.uint8)).all()
         ok = ok and (scene.trace_any(rays) == (ref["prim"] != O.MISS)).all()
+        # single-call / tiny host batches (pinned slots + spin wait) and the persistent grid with reserved CUs
+        for k in (1, 3, 256):
+            kk = min(k, m)
+            ok = ok and (scene.trace_closest(rays[:kk]).view(np.uint8) == ref[:kk].view(np.uint8)).all()
+            ok = ok and (scene.trace_any(rays[-kk:]) == (ref["prim"][-kk:] != O.MISS)).all()
+        if mode == 1 and seed % 3 == 0:
+            eng.set_option("reserved_cus", 32)
+            ok = ok and (scene.trace_closest(rays).view(np.uint8) == ref.view(np.uint8)).all()
+            eng.set_option("reserved_cus", 0)
         if not ok:
             bad += 1
             print(f"MISMATCH seed {seed} mode {mode} n {n} m {m}", flush=True)
