@@ -72,6 +72,7 @@ def main():
             "auto_static_factor", "static_overflow_mb", "coherent_detect"]
     defaults = {k: engine.get_option(k) for k in keys}
     times = {v: [] for v in variants}
+    infos = {}
     ref = None
     for r in range(args.rounds + 1):
         for v in variants:
@@ -85,6 +86,7 @@ def main():
             else:
                 tp.trace_closest(scene, d_rays, n, d_hits)
             ms = engine.last_kernel_ms()
+            infos[v] = engine.launch_info()
             if r > 0:
                 times[v].append(ms)
             elif not args.any:
@@ -97,7 +99,7 @@ def main():
         t = np.array(times[v])
         med = float(np.median(t))
         print(f"{v:60s} median {med:8.3f} ms  min {t.min():8.3f} ms  {n / med / 1e3:9.1f} Mrays/s  "
-              f"alg {alg / med / 1e6:8.1f} GB/s  info {engine.launch_info() if v == variants[-1] else ''}", flush=True)
+              f"alg {alg / med / 1e6:8.1f} GB/s  info {infos.get(v)}", flush=True)
 
 
 if __name__ == "__main__":

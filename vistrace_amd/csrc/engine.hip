@@ -33,6 +33,7 @@ struct vt_engine {
     hipStream_t stream = nullptr;
     int         cu_count = 0;
     size_t      lds_per_block_max = 0;
+    size_t      lds_per_cu = 160 * 1024;
 
     // launch configuration (vt_engine_set_option)
     int      persistent       = 2;    // 0 static (one ray per lane), 1 persistent waves, 2 auto by batch size
@@ -158,7 +159,11 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool 
         // persistent grid = what is resident at once (registers/LDS decide), capped by the option
         int occ = 0;
         VT_HIP(trace_blocks_per_cu(any_hit, stats, true, p.fetch_dma, trace_lds_bytes(p.lds_entries, p.fetch_dma), &occ));
-        const uint32_t per_cu = std::max(1u, std::min(e->blocks_per_cu, uint32_t(std::max(occ, 1))));
+        // LDS is granted in 1 280-B granules of the CU's 160 KB, which the occupancy query does not model
+        const size_t lds_need = trace_lds_bytes(p.lds_entries, p.fetch_dma);
+        const size_t lds_granted = (lds_need + 1279) / 1280 * 1280;
+        const uint32_t by_lds = lds_granted ? uint32_t(e->lds_per_cu / lds_granted) : 64u;
+        const uint32_t per_cu = std::max(1u, std::min({e->blocks_per_cu, uint32_t(std::max(occ, 1)), std::max(by_lds, 1u)}));
         // with reserved CUs the blocks that land there leave at once; surplus blocks make up for the ones the
         // dispatcher keeps sending to the emptied CUs while the grid is still being placed
         const uint64_t surplus = e->reserved_cus && e->d_reserved ? uint64_t(4) * e->reserved_cus * per_cu : 0;
@@ -323,6 +328,7 @@ int vt_engine_open(int device, vt_engine** out)
     e->device = device;
     e->cu_count = prop.multiProcessorCount;
     e->lds_per_block_max = prop.sharedMemPerBlock; // 64 KiB default window; plenty for the stack
+    if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) e->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
     e->persistent = int(env_long("VT_PERSISTENT", e->persistent));
     e->lds_entries = uint32_t(env_long("VT_LDS_ENTRIES", e->lds_entries));
     e->blocks_per_cu = uint32_t(env_long("VT_BLOCKS_PER_CU", e->blocks_per_cu));
