@@ -45,7 +45,7 @@ enum vt_status {
 
 /* triangle flags, resolved from Material::flags at upload time */
 #define VT_TRI_CULL_BACKFACE 1u /* oneSided && !(mat.flags & nocull): source/objects/Primitives.h:174 */
-#define VT_TRI_ALPHATEST     2u /* mat.flags & alphatest: source/objects/Primitives.h:196 (not yet on device) */
+#define VT_TRI_ALPHATEST     2u /* mat.flags & alphatest: source/objects/Primitives.h:196 (needs vt_scene_set_alpha) */
 
 /* bvh::Ray<float> without the pAccel pointer: source/objects/Primitives.h:11-33.  32 B. */
 typedef struct vt_ray { float org[3]; float dir[3]; float tmin; float tmax; } vt_ray;
@@ -233,6 +233,28 @@ int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_o
 
 /* Optional per-triangle side table (n must equal the scene's triangle count); copied to the device. */
 int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_t n);
+/* Alpha test inside the triangle test (source/objects/Primitives.h:196-208).  In tree and followed exactly: texUV
+ * = (1-u-v)*uvs[0] + u*uvs[1] + v*uvs[2], TransformTexcoord (source/Utils.h:65-72), `alpha < alphatestreference`
+ * discards the hit (the walk continues, tmax unchanged).  NOT in tree: `baseTexture->Sample(u, v, 0.f).a` forwards
+ * to the VTFParser submodule (source/objects/VTFTexture.cpp:68-72), which is absent and unpinned -- the lookup is
+ * therefore DEFINED here: the host hands over the decoded mip-0 alpha plane of each material's base texture
+ * (8 bits, row-major), addressing is repeat, alpha = a / 255, filter 0 = nearest texel floor(s*W), filter 1 =
+ * bilinear with texel centres at (i + 0.5) / W.  A maintainer with VTFParser at hand picks the filter that matches
+ * (or pre-filters the plane).  width = height = 0: no texture, alpha 1.  64 B. */
+typedef struct vt_alpha_material {
+    float tex_mat[2][4];     /* Material::baseTexMat (source/objects/Material.h): tex_mat[r] = transform[r]   */
+    float tex_scale;         /* Material::texScale                                                            */
+    float alpha_ref;         /* Material::alphatestreference (default 0.5, Material.h:122)                    */
+    uint32_t width, height;
+    uint32_t filter;
+    uint32_t pad;
+    uint64_t offset;         /* first texel of this material in `texels`                                      */
+} vt_alpha_material;
+/* Materials are indexed by vt_tri_attribs::material, uvs come from vt_tri_attribs::uv: call
+ * vt_scene_set_tri_attribs first.  A scene that holds VT_TRI_ALPHATEST triangles cannot be traced until this is
+ * set (VT_ERR_UNSUPPORTED); scenes without such triangles run the kernels compiled without the test. */
+int vt_scene_set_alpha(vt_scene* s, const vt_alpha_material* mats, uint32_t nmats, const uint8_t* texels, uint64_t ntexels);
+
 /* entIdx / texUV / blendFactor / submatIdx per hit (needs vt_scene_set_tri_attribs). d_out: n x vt_hit_shade. */
 int vt_hit_shade_dev(vt_scene* s, const void* d_hits, uint64_t n, void* d_out, void* stream);
 

@@ -20,6 +20,8 @@ RAY = np.dtype([("org", "<f4", 3), ("dir", "<f4", 3), ("tmin", "<f4"), ("tmax", 
 TRI = np.dtype([("p0", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3), ("n", "<f4", 3), ("flags", "<u4")])
 NODE = np.dtype([("bounds", "<f4", 6), ("prim_count", "<u4"), ("first", "<u4")])
 HIT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+ALPHA_MATERIAL = np.dtype([("tex_mat", "<f4", (2, 4)), ("tex_scale", "<f4"), ("alpha_ref", "<f4"), ("width", "<u4"),
+                           ("height", "<u4"), ("filter", "<u4"), ("pad", "<u4"), ("offset", "<u8")])
 SKIN_VERTEX = np.dtype([("weight", "<f4", 3), ("bone", "i1", 3), ("num_bones", "u1")])
 ATTRS = np.dtype([("pos", "<f4", 3), ("uvw", "<f4", 3), ("ngeo", "<f4", 3), ("wo", "<f4", 3), ("front", "<u4")])
 
@@ -57,6 +59,11 @@ def lib() -> C.CDLL:
         L.vto_hit_shade.argtypes = [C.c_float, C.c_float, vp, vp, vp, vp]
         L.vto_calc_ray_origin.argtypes = [vp, vp, vp]
         L.vto_hemisphere_cos.argtypes = [C.c_float, C.c_float, vp]
+        L.vto_set_alpha.argtypes = [vp]
+        L.vto_alpha_sample.argtypes = [vp, vp, C.c_float, C.c_float]
+        L.vto_alpha_sample.restype = C.c_float
+        L.vto_alpha_pass.argtypes = [vp, u32, C.c_float, C.c_float]
+        L.vto_alpha_pass.restype = C.c_int
         L.vto_skin_matrices.argtypes = [vp, vp, u32, vp]
         L.vto_skin_verts.argtypes = [vp, vp, vp, u32, vp, vp]
         _lib = L
@@ -172,3 +179,36 @@ def skin_verts(bind_verts: np.ndarray, skin: np.ndarray, matrix_base: np.ndarray
     lib().vto_skin_verts(bind_verts.ctypes.data, skin.ctypes.data, matrix_base.ctypes.data, n, mats.ctypes.data,
                          out.ctypes.data)
     return out
+
+
+class _AlphaCtx(C.Structure):
+    _fields_ = [("tris_base", C.c_void_p), ("tri_uv", C.c_void_p), ("tri_material", C.c_void_p), ("mats", C.c_void_p),
+                ("nmats", C.c_uint32), ("texels", C.c_void_p)]
+
+
+_alpha_keep = None
+
+
+def set_alpha(tris=None, tri_uv=None, tri_material=None, mats=None, texels=None):
+    """Install (or with no arguments clear) the alpha-test side data used for triangles flagged TRI_ALPHATEST.
+    `tris` must be the very array later passed to traverse_batch / trace_brute (its address names the triangles)."""
+    global _alpha_keep
+    if tris is None:
+        lib().vto_set_alpha(None)
+        _alpha_keep = None
+        return None
+    assert tris.dtype == TRI and tris.flags.c_contiguous
+    tri_uv = np.ascontiguousarray(tri_uv, np.float32).reshape(len(tris), 6)
+    tri_material = np.ascontiguousarray(tri_material, np.uint32).reshape(len(tris))
+    mats = np.ascontiguousarray(mats, ALPHA_MATERIAL)
+    texels = np.ascontiguousarray(texels, np.uint8)
+    ctx = _AlphaCtx(tris.ctypes.data, tri_uv.ctypes.data, tri_material.ctypes.data, mats.ctypes.data, len(mats), texels.ctypes.data)
+    _alpha_keep = (ctx, tris, tri_uv, tri_material, mats, texels)
+    lib().vto_set_alpha(C.addressof(ctx))
+    return ctx
+
+
+def alpha_sample(mat: np.ndarray, texels: np.ndarray, s: float, t: float) -> float:
+    mat = np.ascontiguousarray(mat, ALPHA_MATERIAL).reshape(1)
+    texels = np.ascontiguousarray(texels, np.uint8)
+    return float(lib().vto_alpha_sample(mat.ctypes.data, texels.ctypes.data, float(s), float(t)))

@@ -55,6 +55,58 @@ void vto_tri_setup(const float p0[3], const float p1[3], const float p2[3],
 }
 
 /* ---- Primitives.h:168-215 --------------------------------------------------*/
+/* ---- Primitives.h:196-208 + Utils.h:65-72; the texel lookup itself is defined in vt_oracle.h ----*/
+static const vto_alpha_ctx* g_alpha = 0;
+
+void vto_set_alpha(const vto_alpha_ctx* ctx) { g_alpha = ctx; }
+
+static uint32_t wrap_index(float f, uint32_t n)
+{
+    int64_t i = (int64_t)f;                     /* f is integral and |f| < 1e9 */
+    int64_t m = i % (int64_t)n;
+    return (uint32_t)(m < 0 ? m + (int64_t)n : m);
+}
+
+float vto_alpha_sample(const vto_alpha_material* m, const uint8_t* texels, float s, float t)
+{
+    if (m->width == 0 || m->height == 0) return 1.0f;
+    const float W = (float)m->width, H = (float)m->height;
+    const uint8_t* img = texels + m->offset;
+    float x = s * W, y = t * H;
+    if (!(fabsf(x) < 1.0e9f)) x = 0.0f;         /* NaN, inf or absurd coordinates: texel (0, 0) */
+    if (!(fabsf(y) < 1.0e9f)) y = 0.0f;
+    if (m->filter == 0) {
+        const uint32_t xi = wrap_index(floorf(x), m->width), yi = wrap_index(floorf(y), m->height);
+        return (float)img[(size_t)yi * m->width + xi] / 255.0f;
+    }
+    const float fx = x - 0.5f, fy = y - 0.5f;
+    const float x0 = floorf(fx), y0 = floorf(fy);
+    const float ax = fx - x0, ay = fy - y0;
+    const uint32_t i0 = wrap_index(x0, m->width), i1 = wrap_index(x0 + 1.0f, m->width);
+    const uint32_t j0 = wrap_index(y0, m->height), j1 = wrap_index(y0 + 1.0f, m->height);
+    const float a00 = (float)img[(size_t)j0 * m->width + i0], a10 = (float)img[(size_t)j0 * m->width + i1];
+    const float a01 = (float)img[(size_t)j1 * m->width + i0], a11 = (float)img[(size_t)j1 * m->width + i1];
+    const float top = a00 * (1.0f - ax) + a10 * ax;
+    const float bot = a01 * (1.0f - ax) + a11 * ax;
+    return (top * (1.0f - ay) + bot * ay) / 255.0f;
+}
+
+int vto_alpha_pass(const vto_alpha_ctx* ctx, uint32_t prim, float u, float v)
+{
+    const float* uv = ctx->tri_uv + (size_t)prim * 6;
+    const uint32_t mi = ctx->tri_material[prim];
+    if (mi >= ctx->nmats) return 1;
+    const vto_alpha_material* m = &ctx->mats[mi];
+    const float w = 1.0f - u - v;                                             /* :198 */
+    const float tx = (w * uv[0] + u * uv[2]) + v * uv[4];
+    const float ty = (w * uv[1] + u * uv[3]) + v * uv[5];
+    /* TransformTexcoord: dot(vec4(texcoord, 1, 1), transform[r]) * scale; glm dot(vec4) = (x + y) + (z + w) */
+    const float sx = ((tx * m->tex_mat[0][0] + ty * m->tex_mat[0][1]) + (m->tex_mat[0][2] + m->tex_mat[0][3])) * m->tex_scale;
+    const float sy = ((tx * m->tex_mat[1][0] + ty * m->tex_mat[1][1]) + (m->tex_mat[1][2] + m->tex_mat[1][3])) * m->tex_scale;
+    const float alpha = vto_alpha_sample(m, ctx->texels, sx, sy);             /* :202 (sampler defined here) */
+    return alpha < m->alpha_ref ? 0 : 1;                                      /* :205 */
+}
+
 int vto_tri_intersect(const vto_tri* tri, const float org[3], const float dir[3],
                       float tmin, float tmax, float* t_out, float* u_out, float* v_out)
 {
@@ -75,8 +127,11 @@ int vto_tri_intersect(const vto_tri* tri, const float org[3], const float dir[3]
     if (u >= 0.0f && v >= 0.0f && w >= 0.0f) {
         float t = dot3(tri->n, c) * inv_det;                         /* :188 */
         if (t >= tmin && t <= tmax) {                                /* :189 */
-            /* :196-208 alpha-test branch is not restated;
-             * callers never build oracle scenes with VTO_TRI_ALPHATEST. */
+            /* :196-208: a material with the alphatest flag discards the hit when the base texture's alpha at
+             * the hit point is below the reference */
+            if ((tri->flags & VTO_TRI_ALPHATEST) && g_alpha &&
+                !vto_alpha_pass(g_alpha, (uint32_t)(tri - g_alpha->tris_base), u, v))
+                return 0;
             *t_out = t; *u_out = u; *v_out = v;
             return 1;
         }

@@ -40,7 +40,7 @@ extern "C" {
 
 /* flags of a triangle as the intersector sees them */
 #define VTO_TRI_CULL_BACKFACE 1u /* oneSided && !(mat.flags & nocull)   Primitives.h:174 */
-#define VTO_TRI_ALPHATEST     2u /* mat.flags & alphatest (Primitives.h:196); NOT restated */
+#define VTO_TRI_ALPHATEST     2u /* mat.flags & alphatest (Primitives.h:196): needs vto_set_alpha */
 
 /* bvh::Ray<float> minus the pAccel back-pointer (Primitives.h:11-33) */
 typedef struct { float org[3]; float dir[3]; float tmin; float tmax; } vto_ray;
@@ -118,6 +118,39 @@ void vto_calc_ray_origin(const float pos[3], const float normal[3], float out[3]
 
 /* hemisphere_cos, BSDF.cpp:69-77 (r1, r2 are the two sampler floats, in call order) */
 void vto_hemisphere_cos(float r1, float r2, float out[3]);
+
+/* ---- alpha test inside intersect(), source/objects/Primitives.h:196-208 ---------------------
+ * In tree: texUV = (1-u-v)*uvs[0] + u*uvs[1] + v*uvs[2] (:198), TransformTexcoord (source/Utils.h:65-72),
+ * the comparison alpha < mat.alphatestreference (:205, default 0.5: Material.h:122).
+ * NOT in tree: mat.baseTexture->Sample(u, v, 0.f).a -- IVTFTexture::Sample forwards to the VTFParser
+ * submodule (source/objects/VTFTexture.cpp:68-72), absent and unpinned.  The sampler is therefore DEFINED
+ * here (and identically on the device): alpha plane of mip 0, 8 bits, repeat addressing, alpha = a / 255;
+ * filter 0 = nearest texel floor(s*W), filter 1 = bilinear with texel centres at (i + 0.5) / W. */
+typedef struct {
+    float tex_mat[2][4];     /* Material::baseTexMat: tex_mat[r] = transform[r] of TransformTexcoord    */
+    float tex_scale;         /* Material::texScale                                                       */
+    float alpha_ref;         /* Material::alphatestreference                                             */
+    uint32_t width, height;  /* alpha plane size (0 x 0: no texture -> alpha 1, the hit is kept)          */
+    uint32_t filter;         /* 0 nearest, 1 bilinear                                                    */
+    uint32_t pad;
+    uint64_t offset;         /* first texel of this material in the texel array, row-major               */
+} vto_alpha_material;
+
+typedef struct {
+    const vto_tri* tris_base;          /* the triangle array the walk indexes (original order)           */
+    const float* tri_uv;               /* 6 floats per triangle: uvs[0..2]  (Primitives.h:65)            */
+    const uint32_t* tri_material;      /* material index per triangle                                     */
+    const vto_alpha_material* mats; uint32_t nmats;
+    const uint8_t* texels;
+} vto_alpha_ctx;
+
+/* Side data for triangles flagged VTO_TRI_ALPHATEST (NULL = none: such a flag is then ignored).  Process-wide;
+ * set it before a batch, not during one. */
+void vto_set_alpha(const vto_alpha_ctx* ctx);
+/* The alpha plane lookup defined above. */
+float vto_alpha_sample(const vto_alpha_material* m, const uint8_t* texels, float s, float t);
+/* 1 = the hit (u, v) on triangle `prim` survives the alpha test of Primitives.h:196-208. */
+int vto_alpha_pass(const vto_alpha_ctx* ctx, uint32_t prim, float u, float v);
 
 /* ---- skinning on Rebuild, source/objects/AccelStruct.cpp:34-102 ----------------
  * One vertex's Triangle::weights / boneIds / numBones (Primitives.h:68-70). 16 B. */

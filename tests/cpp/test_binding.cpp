@@ -255,18 +255,32 @@ static void test_gpu_side()
         CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1)}) == 1);
         delete L.GetUserType<TraceResult>(1, TraceResult::id);
     }
-    // alpha-tested material: not supported on the device yet -> loud error at build, accel left invalid
+    // alpha-tested material (Primitives.h:196-208): a fence triangle whose 2x2 checker alpha plane [[0,255],[255,0]]
+    // lets the ray through where alpha < alphatestreference and stops it elsewhere
     {
-        world.materials.push_back(Material{"brush/fence", MATFLAG_ALPHATEST});
-        world.triangles.push_back(make_tri({40, 0, 0}, {50, 0, 0}, {40, 10, 0}, false, 2));
+        Material fence{"brush/fence", MATFLAG_ALPHATEST};
+        fence.alphaWidth = fence.alphaHeight = 2;
+        fence.baseAlpha = {0, 255, 255, 0};
+        world.materials.push_back(fence);
+        world.triangles.push_back(make_tri({40, 0, 0}, {50, 0, 0}, {40, 10, 0}, false, 2));   // uvs (0,0) (1,0) (0,1)
         L.Pop(L.Top());
         L.PushUserType(accel, AccelStruct_id);
-        std::string err = error_of([&] { AccelStruct_Rebuild(&L); });
-        CHECK(contains(err, "alpha-tested"));
-        CHECK(!accel->IsBuilt());
-        err = error_of([&] { call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1)}); });
-        CHECK(contains(err, "acceleration structure invalid"));
+        CHECK(AccelStruct_Rebuild(&L) == 0);
+        CHECK(accel->IsBuilt());
+        // barycentric (u,v) = (0.2,0.2) -> texel (0,0): alpha 0 -> the ray passes through the fence
+        CHECK(call_traverse(L, accel, {State::Vec(42, 2, 8), State::Vec(0, 0, -1)}) == 0);
+        // (0.7,0.2) -> texel (1,0): alpha 1 -> hit
+        CHECK(call_traverse(L, accel, {State::Vec(47, 2, 8), State::Vec(0, 0, -1)}) == 1);
+        delete L.GetUserType<TraceResult>(1, TraceResult::id);
+        // a reference of 0 keeps every hit (alpha < 0 never holds)
+        world.materials.back().alphatestreference = 0.f;
+        L.Pop(L.Top());
+        L.PushUserType(accel, AccelStruct_id);
+        CHECK(AccelStruct_Rebuild(&L) == 0);
+        CHECK(call_traverse(L, accel, {State::Vec(42, 2, 8), State::Vec(0, 0, -1)}) == 1);
+        delete L.GetUserType<TraceResult>(1, TraceResult::id);
         world.triangles.pop_back();
+        world.materials.pop_back();
     }
     L.Pop(L.Top());
     L.PushUserType(accel, AccelStruct_id);

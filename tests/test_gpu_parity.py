@@ -625,3 +625,53 @@ def test_host_buffer_pipeline_ragged(va, engine, make_bundle):
     assert_hits_equal(got[idx], b.oracle(rays[idx]))
     again = scene.trace_closest(rays[: 2 * (1 << 20) + 1])          # a second call re-uses the staging buffers
     assert_hits_equal(again, ref[: 2 * (1 << 20) + 1])
+
+
+def test_alpha_test_in_kernel(va, engine, O):
+    """Primitives.h:196-208 on the device (ALPHA kernel variants): texUV, TransformTexcoord, the alpha plane lookup
+    defined in include/vistrace_hip.h and the reference comparison -- hits, any-hit flags and counters equal the
+    oracle's; tracing such a scene without its side data fails loudly."""
+    from vistrace_amd import workloads as W
+    verts = W.make_scene("S10k")
+    n = len(verts)
+    flags, attribs, mats, texels = W.alpha_test_rig(n)
+    tris = va.tris_setup(verts, flags)
+    bvh = va.HostBvh(tris)
+    scene = va.Scene(engine, va.HostScene(bvh))
+    rays = np.concatenate([W.primary_rays(96, 96), W.sphere_rays(30000, 41, origin=(-120.0, 80.0, 15.0))])
+    with pytest.raises(va._lib.VisTraceError) as err:
+        scene.trace_closest(rays[:10])
+    assert err.value.code == va._lib.VT_ERR_UNSUPPORTED
+    scene.set_tri_attribs(attribs.view(va.TRI_ATTRIBS))
+    scene.set_alpha(mats.view(va.ALPHA_MATERIAL), texels)
+    otris = O.tris_from_tri64(tris)
+    try:
+        plain = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays)[0]
+        O.set_alpha(otris, attribs["uv"].reshape(n, 6), attribs["material"], mats.view(O.ALPHA_MATERIAL), texels)
+        ref, ref_st, _, _, _ = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays, want_stats=True)
+        any_ref = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays, any_hit=True)[0]
+    finally:
+        O.set_alpha()
+    assert 500 < int((plain["prim"] != ref["prim"]).sum())               # the test changes a good share of the results
+    assert_hits_equal(scene.trace_closest(rays), ref)
+    assert (scene.trace_any(rays) == (any_ref["prim"] != O_MISS)).all()
+    got, st = stats_on_device(va, scene, rays)
+    assert_hits_equal(got, ref)
+    assert (st["steps"] == ref_st[:, 0]).all() and (st["tests"] == ref_st[:, 1]).all()
+    assert_hits_equal(scene.trace_closest(rays[:200]), ref[:200])        # tiny host batch, one ray per lane
+
+
+def test_scene_outliving_its_engine_is_inert(va, make_bundle):
+    """Closing an engine releases the device memory of its scenes; a scene object that is still referenced
+    afterwards reports the closed engine instead of touching freed state, and can be freed safely."""
+    from vistrace_amd import workloads as W
+    b = make_bundle("S1k")
+    eng = va.Engine(0)
+    scene = va.Scene(eng, b.host_scene)
+    rays = W.sphere_rays(500, 2)
+    assert_hits_equal(scene.trace_closest(rays), b.oracle(rays))
+    eng.close()
+    with pytest.raises(va._lib.VisTraceError) as err:
+        scene.trace_closest(rays)
+    assert "closed" in str(err.value)
+    scene.free()

@@ -265,3 +265,85 @@ def test_skin_matches_float64_model(O):
             for q in range(skin["num_bones"][t, vi]):
                 exp[t, vi] += (M64[base[t] + skin["bone"][t, vi, q]] @ p)[:3] * skin["weight"][t, vi, q]
     assert np.allclose(out, exp, rtol=1e-4, atol=2e-3)
+
+
+# ---- alpha test inside intersect(): Primitives.h:196-208 ---------------------------------------------------------
+def _alpha_scene(O, va, filter_mode, ref=0.5, tex_mat=((1, 0, 0, 0), (0, 1, 0, 0)), scale=1.0):
+    """Unit right triangle in z = 0 with uvs = its xy corners and a 2x2 checker alpha plane [[0,255],[255,0]]."""
+    verts = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32)
+    tris = O.tris_setup(verts, np.array([O_ALPHA], np.uint8))
+    mats = np.zeros(1, O.ALPHA_MATERIAL)
+    mats["tex_mat"][0], mats["tex_scale"], mats["alpha_ref"] = tex_mat, scale, ref
+    mats["width"], mats["height"], mats["filter"] = 2, 2, filter_mode
+    texels = np.array([0, 255, 255, 0], np.uint8)
+    O.set_alpha(tris, np.array([[0, 0, 1, 0, 0, 1]], np.float32), np.zeros(1, np.uint32), mats, texels)
+    return tris
+
+
+O_ALPHA = 2
+
+
+def _hits(O, tris, x, y):
+    rays = np.zeros(1, O.RAY)
+    rays["org"], rays["dir"], rays["tmax"] = (x, y, 1.0), (0, 0, -1), np.finfo(np.float32).max
+    return O.trace_brute(tris, rays)["prim"][0] != O.MISS
+
+
+def test_alpha_test_nearest_checker(O, va):
+    try:
+        tris = _alpha_scene(O, va, 0)
+        assert not _hits(O, tris, 0.2, 0.2)       # texel (0,0) = 0   -> alpha 0 < 0.5: discarded
+        assert _hits(O, tris, 0.7, 0.2)           # texel (1,0) = 255 -> kept
+        assert _hits(O, tris, 0.2, 0.7)           # texel (0,1) = 255 -> kept
+        O.set_alpha()                             # no side data: the flag is ignored
+        assert _hits(O, tris, 0.2, 0.2)
+        tris = _alpha_scene(O, va, 0, ref=0.0)    # alpha < 0 never holds
+        assert _hits(O, tris, 0.2, 0.2)
+        # TransformTexcoord: shift s by half a plane -> the checker flips; scale 2 wraps around
+        tris = _alpha_scene(O, va, 0, tex_mat=((1, 0, 0.25, 0.25), (0, 1, 0, 0)))
+        assert _hits(O, tris, 0.2, 0.2) and not _hits(O, tris, 0.7, 0.2)
+        tris = _alpha_scene(O, va, 0, scale=2.0)
+        assert not _hits(O, tris, 0.1, 0.1) and _hits(O, tris, 0.3, 0.1) and not _hits(O, tris, 0.6, 0.1)
+    finally:
+        O.set_alpha()
+
+
+def test_alpha_sampler_definition(O):
+    m = np.zeros(1, O.ALPHA_MATERIAL)
+    m["width"], m["height"], m["tex_scale"] = 2, 2, 1
+    tex = np.array([0, 255, 255, 0], np.uint8)
+    assert O.alpha_sample(m, tex, 0.25, 0.25) == 0.0 and O.alpha_sample(m, tex, 0.75, 0.25) == 1.0
+    assert O.alpha_sample(m, tex, 1.25, -0.75) == 0.0                      # repeat addressing, negative side too
+    assert O.alpha_sample(m, tex, float("nan"), 0.25) == 0.0               # non-finite coordinate -> texel column 0
+    m["filter"] = 1
+    assert O.alpha_sample(m, tex, 0.25, 0.25) == 0.0                       # texel centre
+    assert O.alpha_sample(m, tex, 0.5, 0.25) == 0.5                        # half way between two centres
+    assert O.alpha_sample(m, tex, 0.5, 0.5) == 0.5
+    assert O.alpha_sample(m, tex, 0.0, 0.25) == 0.5                        # wraps to the last column
+    m["width"], m["height"] = 0, 0
+    assert O.alpha_sample(m, tex, 0.3, 0.3) == 1.0                         # no texture: opaque
+
+
+def test_alpha_test_walk_equals_brute_force(O, va):
+    """Random scene with ~40 % alpha-tested triangles: the BVH walk and the brute-force loop agree (a discarded hit
+    must not shrink tmax nor end the walk)."""
+    from vistrace_amd import workloads as W
+    rng = np.random.default_rng(17)
+    n = 3000
+    verts = (rng.normal(scale=30, size=(n, 1, 3)) + rng.normal(scale=4, size=(n, 3, 3))).astype(np.float32)
+    flags, attribs, mats, texels = W.alpha_test_rig(n)
+    tris64 = va.tris_setup(verts, flags)
+    bvh = va.HostBvh(tris64)
+    otris = O.tris_from_tri64(tris64)
+    rays = W.sphere_rays(5000, 3, origin=(1.0, 2.0, 3.0))
+    try:
+        plain = O.trace_brute(otris, rays)
+        O.set_alpha(otris, attribs["uv"].reshape(n, 6), attribs["material"], mats.view(O.ALPHA_MATERIAL), texels)
+        ref, _, _, _, _ = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays)
+        brute = O.trace_brute(otris, rays)
+        assert (ref["t"].view(np.uint32) == brute["t"].view(np.uint32)).all()
+        assert ((ref["prim"] == O.MISS) == (brute["prim"] == O.MISS)).all()
+        changed = int((plain["t"] != brute["t"]).sum())
+        assert 200 < changed < 4000                                         # the test discards a good share of the hits
+    finally:
+        O.set_alpha()

@@ -37,8 +37,10 @@ HIT_ATTRS = np.dtype([("pos", "<f4", 3), ("t", "<f4"), ("ngeo", "<f4", 3), ("pri
 TRI_ATTRIBS = np.dtype([("uv", "<f4", (3, 2)), ("alpha", "<f4", 3), ("ent_id", "<u4"), ("material", "<u4"), ("pad", "<u4")])
 HIT_SHADE = np.dtype([("tex_uv", "<f4", 2), ("blend", "<f4"), ("ent_id", "<u4"), ("material", "<u4"), ("pad", "<u4", 3)])
 CAMERA = np.dtype([("pos", "<f4", 3), ("forward", "<f4", 3), ("up", "<f4", 3), ("vfov_deg", "<f4"), ("width", "<u4"), ("height", "<u4")])
+ALPHA_MATERIAL = np.dtype([("tex_mat", "<f4", (2, 4)), ("tex_scale", "<f4"), ("alpha_ref", "<f4"), ("width", "<u4"),
+                           ("height", "<u4"), ("filter", "<u4"), ("pad", "<u4"), ("offset", "<u8")])
 SKIN_VERTEX = np.dtype([("weight", "<f4", 3), ("bone", "i1", 3), ("num_bones", "u1")])
-assert TRI_ATTRIBS.itemsize == 48 and HIT_SHADE.itemsize == 32 and SKIN_VERTEX.itemsize == 16
+assert TRI_ATTRIBS.itemsize == 48 and HIT_SHADE.itemsize == 32 and SKIN_VERTEX.itemsize == 16 and ALPHA_MATERIAL.itemsize == 64
 assert RAY.itemsize == 32 and HIT.itemsize == 16 and BVH_NODE.itemsize == 32
 assert NODE_PAIR.itemsize == 64 and TRI64.itemsize == 64 and HIT_ATTRS.itemsize == 64
 
@@ -80,6 +82,7 @@ SYMBOLS = {
     "vt_trace_stats_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "vt_hit_attrs_dev": (C.c_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     "vt_scene_refit": (C.c_int, [_vp, _vp, _vp, _u32]),
+    "vt_scene_set_alpha": (C.c_int, [_vp, _vp, _u32, _vp, _u64]),
     "vt_scene_set_skin": (C.c_int, [_vp, _vp, _vp, _vp, _u32]),
     "vt_scene_skin_refit": (C.c_int, [_vp, _vp, _vp, _u32]),
     "vt_scene_read_records": (C.c_int, [_vp, _vp, _vp]),

@@ -14,7 +14,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from ._lib import (BVH_NODE, HIT, HIT_ATTRS, HIT_SHADE, NODE_PAIR, RAY, RAY_STATS, SKIN_VERTEX, TRI64, TRI_ATTRIBS, check, lib,
+from ._lib import (ALPHA_MATERIAL, BVH_NODE, HIT, HIT_ATTRS, HIT_SHADE, NODE_PAIR, RAY, RAY_STATS, SKIN_VERTEX, TRI64, TRI_ATTRIBS, check, lib,
                    ptr)
 
 FLT_MAX = float(np.finfo(np.float32).max)
@@ -253,6 +253,13 @@ class Scene:
         fl = np.ascontiguousarray(flags, dtype=np.uint8) if flags is not None else None
         check(lib.vt_scene_refit(self._h, ptr(verts) if len(verts) else None, ptr(fl) if fl is not None else None, len(verts)))
 
+    def set_alpha(self, mats: np.ndarray, texels: np.ndarray) -> None:
+        """Alpha-test side data: ALPHA_MATERIAL records (indexed by TRI_ATTRIBS.material) and their 8-bit alpha planes."""
+        mats = np.ascontiguousarray(mats, ALPHA_MATERIAL)
+        texels = np.ascontiguousarray(texels, np.uint8)
+        check(lib.vt_scene_set_alpha(self._h, ptr(mats) if len(mats) else None, len(mats), ptr(texels) if len(texels) else None,
+                                     len(texels)))
+
     def set_skin(self, bind_verts: np.ndarray, skin: np.ndarray, matrix_base: np.ndarray) -> None:
         """Bind-pose triangles (n,3,3), their (n,3) SKIN_VERTEX records and each triangle's first-matrix index."""
         bind_verts = np.ascontiguousarray(bind_verts, np.float32).reshape(-1, 9)
@@ -294,5 +301,5 @@ def build_scene(engine: Engine, verts: np.ndarray, flags: Optional[np.ndarray] =
 
 
 __all__ = ["Engine", "Scene", "HostBvh", "HostScene", "tris_setup", "build_scene", "make_rays", "device_count",
-           "RAY", "HIT", "TRI64", "BVH_NODE", "NODE_PAIR", "RAY_STATS", "HIT_ATTRS", "TRI_ATTRIBS", "HIT_SHADE", "SKIN_VERTEX",
+           "RAY", "HIT", "TRI64", "BVH_NODE", "NODE_PAIR", "RAY_STATS", "HIT_ATTRS", "TRI_ATTRIBS", "HIT_SHADE", "SKIN_VERTEX", "ALPHA_MATERIAL",
            "FLT_MAX", "_lib"]

@@ -80,6 +80,9 @@ struct vt_engine {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool       ev_valid = false;
 
+    // scenes uploaded through this engine: closing the engine releases their device memory and detaches them
+    std::vector<vt_scene*> scenes;
+
     // last launch geometry
     uint32_t last_blocks = 0, last_threads = 0, last_lds = 0;
     int      last_persistent = 0, last_dma = 0;
@@ -101,6 +104,11 @@ struct vt_scene {
     uint32_t*       d_matrix_base = nullptr;
     float*          d_skin_mats = nullptr;   // 3 x mats_cap matrices: bones | binds | products
     uint32_t        mats_cap = 0;
+    // alpha test: set when a triangle carries VT_TRI_ALPHATEST; materials + alpha planes from vt_scene_set_alpha
+    bool               has_alpha = false;
+    vt_alpha_material* d_alpha_mats = nullptr;
+    uint8_t*           d_alpha_texels = nullptr;
+    uint32_t           n_alpha_mats = 0;
     hipGraphExec_t  refit_graph = nullptr;   // the level-by-level refit launches, captured once (launch-bound: ~30 tiny kernels)
     uint32_t      npairs = 0, ntris = 0, max_depth = 0, root_leaf_count = 0;
     uint64_t      bytes = 0;
@@ -158,7 +166,7 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool 
         p.ovf_entries = need > p.lds_entries ? need - p.lds_entries : 0;
         // persistent grid = what is resident at once (registers/LDS decide), capped by the option
         int occ = 0;
-        VT_HIP(trace_blocks_per_cu(any_hit, stats, true, p.fetch_dma, trace_lds_bytes(p.lds_entries, p.fetch_dma), &occ));
+        VT_HIP(trace_blocks_per_cu(any_hit, stats, true, p.fetch_dma, s->has_alpha, trace_lds_bytes(p.lds_entries, p.fetch_dma), &occ));
         // LDS is granted in 1 280-B granules of the CU's 160 KB, which the occupancy query does not model
         const size_t lds_need = trace_lds_bytes(p.lds_entries, p.fetch_dma);
         const size_t lds_granted = (lds_need + 1279) / 1280 * 1280;
@@ -191,6 +199,9 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
 {
     vt_engine* e = s->engine;
     if (n == 0) return VT_OK;
+    if (s->has_alpha && (!s->d_attribs || !s->d_alpha_mats))
+        return fail(VT_ERR_UNSUPPORTED, "the scene holds alpha-tested triangles (Primitives.h:196-208): call "
+                                        "vt_scene_set_tri_attribs and vt_scene_set_alpha before tracing");
     LaunchPlan p;
     int rc = plan_launch(e, s, n, any_hit, stats, p);
     if (rc != VT_OK) return rc;
@@ -229,6 +240,10 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     a.refill_threshold = std::min(std::max(e->refill_threshold, 1u), 64u);
     a.tri_threshold = std::min(std::max(e->tri_threshold, 1u), 64u);
     a.coherent_detect = e->coherent_detect;
+    a.attribs = s->d_attribs;
+    a.alpha_mats = s->d_alpha_mats;
+    a.alpha_texels = s->d_alpha_texels;
+    a.n_alpha_mats = s->n_alpha_mats;
     a.reserved_cus = p.persistent && e->reserved_cus ? e->d_reserved : nullptr;
     a.cu_slots = e->d_reserved ? e->d_reserved + 32 : nullptr;
     a.reserved_limit = e->reserved_limit;
@@ -239,7 +254,7 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
         VT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_cursor),
                                  a.reserved_cus ? 0 : int(p.grid_blocks * (kBlockThreads / 64)), 1, stream));
     if (e->timing) VT_HIP(hipEventRecord(e->ev_start, stream));
-    VT_HIP(launch_trace(a, any_hit, stats, p.persistent, p.fetch_dma, p.grid_blocks, p.lds_bytes, stream));
+    VT_HIP(launch_trace(a, any_hit, stats, p.persistent, p.fetch_dma, s->has_alpha, p.grid_blocks, p.lds_bytes, stream));
     if (e->timing) { VT_HIP(hipEventRecord(e->ev_stop, stream)); e->ev_valid = true; }
     e->last_blocks = p.grid_blocks; e->last_threads = kBlockThreads; e->last_lds = uint32_t(p.lds_bytes);
     e->last_persistent = p.persistent; e->last_dma = p.fetch_dma;
@@ -352,11 +367,18 @@ int vt_engine_open(int device, vt_engine** out)
     return VT_OK;
 }
 
+static void release_scene_device(vt_scene* s);
+
 void vt_engine_close(vt_engine* e)
 {
     if (!e) return;
     DeviceGuard guard(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (vt_scene* sc : e->scenes) {            // scenes that outlive their engine become inert shells
+        release_scene_device(sc);
+        sc->engine = nullptr;
+    }
+    e->scenes.clear();
     if (e->d_cursor) (void)hipFree(e->d_cursor);
     if (e->d_overflow) (void)hipFree(e->d_overflow);
     if (e->d_rays) (void)hipFree(e->d_rays);
@@ -432,15 +454,14 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
     if (!e || !hsw || !out) return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: NULL argument");
     *out = nullptr;
     const HostScene& hs = hsw->hs;
-    for (const vt_tri64& t : hs.tris)
-        if (t.flags & VT_TRI_ALPHATEST)
-            return fail(VT_ERR_UNSUPPORTED,
-                        "vt_scene_upload: alpha-tested triangles (Primitives.h:196-208) are not supported on the device yet");
+    bool has_alpha = false;                              // Primitives.h:196-208: needs vt_scene_set_alpha before tracing
+    for (const vt_tri64& t : hs.tris) has_alpha = has_alpha || (t.flags & VT_TRI_ALPHATEST) != 0;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_upload: hipSetDevice failed");
 
     vt_scene* s = new vt_scene();
     s->engine = e;
+    s->has_alpha = has_alpha;
     s->npairs = uint32_t(hs.pairs.size());
     s->ntris = uint32_t(hs.tris.size());
     s->max_depth = hs.max_depth;
@@ -492,24 +513,37 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
         vt_scene_free(s);
         return fail(VT_ERR_HIP, std::string("vt_scene_upload: ") + hipGetErrorString(err));
     }
+    e->scenes.push_back(s);
     *out = s;
     return VT_OK;
+}
+
+// frees a scene's device memory (its engine's device is current); the shell stays
+static void release_scene_device(vt_scene* s)
+{
+    void** bufs[] = {reinterpret_cast<void**>(&s->d_records), reinterpret_cast<void**>(&s->d_prim_to_slot),
+                     reinterpret_cast<void**>(&s->d_attribs), reinterpret_cast<void**>(&s->d_level_pairs),
+                     reinterpret_cast<void**>(&s->d_alpha_mats), reinterpret_cast<void**>(&s->d_alpha_texels),
+                     reinterpret_cast<void**>(&s->d_bind_verts), reinterpret_cast<void**>(&s->d_skin),
+                     reinterpret_cast<void**>(&s->d_matrix_base), reinterpret_cast<void**>(&s->d_skin_mats)};
+    for (void** b : bufs) {
+        if (*b) (void)hipFree(*b);
+        *b = nullptr;
+    }
+    if (s->refit_graph) (void)hipGraphExecDestroy(s->refit_graph);
+    s->refit_graph = nullptr;
+    s->d_tris = nullptr;
 }
 
 void vt_scene_free(vt_scene* s)
 {
     if (!s) return;
-    DeviceGuard guard(s->engine->device);
-    (void)hipStreamSynchronize(s->engine->stream);
-    if (s->d_records) (void)hipFree(s->d_records);
-    if (s->d_prim_to_slot) (void)hipFree(s->d_prim_to_slot);
-    if (s->d_attribs) (void)hipFree(s->d_attribs);
-    if (s->d_level_pairs) (void)hipFree(s->d_level_pairs);
-    if (s->refit_graph) (void)hipGraphExecDestroy(s->refit_graph);
-    if (s->d_bind_verts) (void)hipFree(s->d_bind_verts);
-    if (s->d_skin) (void)hipFree(s->d_skin);
-    if (s->d_matrix_base) (void)hipFree(s->d_matrix_base);
-    if (s->d_skin_mats) (void)hipFree(s->d_skin_mats);
+    if (vt_engine* e = s->engine) {             // NULL once the engine was closed: only the shell is left
+        DeviceGuard guard(e->device);
+        (void)hipStreamSynchronize(e->stream);
+        release_scene_device(s);
+        e->scenes.erase(std::remove(e->scenes.begin(), e->scenes.end(), s), e->scenes.end());
+    }
     delete s;
 }
 
@@ -518,6 +552,7 @@ uint64_t vt_scene_device_bytes(const vt_scene* s) { return s ? s->bytes : 0; }
 static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, size_t out_elem, bool any_hit)
 {
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_trace: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_trace: the scene\'s engine has been closed");
     if (n == 0) return VT_OK;
     if (!rays || !out) return fail(VT_ERR_INVALID_ARG, "vt_trace: NULL buffer");
     vt_engine* e = s->engine;
@@ -633,6 +668,7 @@ static int trace_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, 
                      bool stats, void* stream)
 {
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_trace_dev: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_trace_dev: the scene\'s engine has been closed");
     if (n == 0) return VT_OK;
     if (!d_rays || (!d_hits && !d_occ)) return fail(VT_ERR_INVALID_ARG, "vt_trace_dev: NULL device buffer");
     vt_engine* e = s->engine;
@@ -660,6 +696,7 @@ int vt_trace_stats_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits
 int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64_t n, void* d_attrs, void* stream)
 {
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_hit_attrs_dev: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_hit_attrs_dev: the scene\'s engine has been closed");
     if (n == 0) return VT_OK;
     if (!d_rays || !d_hits || !d_attrs) return fail(VT_ERR_INVALID_ARG, "vt_hit_attrs_dev: NULL device buffer");
     vt_engine* e = s->engine;
@@ -680,6 +717,7 @@ int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t dep
                        uint64_t* live_out, void* stream_)
 {
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_bounce_loop_dev: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_bounce_loop_dev: the scene\'s engine has been closed");
     if (n == 0 || depth == 0) return VT_OK;
     if (!d_rays || !d_hits) return fail(VT_ERR_INVALID_ARG, "vt_bounce_loop_dev: NULL device buffer");
     if (n >= (uint64_t(1) << 32)) return fail(VT_ERR_INVALID_ARG, "vt_bounce_loop_dev: more than 2^32-1 paths");
@@ -771,12 +809,12 @@ static int refit_levels(vt_scene* s)
 int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32_t n)
 {
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: the scene\'s engine has been closed");
     if (n != s->ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: n differs from the scene's triangle count");
     if (n == 0) return VT_OK;
     if (!verts) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: verts is NULL");
     if (flags)
-        for (uint32_t i = 0; i < n; ++i)
-            if (flags[i] & VT_TRI_ALPHATEST) return fail(VT_ERR_UNSUPPORTED, "vt_scene_refit: alpha-tested triangles are not supported");
+        for (uint32_t i = 0; i < n; ++i) s->has_alpha = s->has_alpha || (flags[i] & VT_TRI_ALPHATEST) != 0;
     vt_engine* e = s->engine;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_refit: hipSetDevice failed");
@@ -794,6 +832,7 @@ int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32
 int vt_scene_set_skin(vt_scene* s, const float* bind_verts, const vt_skin_vertex* skin, const uint32_t* matrix_base, uint32_t n)
 {
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_skin: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_skin: the scene\'s engine has been closed");
     if (n != s->ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_skin: n differs from the scene's triangle count");
     if (n == 0) return VT_OK;
     if (!bind_verts || !skin || !matrix_base) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_skin: NULL argument");
@@ -822,6 +861,7 @@ int vt_scene_set_skin(vt_scene* s, const float* bind_verts, const vt_skin_vertex
 int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uint32_t nmat)
 {
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: the scene\'s engine has been closed");
     if (s->ntris == 0) return VT_OK;
     if (!s->d_bind_verts) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: no skin data (call vt_scene_set_skin first)");
     if (nmat == 0 || !bones || !binds) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: no matrices");
@@ -847,6 +887,7 @@ int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uin
 int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_out)
 {
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_read_records: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_read_records: the scene\'s engine has been closed");
     DeviceGuard guard(s->engine->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_read_records: hipSetDevice failed");
     VT_HIP(hipStreamSynchronize(s->engine->stream));
@@ -858,6 +899,7 @@ int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_o
 int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_t n)
 {
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_tri_attribs: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_tri_attribs: the scene\'s engine has been closed");
     if (n != s->ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_tri_attribs: n differs from the scene's triangle count");
     if (n != 0 && !attribs) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_tri_attribs: attribs is NULL");
     DeviceGuard guard(s->engine->device);
@@ -872,9 +914,37 @@ int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_
     return VT_OK;
 }
 
+int vt_scene_set_alpha(vt_scene* s, const vt_alpha_material* mats, uint32_t nmats, const uint8_t* texels, uint64_t ntexels)
+{
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_alpha: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_alpha: the scene\'s engine has been closed");
+    if (nmats == 0 || !mats) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_alpha: no materials");
+    for (uint32_t i = 0; i < nmats; ++i) {
+        const vt_alpha_material& m = mats[i];
+        if (m.filter > 1) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_alpha: filter must be 0 (nearest) or 1 (bilinear)");
+        if ((m.width == 0) != (m.height == 0)) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_alpha: width and height must both be 0 or both be set");
+        if (m.width && (m.offset > ntexels || uint64_t(m.width) * m.height > ntexels - m.offset || !texels))
+            return fail(VT_ERR_INVALID_ARG, "vt_scene_set_alpha: an alpha plane lies outside the texel array");
+    }
+    vt_engine* e = s->engine;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_set_alpha: hipSetDevice failed");
+    VT_HIP(hipDeviceSynchronize());                              // no launch may still read the old tables
+    if (s->d_alpha_mats) { VT_HIP(hipFree(s->d_alpha_mats)); s->d_alpha_mats = nullptr; }
+    if (s->d_alpha_texels) { VT_HIP(hipFree(s->d_alpha_texels)); s->d_alpha_texels = nullptr; }
+    VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_alpha_mats), size_t(nmats) * sizeof(vt_alpha_material)));
+    VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_alpha_texels), std::max<uint64_t>(ntexels, 16)));
+    VT_HIP(hipMemcpy(s->d_alpha_mats, mats, size_t(nmats) * sizeof(vt_alpha_material), hipMemcpyHostToDevice));
+    if (ntexels) VT_HIP(hipMemcpy(s->d_alpha_texels, texels, ntexels, hipMemcpyHostToDevice));
+    s->n_alpha_mats = nmats;
+    s->bytes += size_t(nmats) * sizeof(vt_alpha_material) + ntexels;
+    return VT_OK;
+}
+
 int vt_hit_shade_dev(vt_scene* s, const void* d_hits, uint64_t n, void* d_out, void* stream)
 {
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_hit_shade_dev: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_hit_shade_dev: the scene\'s engine has been closed");
     if (n == 0) return VT_OK;
     if (!d_hits || !d_out) return fail(VT_ERR_INVALID_ARG, "vt_hit_shade_dev: NULL device buffer");
     if (!s->d_attribs) return fail(VT_ERR_INVALID_ARG, "vt_hit_shade_dev: call vt_scene_set_tri_attribs first");

@@ -108,6 +108,7 @@ void AccelStruct::PopulateAccel(ILuaBase* LUA, const World* pWorld)
     vt_engine* eng = nullptr;
     if (rc == VT_OK) eng = Engine(LUA);
     if (rc == VT_OK) rc = vt_scene_upload(eng, hs, &mpScene);
+    if (rc == VT_OK) rc = UploadAlphaTestData(flags);
     if (hs) vt_host_scene_free(hs);
     if (bvh) vt_bvh_free(bvh);
     if (rc != VT_OK) {
@@ -116,6 +117,45 @@ void AccelStruct::PopulateAccel(ILuaBase* LUA, const World* pWorld)
         LUA->ThrowError(msg.c_str());
     }
     mAccelBuilt = true;
+}
+
+// Side data of the in-kernel alpha test (Primitives.h:196-208), only when a material carries the flag: per-triangle
+// uvs + material index, per-material transform / reference / alpha plane.
+int AccelStruct::UploadAlphaTestData(const std::vector<uint8_t>& flags)
+{
+    bool any = false;
+    for (uint8_t f : flags) any = any || (f & VT_TRI_ALPHATEST);
+    if (!any) return VT_OK;
+    std::vector<vt_tri_attribs> attribs(mTriangles.size());
+    for (size_t i = 0; i < mTriangles.size(); ++i) {
+        const Triangle& t = mTriangles[i];
+        vt_tri_attribs& a = attribs[i];
+        for (int k = 0; k < 3; ++k) { a.uv[k][0] = t.uvs[k].x; a.uv[k][1] = t.uvs[k].y; a.alpha[k] = t.alphas[k]; }
+        a.ent_id = t.entIdx < mEntities.size() ? mEntities[t.entIdx].id : 0u;
+        a.material = uint32_t(t.material);
+        a.pad = 0;
+    }
+    std::vector<vt_alpha_material> mats(mMaterials.size());
+    std::vector<uint8_t> texels;
+    for (size_t i = 0; i < mMaterials.size(); ++i) {
+        const Material& m = mMaterials[i];
+        vt_alpha_material& o = mats[i];
+        std::memcpy(o.tex_mat, m.baseTexMat, sizeof(o.tex_mat));
+        o.tex_scale = m.texScale;
+        o.alpha_ref = m.alphatestreference;
+        const bool has_plane = (m.flags & MATFLAG_ALPHATEST) && m.alphaWidth && m.alphaHeight &&
+                               m.baseAlpha.size() >= size_t(m.alphaWidth) * m.alphaHeight;
+        o.width = has_plane ? m.alphaWidth : 0;
+        o.height = has_plane ? m.alphaHeight : 0;
+        o.filter = m.alphaBilinear ? 1u : 0u;
+        o.pad = 0;
+        o.offset = texels.size();
+        if (has_plane) texels.insert(texels.end(), m.baseAlpha.begin(), m.baseAlpha.begin() + size_t(m.alphaWidth) * m.alphaHeight);
+    }
+    int rc = vt_scene_set_tri_attribs(mpScene, attribs.data(), uint32_t(attribs.size()));
+    if (rc == VT_OK) rc = vt_scene_set_alpha(mpScene, mats.data(), uint32_t(mats.size()), texels.data(), texels.size());
+    if (rc != VT_OK) { vt_scene_free(mpScene); mpScene = nullptr; }
+    return rc;
 }
 
 TraceResult* AccelStruct::MakeResult(const vt_ray& ray, const vt_hit& hit, float coneWidth, float coneAngle) const

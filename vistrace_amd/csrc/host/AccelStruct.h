@@ -48,6 +48,7 @@ private:
     std::vector<Material> mMaterials;
 
     void ReleaseDevice();
+    int  UploadAlphaTestData(const std::vector<uint8_t>& flags);
     TraceResult* MakeResult(const vt_ray& ray, const vt_hit& hit, float coneWidth, float coneAngle) const;
 };
 

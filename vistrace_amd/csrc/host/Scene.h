@@ -26,6 +26,14 @@ enum MaterialFlags : uint32_t {           // values of source/objects/Material.h
 struct Material {
     std::string path;
     uint32_t    flags = MATFLAG_NONE;
+    // what the alpha test of Primitives.h:196-208 reads (Material.h:81-122).  The decoded mip-0 alpha plane of
+    // the base texture stands in for `const IVTFTexture* baseTexture`: VTF decoding stays with the module.
+    float    baseTexMat[2][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}};   // glm::mat2x4 baseTexMat: row r = transform[r]
+    float    texScale = 1.f;
+    float    alphatestreference = 0.5f;                         // Material.h:122
+    uint32_t alphaWidth = 0, alphaHeight = 0;                   // 0 x 0: no texture, the hit is kept
+    bool     alphaBilinear = false;                             // lookup: nearest texel, or bilinear
+    std::vector<uint8_t> baseAlpha;                             // alphaWidth x alphaHeight, row-major
 };
 
 struct Triangle {

@@ -28,6 +28,11 @@ struct TraceArgs {
     uint32_t            refill_threshold; // re-fill a wave once this many lanes are idle
     uint32_t            tri_threshold;    // run the TRI branch once this many lanes wait for it
     uint32_t            coherent_detect;  // DMA kernel: per-wave octant probe -> direct fetch, whole-wave re-fill
+    // alpha test (ALPHA variants only): per-triangle uvs + material (original order), materials, alpha planes
+    const vt_tri_attribs*     attribs;
+    const vt_alpha_material*  alpha_mats;
+    const uint8_t*            alpha_texels;
+    uint32_t                  n_alpha_mats;
     const uint32_t*     reserved_cus;     // persistent mode: 1024-bit set of __smid() values of the reserved CUs, or NULL
     uint32_t*           cu_slots;         // 1024 counters (zeroed per launch): blocks that asked to stay on a reserved CU
     uint32_t            reserved_limit;   // blocks a reserved CU keeps (0 = none)
@@ -79,9 +84,9 @@ hipError_t launch_skin_tris(const SkinTrisArgs& a, hipStream_t stream);
 hipError_t launch_refit_level(const RefitLevelArgs& a, hipStream_t stream);
 
 size_t     trace_lds_bytes(uint32_t lds_entries, bool fetch_dma);
-hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, bool fetch_dma,
+hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, bool fetch_dma, bool alpha,
                         uint32_t grid_blocks, size_t lds_bytes, hipStream_t stream);
-hipError_t trace_blocks_per_cu(bool any_hit, bool stats, bool persistent, bool fetch_dma, size_t lds_bytes, int* out);
+hipError_t trace_blocks_per_cu(bool any_hit, bool stats, bool persistent, bool fetch_dma, bool alpha, size_t lds_bytes, int* out);
 hipError_t launch_hit_attrs(const HitAttrsArgs& a, hipStream_t stream);
 // every CU that receives a block sets bit __smid() of the 1024-bit set `seen` (32 words, zeroed by the caller)
 hipError_t launch_cu_probe(uint32_t* seen, uint32_t blocks, hipStream_t stream);

@@ -129,7 +129,52 @@ constexpr uint32_t kStageBytes = 4 * kStageRow;  // the four rows start on diffe
 
 } // namespace
 
-template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA>
+// ---- alpha test inside intersect(): Primitives.h:196-208, TransformTexcoord Utils.h:65-72 -------------------
+// The texel lookup (IVTFTexture::Sample lives in the absent VTFParser submodule) is the one defined in
+// include/vistrace_hip.h at vt_alpha_material: mip 0 alpha plane, repeat addressing, nearest or bilinear.
+__device__ __forceinline__ uint32_t wrap_index(float f, uint32_t n)
+{
+    const long long i = (long long)f;            // f is integral and |f| < 1e9
+    const long long m = i % (long long)n;
+    return uint32_t(m < 0 ? m + (long long)n : m);
+}
+
+__device__ __forceinline__ bool alpha_pass(const TraceArgs& a, uint32_t prim, float u, float v)
+{
+    const vt_tri_attribs A = a.attribs[prim];
+    if (A.material >= a.n_alpha_mats) return true;
+    const vt_alpha_material M = a.alpha_mats[A.material];
+    const float w = 1.0f - u - v;                                                       // :198
+    const float tx = (w * A.uv[0][0] + u * A.uv[1][0]) + v * A.uv[2][0];
+    const float ty = (w * A.uv[0][1] + u * A.uv[1][1]) + v * A.uv[2][1];
+    const float s = ((tx * M.tex_mat[0][0] + ty * M.tex_mat[0][1]) + (M.tex_mat[0][2] + M.tex_mat[0][3])) * M.tex_scale;
+    const float t = ((tx * M.tex_mat[1][0] + ty * M.tex_mat[1][1]) + (M.tex_mat[1][2] + M.tex_mat[1][3])) * M.tex_scale;
+    float alpha = 1.0f;
+    if (M.width != 0 && M.height != 0) {
+        const uint8_t* img = a.alpha_texels + M.offset;
+        float x = s * float(M.width), y = t * float(M.height);
+        if (!(fabsf(x) < 1.0e9f)) x = 0.0f;
+        if (!(fabsf(y) < 1.0e9f)) y = 0.0f;
+        if (M.filter == 0) {
+            const uint32_t xi = wrap_index(floorf(x), M.width), yi = wrap_index(floorf(y), M.height);
+            alpha = float(img[size_t(yi) * M.width + xi]) / 255.0f;
+        } else {
+            const float fx = x - 0.5f, fy = y - 0.5f;
+            const float x0 = floorf(fx), y0 = floorf(fy);
+            const float ax = fx - x0, ay = fy - y0;
+            const uint32_t i0 = wrap_index(x0, M.width), i1 = wrap_index(x0 + 1.0f, M.width);
+            const uint32_t j0 = wrap_index(y0, M.height), j1 = wrap_index(y0 + 1.0f, M.height);
+            const float a00 = float(img[size_t(j0) * M.width + i0]), a10 = float(img[size_t(j0) * M.width + i1]);
+            const float a01 = float(img[size_t(j1) * M.width + i0]), a11 = float(img[size_t(j1) * M.width + i1]);
+            const float top = a00 * (1.0f - ax) + a10 * ax;
+            const float bot = a01 * (1.0f - ax) + a11 * ax;
+            alpha = (top * (1.0f - ay) + bot * ay) / 255.0f;
+        }
+    }
+    return !(alpha < M.alpha_ref);                                                       // :205
+}
+
+template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA>
 __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
@@ -361,8 +406,12 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
             const float v = ((rx * e1x + ry * e1y) + rz * e1z) * inv_det;              // :181
             const float w = 1.0f - u - v;                                              // :182
             const float t = ((nx * cx + ny * cy) + nz * cz) * inv_det;                 // :188
-            if (!culled && u >= 0.0f && v >= 0.0f && w >= 0.0f &&                      // :187
-                t >= L.tmin && t <= L.tmax) {                                          // :189
+            bool hit = !culled && u >= 0.0f && v >= 0.0f && w >= 0.0f &&               // :187
+                       t >= L.tmin && t <= L.tmax;                                     // :189
+            if constexpr (ALPHA) {                                                     // :196-208
+                if (hit && (tflags & VT_TRI_ALPHATEST)) hit = alpha_pass(a, tprim, u, v);
+            }
+            if (hit) {
                 L.prim = tprim; L.u = u; L.v = v; L.tmax = t;
                 if constexpr (ANY_HIT) { L.tri_cur = L.tri_end; L.node = kDone; }
             }
@@ -748,10 +797,10 @@ __global__ __launch_bounds__(kBlockThreads) void refit_level_kernel(RefitLevelAr
 }
 
 // ---- launchers ---------------------------------------------------------------------------
-template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA>
+template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA>
 static hipError_t launch_one(const TraceArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA>), grid, dim3(kBlockThreads), lds_bytes,
+    hipLaunchKernelGGL((trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>), grid, dim3(kBlockThreads), lds_bytes,
                        stream, a);
     return hipGetLastError();
 }
@@ -771,44 +820,47 @@ size_t trace_lds_bytes(uint32_t lds_entries, bool fetch_dma)
 namespace {
 
 // one entry per compiled variant: launch it, or ask how many blocks fit on a CU
-template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA>
+template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA>
 hipError_t variant_op(const TraceArgs* a, dim3 grid, size_t lds_bytes, hipStream_t stream, int* blocks_per_cu)
 {
     if (blocks_per_cu)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            blocks_per_cu, trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA>, int(kBlockThreads), lds_bytes);
-    return launch_one<ANY_HIT, STATS, PERSISTENT, FETCH_DMA>(*a, grid, lds_bytes, stream);
+            blocks_per_cu, trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>, int(kBlockThreads), lds_bytes);
+    return launch_one<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>(*a, grid, lds_bytes, stream);
 }
 
+template <bool ALPHA>
 hipError_t dispatch(const TraceArgs* a, bool any_hit, bool stats, bool persistent, bool fetch_dma, dim3 grid,
                     size_t lds_bytes, hipStream_t stream, int* occ)
 {
     if (persistent && fetch_dma) {
-        if (any_hit) return variant_op<true, false, true, true>(a, grid, lds_bytes, stream, occ);
-        if (stats)   return variant_op<false, true, true, true>(a, grid, lds_bytes, stream, occ);
-        return variant_op<false, false, true, true>(a, grid, lds_bytes, stream, occ);
+        if (any_hit) return variant_op<true, false, true, true, ALPHA>(a, grid, lds_bytes, stream, occ);
+        if (stats)   return variant_op<false, true, true, true, ALPHA>(a, grid, lds_bytes, stream, occ);
+        return variant_op<false, false, true, true, ALPHA>(a, grid, lds_bytes, stream, occ);
     }
     if (persistent) {
-        if (any_hit) return variant_op<true, false, true, false>(a, grid, lds_bytes, stream, occ);
-        if (stats)   return variant_op<false, true, true, false>(a, grid, lds_bytes, stream, occ);
-        return variant_op<false, false, true, false>(a, grid, lds_bytes, stream, occ);
+        if (any_hit) return variant_op<true, false, true, false, ALPHA>(a, grid, lds_bytes, stream, occ);
+        if (stats)   return variant_op<false, true, true, false, ALPHA>(a, grid, lds_bytes, stream, occ);
+        return variant_op<false, false, true, false, ALPHA>(a, grid, lds_bytes, stream, occ);
     }
-    if (any_hit) return variant_op<true, false, false, false>(a, grid, lds_bytes, stream, occ);
-    if (stats)   return variant_op<false, true, false, false>(a, grid, lds_bytes, stream, occ);
-    return variant_op<false, false, false, false>(a, grid, lds_bytes, stream, occ);
+    if (any_hit) return variant_op<true, false, false, false, ALPHA>(a, grid, lds_bytes, stream, occ);
+    if (stats)   return variant_op<false, true, false, false, ALPHA>(a, grid, lds_bytes, stream, occ);
+    return variant_op<false, false, false, false, ALPHA>(a, grid, lds_bytes, stream, occ);
 }
 
 } // namespace
 
-hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, bool fetch_dma,
+hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, bool fetch_dma, bool alpha,
                         uint32_t grid_blocks, size_t lds_bytes, hipStream_t stream)
 {
-    return dispatch(&a, any_hit, stats, persistent, fetch_dma, dim3(grid_blocks), lds_bytes, stream, nullptr);
+    return alpha ? dispatch<true>(&a, any_hit, stats, persistent, fetch_dma, dim3(grid_blocks), lds_bytes, stream, nullptr)
+                 : dispatch<false>(&a, any_hit, stats, persistent, fetch_dma, dim3(grid_blocks), lds_bytes, stream, nullptr);
 }
 
-hipError_t trace_blocks_per_cu(bool any_hit, bool stats, bool persistent, bool fetch_dma, size_t lds_bytes, int* out)
+hipError_t trace_blocks_per_cu(bool any_hit, bool stats, bool persistent, bool fetch_dma, bool alpha, size_t lds_bytes, int* out)
 {
-    return dispatch(nullptr, any_hit, stats, persistent, fetch_dma, dim3(1), lds_bytes, nullptr, out);
+    return alpha ? dispatch<true>(nullptr, any_hit, stats, persistent, fetch_dma, dim3(1), lds_bytes, nullptr, out)
+                 : dispatch<false>(nullptr, any_hit, stats, persistent, fetch_dma, dim3(1), lds_bytes, nullptr, out);
 }
 
 __global__ __launch_bounds__(kBlockThreads) void cu_probe_kernel(uint32_t* seen)

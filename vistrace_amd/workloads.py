@@ -281,3 +281,33 @@ def rig_pose(nmat: int, frame: int, seed: int = SEED + 10):
     bone = move @ np.linalg.inv(bind)
     cm = lambda M: np.ascontiguousarray(np.transpose(M, (0, 2, 1)).reshape(nmat, 16), np.float32)   # column-major
     return cm(bone), cm(bind)
+
+
+def alpha_test_rig(ntris: int, nmats: int = 6, alpha_fraction: float = 0.4, seed: int = SEED + 11):
+    """Seeded alpha-test inputs: (flags u8 with bit 1 = VT_TRI_ALPHATEST on ~alpha_fraction of the triangles,
+    TRI_ATTRIBS-compatible array with uvs + material, ALPHA_MATERIAL-compatible array, texels u8).
+    Materials mix nearest / bilinear, odd plane sizes, a 1x1 plane and one material without a texture."""
+    rng = np.random.default_rng(seed)
+    flags = (rng.random(ntris) < alpha_fraction).astype(np.uint8) * np.uint8(2)
+    attribs = np.zeros(ntris, np.dtype([("uv", "<f4", (3, 2)), ("alpha", "<f4", 3), ("ent_id", "<u4"), ("material", "<u4"), ("pad", "<u4")]))
+    attribs["uv"] = rng.uniform(-2.0, 3.0, (ntris, 3, 2)).astype(np.float32)
+    attribs["alpha"] = 1.0
+    attribs["material"] = rng.integers(0, nmats, ntris).astype(np.uint32)
+    mats = np.zeros(nmats, np.dtype([("tex_mat", "<f4", (2, 4)), ("tex_scale", "<f4"), ("alpha_ref", "<f4"), ("width", "<u4"),
+                                     ("height", "<u4"), ("filter", "<u4"), ("pad", "<u4"), ("offset", "<u8")]))
+    sizes = [(8, 8), (16, 5), (1, 1), (0, 0), (7, 13), (32, 32), (3, 2), (64, 16)]
+    planes, off = [], 0
+    for i in range(nmats):
+        w, h = sizes[i % len(sizes)]
+        mats["tex_mat"][i] = [[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0]]
+        mats["tex_mat"][i] += rng.normal(scale=0.2, size=(2, 4)).astype(np.float32)
+        mats["tex_scale"][i] = np.float32(rng.choice([1.0, 0.5, 2.0, 4.0]))
+        mats["alpha_ref"][i] = np.float32(rng.choice([0.5, 0.5, 0.25, 0.9]))
+        mats["width"][i], mats["height"][i] = w, h
+        mats["filter"][i] = i % 2
+        mats["offset"][i] = off
+        plane = np.where(rng.random(w * h) < 0.5, 255, rng.integers(0, 256, w * h)).astype(np.uint8)
+        planes.append(plane)
+        off += w * h
+    texels = np.concatenate(planes) if off else np.zeros(0, np.uint8)
+    return flags, attribs, mats, texels
