@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--any", action="store_true")
+    ap.add_argument("--alpha", type=float, default=0.0, help="fraction of alpha-tested triangles (ALPHA kernel variants)")
     args = ap.parse_args()
 
     import torch
@@ -39,11 +40,15 @@ def main():
 
     device = torch.device("cuda", 0)
     verts = W.make_scene(args.scene)
-    tris = va.tris_setup(verts)
+    rig = W.alpha_test_rig(len(verts), alpha_fraction=args.alpha) if args.alpha > 0 else None
+    tris = va.tris_setup(verts, rig[0] if rig else None)
     bvh = va.HostBvh(tris)
     hs = va.HostScene(bvh)
     engine = va.Engine(0)
     scene = va.Scene(engine, hs)
+    if rig:
+        scene.set_tri_attribs(rig[1].view(va.TRI_ATTRIBS))
+        scene.set_alpha(rig[2].view(va.ALPHA_MATERIAL), rig[3])
     side = args.side
     n = side * side
     prim = W.primary_rays(side, side)
