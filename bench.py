@@ -262,7 +262,7 @@ def main() -> None:
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
             "traffic_source": "profiles/r1/traffic.json: FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass of this command (factor calibrated: profiles/r1/calib_fetch.txt)" if traffic else None,
-            "kernel": "vt::trace_kernel<false,false,%s,%s>" % (
+            "kernel": "vt::trace_kernel<false,false,%s,%s,false>" % (   # <ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>
                 "true" if engine.get_option("last_persistent") else "false",
                 "true" if engine.get_option("last_fetch_dma") else "false"),
             "kernel_ms": round(k_ms, 4),
