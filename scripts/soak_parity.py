@@ -27,9 +27,23 @@ for seed in range(first, first + count):
         verts[::17, 1] = verts[::17, 0]
         verts[3::29] = verts[2::29][: len(verts[3::29])]
     flags = (rng.random(n) < rng.random()).astype(np.uint8)
+    rig = None
+    if seed % 4 == 0:                                         # alpha-tested triangles: ALPHA kernel variants
+        from vistrace_amd import workloads as W
+        rig = W.alpha_test_rig(n, nmats=int(rng.integers(1, 9)), alpha_fraction=float(rng.random()), seed=seed)
+        flags = flags | rig[0]
+        rig[1]["uv"][::11] *= np.float32(1e6)                 # absurd texture coordinates
+        rig[1]["uv"][5::23, 0, 0] = np.nan
     tris = va.tris_setup(verts, flags)
     bvh = va.HostBvh(tris, builder="sah" if seed % 5 == 0 else "ploc")
     scene = va.Scene(eng, va.HostScene(bvh))
+    otris = O.tris_from_tri64(tris)
+    if rig is not None:
+        scene.set_tri_attribs(rig[1].view(va.TRI_ATTRIBS))
+        scene.set_alpha(rig[2].view(va.ALPHA_MATERIAL), rig[3])
+        O.set_alpha(otris, rig[1]["uv"].reshape(n, 6), rig[1]["material"], rig[2].view(O.ALPHA_MATERIAL), rig[3])
+    else:
+        O.set_alpha()
     m = int(rng.integers(1, 30000))
     org = rng.uniform(-2 * spread, 2 * spread, (m, 3)).astype(np.float32)
     d = rng.normal(size=(m, 3)).astype(np.float32) * np.float32(10.0 ** rng.uniform(-3, 3))
@@ -39,7 +53,8 @@ for seed in range(first, first + count):
     tmin = np.where(rng.random(m) < 0.3, rng.uniform(0, spread, m), 0.0).astype(np.float32)
     tmax = np.where(rng.random(m) < 0.3, tmin + rng.uniform(1e-3, 4 * spread, m), np.finfo(np.float32).max).astype(np.float32)
     rays = va.make_rays(org, d, tmin, tmax)
-    ref, ref_st, _, _, _ = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris), rays, want_stats=True)
+    ref, ref_st, _, _, _ = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays, want_stats=True)
+    any_ref = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays, any_hit=True)[0]
     for mode in (1, 0, 2):
         eng.set_option("persistent", mode)
         d_rays = tp.to_device(rays, dev)
@@ -48,12 +63,12 @@ for seed in range(first, first + count):
         got, st = tp.to_host(d_hits, va.HIT), tp.to_host(d_stats, va.RAY_STATS)
         ok = (got.view(np.uint8) == ref.view(np.uint8)).all() and (st["steps"] == ref_st[:, 0]).all() and (st["tests"] == ref_st[:, 1]).all()
         ok = ok and (scene.trace_closest(rays).view(np.uint8) == ref.view(np.uint8)).all()
-        ok = ok and (scene.trace_any(rays) == (ref["prim"] != O.MISS)).all()
+        ok = ok and (scene.trace_any(rays) == (any_ref["prim"] != O.MISS)).all()
         # single-call / tiny host batches (pinned slots + spin wait) and the persistent grid with reserved CUs
         for k in (1, 3, 256):
             kk = min(k, m)
             ok = ok and (scene.trace_closest(rays[:kk]).view(np.uint8) == ref[:kk].view(np.uint8)).all()
-            ok = ok and (scene.trace_any(rays[-kk:]) == (ref["prim"][-kk:] != O.MISS)).all()
+            ok = ok and (scene.trace_any(rays[-kk:]) == (any_ref["prim"][-kk:] != O.MISS)).all()
         if mode == 1 and seed % 3 == 0:
             eng.set_option("reserved_cus", 32)
             ok = ok and (scene.trace_closest(rays).view(np.uint8) == ref.view(np.uint8)).all()
