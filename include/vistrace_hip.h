@@ -36,7 +36,7 @@ enum vt_status {
     VT_OK              = 0,
     VT_ERR_INVALID_ARG = 1,
     VT_ERR_HIP         = 2, /* HIP runtime/driver error or no device   */
-    VT_ERR_UNSUPPORTED = 3, /* e.g. alpha-tested triangles (see below) */
+    VT_ERR_UNSUPPORTED = 3, /* e.g. tracing alpha-tested triangles before vt_scene_set_alpha */
     VT_ERR_NOMEM       = 4,
     VT_ERR_STACK       = 5  /* tree deeper than the traversal stack    */
 };
