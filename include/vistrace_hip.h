@@ -186,6 +186,10 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
  *   "refill_threshold"   idle lanes that trigger a re-fill (8);  "tri_threshold": waiting lanes that
  *                        trigger the triangle branch (4);  "static_overflow_mb": overflow-area cap of the
  *                        one-ray-per-lane kernel (256)
+ *   "xcd_cursors"        persistent kernel: one ray-block cursor per XCD, each over its own eighth of the batch, with
+ *                        stealing (default 0).  Keeps neighbouring rays in one L2: S1M primary rays 3.34 -> 3.20 ms,
+ *                        but eight distant ray ranges in flight enlarge the Infinity-Cache working set: S10M bounce
+ *                        rays 8.28 -> 8.62 ms; no effect on S1M bounce / S10M primary.
  *   "spin_wait"          host batches of <= 256 rays: watch the pinned result slots change instead of waiting on
  *                        the stream (default 1; saves ~5 us of the ~24 us single-ray call)
  *   "reserved_cus"       CUs on which the persistent grid leaves room (0 = off): set it when another stream runs

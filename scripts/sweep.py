@@ -74,7 +74,7 @@ def main():
     engine.set_timing(True)
     variants = args.opt or ["persistent=2"]
     keys = ["persistent", "fetch_dma", "lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold",
-            "auto_static_factor", "static_overflow_mb", "coherent_detect"]
+            "auto_static_factor", "static_overflow_mb", "coherent_detect", "xcd_cursors"]
     defaults = {k: engine.get_option(k) for k in keys}
     times = {v: [] for v in variants}
     infos = {}

@@ -46,6 +46,7 @@ struct vt_engine {
     uint32_t refill_threshold = 8;    // idle lanes that trigger a re-fill
     uint32_t tri_threshold    = 4;    // lanes with pending triangles that trigger the TRI branch
     int      fetch_dma        = 1;    // quad-cooperative global->LDS record fetch (persistent mode)
+    int      xcd_cursors      = 0;    // persistent mode: one ray-block cursor per XCD over its own eighth of the batch (opt-in)
     int      spin_wait        = 1;    // tiny host batches: watch the pinned result slots instead of a stream sync
     uint32_t reserved_cus     = 0;    // CUs on which the persistent grid leaves room (for a concurrent collective's kernels)
     uint32_t reserved_limit   = 2;    // blocks of the grid a reserved CU still keeps
@@ -250,7 +251,11 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
 
     // the first block of every wave is static (block w -> wave w); the cursor hands out the rest
     if (a.reserved_cus) VT_HIP(hipMemsetAsync(a.cu_slots, 0, 4096, stream));
-    if (p.persistent)
+    a.xcd_cursors = e->xcd_cursors != 0;
+    a.nblocks = uint32_t((n + a.block_rays - 1) / a.block_rays);
+    if (p.persistent && a.xcd_cursors)
+        VT_HIP(hipMemsetAsync(e->d_cursor, 0, 512, stream));                 // eight cursors, 64 B apart
+    else if (p.persistent)
         VT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_cursor),
                                  a.reserved_cus ? 0 : int(p.grid_blocks * (kBlockThreads / 64)), 1, stream));
     if (e->timing) VT_HIP(hipEventRecord(e->ev_start, stream));
@@ -352,7 +357,7 @@ int vt_engine_open(int device, vt_engine** out)
     e->tri_threshold = uint32_t(env_long("VT_TRI_THRESHOLD", e->tri_threshold));
     e->fetch_dma = int(env_long("VT_FETCH_DMA", e->fetch_dma));
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->d_cursor), 256);
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->d_cursor), 1024);
     if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&e->h_tiny_rays), vt_engine::kTinyRays * sizeof(vt_ray), hipHostMallocMapped);
     if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&e->h_tiny_out), vt_engine::kTinyRays * sizeof(vt_hit), hipHostMallocMapped);
     if (err == hipSuccess) err = hipHostGetDevicePointer(&e->d_tiny_rays, e->h_tiny_rays, 0);
@@ -418,6 +423,7 @@ int vt_engine_set_option(vt_engine* e, const char* key, int64_t value)
     else if (k == "tri_threshold" && value >= 1 && value <= 64) e->tri_threshold = uint32_t(value);
     else if (k == "fetch_dma") e->fetch_dma = value != 0;
     else if (k == "spin_wait") e->spin_wait = value != 0;
+    else if (k == "xcd_cursors") e->xcd_cursors = value != 0;
     else if (k == "reserved_cus" && value >= 0 && value <= e->cu_count / 2) return reserve_cus(e, uint32_t(value));
     else if (k == "reserved_limit" && value >= 0 && value <= 64) e->reserved_limit = uint32_t(value);
     else return fail(VT_ERR_INVALID_ARG, "vt_engine_set_option: unknown key or value out of range: " + k);
@@ -439,6 +445,7 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
     else if (k == "tri_threshold") *value = e->tri_threshold;
     else if (k == "fetch_dma") *value = e->fetch_dma;
     else if (k == "spin_wait") *value = e->spin_wait;
+    else if (k == "xcd_cursors") *value = e->xcd_cursors;
     else if (k == "reserved_cus") *value = e->reserved_cus;
     else if (k == "reserved_limit") *value = e->reserved_limit;
     else if (k == "cu_count") *value = e->cu_count;

@@ -223,7 +223,11 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
     bool coherent = false;   // wave-uniform: this wave's rays share a direction octant
     // wave-uniform: the first block of rays is assigned statically (not with reserved CUs: a block that
     // leaves must not take rays with it, so the cursor hands out everything)
-    bool first_block = a.reserved_cus == nullptr;
+    bool first_block = a.reserved_cus == nullptr && a.xcd_cursors == 0;
+    // per-XCD cursors: XCD x hands out the x-th eighth of the ray blocks, so that neighbouring rays meet in one
+    // L2; a wave whose XCD has run dry steals from the next ones
+    const uint32_t my_xcd = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;   // XCC_ID[3:0]
+    uint32_t xcd_off = 0;    // wave-uniform: XCDs (starting at its own) this wave has found exhausted
 
     auto start_ray = [&](uint64_t idx) {
         const float4* r4 = reinterpret_cast<const float4*>(a.rays + idx);
@@ -284,6 +288,19 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                         if (first_block) {            // block w goes to wave w without touching the cursor,
                             b = blockIdx.x * (kBlockThreads / 64) + wave;   // which the host starts at #waves
                             first_block = false;
+                        } else if (a.xcd_cursors != 0) {
+                            b = 0xFFFFFFFFu;
+                            while (xcd_off < 8u) {
+                                const uint32_t x = (my_xcd + xcd_off) & 7u;
+                                const uint32_t lo = uint32_t((uint64_t(x) * a.nblocks) >> 3);
+                                const uint32_t hi = uint32_t((uint64_t(x + 1) * a.nblocks) >> 3);
+                                uint32_t t = 0xFFFFFFFFu;
+                                if (lane == 0 && lo < hi) t = atomicAdd(a.block_cursor + 16u * x, 1u);
+                                t = __builtin_amdgcn_readfirstlane(t);
+                                if (lo < hi && t < hi - lo) { b = lo + t; break; }
+                                ++xcd_off;
+                            }
+                            if (b == 0xFFFFFFFFu) b = a.nblocks;          // everything handed out
                         } else if (lane == 0) {
                             b = atomicAdd(a.block_cursor, 1u);
                         }
