@@ -166,7 +166,10 @@ def main() -> None:
     engine.set_timing(True)
     if dist_on and args.reserve_cus > 0:
         # the gather of batch b runs while batch b+1 is traced: its kernels need somewhere to run
-        engine.set_option("reserved_cus", args.reserve_cus)
+        try:
+            engine.set_option("reserved_cus", args.reserve_cus)
+        except Exception as exc:   # never lose the run over an optimisation: trace without the reservation
+            log(f"[bench] reserved_cus not available ({exc}); the gather will not overlap the resident trace grid")
         log(f"[bench] {engine.get_option('reserved_cus')} CUs keep room for the collective "
             f"({engine.get_option('reserved_limit')} trace blocks each instead of {engine.launch_info()['blocks'] // max(1, engine.get_option('cu_count'))})")
 
