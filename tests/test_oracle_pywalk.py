@@ -1,0 +1,42 @@
+"""The C oracle against an independent pure-Python fp32 restatement of the walk (oracle/py_walk.py, written from
+SURVEY.md 3.2, small cases only): hits bit for bit, same traversal-step and triangle-test counters, i.e. the same
+visitation order and tie-breaks -- including duplicate triangles, cull flags, clamped directions and t windows."""
+import numpy as np
+import pytest
+
+FLT_MAX = np.finfo(np.float32).max
+
+
+@pytest.mark.parametrize("seed,ntris,any_hit", [(1, 1, False), (2, 7, False), (3, 60, False), (4, 250, False), (5, 120, True), (6, 400, False)])
+def test_c_oracle_equals_python_walk(va, O, seed, ntris, any_hit):
+    from oracle import py_walk
+    rng = np.random.default_rng(seed)
+    verts = (rng.normal(scale=20, size=(ntris, 1, 3)) + rng.normal(scale=5, size=(ntris, 3, 3))).astype(np.float32)
+    if ntris > 10:
+        verts[5] = verts[4]; verts[6] = verts[4]                       # three coincident triangles: ties on t
+    flags = rng.integers(0, 2, ntris).astype(np.uint8)
+    tris64 = va.tris_setup(verts, flags)
+    bvh = va.HostBvh(tris64)
+    otris = O.tris_from_tri64(tris64)
+    nodes, pidx = bvh.nodes().view(O.NODE), bvh.prim_indices()
+    nr = 120
+    org = rng.normal(scale=40, size=(nr, 3)).astype(np.float32)
+    tgt = verts[rng.integers(0, ntris, nr)].mean(axis=1) + rng.normal(scale=1.0, size=(nr, 3))
+    d = (tgt - org).astype(np.float32)
+    d[::9, 1] = 0.0
+    if ntris > 10:
+        d[:10] = (verts[4].mean(axis=0) - org[:10]).astype(np.float32)   # aim at the coincident triangles
+    rays = va.make_rays(org, d, 0.0, FLT_MAX)
+    rays["tmin"][::5] = 0.2
+    rays["tmax"][::7] = 1.1
+    ref, st, _, _, _ = O.traverse_batch(nodes, pidx, otris, rays, any_hit=any_hit, want_stats=True)
+    ties = 0
+    for i in range(nr):
+        prim, t, u, v, steps, tests = py_walk.walk(nodes, pidx, otris, rays[i], any_hit=any_hit)
+        assert prim == ref["prim"][i], (i, prim, ref["prim"][i])
+        assert (np.float32(t).view(np.uint32), np.float32(u).view(np.uint32), np.float32(v).view(np.uint32)) == \
+               (ref["t"][i:i + 1].view(np.uint32)[0], ref["u"][i:i + 1].view(np.uint32)[0], ref["v"][i:i + 1].view(np.uint32)[0])
+        assert (steps, tests) == (st[i, 0], st[i, 1])
+        ties += prim in (4, 5, 6)
+    if ntris > 10 and not any_hit:
+        assert ties >= 1
