@@ -186,6 +186,12 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
  *   "refill_threshold"   idle lanes that trigger a re-fill (8);  "tri_threshold": waiting lanes that
  *                        trigger the triangle branch (4);  "static_overflow_mb": overflow-area cap of the
  *                        one-ray-per-lane kernel (256)
+ *   "max_claim"          persistent kernel: ray blocks one atomic on the cursor may claim while plenty are left (guided
+ *                        self-scheduling; single blocks near the end).  The cursor is ONE word and serves ~90 M
+ *                        claims per second, i.e. at most 5.8 Grays/s with 64-ray claims: rays into small scenes are
+ *                        cheaper than that (16 Mi bounce rays into 100 k triangles: 3.15 -> 2.48 ms with 4, primary
+ *                        3.03 -> 1.45 ms), rays into 1 M triangles are not and lose locality (5.23 -> 5.36 ms with 8).
+ *                        0 (default) = 4 for scenes up to 200 k node pairs, else 1.
  *   "xcd_cursors"        persistent kernel: one ray-block cursor per XCD, each over its own eighth of the batch, with
  *                        stealing (default 0).  Keeps neighbouring rays in one L2: S1M primary rays 3.34 -> 3.20 ms,
  *                        but eight distant ray ranges in flight enlarge the Infinity-Cache working set: S10M bounce

@@ -74,8 +74,13 @@ def main():
     engine.set_timing(True)
     variants = args.opt or ["persistent=2"]
     keys = ["persistent", "fetch_dma", "lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold",
-            "auto_static_factor", "static_overflow_mb", "coherent_detect", "xcd_cursors"]
-    defaults = {k: engine.get_option(k) for k in keys}
+            "auto_static_factor", "static_overflow_mb", "coherent_detect", "xcd_cursors", "max_claim"]
+    defaults = {}
+    for k in keys:                                       # older builds (A/B runs) may not know every key
+        try:
+            defaults[k] = engine.get_option(k)
+        except Exception:
+            pass
     times = {v: [] for v in variants}
     infos = {}
     ref = None

@@ -204,7 +204,8 @@ def test_launch_options_do_not_change_results(va, make_bundle):
                dict(refill_threshold=64, tri_threshold=64, block_rays=4096), dict(blocks_per_cu=1),
                dict(fetch_dma=0, lds_entries=1, refill_threshold=3, tri_threshold=7),
                dict(persistent=1, fetch_dma=1, lds_entries=10, xcd_cursors=1, block_rays=64),
-               dict(persistent=1, xcd_cursors=1, block_rays=4096, blocks_per_cu=2), dict(xcd_cursors=0, spin_wait=0)]
+               dict(persistent=1, xcd_cursors=1, block_rays=4096, blocks_per_cu=2), dict(xcd_cursors=0, spin_wait=0),
+               dict(persistent=1, max_claim=8, block_rays=64), dict(persistent=1, max_claim=1), dict(max_claim=0)]
     for cfg in configs:
         for k, v in cfg.items():
             eng.set_option(k, v)

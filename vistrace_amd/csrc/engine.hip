@@ -46,6 +46,7 @@ struct vt_engine {
     uint32_t refill_threshold = 8;    // idle lanes that trigger a re-fill
     uint32_t tri_threshold    = 4;    // lanes with pending triangles that trigger the TRI branch
     int      fetch_dma        = 1;    // quad-cooperative global->LDS record fetch (persistent mode)
+    uint32_t max_claim        = 0;    // persistent mode: ray blocks one cursor atomic may claim while plenty are left (0 = auto)
     int      xcd_cursors      = 0;    // persistent mode: one ray-block cursor per XCD over its own eighth of the batch (opt-in)
     int      spin_wait        = 1;    // tiny host batches: watch the pinned result slots instead of a stream sync
     uint32_t reserved_cus     = 0;    // CUs on which the persistent grid leaves room (for a concurrent collective's kernels)
@@ -253,6 +254,8 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     if (a.reserved_cus) VT_HIP(hipMemsetAsync(a.cu_slots, 0, 4096, stream));
     a.xcd_cursors = e->xcd_cursors != 0;
     a.nblocks = uint32_t((n + a.block_rays - 1) / a.block_rays);
+    // 0 = by scene size: cheap rays (small trees) finish fast enough for the single cursor word to become the limit
+    a.max_claim = e->max_claim ? e->max_claim : (s->npairs <= 200000u ? 4u : 1u);
     if (p.persistent && a.xcd_cursors)
         VT_HIP(hipMemsetAsync(e->d_cursor, 0, 512, stream));                 // eight cursors, 64 B apart
     else if (p.persistent)
@@ -424,6 +427,7 @@ int vt_engine_set_option(vt_engine* e, const char* key, int64_t value)
     else if (k == "fetch_dma") e->fetch_dma = value != 0;
     else if (k == "spin_wait") e->spin_wait = value != 0;
     else if (k == "xcd_cursors") e->xcd_cursors = value != 0;
+    else if (k == "max_claim" && value >= 0 && value <= 1024) e->max_claim = uint32_t(value);
     else if (k == "reserved_cus" && value >= 0 && value <= e->cu_count / 2) return reserve_cus(e, uint32_t(value));
     else if (k == "reserved_limit" && value >= 0 && value <= 64) e->reserved_limit = uint32_t(value);
     else return fail(VT_ERR_INVALID_ARG, "vt_engine_set_option: unknown key or value out of range: " + k);
@@ -446,6 +450,7 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
     else if (k == "fetch_dma") *value = e->fetch_dma;
     else if (k == "spin_wait") *value = e->spin_wait;
     else if (k == "xcd_cursors") *value = e->xcd_cursors;
+    else if (k == "max_claim") *value = e->max_claim;
     else if (k == "reserved_cus") *value = e->reserved_cus;
     else if (k == "reserved_limit") *value = e->reserved_limit;
     else if (k == "cu_count") *value = e->cu_count;

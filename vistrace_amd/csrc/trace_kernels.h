@@ -35,7 +35,8 @@ struct TraceArgs {
     uint32_t                  n_alpha_mats;
     uint32_t            xcd_cursors;      // persistent mode: 1 = one cursor per XCD (block_cursor[16 * xcd]), each over its own
                                           // eighth of the ray blocks, with stealing; 0 = one global cursor
-    uint32_t            nblocks;          // ray blocks in the batch (xcd_cursors)
+    uint32_t            nblocks;          // ray blocks in the batch
+    uint32_t            max_claim;        // most ray blocks one cursor atomic may claim (guided self-scheduling), >= 1
     const uint32_t*     reserved_cus;     // persistent mode: 1024-bit set of __smid() values of the reserved CUs, or NULL
     uint32_t*           cu_slots;         // 1024 counters (zeroed per launch): blocks that asked to stay on a reserved CU
     uint32_t            reserved_limit;   // blocks a reserved CU keeps (0 = none)

@@ -228,6 +228,10 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
     // L2; a wave whose XCD has run dry steals from the next ones
     const uint32_t my_xcd = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;   // XCC_ID[3:0]
     uint32_t xcd_off = 0;    // wave-uniform: XCDs (starting at its own) this wave has found exhausted
+    // guided self-scheduling on the global cursor: one atomic claims several consecutive ray blocks while plenty
+    // are left, single blocks near the end.  Every wave of the grid adds to ONE word; that word hands out at most
+    // ~90 M claims per second (11 ns each, measured), i.e. 5.8 Grays/s with 64-ray claims.
+    uint32_t claim_cur = 0, claim_end = 0;   // wave-uniform: ray blocks claimed but not yet started
 
     auto start_ray = [&](uint64_t idx) {
         const float4* r4 = reinterpret_cast<const float4*>(a.rays + idx);
@@ -301,8 +305,18 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                                 ++xcd_off;
                             }
                             if (b == 0xFFFFFFFFu) b = a.nblocks;          // everything handed out
-                        } else if (lane == 0) {
-                            b = atomicAdd(a.block_cursor, 1u);
+                        } else {
+                            if (claim_cur == claim_end) {
+                                const uint32_t left = a.nblocks > claim_end ? a.nblocks - claim_end : 0u;   // stale, fine
+                                const uint32_t waves = gridDim.x * (kBlockThreads / 64);
+                                uint32_t k = left / (2u * waves);
+                                k = k < 1u ? 1u : (k > a.max_claim ? a.max_claim : k);
+                                uint32_t c = 0;
+                                if (lane == 0) c = atomicAdd(a.block_cursor, k);
+                                claim_cur = __builtin_amdgcn_readfirstlane(c);
+                                claim_end = claim_cur + k;
+                            }
+                            b = claim_cur++;
                         }
                         b = __builtin_amdgcn_readfirstlane(b);
                         blk_cur = uint64_t(b) * a.block_rays;
