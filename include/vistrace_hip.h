@@ -177,7 +177,8 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
 
 /* Launch configuration (also readable from VT_* environment variables at vt_engine_open).  Keys:
  *   "persistent"         0 = one ray per lane, 1 = persistent waves, 2 = auto by batch size (default)
- *   "auto_static_factor" auto: one ray per lane when n <= factor x (CUs x 8 x 256) rays (default 2)
+ *   "auto_static_factor" auto: one ray per lane when n <= f x (CUs x 8 x 256) rays; f = 2 x factor for scenes up to
+ *                        200 k node pairs, factor / 2 above (default factor 2: 2 Mi rays / 512 Ki rays on MI355X)
  *   "fetch_dma"          persistent kernel: quad-cooperative global->LDS record fetch (default 1)
  *   "coherent_detect"    persistent kernel: per-wave octant probe -> direct fetch + whole-wave re-fill (1)
  *   "lds_entries"        stack entries per lane kept in LDS, the rest spills to global memory (10)

@@ -157,8 +157,11 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool 
     const uint32_t need = s->max_depth;
     // persistent = 2 (default): small batches (a few rays per resident lane) finish sooner with one
     // ray per lane -- no block cursor, no re-fill, and no end-of-queue tail across the whole grid
-    p.persistent = e->persistent == 1 ||
-                   (e->persistent == 2 && n > uint64_t(e->auto_static_factor) * e->cu_count * 8 * kBlockThreads);
+    // (the persistent launch carries ~0.22 ms of fixed cost -- grid start, first fill, end-of-queue tail; rays into
+    // small trees are cheap enough for one ray per lane to win up to twice the batch size, rays into large trees only
+    // up to half of it: scripts/sweep.py tables in profiles/r1/notes.md)
+    const uint64_t factor = s->npairs <= 200000u ? uint64_t(e->auto_static_factor) * 2 : (uint64_t(e->auto_static_factor) + 1) / 2;
+    p.persistent = e->persistent == 1 || (e->persistent == 2 && n > factor * e->cu_count * 8 * kBlockThreads);
     // the DMA-fetch kernel addresses records as base + 32-bit byte offset: scenes below 4 GiB
     const uint64_t rec_bytes = (uint64_t(s->tri_base) + s->ntris) * 64;
     p.fetch_dma = p.persistent && e->fetch_dma != 0 && rec_bytes < (uint64_t(1) << 32);
