@@ -183,7 +183,7 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
  *   "coherent_detect"    persistent kernel: per-wave octant probe -> direct fetch + whole-wave re-fill (1)
  *   "lds_entries"        stack entries per lane kept in LDS, the rest spills to global memory (10)
  *   "blocks_per_cu"      cap on resident 256-thread blocks per CU (8; the occupancy query decides below it)
- *   "block_rays"         consecutive rays handed to a wave at a time (64)
+ *   "block_rays"         consecutive rays handed to a wave at a time (128)
  *   "refill_threshold"   idle lanes that trigger a re-fill (8);  "tri_threshold": waiting lanes that
  *                        trigger the triangle branch (4);  "static_overflow_mb": overflow-area cap of the
  *                        one-ray-per-lane kernel (256)

@@ -42,7 +42,7 @@ struct vt_engine {
     uint32_t auto_static_factor = 2;  // auto: static when n <= factor * (CUs * 8 blocks * 256 lanes)
     uint32_t lds_entries      = 10;   // stack entries per lane in LDS (rest spills to global)
     uint32_t blocks_per_cu    = 8;    // persistent grid = cu_count * blocks_per_cu
-    uint32_t block_rays       = 64;   // consecutive rays handed to a wave at a time
+    uint32_t block_rays       = 128;  // consecutive rays handed to a wave at a time (128: primary rays -4 %, bounce rays unchanged)
     uint32_t refill_threshold = 8;    // idle lanes that trigger a re-fill
     uint32_t tri_threshold    = 4;    // lanes with pending triangles that trigger the TRI branch
     int      fetch_dma        = 1;    // quad-cooperative global->LDS record fetch (persistent mode)
