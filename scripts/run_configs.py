@@ -53,13 +53,14 @@ def main():
         del d_stats, st
         out = torch.empty(n if any_hit else n * 16, dtype=torch.uint8, device=dev)
         ms = []
-        for _ in range(reps + 1):
+        warm = 4                                        # the clocks need a few launches after the idle CPU build phase
+        for _ in range(reps + warm):
             if any_hit:
                 tp.trace_any(sc, d_rays, n, out)
             else:
                 tp.trace_closest(sc, d_rays, n, out)
             ms.append(engine.last_kernel_ms())
-        k = float(np.median(ms[1:]))
+        k = float(np.median(ms[warm:]))
         alg = n * (32 + (1 if any_hit else 16)) + 64 * (steps + tests)   # closest-hit counters as the yardstick
         return {"config": cfg, "scene": name, "rays": n, "query": "any-hit" if any_hit else "closest-hit",
                 "kernel_ms": round(k, 3), "mrays_s": round(n / k / 1e3, 1), "steps_per_ray": round(steps / n, 2),
