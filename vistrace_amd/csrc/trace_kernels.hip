@@ -24,7 +24,12 @@
 //    `lds_entries` deep, with a per-lane global overflow area for deeper trees;
 //  * persistent waves: a wave pulls blocks of consecutive rays from a global cursor and
 //    re-fills idle lanes (ballot + mbcnt prefix) once enough of them have retired, so
-//    divergent ray lengths do not leave lanes empty;
+//    divergent ray lengths do not leave lanes empty.  The cursor is one word (~90 M claims/s):
+//    block w goes to wave w without an atomic, and for small scenes one atomic claims several
+//    blocks while plenty are left (guided self-scheduling); optional per-XCD cursors;
+//  * software CU reservation: blocks landing on a reserved CU beyond its quota exit at once,
+//    leaving registers and LDS for the kernels of a concurrent collective (RCCL gather);
+//  * ALPHA variants add the alpha test of Primitives.h:196-208 to the triangle step;
 //  * coherence probe: a wave that starts from empty with all rays in one direction octant
 //    (camera-like packets) fetches records directly and is only re-filled as a whole;
 //  * PERSISTENT=false: one ray per lane, no cursor and no re-fill -- what the engine's auto mode
