@@ -346,8 +346,18 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                                 const uint64_t ax = __ballot(has_ray && (__float_as_uint(L.dx) >> 31)),
                                                ay = __ballot(has_ray && (__float_as_uint(L.dy) >> 31)),
                                                az = __ballot(has_ray && (__float_as_uint(L.dz) >> 31));
+                                // ... and point the same way: within ~18 degrees of the wave's first ray.  (Sharing
+                                // an octant alone is not coherence: a batch of bounce rays sorted by octant would
+                                // otherwise run in this mode, 8.2 instead of 5.3 ms.)
+                                const int first = act != 0 ? __builtin_ctzll(act) : 0;
+                                const float fx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(L.dx), first)),
+                                            fy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(L.dy), first)),
+                                            fz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(L.dz), first));
+                                const float dd = L.dx * fx + L.dy * fy + L.dz * fz;
+                                const float l2 = (L.dx * L.dx + L.dy * L.dy + L.dz * L.dz) * (fx * fx + fy * fy + fz * fz);
+                                const uint64_t narrow = __ballot(!has_ray || (dd > 0.0f && dd * dd >= 0.9f * l2));
                                 coherent = a.coherent_detect != 0 && (ax == 0 || ax == act) && (ay == 0 || ay == act) &&
-                                           (az == 0 || az == act);
+                                           (az == 0 || az == act) && narrow == ~0ull;
                             } else {
                                 coherent = false;
                             }
