@@ -158,6 +158,9 @@ void vt_scene_free(vt_scene* s);
 uint64_t vt_scene_device_bytes(const vt_scene* s);
 
 /* The call at source/objects/AccelStruct.cpp:818, batched: closest hit per ray. */
+/* Rays with a NaN or infinite origin / direction component miss, as in the reference -- but without the walk the
+ * reference performs for them (its slab test ignores NaN terms, so such a ray can visit the whole tree before
+ * missing); vt_trace_stats_dev alone still walks, to report the reference's counters. */
 int vt_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_hit* hits);
 /* bvh v1 AnyPrimitiveIntersector semantics (any_hit early-out): occluded[i] = 0/1. */
 int vt_trace_any(vt_scene* s, const vt_ray* rays, uint64_t n, uint8_t* occluded);

@@ -189,6 +189,21 @@ def test_weird_rays(va, engine, make_bundle):
     assert_hits_equal(got, ref)
     assert_hits_equal(scene.trace_closest(rays), ref)
     assert (st["steps"] == ref_st[:, 0]).all() and (st["tests"] == ref_st[:, 1]).all()
+    # every kind of non-finite origin / direction: the reference walks (possibly the whole tree) and misses;
+    # the product kernels skip the walk and report the same miss, any-hit included
+    bad = np.concatenate([base[:64]] * 9)
+    vals = [np.nan, np.inf, -np.inf]
+    for k in range(9):
+        bad["dir" if k % 2 == 0 else "org"][k * 64:(k + 1) * 64, k % 3] = vals[k // 3]
+    bad["dir"][512:] = np.nan                                    # fully poisoned: the reference visits every pair
+    bad["dir"][544:] = np.inf
+    ref_bad, st_bad = b.oracle(bad, want_stats=True)
+    assert (ref_bad["prim"] == O_MISS).all() and st_bad[512:544, 0].min() == b.host_scene.pair_count
+    assert_hits_equal(scene.trace_closest(bad), ref_bad)
+    assert (scene.trace_any(bad) == 0).all()
+    got_bad, st2 = stats_on_device(va, scene, bad)
+    assert_hits_equal(got_bad, ref_bad)
+    assert (st2["steps"] == st_bad[:, 0]).all() and (st2["tests"] == st_bad[:, 1]).all()
 
 
 def test_launch_options_do_not_change_results(va, make_bundle):

@@ -252,6 +252,18 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
         } else {
             L.node = a.npairs != 0 ? 0u : kDone; L.tri_cur = 0; L.tri_end = 0;
         }
+        // A NaN or infinite origin / direction component can never produce a hit: the triangle test needs
+        // u, v, w >= 0 and t in range, and with a non-finite component n.d or cross(d, p0 - o) is NaN or
+        // infinite in a way that makes u or v NaN, or u, v infinite with w = -inf (Primitives.h:173-189).
+        // The reference nevertheless WALKS for such a ray -- NaN slab terms drop out of robust_max/min, so
+        // with all three axes poisoned every box passes and one ray visits the whole tree (555 k steps on
+        // S1M; 8 Mi such rays kept this kernel busy for 54 s).  The result is known, so the walk is skipped;
+        // only the STATS variant, which must also report the reference's step and test counts, still walks.
+        if constexpr (!STATS) {
+            const bool finite = fabsf(L.ox) <= FLT_MAX && fabsf(L.oy) <= FLT_MAX && fabsf(L.oz) <= FLT_MAX &&
+                                fabsf(L.dx) <= FLT_MAX && fabsf(L.dy) <= FLT_MAX && fabsf(L.dz) <= FLT_MAX;
+            if (!finite) { L.node = kDone; L.tri_cur = 0; L.tri_end = 0; }
+        }
         // A NaN tmin or tmax makes every slab test and every triangle range test of the
         // reference false: the ray misses after one step (or after testing a leaf root).
         if (L.tmin != L.tmin || L.tmax != L.tmax) {
