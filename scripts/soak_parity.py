@@ -50,6 +50,9 @@ for seed in range(first, first + count):
     k = m // 3
     d[:k] = (centre[rng.integers(0, n, k), 0] - org[:k]).astype(np.float32)
     d[::37, rng.integers(0, 3)] = 0.0
+    d[5::101] = np.nan                                        # fully poisoned: the reference walks the whole tree and misses
+    d[7::103, rng.integers(0, 3)] = np.inf
+    org[9::107, rng.integers(0, 3)] = -np.inf
     tmin = np.where(rng.random(m) < 0.3, rng.uniform(0, spread, m), 0.0).astype(np.float32)
     tmax = np.where(rng.random(m) < 0.3, tmin + rng.uniform(1e-3, 4 * spread, m), np.finfo(np.float32).max).astype(np.float32)
     rays = va.make_rays(org, d, tmin, tmax)
