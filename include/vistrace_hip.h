@@ -222,7 +222,10 @@ int vt_engine_synchronize(vt_engine* e);
 /* Device-side refit of an uploaded scene: new vertices (n x 9 floats, host memory, original triangle
  * order; n = the scene's triangle count; flags may be NULL = unchanged) -> triangle records and all
  * pair bounds are recomputed in place on the device, level by level from the leaves up.  Produces
- * exactly the records vt_tris_setup + vt_bvh_refit + vt_scene_linearise would. */
+ * exactly the records vt_tris_setup + vt_bvh_refit + vt_scene_linearise would.  Vertices must be finite: NaN boxes
+ * pass every slab test, so every ray would walk the poisoned subtree -- the call then fails with VT_ERR_INVALID_ARG
+ * (the message counts the triangles) and the scene refuses to trace until a refit with finite data (the same holds
+ * for vt_scene_skin_refit, e.g. with a NaN bone matrix). */
 int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32_t n);
 
 /* Device-side skinning + refit (the per-frame half of AccelStruct::Rebuild for animated entities,

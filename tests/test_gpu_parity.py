@@ -693,3 +693,32 @@ def test_scene_outliving_its_engine_is_inert(va, make_bundle):
         scene.trace_closest(rays)
     assert "closed" in str(err.value)
     scene.free()
+
+
+def test_refit_with_non_finite_vertices_is_refused(va, engine, make_bundle):
+    """A refit / skinning pass that produces NaN or infinite vertices would leave NaN boxes that every ray walks
+    into (the slab test ignores NaN terms): the call fails loudly and the scene refuses to trace until a clean refit."""
+    from vistrace_amd import workloads as W
+    verts = W.make_scene("S1k")
+    n = len(verts)
+    scene = va.Scene(engine, va.HostScene(va.HostBvh(va.tris_setup(verts))))
+    rays = W.sphere_rays(2000, 4, origin=(5.0, 5.0, 5.0))
+    ref = scene.trace_closest(rays)
+    bad = verts.copy(); bad[17, 1, 2] = np.nan; bad[400:410] = np.inf
+    with pytest.raises(va._lib.VisTraceError) as err:
+        scene.refit(bad)
+    assert "11 triangles" in str(err.value)
+    with pytest.raises(va._lib.VisTraceError):
+        scene.trace_closest(rays)
+    scene.refit(verts)                                           # a clean refit heals the scene
+    assert_hits_equal(scene.trace_closest(rays), ref)
+    skin, base, nmat = W.skinned_rig(n)
+    scene.set_skin(verts, skin, base)
+    bones, binds = W.rig_pose(nmat, 0)
+    bones_bad = bones.copy(); bones_bad[3, 5] = np.nan
+    with pytest.raises(va._lib.VisTraceError):
+        scene.skin_refit(bones_bad, binds)
+    with pytest.raises(va._lib.VisTraceError):
+        scene.trace_any(rays)
+    scene.skin_refit(bones, binds)
+    scene.trace_closest(rays)

@@ -111,6 +111,10 @@ struct vt_scene {
     vt_alpha_material* d_alpha_mats = nullptr;
     uint8_t*           d_alpha_texels = nullptr;
     uint32_t           n_alpha_mats = 0;
+    // refit / skinning with non-finite vertices: NaN boxes pass every slab test, so a poisoned subtree is walked by
+    // every ray -- the scene is refused until it has been refitted with finite data
+    uint32_t*       d_bad = nullptr;
+    bool            poisoned = false;
     hipGraphExec_t  refit_graph = nullptr;   // the level-by-level refit launches, captured once (launch-bound: ~30 tiny kernels)
     uint32_t      npairs = 0, ntris = 0, max_depth = 0, root_leaf_count = 0;
     uint64_t      bytes = 0;
@@ -204,6 +208,8 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
 {
     vt_engine* e = s->engine;
     if (n == 0) return VT_OK;
+    if (s->poisoned)
+        return fail(VT_ERR_INVALID_ARG, "the scene was last refitted with non-finite vertex positions; refit it with finite data");
     if (s->has_alpha && (!s->d_attribs || !s->d_alpha_mats))
         return fail(VT_ERR_UNSUPPORTED, "the scene holds alpha-tested triangles (Primitives.h:196-208): call "
                                         "vt_scene_set_tri_attribs and vt_scene_set_alpha before tracing");
@@ -540,7 +546,8 @@ static void release_scene_device(vt_scene* s)
                      reinterpret_cast<void**>(&s->d_attribs), reinterpret_cast<void**>(&s->d_level_pairs),
                      reinterpret_cast<void**>(&s->d_alpha_mats), reinterpret_cast<void**>(&s->d_alpha_texels),
                      reinterpret_cast<void**>(&s->d_bind_verts), reinterpret_cast<void**>(&s->d_skin),
-                     reinterpret_cast<void**>(&s->d_matrix_base), reinterpret_cast<void**>(&s->d_skin_mats)};
+                     reinterpret_cast<void**>(&s->d_matrix_base), reinterpret_cast<void**>(&s->d_skin_mats),
+                     reinterpret_cast<void**>(&s->d_bad)};
     for (void** b : bufs) {
         if (*b) (void)hipFree(*b);
         *b = nullptr;
@@ -784,6 +791,25 @@ int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t dep
 
 void* vt_engine_stream(vt_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
 
+static int begin_finite_check(vt_scene* s)
+{
+    if (!s->d_bad) VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_bad), 64));
+    VT_HIP(hipMemsetAsync(s->d_bad, 0, 4, s->engine->stream));
+    return VT_OK;
+}
+
+// after the (synchronous) refit: how many triangles had a non-finite vertex?
+static int end_finite_check(vt_scene* s, const char* who)
+{
+    uint32_t bad = 0;
+    VT_HIP(hipMemcpy(&bad, s->d_bad, 4, hipMemcpyDeviceToHost));
+    s->poisoned = bad != 0;
+    if (bad != 0)
+        return fail(VT_ERR_INVALID_ARG, std::string(who) + ": " + std::to_string(bad) + " triangles have a non-finite (NaN / inf) vertex; "
+                                        "the scene cannot be traced until it is refitted with finite data");
+    return VT_OK;
+}
+
 // all pair bounds from the (already rewritten) triangle records, deepest level first; waits for the result
 static int refit_levels(vt_scene* s)
 {
@@ -838,10 +864,13 @@ int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32
     if (rc != VT_OK) return rc;
     VT_HIP(hipMemcpyAsync(e->d_rays, verts, size_t(n) * 9 * sizeof(float), hipMemcpyHostToDevice, e->stream));
     if (flags) VT_HIP(hipMemcpyAsync(e->d_out, flags, n, hipMemcpyHostToDevice, e->stream));
+    rc = begin_finite_check(s);
+    if (rc != VT_OK) return rc;
     RefitTrisArgs ta{static_cast<const float*>(e->d_rays), flags ? static_cast<const uint8_t*>(e->d_out) : nullptr,
-                     s->d_prim_to_slot, s->d_tris, n};
+                     s->d_prim_to_slot, s->d_tris, n, s->d_bad};
     VT_HIP(launch_refit_tris(ta, e->stream));
-    return refit_levels(s);
+    rc = refit_levels(s);
+    return rc != VT_OK ? rc : end_finite_check(s, "vt_scene_refit");
 }
 
 int vt_scene_set_skin(vt_scene* s, const float* bind_verts, const vt_skin_vertex* skin, const uint32_t* matrix_base, uint32_t n)
@@ -894,9 +923,12 @@ int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uin
     VT_HIP(hipMemcpyAsync(d_bones, bones, size_t(nmat) * 64, hipMemcpyHostToDevice, e->stream));
     VT_HIP(hipMemcpyAsync(d_binds, binds, size_t(nmat) * 64, hipMemcpyHostToDevice, e->stream));
     VT_HIP(launch_skin_matrices(SkinMatricesArgs{d_bones, d_binds, d_prod, nmat}, e->stream));
-    SkinTrisArgs ta{s->d_bind_verts, s->d_skin, s->d_matrix_base, d_prod, s->d_prim_to_slot, s->d_tris, s->ntris, nmat};
+    int rc = begin_finite_check(s);
+    if (rc != VT_OK) return rc;
+    SkinTrisArgs ta{s->d_bind_verts, s->d_skin, s->d_matrix_base, d_prod, s->d_prim_to_slot, s->d_tris, s->ntris, nmat, s->d_bad};
     VT_HIP(launch_skin_tris(ta, e->stream));
-    return refit_levels(s);
+    rc = refit_levels(s);
+    return rc != VT_OK ? rc : end_finite_check(s, "vt_scene_skin_refit");
 }
 
 int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_out)

@@ -75,13 +75,15 @@ struct QueueArgs {
 hipError_t launch_queue_step(const QueueArgs& a, uint32_t* live_out, hipStream_t stream);
 hipError_t launch_fill_miss(vt_hit* hits, uint64_t n, hipStream_t stream);
 
-struct RefitTrisArgs { const float* verts; const uint8_t* flags; const uint32_t* prim_to_slot; vt_tri64* tris; uint32_t n; };
+struct RefitTrisArgs { const float* verts; const uint8_t* flags; const uint32_t* prim_to_slot; vt_tri64* tris; uint32_t n;
+                       uint32_t* bad; /* counts triangles with a non-finite vertex */ };
 struct RefitLevelArgs { vt_node_pair* pairs; const vt_tri64* tris; const uint32_t* level_pairs; uint32_t count; };
 hipError_t launch_refit_tris(const RefitTrisArgs& a, hipStream_t stream);
 struct SkinMatricesArgs { const float* bones; const float* binds; float* mats; uint32_t nmat; };
 struct SkinTrisArgs {
     const float* bind_verts; const vt_skin_vertex* skin; const uint32_t* matrix_base; const float* mats;
     const uint32_t* prim_to_slot; vt_tri64* tris; uint32_t n; uint32_t nmat;
+    uint32_t* bad;   // counts triangles with a non-finite vertex
 };
 hipError_t launch_skin_matrices(const SkinMatricesArgs& a, hipStream_t stream);
 hipError_t launch_skin_tris(const SkinTrisArgs& a, hipStream_t stream);

@@ -739,8 +739,11 @@ __global__ __launch_bounds__(kBlockThreads) void fill_miss_kernel(vt_hit* hits, 
 
 // ---- refit: triangle records and pair bounds recomputed in place ----------
 // triangle record from three vertices: Triangle ctor Primitives.h:82 + ComputeNormalAndLoD :93
-__device__ __forceinline__ void store_tri_record(const float* v, uint32_t prim, uint32_t flags, vt_tri64* dst)
+__device__ __forceinline__ void store_tri_record(const float* v, uint32_t prim, uint32_t flags, vt_tri64* dst, uint32_t* bad)
 {
+    bool finite = true;
+    for (int k = 0; k < 9; ++k) finite = finite && fabsf(v[k]) <= FLT_MAX;
+    if (!finite && bad) atomicAdd(bad, 1u);          // the engine refuses to trace a scene refitted with such data
     vt_tri64 t;
     for (int k = 0; k < 3; ++k) {
         t.p0[k] = v[k];
@@ -764,7 +767,7 @@ __global__ __launch_bounds__(kBlockThreads) void refit_tris_kernel(RefitTrisArgs
     float v[9];
     for (int k = 0; k < 9; ++k) v[k] = src[k];
     const uint32_t slot = a.prim_to_slot[i];
-    store_tri_record(v, i, a.flags ? uint32_t(a.flags[i]) : a.tris[slot].flags, &a.tris[slot]);
+    store_tri_record(v, i, a.flags ? uint32_t(a.flags[i]) : a.tris[slot].flags, &a.tris[slot], a.bad);
 }
 
 // bones[i] * binds[i], the product TransformToBone forms per vertex and bone (AccelStruct.cpp:44);
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(kBlockThreads) void skin_tris_kernel(SkinTrisArgs a
         v[vi * 3] = fin[0]; v[vi * 3 + 1] = fin[1]; v[vi * 3 + 2] = fin[2];
     }
     const uint32_t slot = a.prim_to_slot[i];
-    store_tri_record(v, i, a.tris[slot].flags, &a.tris[slot]);
+    store_tri_record(v, i, a.tris[slot].flags, &a.tris[slot], a.bad);
 }
 
 __device__ __forceinline__ void box_of_child(const vt_node_pair* pairs, const vt_tri64* tris, const vt_bvh_node& c, float* b)
