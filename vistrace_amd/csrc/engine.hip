@@ -390,7 +390,7 @@ void vt_engine_close(vt_engine* e)
 {
     if (!e) return;
     DeviceGuard guard(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    (void)hipDeviceSynchronize();               // launches on caller streams may still use the cursor / overflow areas
     for (vt_scene* sc : e->scenes) {            // scenes that outlive their engine become inert shells
         release_scene_device(sc);
         sc->engine = nullptr;
@@ -562,7 +562,7 @@ void vt_scene_free(vt_scene* s)
     if (!s) return;
     if (vt_engine* e = s->engine) {             // NULL once the engine was closed: only the shell is left
         DeviceGuard guard(e->device);
-        (void)hipStreamSynchronize(e->stream);
+        (void)hipDeviceSynchronize();           // traces of this scene may be in flight on caller streams
         release_scene_device(s);
         e->scenes.erase(std::remove(e->scenes.begin(), e->scenes.end(), s), e->scenes.end());
     }
