@@ -18,6 +18,7 @@ r = base.copy(); r[:] = base[12345]; cases["16 Mi copies of one ray"] = r
 r = base.copy(); r["tmax"] = 1e-30; cases["null rays (tmax 1e-30)"] = r
 r = base.copy(); r["dir"][:, 1] = 0.0; r["dir"][:, 2] = 0.0; r["dir"][:, 0] = 1.0; cases["parallel rays, one origin"] = r
 r = base.copy(); r["org"] = rng.uniform(-900, 900, (n, 3)).astype(np.float32); cases["random origins and directions"] = r
+r = r.copy(); r["dir"] = (0.3, -0.5, 0.8); cases["one direction, random origins"] = r
 r = base.copy(); r["dir"][::2] = np.nan; cases["every other ray NaN"] = r
 d_hits = tp.empty_records(n, va.HIT, dev)
 for name, rays in cases.items():

@@ -113,6 +113,7 @@ struct vt_scene {
     uint32_t           n_alpha_mats = 0;
     // refit / skinning with non-finite vertices: NaN boxes pass every slab test, so a poisoned subtree is walked by
     // every ray -- the scene is refused until it has been refitted with finite data
+    float           coherent_radius2 = 0.f;   // (2 % of the scene's diagonal)^2: how far apart the origins of a ray packet may lie
     uint32_t*       d_bad = nullptr;
     bool            poisoned = false;
     hipGraphExec_t  refit_graph = nullptr;   // the level-by-level refit launches, captured once (launch-bound: ~30 tiny kernels)
@@ -251,6 +252,7 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     a.refill_threshold = std::min(std::max(e->refill_threshold, 1u), 64u);
     a.tri_threshold = std::min(std::max(e->tri_threshold, 1u), 64u);
     a.coherent_detect = e->coherent_detect;
+    a.coherent_radius2 = s->coherent_radius2;
     a.attribs = s->d_attribs;
     a.alpha_mats = s->d_alpha_mats;
     a.alpha_texels = s->d_alpha_texels;
@@ -483,6 +485,17 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
     vt_scene* s = new vt_scene();
     s->engine = e;
     s->has_alpha = has_alpha;
+    if (!hs.pairs.empty()) {                             // scene extent from the root's two children
+        float d2 = 0.f;
+        for (int k = 0; k < 3; ++k) {
+            const vt_bvh_node& l = hs.pairs[0].child[0];
+            const vt_bvh_node& r = hs.pairs[0].child[1];
+            const float lo = std::min(l.bounds[2 * k], r.bounds[2 * k]), hi = std::max(l.bounds[2 * k + 1], r.bounds[2 * k + 1]);
+            const float ext = hi - lo;
+            if (ext == ext && ext > 0.f && ext < 1e18f) d2 += ext * ext;
+        }
+        s->coherent_radius2 = 0.02f * 0.02f * d2;
+    }
     s->npairs = uint32_t(hs.pairs.size());
     s->ntris = uint32_t(hs.tris.size());
     s->max_depth = hs.max_depth;

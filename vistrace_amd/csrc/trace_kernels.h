@@ -28,6 +28,7 @@ struct TraceArgs {
     uint32_t            refill_threshold; // re-fill a wave once this many lanes are idle
     uint32_t            tri_threshold;    // run the TRI branch once this many lanes wait for it
     uint32_t            coherent_detect;  // DMA kernel: per-wave octant probe -> direct fetch, whole-wave re-fill
+    float               coherent_radius2; // ... only for rays whose origins lie within this squared distance of the first
     // alpha test (ALPHA variants only): per-triangle uvs + material (original order), materials, alpha planes
     const vt_tri_attribs*     attribs;
     const vt_alpha_material*  alpha_mats;

@@ -367,7 +367,14 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                                             fz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(L.dz), first));
                                 const float dd = L.dx * fx + L.dy * fy + L.dz * fz;
                                 const float l2 = (L.dx * L.dx + L.dy * L.dy + L.dz * L.dz) * (fx * fx + fy * fy + fz * fz);
-                                const uint64_t narrow = __ballot(!has_ray || (dd > 0.0f && dd * dd >= 0.9f * l2));
+                                // ... and start close together (camera rays share their origin; one direction from
+                                // origins scattered over the scene is not a packet: 7.5 instead of 4.4 ms)
+                                const float gx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(L.ox), first)),
+                                            gy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(L.oy), first)),
+                                            gz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(L.oz), first));
+                                const float ex = L.ox - gx, ey = L.oy - gy, ez = L.oz - gz;
+                                const bool near = ex * ex + ey * ey + ez * ez <= a.coherent_radius2;
+                                const uint64_t narrow = __ballot(!has_ray || (near && dd > 0.0f && dd * dd >= 0.9f * l2));
                                 coherent = a.coherent_detect != 0 && (ax == 0 || ax == act) && (ay == 0 || ay == act) &&
                                            (az == 0 || az == act) && narrow == ~0ull;
                             } else {
