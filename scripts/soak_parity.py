@@ -79,5 +79,18 @@ for seed in range(first, first + count):
         if not ok:
             bad += 1
             print(f"MISMATCH seed {seed} mode {mode} n {n} m {m}", flush=True)
+    if seed % 5 == 1 and rig is None:                         # device refit against the host pipeline, then trace parity
+        moved = (verts + rng.normal(scale=0.05 * spread, size=verts.shape)).astype(np.float32)
+        scene.refit(moved, flags)
+        mtris = va.tris_setup(moved, flags)
+        bvh.refit(mtris)
+        ref_hs = va.HostScene(bvh)
+        pairs, dtris = scene.read_records()
+        ok = (dtris.view(np.uint8) == ref_hs.tris().view(np.uint8)).all() and (pairs.view(np.uint8) == ref_hs.pairs().view(np.uint8)).all()
+        ref2 = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(mtris), rays)[0]
+        ok = ok and (scene.trace_closest(rays).view(np.uint8) == ref2.view(np.uint8)).all()
+        if not ok:
+            bad += 1
+            print(f"REFIT MISMATCH seed {seed} n {n}", flush=True)
 print(f"soak: seeds {first}..{first + count - 1}, {bad} mismatches, {time.time() - t0:.0f}s")
 sys.exit(1 if bad else 0)
