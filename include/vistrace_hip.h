@@ -15,10 +15,14 @@
  * enqueued on the given HIP stream, no host sync).  There is NO CPU fallback:
  * if no HIP device is usable the call fails with VT_ERR_HIP.
  *
- * Threading: like the reference (GMod Lua is single-threaded) an engine and
- * its scenes serve ONE caller at a time.  Launches of one engine share per-launch scratch
- * (ray cursor, stack overflow area), so enqueue them on one stream, or synchronise between
- * streams; different engines (devices) are independent.
+ * Threading and streams: the reference serves one caller (GMod Lua is single-threaded);
+ * this library is safe beyond that.  Every trace launch takes its own scratch (ray cursor, reserved-CU
+ * counters, stack overflow area) from a ring of 16 launch slots, so `_dev` launches of one engine may be
+ * in flight on any number of streams at once and host threads may share an engine (enqueueing is
+ * serialised internally; the host-pointer entry points and vt_bounce_loop_dev, which use engine-wide
+ * staging, run one at a time per engine).  Calls that rewrite a scene in place (vt_scene_refit,
+ * vt_scene_skin_refit, vt_scene_set_alpha, vt_scene_free) first wait for every launch in flight on the
+ * device.  vt_engine_set_timing / vt_engine_last_kernel_ms describe the last launch only.
  */
 #ifndef VISTRACE_HIP_H
 #define VISTRACE_HIP_H
@@ -271,6 +275,21 @@ typedef struct vt_alpha_material {
  * vt_scene_set_tri_attribs first.  A scene that holds VT_TRI_ALPHATEST triangles cannot be traced until this is
  * set (VT_ERR_UNSUPPORTED); scenes without such triangles run the kernels compiled without the test. */
 int vt_scene_set_alpha(vt_scene* s, const vt_alpha_material* mats, uint32_t nmats, const uint8_t* texels, uint64_t ntexels);
+
+/* ---- host side: the single-ray latency path (BASELINE config 1) -------------------------------
+ * What one `accel:Traverse(origin, dir)` call from GLua does (source/objects/AccelStruct.cpp:810-820): ONE ray.  A
+ * lone ray on the GPU is launch bound (~20 us) while the same walk takes 1-2 us on a host core, so the host class
+ * keeps the vt_host_scene it uploaded and answers single rays and batches below the crossover (~16 rays) here: the
+ * reference's scalar walk (bvh v1 SingleRayTraverser + FastNodeIntersector + the in-tree triangle test) on the
+ * linearised records, bit-identical to the device kernels' results.  This is a separate, explicitly named path, NOT
+ * a fallback: vt_trace_* and the *_dev entries never run on the CPU, and without a HIP device no vt_scene exists.
+ * Serial; callable from any thread (the scene is read-only).  Non-finite rays miss without the reference's walk,
+ * as on the device.  Scenes with VT_TRI_ALPHATEST triangles need vt_host_scene_set_alpha first (VT_ERR_UNSUPPORTED). */
+int vt_host_scene_trace_closest(const vt_host_scene* hs, const vt_ray* rays, uint64_t n, vt_hit* hits);
+int vt_host_scene_trace_any(const vt_host_scene* hs, const vt_ray* rays, uint64_t n, uint8_t* occluded);
+/* The alpha-test side data for the host walk: the same tables vt_scene_set_tri_attribs + vt_scene_set_alpha take. */
+int vt_host_scene_set_alpha(vt_host_scene* hs, const vt_tri_attribs* attribs, uint32_t ntris, const vt_alpha_material* mats,
+                            uint32_t nmats, const uint8_t* texels, uint64_t ntexels);
 
 /* entIdx / texUV / blendFactor / submatIdx per hit (needs vt_scene_set_tri_attribs). d_out: n x vt_hit_shade. */
 int vt_hit_shade_dev(vt_scene* s, const void* d_hits, uint64_t n, void* d_out, void* stream);

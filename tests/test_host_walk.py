@@ -1,0 +1,117 @@
+"""The single-ray latency path (vt_host_scene_trace_*, vistrace_amd/csrc/host_walk.cpp) against the oracle.
+
+BASELINE config 1: single `AccelStruct:Traverse`-equivalent calls on S10k, CPU path, no GPU.  The host walk is product
+code (what `accel:Traverse` runs); the oracle and its brute-force intersector are the checkers.  Bit-exact bar:
+primitive index equal, t/u/v bit-identical.  The `-m gpu` suite (test_gpu_parity.py::test_host_walk_equals_device)
+closes the triangle host walk == device kernels == oracle.
+"""
+import numpy as np
+import pytest
+
+O_MISS = 0xFFFFFFFF
+
+
+def assert_hits_equal(got, ref):
+    assert (got["prim"] == ref["prim"]).all()
+    for k in ("t", "u", "v"):
+        assert (got[k].view(np.uint32) == ref[k].view(np.uint32)).all(), k
+
+
+def test_config1_single_calls_s10k(va, O, make_bundle):
+    """10 k single-ray calls from the room centre, uniform sphere directions, [0, FLT_MAX]; parity vs brute force
+    (t identical, index in the min-t set) and vs the oracle's walk (index, t, u, v bit-exact)."""
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    rays = W.sphere_rays(10000, W.SEED + 1)
+    single = np.concatenate([b.host_scene.trace_closest_host(rays[i:i + 1]) for i in range(len(rays))])   # one ray per call
+    assert_hits_equal(single, b.oracle(rays))
+    assert_hits_equal(b.host_scene.trace_closest_host(rays), single)             # a small batch is the same loop
+    brute = O.trace_brute(b.otris, rays)
+    assert (single["t"].view(np.uint32) == brute["t"].view(np.uint32)).all()
+    for i in np.nonzero(single["prim"] != brute["prim"])[0]:
+        _, ids, n = O.min_t_set(b.otris, rays[i:i + 1])
+        assert single["prim"][i] in ids[:n]
+
+
+@pytest.mark.parametrize("name", ["S1k", "terrain"])
+def test_host_walk_matches_oracle(va, O, make_bundle, name):
+    from vistrace_amd import workloads as W
+    b = make_bundle(name)
+    rays = np.concatenate([W.primary_rays(48, 48), W.sphere_rays(6000, 5, origin=(3.0, -4.0, 20.0)),
+                           W.sphere_rays(3000, 6, origin=(3.0, -4.0, -30.0))])
+    rays["tmin"][100:200] = 5.0
+    rays["tmax"][200:300] = 40.0
+    ref = b.oracle(rays)
+    assert_hits_equal(b.host_scene.trace_closest_host(rays), ref)
+    occ = b.host_scene.trace_any_host(rays)
+    any_ref = b.oracle(rays, any_hit=True)
+    assert (occ == (any_ref["prim"] != O_MISS)).all()
+    assert (occ == (ref["prim"] != O_MISS)).all()
+
+
+def test_host_walk_weird_rays(va, O, make_bundle):
+    """safe_inverse clamps, NaN ranges and non-finite rays: same answers as the reference algorithm."""
+    from vistrace_amd import workloads as W
+    b = make_bundle("S1k")
+    base = W.sphere_rays(256, 9, origin=(5.0, 6.0, 7.0))
+    rays = np.concatenate([base] * 8)
+    d = rays["dir"]
+    d[0:256, 0] = 0.0
+    d[256:512, 1] = -0.0
+    d[512:768, 2] = 1e-9
+    d[768:1024, :2] = 0.0
+    rays["tmin"][1024:1280] = np.nan
+    rays["tmax"][1280:1536] = np.nan
+    d[1536:1664, 0] = np.nan
+    d[1664:1792, 1] = np.inf
+    rays["org"][1792:1920, 2] = -np.inf
+    rays["tmax"][1920:] = 1e-30
+    assert_hits_equal(b.host_scene.trace_closest_host(rays), b.oracle(rays))
+    assert (b.host_scene.trace_any_host(rays[1024:1920]) == 0).all()
+
+
+def test_host_walk_degenerate_scenes(va, O):
+    """Empty scene, a root that is a leaf, coincident triangles (later visited wins)."""
+    from vistrace_amd import workloads as W
+    rays = W.sphere_rays(64, 3)
+    empty = va.HostScene(va.HostBvh(va.tris_setup(np.zeros((0, 3, 3), np.float32))))
+    assert (empty.trace_closest_host(rays)["prim"] == O_MISS).all()
+    assert (empty.trace_any_host(rays) == 0).all()
+    tri = np.array([[[10, -5, -5], [10, 5, -5], [10, 0, 5]]], np.float32)
+    for copies in (1, 2, 5):                         # one leaf root; then coincident copies spread over a small tree
+        verts = np.concatenate([tri] * copies)
+        tris = va.tris_setup(verts)
+        bvh = va.HostBvh(tris)
+        hs = va.HostScene(bvh)
+        r = va.make_rays([[0, 0, 0]], [[1, 0, 0]])
+        ref = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris), r)[0]
+        got = hs.trace_closest_host(r)
+        assert_hits_equal(got, ref)
+        assert got["prim"][0] != O_MISS and got["t"][0] == 10.0
+
+
+def test_host_walk_alpha_test(va, O):
+    """Primitives.h:196-208 in the host walk: same hits and any-hit flags as the oracle; refuses without side data."""
+    from vistrace_amd import workloads as W
+    verts = W.make_scene("S1k")
+    n = len(verts)
+    flags, attribs, mats, texels = W.alpha_test_rig(n)
+    tris = va.tris_setup(verts, flags)
+    bvh = va.HostBvh(tris)
+    hs = va.HostScene(bvh)
+    rays = np.concatenate([W.primary_rays(48, 48), W.sphere_rays(6000, 41, origin=(-120.0, 80.0, 15.0))])
+    with pytest.raises(va._lib.VisTraceError) as err:
+        hs.trace_closest_host(rays[:4])
+    assert err.value.code == va._lib.VT_ERR_UNSUPPORTED
+    hs.set_alpha_host(attribs.view(va.TRI_ATTRIBS), mats.view(va.ALPHA_MATERIAL), texels)
+    otris = O.tris_from_tri64(tris)
+    try:
+        plain = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays)[0]
+        O.set_alpha(otris, attribs["uv"].reshape(n, 6), attribs["material"], mats.view(O.ALPHA_MATERIAL), texels)
+        ref = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays)[0]
+        any_ref = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays, any_hit=True)[0]
+    finally:
+        O.set_alpha()
+    assert int((plain["prim"] != ref["prim"]).sum()) > 50
+    assert_hits_equal(hs.trace_closest_host(rays), ref)
+    assert (hs.trace_any_host(rays) == (any_ref["prim"] != O_MISS)).all()

@@ -122,6 +122,29 @@ class HostScene:
     def pairs(self) -> np.ndarray:
         return _copy_from(lib.vt_host_scene_pairs(self._h), self.pair_count, NODE_PAIR)
 
+    # the single-ray latency path (what one accel:Traverse call does): scalar walk on the host copy -----------
+    def trace_closest_host(self, rays: np.ndarray) -> np.ndarray:
+        assert rays.dtype == RAY
+        rays = np.ascontiguousarray(rays)
+        hits = np.zeros(len(rays), dtype=HIT)
+        check(lib.vt_host_scene_trace_closest(self._h, ptr(rays), len(rays), ptr(hits)))
+        return hits
+
+    def trace_any_host(self, rays: np.ndarray) -> np.ndarray:
+        assert rays.dtype == RAY
+        rays = np.ascontiguousarray(rays)
+        occ = np.zeros(len(rays), dtype=np.uint8)
+        check(lib.vt_host_scene_trace_any(self._h, ptr(rays), len(rays), ptr(occ)))
+        return occ
+
+    def set_alpha_host(self, attribs: np.ndarray, mats: np.ndarray, texels: np.ndarray) -> None:
+        attribs = np.ascontiguousarray(attribs, TRI_ATTRIBS)
+        mats = np.ascontiguousarray(mats, ALPHA_MATERIAL)
+        texels = np.ascontiguousarray(texels, np.uint8)
+        check(lib.vt_host_scene_set_alpha(self._h, ptr(attribs) if len(attribs) else None, len(attribs),
+                                          ptr(mats) if len(mats) else None, len(mats),
+                                          ptr(texels) if len(texels) else None, len(texels)))
+
     def tris(self) -> np.ndarray:
         return _copy_from(lib.vt_host_scene_tris(self._h), self.tri_count, TRI64)
 

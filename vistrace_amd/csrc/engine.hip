@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,10 +54,26 @@ struct vt_engine {
     uint32_t reserved_limit   = 2;    // blocks of the grid a reserved CU still keeps
     uint32_t* d_reserved      = nullptr; // 1024-bit set of the reserved CUs' __smid() values, then 1024 per-CU counters
 
-    // per-launch scratch
-    uint32_t* d_cursor = nullptr;
-    uint32_t* d_overflow = nullptr;
-    size_t    overflow_words = 0;
+    // Per-launch scratch: a ring of launch slots, rotated per launch, so that traces in flight on different
+    // streams (or enqueued back to back on one) never share a ray cursor, reserved-CU counters or a stack
+    // overflow area.  A slot is reused kLaunchSlots launches later; the new launch then waits (on the device,
+    // hipStreamWaitEvent) for the event recorded behind the slot's previous launch.
+    static constexpr uint32_t kLaunchSlots = 16;
+    static constexpr size_t   kSlotCtlBytes = 8192;   // 512 B of cursors (8 x 64 B), then 4 KB of reserved-CU counters
+    struct LaunchSlot {
+        uint32_t*  d_ctl = nullptr;          // into d_slot_ctl
+        uint32_t*  d_overflow = nullptr;     // grown on demand, per slot
+        size_t     overflow_words = 0;
+        hipEvent_t done = nullptr;
+        bool       used = false;
+    };
+    LaunchSlot slots[kLaunchSlots];
+    char*      d_slot_ctl = nullptr;
+    uint32_t   next_slot = 0;
+    std::mutex launch_mu;                    // slot rotation + enqueue (host threads may share an engine)
+    std::mutex host_mu;                      // the host-pointer entry points share the staging buffers
+    hipEvent_t ev_loop = nullptr;            // behind the last vt_bounce_loop_dev (its queues are engine-wide)
+    bool       loop_used = false;
 
     // staging for the host-pointer entry points
     void*  d_rays = nullptr;  size_t d_rays_bytes = 0;
@@ -218,15 +235,24 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     int rc = plan_launch(e, s, n, any_hit, stats, p);
     if (rc != VT_OK) return rc;
 
+    // this launch's private scratch: the next slot of the ring (see vt_engine::LaunchSlot)
+    std::lock_guard<std::mutex> lock(e->launch_mu);
+    vt_engine::LaunchSlot& slot = e->slots[e->next_slot % vt_engine::kLaunchSlots];
+    ++e->next_slot;
     const size_t ovf_words = size_t(p.ovf_entries) * p.grid_blocks * kBlockThreads;
-    if (ovf_words > e->overflow_words) {
-        // grow (rare: first launch on a deeper tree); must not race with in-flight launches on any stream
-        VT_HIP(hipDeviceSynchronize());
-        if (e->d_overflow) VT_HIP(hipFree(e->d_overflow));
-        e->d_overflow = nullptr; e->overflow_words = 0;
-        VT_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_overflow), ovf_words * sizeof(uint32_t)));
-        e->overflow_words = ovf_words;
+    if (ovf_words > slot.overflow_words) {
+        // grow this slot's overflow area (rare: first launches on a deeper tree); only the launch that last used
+        // THIS slot has to be over -- nothing else on the device is waited for
+        if (slot.used) VT_HIP(hipEventSynchronize(slot.done));
+        if (slot.d_overflow) VT_HIP(hipFree(slot.d_overflow));
+        slot.d_overflow = nullptr; slot.overflow_words = 0;
+        VT_HIP(hipMalloc(reinterpret_cast<void**>(&slot.d_overflow), ovf_words * sizeof(uint32_t)));
+        slot.overflow_words = ovf_words;
+    } else if (slot.used) {
+        VT_HIP(hipStreamWaitEvent(stream, slot.done, 0));    // kLaunchSlots launches ago: normally long finished
     }
+    uint32_t* const d_cursor = slot.d_ctl;                   // 8 cursors, 64 B apart
+    uint32_t* const d_cu_slots = slot.d_ctl + 128;           // 1024 counters
 
     TraceArgs a{};
     a.records = s->d_records;
@@ -235,8 +261,8 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     a.hits = static_cast<vt_hit*>(d_hits);
     a.occluded = static_cast<uint8_t*>(d_occ);
     a.ray_stats = static_cast<vt_ray_stats*>(d_stats);
-    a.overflow = e->d_overflow;
-    a.block_cursor = e->d_cursor;
+    a.overflow = slot.d_overflow;
+    a.block_cursor = d_cursor;
     a.nrays = n;
     a.npairs = s->npairs;
     a.root_leaf_count = s->root_leaf_count;
@@ -258,7 +284,7 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     a.alpha_texels = s->d_alpha_texels;
     a.n_alpha_mats = s->n_alpha_mats;
     a.reserved_cus = p.persistent && e->reserved_cus ? e->d_reserved : nullptr;
-    a.cu_slots = e->d_reserved ? e->d_reserved + 32 : nullptr;
+    a.cu_slots = d_cu_slots;
     a.reserved_limit = e->reserved_limit;
 
     // the first block of every wave is static (block w -> wave w); the cursor hands out the rest
@@ -268,13 +294,15 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     // 0 = by scene size: cheap rays (small trees) finish fast enough for the single cursor word to become the limit
     a.max_claim = e->max_claim ? e->max_claim : (s->npairs <= 200000u ? 4u : 1u);
     if (p.persistent && a.xcd_cursors)
-        VT_HIP(hipMemsetAsync(e->d_cursor, 0, 512, stream));                 // eight cursors, 64 B apart
+        VT_HIP(hipMemsetAsync(d_cursor, 0, 512, stream));                    // eight cursors, 64 B apart
     else if (p.persistent)
-        VT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_cursor),
+        VT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_cursor),
                                  a.reserved_cus ? 0 : int(p.grid_blocks * (kBlockThreads / 64)), 1, stream));
     if (e->timing) VT_HIP(hipEventRecord(e->ev_start, stream));
     VT_HIP(launch_trace(a, any_hit, stats, p.persistent, p.fetch_dma, s->has_alpha, p.grid_blocks, p.lds_bytes, stream));
     if (e->timing) { VT_HIP(hipEventRecord(e->ev_stop, stream)); e->ev_valid = true; }
+    VT_HIP(hipEventRecord(slot.done, stream));
+    slot.used = true;
     e->last_blocks = p.grid_blocks; e->last_threads = kBlockThreads; e->last_lds = uint32_t(p.lds_bytes);
     e->last_persistent = p.persistent; e->last_dma = p.fetch_dma;
     return VT_OK;
@@ -326,6 +354,20 @@ int reserve_cus(vt_engine* e, uint32_t want)
     return VT_OK;
 }
 
+// (2 % of the scene's diagonal)^2 from the root's two children: how far apart the origins of a ray packet may lie
+float packet_radius2(const vt_node_pair& root)
+{
+    float d2 = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        const vt_bvh_node& l = root.child[0];
+        const vt_bvh_node& r = root.child[1];
+        const float lo = std::min(l.bounds[2 * k], r.bounds[2 * k]), hi = std::max(l.bounds[2 * k + 1], r.bounds[2 * k + 1]);
+        const float ext = hi - lo;
+        if (ext == ext && ext > 0.f && ext < 1e18f) d2 += ext * ext;
+    }
+    return 0.02f * 0.02f * d2;
+}
+
 long env_long(const char* name, long dflt)
 {
     const char* v = std::getenv(name);
@@ -371,7 +413,12 @@ int vt_engine_open(int device, vt_engine** out)
     e->tri_threshold = uint32_t(env_long("VT_TRI_THRESHOLD", e->tri_threshold));
     e->fetch_dma = int(env_long("VT_FETCH_DMA", e->fetch_dma));
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->d_cursor), 1024);
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->d_slot_ctl), vt_engine::kLaunchSlots * vt_engine::kSlotCtlBytes);
+    for (uint32_t k = 0; k < vt_engine::kLaunchSlots && err == hipSuccess; ++k) {
+        e->slots[k].d_ctl = reinterpret_cast<uint32_t*>(e->d_slot_ctl + k * vt_engine::kSlotCtlBytes);
+        err = hipEventCreateWithFlags(&e->slots[k].done, hipEventDisableTiming);
+    }
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_loop, hipEventDisableTiming);
     if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&e->h_tiny_rays), vt_engine::kTinyRays * sizeof(vt_ray), hipHostMallocMapped);
     if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&e->h_tiny_out), vt_engine::kTinyRays * sizeof(vt_hit), hipHostMallocMapped);
     if (err == hipSuccess) err = hipHostGetDevicePointer(&e->d_tiny_rays, e->h_tiny_rays, 0);
@@ -398,8 +445,12 @@ void vt_engine_close(vt_engine* e)
         sc->engine = nullptr;
     }
     e->scenes.clear();
-    if (e->d_cursor) (void)hipFree(e->d_cursor);
-    if (e->d_overflow) (void)hipFree(e->d_overflow);
+    for (vt_engine::LaunchSlot& sl : e->slots) {
+        if (sl.d_overflow) (void)hipFree(sl.d_overflow);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (e->d_slot_ctl) (void)hipFree(e->d_slot_ctl);
+    if (e->ev_loop) (void)hipEventDestroy(e->ev_loop);
     if (e->d_rays) (void)hipFree(e->d_rays);
     if (e->d_out) (void)hipFree(e->d_out);
     if (e->d_loop) (void)hipFree(e->d_loop);
@@ -485,17 +536,7 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
     vt_scene* s = new vt_scene();
     s->engine = e;
     s->has_alpha = has_alpha;
-    if (!hs.pairs.empty()) {                             // scene extent from the root's two children
-        float d2 = 0.f;
-        for (int k = 0; k < 3; ++k) {
-            const vt_bvh_node& l = hs.pairs[0].child[0];
-            const vt_bvh_node& r = hs.pairs[0].child[1];
-            const float lo = std::min(l.bounds[2 * k], r.bounds[2 * k]), hi = std::max(l.bounds[2 * k + 1], r.bounds[2 * k + 1]);
-            const float ext = hi - lo;
-            if (ext == ext && ext > 0.f && ext < 1e18f) d2 += ext * ext;
-        }
-        s->coherent_radius2 = 0.02f * 0.02f * d2;
-    }
+    if (!hs.pairs.empty()) s->coherent_radius2 = packet_radius2(hs.pairs[0]);
     s->npairs = uint32_t(hs.pairs.size());
     s->ntris = uint32_t(hs.tris.size());
     s->max_depth = hs.max_depth;
@@ -593,19 +634,25 @@ static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, si
     vt_engine* e = s->engine;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_trace: hipSetDevice failed");
+    std::lock_guard<std::mutex> host_lock(e->host_mu);       // one host-buffer call at a time per engine (shared staging)
     if (n <= vt_engine::kTinyRays) {
-        // what AccelStruct:Traverse does per call: the kernel works directly on pinned host memory.  The result
-        // slots are pre-set to a value the kernel never writes and the host watches them change (each record is
-        // one 16-B store, each any-hit flag one byte): that is a PCIe write away from the last ray's finish, while
-        // hipStreamSynchronize adds the queue's completion signalling (~10 us per call).  If nothing arrives
-        // within a few milliseconds (a fault, a debugger) the ordinary wait takes over and reports the error.
+        // tiny batches: the kernel works directly on pinned host memory (no copy calls).  The result slots are pre-set
+        // to values the kernel never writes -- prim 0xFFFFFFFE, and a NaN with a payload no arithmetic produces in t, u
+        // and v (a hit's t, u, v are finite, a miss writes zeros) -- and the host watches ALL FOUR words of every
+        // record change (any-hit: the one byte), so nothing depends on a 16-byte device->host store landing as one
+        // piece.  That is a PCIe write away from the last ray's finish, while hipStreamSynchronize adds the queue's
+        // completion signalling (~5-10 us per call).  If nothing arrives within a few milliseconds (a fault, a
+        // debugger) the ordinary wait takes over and reports the error.
         std::memcpy(e->h_tiny_rays, rays, n * sizeof(vt_ray));
         const uint32_t kPendingPrim = 0xFFFFFFFEu;               // not VT_MISS and never a triangle index
+        const uint32_t kPendingF32  = 0x7FA5C3E1u;               // signalling-NaN pattern
         volatile uint32_t* const slots32 = reinterpret_cast<volatile uint32_t*>(e->h_tiny_out);
         volatile uint8_t* const slots8 = reinterpret_cast<volatile uint8_t*>(e->h_tiny_out);
         for (uint64_t i = 0; i < n; ++i) {
-            if (any_hit) slots8[i] = 0xFFu; else slots32[i * 4] = kPendingPrim;
+            if (any_hit) slots8[i] = 0xFFu;
+            else { slots32[i * 4] = kPendingPrim; slots32[i * 4 + 1] = slots32[i * 4 + 2] = slots32[i * 4 + 3] = kPendingF32; }
         }
+        std::atomic_thread_fence(std::memory_order_seq_cst);
         int rc = launch(s, e->d_tiny_rays, n, any_hit ? nullptr : e->d_tiny_out, any_hit ? e->d_tiny_out : nullptr, nullptr,
                         any_hit, false, e->stream);
         if (rc != VT_OK) return rc;
@@ -615,7 +662,9 @@ static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, si
             for (uint32_t spins = 0; !arrived; ++spins) {
                 arrived = true;
                 for (uint64_t i = 0; i < n && arrived; ++i)
-                    arrived = any_hit ? slots8[i] != 0xFFu : slots32[i * 4] != kPendingPrim;
+                    arrived = any_hit ? slots8[i] != 0xFFu
+                                      : (slots32[i * 4] != kPendingPrim && slots32[i * 4 + 1] != kPendingF32 &&
+                                         slots32[i * 4 + 2] != kPendingF32 && slots32[i * 4 + 3] != kPendingF32);
                 if (!arrived && (spins & 1023u) == 1023u &&
                     std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5))
                     break;
@@ -763,7 +812,14 @@ int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t dep
     const uint64_t nblocks = (n + kBlockThreads - 1) / kBlockThreads;
     auto al = [](uint64_t b) { return (b + 255) & ~uint64_t(255); };
     const uint64_t ray_b = al(n * sizeof(vt_ray)), id_b = al(n * 4), hit_b = al(n * sizeof(vt_hit)), off_b = al(nblocks * 4);
-    int rc = ensure_bytes(&e->d_loop, &e->d_loop_bytes, 2 * ray_b + 2 * id_b + hit_b + off_b + 256);
+    // the queues are engine-wide scratch: a loop on another stream may still be using them
+    std::lock_guard<std::mutex> loop_lock(e->host_mu);
+    const size_t loop_need = 2 * ray_b + 2 * id_b + hit_b + off_b + 256;
+    if (e->loop_used) {
+        if (loop_need > e->d_loop_bytes) VT_HIP(hipEventSynchronize(e->ev_loop));     // about to be freed and re-allocated
+        else VT_HIP(hipStreamWaitEvent(stream, e->ev_loop, 0));
+    }
+    int rc = ensure_bytes(&e->d_loop, &e->d_loop_bytes, loop_need);
     if (rc != VT_OK) return rc;
     if (!e->h_live) VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_live), 64));
     char* base = static_cast<char*>(e->d_loop);
@@ -799,6 +855,8 @@ int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t dep
         }
         if (live_out && !last) live_out[d + 1] = m;
     }
+    VT_HIP(hipEventRecord(e->ev_loop, stream));
+    e->loop_used = true;
     return VT_OK;
 }
 
@@ -857,6 +915,11 @@ static int refit_levels(vt_scene* s)
         if (rc != VT_OK) return rc;
     }
     VT_HIP(hipStreamSynchronize(e->stream));
+    if (s->npairs != 0) {                                // the scene's extent moved with the vertices: keep the packet probe's radius current
+        vt_node_pair root;
+        VT_HIP(hipMemcpy(&root, s->d_records, sizeof(root), hipMemcpyDeviceToHost));
+        s->coherent_radius2 = packet_radius2(root);
+    }
     return VT_OK;
 }
 
@@ -867,11 +930,18 @@ int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32
     if (n != s->ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: n differs from the scene's triangle count");
     if (n == 0) return VT_OK;
     if (!verts) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: verts is NULL");
-    if (flags)
-        for (uint32_t i = 0; i < n; ++i) s->has_alpha = s->has_alpha || (flags[i] & VT_TRI_ALPHATEST) != 0;
+    if (flags) {                                         // new flags replace the old ones: so does the scene's alpha-test state
+        bool any = false;
+        for (uint32_t i = 0; i < n && !any; ++i) any = (flags[i] & VT_TRI_ALPHATEST) != 0;
+        s->has_alpha = any;
+    }
     vt_engine* e = s->engine;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_refit: hipSetDevice failed");
+    std::lock_guard<std::mutex> host_lock(e->host_mu);
+    // records and bounds are rewritten in place: traces of this scene still in flight on caller streams must finish
+    // first (vt_trace_*_dev is asynchronous), or rays would read half-updated boxes
+    VT_HIP(hipDeviceSynchronize());
     int rc = ensure_bytes(&e->d_rays, &e->d_rays_bytes, size_t(n) * 9 * sizeof(float));
     if (rc == VT_OK && flags) rc = ensure_bytes(&e->d_out, &e->d_out_bytes, n);
     if (rc != VT_OK) return rc;
@@ -925,6 +995,8 @@ int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uin
     vt_engine* e = s->engine;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_skin_refit: hipSetDevice failed");
+    std::lock_guard<std::mutex> host_lock(e->host_mu);
+    VT_HIP(hipDeviceSynchronize());          // in-flight traces of this scene read the records that are about to change
     if (nmat > s->mats_cap) {
         if (s->d_skin_mats) { VT_HIP(hipFree(s->d_skin_mats)); s->d_skin_mats = nullptr; s->mats_cap = 0; }
         VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_skin_mats), size_t(nmat) * 3 * 64));

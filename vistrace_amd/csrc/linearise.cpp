@@ -48,6 +48,7 @@ int scene_linearise(const Bvh& bvh, const vt_tri64* tris, HostScene& out)
             const uint32_t idx = bvh.prim_indices[leaf.first + q];
             vt_tri64 t = tris[idx];
             t.prim = idx;
+            out.has_alpha = out.has_alpha || (t.flags & VT_TRI_ALPHATEST) != 0;
             out.tris.push_back(t);
         }
         return first;

@@ -31,6 +31,11 @@ struct HostScene {
     std::vector<uint32_t>     pair_depth; // depth of every pair (root's pair = 1), for level-wise refit
     uint32_t max_depth       = 0;      // deepest inner level = stack entries a ray can need
     uint32_t root_leaf_count = 0;      // != 0: the root itself is a leaf over tris[0..count)
+    // host walk only (host_walk.cpp): alpha-test side data, as vt_scene_set_tri_attribs / vt_scene_set_alpha hold it on the device
+    bool                           has_alpha = false;   // a triangle carries VT_TRI_ALPHATEST
+    std::vector<vt_tri_attribs>    attribs;             // original triangle order
+    std::vector<vt_alpha_material> alpha_mats;
+    std::vector<uint8_t>           alpha_texels;
 };
 
 int  bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, int builder, Bvh& out);
