@@ -3,6 +3,7 @@
 // C++ exceptions (the real ThrowError/ArgError/CheckType longjmp out of the C function).
 #pragma once
 
+#include <algorithm>
 #include <cstdio>
 #include <memory>
 #include <stdexcept>
@@ -46,6 +47,30 @@ class State : public ILuaBase {
 public:
     std::vector<Value> stack;
     std::vector<std::string> typeNames;   // user types from CreateMetaTable: id = Type::Count + index
+    std::vector<std::shared_ptr<Table>> metatables;   // same index as typeNames
+    Value globals = NewTable();           // _G
+
+    // obj:name(...) the way Lua resolves it: metatable of the value's type -> __index -> field
+    const Value* find_method(int type, const char* name) const
+    {
+        if (type < Type::Count || size_t(type - Type::Count) >= metatables.size()) return nullptr;
+        const Table& mt = *metatables[size_t(type - Type::Count)];
+        const Table* index = nullptr;
+        for (auto& kv : mt.kv)
+            if (kv.first.type == Type::String && kv.first.str == "__index" && kv.second.type == Type::Table) index = kv.second.tab.get();
+        if (!index) return nullptr;
+        for (auto& kv : index->kv)
+            if (kv.first.type == Type::String && kv.first.str == name) return &kv.second;
+        return nullptr;
+    }
+    const Value* find_global(const char* table, const char* name) const
+    {
+        for (auto& kv : globals.tab->kv)
+            if (kv.first.type == Type::String && kv.first.str == table && kv.second.type == Type::Table)
+                for (auto& f : kv.second.tab->kv)
+                    if (f.first.type == Type::String && f.first.str == name) return &f.second;
+        return nullptr;
+    }
 
     static Value Num(double d) { Value v; v.type = Type::Number; v.num = d; return v; }
     static Value Bool(bool b) { Value v; v.type = Type::Bool; v.b = b; return v; }
@@ -87,6 +112,47 @@ public:
         stack.resize(stack.size() - size_t(amount));
     }
     void CreateTable() override { stack.push_back(NewTable()); }
+    void PushSpecial(int type) override
+    {
+        if (type != SPECIAL_GLOB) throw std::logic_error("FakeLua: only SPECIAL_GLOB is modelled");
+        stack.push_back(globals);
+    }
+    void GetField(int pos, const char* name) override
+    {
+        Value* t = at(pos);
+        if (!t || t->type != Type::Table) throw std::logic_error("FakeLua: GetField on a non-table");
+        Value found = Nil();
+        for (auto& kv : t->tab->kv)
+            if (kv.first.type == Type::String && kv.first.str == name) found = kv.second;
+        stack.push_back(found);
+    }
+    void GetTable(int pos) override
+    {
+        Value* t = at(pos);
+        if (!t || t->type != Type::Table) throw std::logic_error("FakeLua: GetTable on a non-table");
+        std::shared_ptr<Table> tab = t->tab;
+        const Value key = stack.back();
+        stack.pop_back();
+        Value found = Nil();
+        for (auto& kv : tab->kv)
+            if (key_equal(kv.first, key)) found = kv.second;
+        stack.push_back(found);
+    }
+    void Call(int nargs, int nresults) override
+    {
+        if (int(stack.size()) < nargs + 1) throw std::logic_error("FakeLua: Call with too few values on the stack");
+        const size_t base = stack.size() - size_t(nargs) - 1;
+        const Value fn = stack[base];
+        std::vector<Value> frame(stack.begin() + long(base) + 1, stack.end());
+        stack.resize(base);
+        if (fn.type != Type::Function || !fn.fn) throw LuaError("attempt to call a " + type_name(fn.type) + " value");
+        frame.swap(stack);                         // the callee sees only its arguments
+        int nret = 0;
+        try { nret = fn.fn(this); } catch (...) { frame.swap(stack); throw; }
+        std::vector<Value> rets(stack.end() - std::min<long>(nret, long(stack.size())), stack.end());
+        frame.swap(stack);
+        for (int i = 0; i < nresults; ++i) stack.push_back(i < int(rets.size()) ? rets[size_t(i)] : Nil());
+    }
     void SetField(int pos, const char* name) override
     {
         Value val = stack.back();
@@ -154,6 +220,7 @@ public:
     {
         typeNames.push_back(name);
         stack.push_back(NewTable());
+        metatables.push_back(stack.back().tab);
         return Type::Count + int(typeNames.size()) - 1;
     }
     void PushUserType(void* data, int type) override { stack.push_back(User(data, type)); }

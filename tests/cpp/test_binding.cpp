@@ -65,6 +65,29 @@ static void test_cpu_side()
     RegisterTracingApi(&L);
     CHECK(AccelStruct_id >= LT::Count && TraceResult::id >= LT::Count && AccelStruct_id != TraceResult::id);
     CHECK(L.Top() == 0);
+    // the registered surface, by name: the reference's Tracing API (VisTrace.cpp:1693-1720, 1745-1751, 1820) + TraverseBatch
+    for (const char* m : {"__gc", "__tostring", "Pos", "Incident", "Distance", "Entity", "GeometricNormal", "Barycentric", "TextureUV",
+                          "SubMaterialIndex", "MaterialFlags", "SurfaceFlags", "HitSky", "HitWater", "FrontFacing"})
+        CHECK(L.find_method(TraceResult::id, m) != nullptr);
+    for (const char* m : {"__gc", "__tostring", "Traverse", "Rebuild", "TraverseBatch"})
+        CHECK(L.find_method(AccelStruct_id, m) != nullptr);
+    CHECK(L.find_method(TraceResult::id, "EntIndex") == nullptr);       // not a reference name
+    CHECK(L.find_global("vistrace", "CreateAccel") != nullptr && L.find_global("vistrace", "CreateAccel")->fn == vistrace_CreateAccel);
+    CHECK(L.find_global("vistrace", "CalcRayOrigin") != nullptr);
+    {   // vistrace.CalcRayOrigin (VisTrace.cpp:1478-1519): far from the origin the offset is an integer step on the bit pattern
+        L.PushValue(State::Vec(100.f, -100.f, 0.01f));
+        L.PushValue(State::Vec(0.f, 1.f, 1.f));
+        CHECK(L.find_global("vistrace", "CalcRayOrigin")->fn(&L) == 1);
+        ::Vector o = L.GetVector(-1);
+        float y = -100.f; int32_t bits; std::memcpy(&bits, &y, 4); bits += -256; float ey; std::memcpy(&ey, &bits, 4);
+        CHECK(o.x == 100.f && o.y == ey && o.z == 0.01f + 1.f / 65536.f);
+        L.Pop(L.Top());
+    }
+    {
+        fakelua::Value tr = State::User(nullptr, TraceResult::id);
+        CHECK(L.find_method(TraceResult::id, "__tostring")->fn(&L) == 1 && L.stack.back().str == "VisTraceResult");
+        L.Pop(L.Top());
+    }
 
     // Traverse on an accel that was never built -> the reference's message (AccelStruct.cpp:780)
     {
@@ -110,7 +133,11 @@ static void test_cpu_side()
     {
         Triangle t = make_tri({0, 0, 0}, {1, 0, 0}, {0, 1, 0}, false, 3);
         Entity ent; ent.id = 9;
-        TraceResult r(Vec3{0, 0, -2}, 1.0f, -1, -1, t, 5, Vec2{0.25f, 0.5f}, ent);
+        Material mat{"brush/sky", MATFLAG_NOCULL};
+        mat.surfFlags = SURF_SKY | 0x80u;
+        mat.water = true;
+        TraceResult r(Vec3{0, 0, -2}, 1.0f, -1, -1, t, 5, Vec2{0.25f, 0.5f}, ent, mat);
+        CHECK(r.hitSky && r.HitWater() && r.GetMaterialFlags() == MATFLAG_NOCULL && r.GetSurfFlags() == (SURF_SKY | 0x80u));
         CHECK(r.uvw.x == 0.25f && r.uvw.y == 0.5f && r.uvw.z == 0.25f);
         CHECK(r.GetPos().x == 0.25f && r.GetPos().y == 0.5f && r.GetPos().z == 0.0f);
         CHECK(r.geometricNormal.x == 0 && r.geometricNormal.y == 0 && r.geometricNormal.z == -1);   // cross(e1,e2)/|n|
@@ -121,24 +148,53 @@ static void test_cpu_side()
     }
 }
 
+// obj:name(args...) the way a script calls it: the function is looked up BY NAME through the metatable that
+// RegisterTracingApi created for the object's type; the stack holds self + args on entry.
+static int call_method(State& L, const fakelua::Value& self, const char* name, std::vector<fakelua::Value> args = {})
+{
+    const fakelua::Value* f = L.find_method(self.type, name);
+    if (!f || f->type != LT::Function || !f->fn) { ++g_fail; std::printf("FAIL: no method %s registered\n", name); return -1; }
+    L.Pop(L.Top());
+    L.PushValue(self);
+    for (auto& v : args) L.PushValue(v);
+    return f->fn(&L);
+}
+
 static int call_traverse(State& L, AccelStruct* a, std::vector<fakelua::Value> args)
 {
-    L.Pop(L.Top());
-    L.PushUserType(a, AccelStruct_id);
-    for (auto& v : args) L.PushValue(v);
-    return AccelStruct_Traverse(&L);
+    return call_method(L, State::User(a, AccelStruct_id), "Traverse", std::move(args));
+}
+
+// the engine's global Entity(index) as the fake game provides it: index -> entity userdata, anything else -> NULL entity
+static void* g_entityByIndex[64] = {};
+static int Fake_Entity(GarrysMod::Lua::ILuaBase* LUA)
+{
+    const int idx = int(LUA->GetNumber(1));
+    void* p = (idx >= 0 && idx < 64) ? g_entityByIndex[idx] : nullptr;
+    LUA->PushUserType(p, LT::Entity);
+    return 1;
+}
+static void install_entity_global(State& L)
+{
+    L.PushSpecial(GarrysMod::Lua::SPECIAL_GLOB);
+    L.PushCFunction(Fake_Entity);
+    L.SetField(-2, "Entity");
+    L.Pop();
 }
 
 static void test_gpu_side()
 {
     State L;
     RegisterTracingApi(&L);
+    install_entity_global(L);
     FakeMeshSource src;
     AccelStruct::SetEntityMeshSource(&src);
 
     World world;
     world.materials.push_back(Material{"brush/floor", MATFLAG_NONE});
     world.materials.push_back(Material{"brush/nocull", MATFLAG_NOCULL});
+    world.materials[1].surfFlags = SURF_SKY;
+    world.materials[1].water = true;
     world.entities.push_back(Entity{nullptr, 0});
     // one-sided floor: n = cross(e1,e2) with e1=p0-p1, e2=p2-p0 -> (0,0,-1); rays going -z have nDotDir > 0 => culled
     world.triangles.push_back(make_tri({0, 0, 0}, {10, 0, 0}, {0, 10, 0}, true, 0));
@@ -148,11 +204,13 @@ static void test_gpu_side()
 
     // vistrace.CreateAccel({ent}, true)
     int dummyEntity = 0;
+    g_entityByIndex[42] = &dummyEntity;                    // Entity(42) is the entity the accel was built from
     L.PushValue(State::Array({State::User(&dummyEntity, LT::Entity)}));
     L.PushBool(true);
-    CHECK(vistrace_CreateAccel(&L) == 1);
+    CHECK(L.find_global("vistrace", "CreateAccel")->fn(&L) == 1);       // vistrace.CreateAccel, resolved by name
     CHECK(L.Top() >= 1 && L.GetType(-1) == AccelStruct_id);
     AccelStruct* accel = L.GetUserType<AccelStruct>(-1, AccelStruct_id);
+    const fakelua::Value accelValue = L.stack.back();
     CHECK(accel && accel->IsBuilt() && accel->TriangleCount() == 3 && src.calls == 1);
     CHECK(accel->GetMaterial(1).flags == MATFLAG_NOCULL);
 
@@ -162,22 +220,31 @@ static void test_gpu_side()
     {
         TraceResult* r = L.GetUserType<TraceResult>(1, TraceResult::id);
         CHECK(r->distance == 3.0f && r->entIdx == 42 && r->primitiveIndex == 2);
-        CHECK(TraceResult_Pos(&L) == 1);
+        const fakelua::Value res = L.stack[0];
+        CHECK(call_method(L, res, "Pos") == 1);
         ::Vector p = L.GetVector(-1);
         CHECK(p.x == 1.f && p.y == 1.f && p.z == 5.f);
-        L.Pop();
-        CHECK(TraceResult_Distance(&L) == 1 && L.GetNumber(-1) == 3.0); L.Pop();
-        CHECK(TraceResult_Barycentric(&L) == 1);
+        CHECK(call_method(L, res, "Distance") == 1 && L.GetNumber(-1) == 3.0);
+        CHECK(call_method(L, res, "Barycentric") == 1);
         ::Vector b = L.GetVector(-1);
         CHECK(b.x == 0.25f && b.y == 0.25f && b.z == 0.5f);
-        L.Pop();
-        CHECK(TraceResult_EntIndex(&L) == 1 && L.GetNumber(-1) == 42); L.Pop();
-        CHECK(TraceResult_GeometricNormal(&L) == 1 && L.GetVector(-1).z == -1.f); L.Pop();
-        CHECK(TraceResult_FrontFacing(&L) == 1 && L.GetBool(-1) == false); L.Pop();
-        CHECK(TraceResult_SubMaterialIndex(&L) == 1 && L.GetNumber(-1) == 3); L.Pop();   // 2 world mats + 0, 1-based
-        CHECK(TraceResult_Incident(&L) == 1 && L.GetVector(-1).z == 1.f); L.Pop();
-        CHECK(TraceResult_TextureUV(&L) == 1); L.Pop();
-        CHECK(TraceResult_gc(&L) == 0);
+        // TraceResult:Entity() goes through the game's global Entity(entIdx) (VisTrace.cpp:495-513)
+        CHECK(call_method(L, res, "Entity") == 1 && L.GetType(-1) == LT::Entity && L.GetUserdataRaw(-1, LT::Entity) == &dummyEntity);
+        int other = 0;
+        g_entityByIndex[42] = &other;                          // the index now names another entity -> NULL entity (Entity(-1))
+        CHECK(call_method(L, res, "Entity") == 1 && L.GetType(-1) == LT::Entity && L.GetUserdataRaw(-1, LT::Entity) == nullptr);
+        g_entityByIndex[42] = &dummyEntity;
+        CHECK(call_method(L, res, "GeometricNormal") == 1 && L.GetVector(-1).z == -1.f);
+        CHECK(call_method(L, res, "FrontFacing") == 1 && L.GetBool(-1) == false);
+        CHECK(call_method(L, res, "SubMaterialIndex") == 1 && L.GetNumber(-1) == 3);   // 2 world mats + 0, 1-based
+        CHECK(call_method(L, res, "MaterialFlags") == 1 && L.GetNumber(-1) == double(MATFLAG_NONE));
+        CHECK(call_method(L, res, "SurfaceFlags") == 1 && L.GetNumber(-1) == 0.0);
+        CHECK(call_method(L, res, "HitSky") == 1 && L.GetBool(-1) == false);
+        CHECK(call_method(L, res, "HitWater") == 1 && L.GetBool(-1) == false);
+        CHECK(call_method(L, res, "Incident") == 1 && L.GetVector(-1).z == 1.f);
+        CHECK(call_method(L, res, "TextureUV") == 1 && L.GetType(-1) == LT::Table);
+        CHECK(call_method(L, res, "__tostring") == 1 && L.stack.back().str == "VisTraceResult");
+        CHECK(call_method(L, res, "__gc") == 0);
         CHECK(L.GetUserType<TraceResult>(1, TraceResult::id) == nullptr);
     }
     // un-normalised direction: t scales, Incident is normalised
@@ -192,7 +259,15 @@ static void test_gpu_side()
     CHECK(call_traverse(L, accel, {State::Vec(3, 3, -3), State::Vec(0, 0, 1)}) == 1);
     delete L.GetUserType<TraceResult>(1, TraceResult::id);
     CHECK(call_traverse(L, accel, {State::Vec(22, 2, 3), State::Vec(0, 0, -1)}) == 1);
-    delete L.GetUserType<TraceResult>(1, TraceResult::id);
+    {   // the nocull floor's material carries SURF_SKY and water (VisTrace.cpp:613-641)
+        const fakelua::Value res = L.stack[0];
+        CHECK(call_method(L, res, "MaterialFlags") == 1 && L.GetNumber(-1) == double(MATFLAG_NOCULL));
+        CHECK(call_method(L, res, "SurfaceFlags") == 1 && L.GetNumber(-1) == double(SURF_SKY));
+        CHECK(call_method(L, res, "HitSky") == 1 && L.GetBool(-1) == true);
+        CHECK(call_method(L, res, "HitWater") == 1 && L.GetBool(-1) == true);
+        CHECK(call_method(L, res, "Entity") == 1 && L.GetUserdataRaw(-1, LT::Entity) == nullptr);   // world: Entity(0) is not rawEnt... NULL
+        CHECK(call_method(L, res, "__gc") == 0);
+    }
     // tMin / tMax window and nil placeholders
     CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1), State::Num(0), State::Num(2.5)}) == 0);
     CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1), State::Nil(), State::Num(3.0)}) == 1);
@@ -214,17 +289,15 @@ static void test_gpu_side()
     e = error_of([&] { call_traverse(L, accel, {State::Vec(0, 0, 1), State::Vec(0, 0, -1), State::Str("x")}); }, &arg);
     CHECK(contains(e, "number expected") && arg == 4);
 
-    // TraverseBatch agrees with Traverse ray by ray
+    // TraverseBatch: a small batch (host walk) and a batch above the device crossover (one GPU launch) agree with
+    // Traverse ray by ray; fields are read by index, so a nil tMin keeps its default and tMax stays field 4
     {
-        L.Pop(L.Top());
-        L.PushUserType(accel, AccelStruct_id);
-        L.PushValue(State::Array({
+        CHECK(call_method(L, accelValue, "TraverseBatch", {State::Array({
             State::Array({State::Vec(1, 1, 8), State::Vec(0, 0, -1)}),
             State::Array({State::Vec(100, 100, 8), State::Vec(0, 0, 1)}),
             State::Array({State::Vec(3, 3, -3), State::Vec(0, 0, 1), State::Num(0), State::Num(10)}),
             State::Array({State::Vec(3, 3, -3), State::Vec(0, 0, 1), State::Num(0), State::Num(2)}),
-        }));
-        CHECK(AccelStruct_TraverseBatch(&L) == 1);
+        })}) == 1);
         CHECK(L.Top() == 1 && L.GetType(1) == LT::Table);
         auto& kv = L.stack.back().tab->kv;
         CHECK(kv.size() == 4);
@@ -235,22 +308,58 @@ static void test_gpu_side()
         CHECK(r0->distance == 3.0f && r0->entIdx == 42 && r2->distance == 3.0f && r2->primitiveIndex == 0);
         delete r0; delete r2;
         L.Pop(L.Top());
+
+        // {o, d, nil, tMax}: a table with a hole at 3 (lua_next would skip it)
+        fakelua::Value holed = State::NewTable();
+        holed.tab->kv.push_back({State::Num(1), State::Vec(1, 1, 8)});
+        holed.tab->kv.push_back({State::Num(2), State::Vec(0, 0, -1)});
+        holed.tab->kv.push_back({State::Num(4), State::Num(2.5)});              // tMax 2.5 < t = 3 -> miss
+        CHECK(call_method(L, accelValue, "TraverseBatch", {State::Array({holed})}) == 1);
+        CHECK(L.stack.back().tab->kv.size() == 1 && L.stack.back().tab->kv[0].second.type == LT::Bool);
+        std::string be = error_of([&] { call_method(L, accelValue, "TraverseBatch", {State::Array({State::Array({State::Vec(0, 0, 1)})})}); });
+        CHECK(be == "Each ray must be a table {origin, direction[, tMin[, tMax]]}");
+        be = error_of([&] { call_method(L, accelValue, "TraverseBatch", {State::Array({State::Array({State::Vec(0, 0, 1), State::Vec(0, 0, 1), State::Num(3), State::Num(2)})})}); });
+        CHECK(be == "tMax must be greater than tMin");
+
+        // 400 rays over the three surfaces: above AccelStruct::kDeviceBatchMin -> the device; each must equal the
+        // single-ray Traverse (host walk) bit for bit
+        std::vector<fakelua::Value> many;
+        std::vector<std::pair<::Vector, ::Vector>> od;
+        for (int i = 0; i < 400; ++i) {
+            const float x = float((i * 37) % 320) * 0.1f - 1.f, y = float((i * 53) % 120) * 0.1f - 1.f;
+            const bool up = (i % 3) == 0;
+            od.push_back({::Vector{x, y, up ? -4.f : 9.f}, ::Vector{0.01f * float(i % 7), 0.02f, up ? 1.f : -1.f}});
+            many.push_back(State::Array({State::Vec(od.back().first.x, od.back().first.y, od.back().first.z),
+                                         State::Vec(od.back().second.x, od.back().second.y, od.back().second.z)}));
+        }
+        CHECK(call_method(L, accelValue, "TraverseBatch", {State::Array(many)}) == 1);
+        const fakelua::Value batch = L.stack.back();
+        CHECK(batch.tab->kv.size() == 400);
+        int nhit = 0;
+        for (int i = 0; i < 400 && batch.tab->kv.size() == 400; ++i) {
+            const int got = call_traverse(L, accel, {State::Vec(od[i].first.x, od[i].first.y, od[i].first.z),
+                                                     State::Vec(od[i].second.x, od[i].second.y, od[i].second.z)});
+            const fakelua::Value& bv = batch.tab->kv[size_t(i)].second;
+            CHECK((got == 1) == (bv.type == TraceResult::id));
+            if (got == 1 && bv.type == TraceResult::id) {
+                TraceResult* a = L.GetUserType<TraceResult>(1, TraceResult::id);
+                TraceResult* b = static_cast<TraceResult*>(*bv.ud);
+                CHECK(a->primitiveIndex == b->primitiveIndex && a->distance == b->distance && a->uvw.x == b->uvw.x && a->uvw.y == b->uvw.y);
+                ++nhit;
+                delete a; delete b;
+            }
+        }
+        CHECK(nhit > 100 && nhit < 400);
+        L.Pop(L.Top());
     }
 
     // Rebuild(nil, false): no world, no entities -> empty but valid accel, every trace misses
     {
-        L.Pop(L.Top());
-        L.PushUserType(accel, AccelStruct_id);
-        L.PushNil();
-        L.PushBool(false);
-        CHECK(AccelStruct_Rebuild(&L) == 0);
+        CHECK(call_method(L, accelValue, "Rebuild", {State::Nil(), State::Bool(false)}) == 0);
         CHECK(accel->IsBuilt() && accel->TriangleCount() == 0);
         CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1)}) == 0);
         // Rebuild({ent}) with the world again
-        L.Pop(L.Top());
-        L.PushUserType(accel, AccelStruct_id);
-        L.PushValue(State::Array({State::User(&dummyEntity, LT::Entity), State::User(&dummyEntity, LT::Entity)}));
-        CHECK(AccelStruct_Rebuild(&L) == 0);
+        CHECK(call_method(L, accelValue, "Rebuild", {State::Array({State::User(&dummyEntity, LT::Entity), State::User(&dummyEntity, LT::Entity)})}) == 0);
         CHECK(accel->TriangleCount() == 4 && src.calls == 3);
         CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1)}) == 1);
         delete L.GetUserType<TraceResult>(1, TraceResult::id);
@@ -263,9 +372,7 @@ static void test_gpu_side()
         fence.baseAlpha = {0, 255, 255, 0};
         world.materials.push_back(fence);
         world.triangles.push_back(make_tri({40, 0, 0}, {50, 0, 0}, {40, 10, 0}, false, 2));   // uvs (0,0) (1,0) (0,1)
-        L.Pop(L.Top());
-        L.PushUserType(accel, AccelStruct_id);
-        CHECK(AccelStruct_Rebuild(&L) == 0);
+        CHECK(call_method(L, accelValue, "Rebuild") == 0);
         CHECK(accel->IsBuilt());
         // barycentric (u,v) = (0.2,0.2) -> texel (0,0): alpha 0 -> the ray passes through the fence
         CHECK(call_traverse(L, accel, {State::Vec(42, 2, 8), State::Vec(0, 0, -1)}) == 0);
@@ -274,17 +381,14 @@ static void test_gpu_side()
         delete L.GetUserType<TraceResult>(1, TraceResult::id);
         // a reference of 0 keeps every hit (alpha < 0 never holds)
         world.materials.back().alphatestreference = 0.f;
-        L.Pop(L.Top());
-        L.PushUserType(accel, AccelStruct_id);
-        CHECK(AccelStruct_Rebuild(&L) == 0);
+        CHECK(call_method(L, accelValue, "Rebuild") == 0);
         CHECK(call_traverse(L, accel, {State::Vec(42, 2, 8), State::Vec(0, 0, -1)}) == 1);
         delete L.GetUserType<TraceResult>(1, TraceResult::id);
         world.triangles.pop_back();
         world.materials.pop_back();
     }
-    L.Pop(L.Top());
-    L.PushUserType(accel, AccelStruct_id);
-    CHECK(AccelStruct_gc(&L) == 0);
+    CHECK(call_method(L, accelValue, "__tostring") == 1 && L.stack.back().str == "AccelStruct");
+    CHECK(call_method(L, accelValue, "__gc") == 0);
     SetWorld(nullptr);
     AccelStruct::SetEntityMeshSource(nullptr);
 }
@@ -328,6 +432,32 @@ static void bench_single_calls()
         if (pass) std::printf("config 1 through the binding: %d accel:Traverse calls, %d hits, %.1f us per call\n", calls, hits, us);
     }
     CHECK(hits > calls / 2);
+    // host walk against the device for small batches: where does a launch start to pay?  (AccelStruct::kDeviceBatchMin)
+    {
+        std::vector<vt_ray> rays(4096);
+        for (auto& r : rays) {
+            r = vt_ray{{next() * 40 - 20, next() * 40 - 20, 60}, {next() * 2 - 1, next() * 2 - 1, -(0.2f + next())}, 0.f, FLT_MAX};
+        }
+        std::vector<vt_hit> h_host(rays.size()), h_dev(rays.size());
+        for (uint64_t n : {1ull, 4ull, 8ull, 16ull, 32ull, 64ull, 256ull, 4096ull}) {
+            double us[2] = {0, 0};
+            for (int side = 0; side < 2; ++side) {
+                const int reps = n >= 4096 ? 50 : 2000;
+                for (int pass = 0; pass < 2; ++pass) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    for (int r = 0; r < reps; ++r) {
+                        const vt_ray* src = rays.data() + (uint64_t(r) * n) % (rays.size() - n + 1);
+                        const int rc = side == 0 ? accel->TraceClosestHost(src, n, h_host.data()) : accel->TraceClosestDevice(src, n, h_dev.data());
+                        if (rc != VT_OK) { ++g_fail; std::printf("FAIL trace rc %d: %s\n", rc, vt_last_error()); r = reps; }
+                    }
+                    us[side] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+                }
+            }
+            CHECK(accel->TraceClosestHost(rays.data(), n, h_host.data()) == VT_OK && accel->TraceClosestDevice(rays.data(), n, h_dev.data()) == VT_OK);
+            CHECK(std::memcmp(h_host.data(), h_dev.data(), n * sizeof(vt_hit)) == 0);    // host walk == device, bit for bit
+            std::printf("batch of %5llu rays: host walk %8.2f us, device %8.2f us per call\n", (unsigned long long)n, us[0], us[1]);
+        }
+    }
     L.Pop(L.Top());
     L.PushUserType(accel, AccelStruct_id);
     CHECK(AccelStruct_gc(&L) == 0);

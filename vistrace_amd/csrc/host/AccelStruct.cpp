@@ -4,6 +4,8 @@
 #include "AccelStruct.h"
 
 #include <cfloat>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -26,8 +28,9 @@ vt_engine* Engine(ILuaBase* LUA)
         if (const char* e = std::getenv("VISTRACE_DEVICE")) dev = std::atoi(e);
         if (vt_engine_open(dev, &g_engine) != VT_OK) {
             g_engine = nullptr;
-            std::string msg = std::string("VisTrace: cannot open the HIP device: ") + vt_last_error();
-            LUA->ThrowError(msg.c_str());
+            static thread_local char msg[512];
+            std::snprintf(msg, sizeof(msg), "VisTrace: cannot open the HIP device: %s", vt_last_error());
+            LUA->ThrowError(msg);
         }
     }
     return g_engine;
@@ -37,7 +40,7 @@ vt_engine* Engine(ILuaBase* LUA)
 
 void AccelStruct::SetEntityMeshSource(IEntityMeshSource* src) { g_meshSource = src; }
 
-AccelStruct::AccelStruct() : mAccelBuilt(false), mpScene(nullptr) {}
+AccelStruct::AccelStruct() : mAccelBuilt(false), mpScene(nullptr), mpHostScene(nullptr) {}
 
 AccelStruct::~AccelStruct() { ReleaseDevice(); }                       // AccelStruct.cpp:525-531
 
@@ -45,10 +48,16 @@ void AccelStruct::ReleaseDevice()
 {
     if (mpScene) vt_scene_free(mpScene);
     mpScene = nullptr;
+    if (mpHostScene) vt_host_scene_free(mpHostScene);
+    mpHostScene = nullptr;
 }
 
 void AccelStruct::PopulateAccel(ILuaBase* LUA, const World* pWorld)
 {
+    // ThrowError does not return and (in the real module: longjmp) does not unwind C++ frames, so every raise below
+    // happens while no local with a destructor is alive: entities are appended in AppendEntity(), the engine is opened
+    // between the entity loop and the build, and the build runs in BuildAndUpload(), whose vectors are gone when its
+    // status is turned into a Lua error.
     // tear down the previous build (AccelStruct.cpp:537-550)
     mAccelBuilt = false;
     ReleaseDevice();
@@ -67,25 +76,39 @@ void AccelStruct::PopulateAccel(ILuaBase* LUA, const World* pWorld)
     while (LUA->Next(-2) != 0) {
         if (!LUA->IsType(-1, Type::Entity)) LUA->ThrowError("Build list must only contain entities");   // :575
         if (g_meshSource) {
-            Entity ent;
-            std::vector<Triangle> tris;
-            std::vector<Material> mats;
-            void* ud = LUA->GetUserdataRaw(-1, Type::Entity);
-            if (g_meshSource->AppendEntity(ud, ent, tris, mats)) {
-                if (mEntities.size() >= 65535) LUA->ThrowError("Too many entities in build list");       // uint16_t entIdx
-                const size_t matBase = mMaterials.size();
-                const uint16_t entIdx = uint16_t(mEntities.size());
-                for (Triangle& t : tris) { t.material += matBase; t.entIdx = entIdx; }
-                mMaterials.insert(mMaterials.end(), mats.begin(), mats.end());
-                mTriangles.insert(mTriangles.end(), tris.begin(), tris.end());
-                mEntities.push_back(ent);
-            }
+            if (mEntities.size() >= 65535) LUA->ThrowError("Too many entities in build list");           // uint16_t entIdx
+            AppendEntity(LUA->GetUserdataRaw(-1, Type::Entity));
         }
         LUA->Pop();                                                     // pop value, keep key
     }
     LUA->Pop();                                                         // pop entity table (:760)
 
     // Build BVH (:762-775): CPU PLOC + leaf collapse, re-pack, upload once per Rebuild
+    vt_engine* eng = Engine(LUA);
+    if (BuildAndUpload(eng) != VT_OK) {
+        static thread_local char msg[512];
+        std::snprintf(msg, sizeof(msg), "VisTrace: acceleration structure build failed: %s", vt_last_error());
+        LUA->ThrowError(msg);
+    }
+    mAccelBuilt = true;
+}
+
+void AccelStruct::AppendEntity(void* entityUserData)
+{
+    Entity ent;
+    std::vector<Triangle> tris;
+    std::vector<Material> mats;
+    if (!g_meshSource->AppendEntity(entityUserData, ent, tris, mats)) return;
+    const size_t matBase = mMaterials.size();
+    const uint16_t entIdx = uint16_t(mEntities.size());
+    for (Triangle& t : tris) { t.material += matBase; t.entIdx = entIdx; }
+    mMaterials.insert(mMaterials.end(), mats.begin(), mats.end());
+    mTriangles.insert(mTriangles.end(), tris.begin(), tris.end());
+    mEntities.push_back(ent);
+}
+
+int AccelStruct::BuildAndUpload(vt_engine* eng)
+{
     const uint32_t n = uint32_t(mTriangles.size());
     std::vector<float> verts(size_t(n) * 9);
     std::vector<uint8_t> flags(n);
@@ -101,22 +124,14 @@ void AccelStruct::PopulateAccel(ILuaBase* LUA, const World* pWorld)
     }
     std::vector<vt_tri64> recs(n);
     vt_bvh* bvh = nullptr;
-    vt_host_scene* hs = nullptr;
     int rc = vt_tris_setup(verts.data(), flags.data(), n, recs.data());
     if (rc == VT_OK) rc = vt_bvh_build(recs.data(), n, 0, &bvh);
-    if (rc == VT_OK) rc = vt_scene_linearise(bvh, recs.data(), &hs);
-    vt_engine* eng = nullptr;
-    if (rc == VT_OK) eng = Engine(LUA);
-    if (rc == VT_OK) rc = vt_scene_upload(eng, hs, &mpScene);
-    if (rc == VT_OK) rc = UploadAlphaTestData(flags);
-    if (hs) vt_host_scene_free(hs);
+    if (rc == VT_OK) rc = vt_scene_linearise(bvh, recs.data(), &mpHostScene);   // kept: single rays are walked on the host
     if (bvh) vt_bvh_free(bvh);
-    if (rc != VT_OK) {
-        mpScene = nullptr;
-        std::string msg = std::string("VisTrace: acceleration structure build failed: ") + vt_last_error();
-        LUA->ThrowError(msg.c_str());
-    }
-    mAccelBuilt = true;
+    if (rc == VT_OK) rc = vt_scene_upload(eng, mpHostScene, &mpScene);           // replicated to every device of the engine
+    if (rc == VT_OK) rc = UploadAlphaTestData(flags);
+    if (rc != VT_OK) ReleaseDevice();
+    return rc;
 }
 
 // Side data of the in-kernel alpha test (Primitives.h:196-208), only when a material carries the flag: per-triangle
@@ -154,7 +169,9 @@ int AccelStruct::UploadAlphaTestData(const std::vector<uint8_t>& flags)
     }
     int rc = vt_scene_set_tri_attribs(mpScene, attribs.data(), uint32_t(attribs.size()));
     if (rc == VT_OK) rc = vt_scene_set_alpha(mpScene, mats.data(), uint32_t(mats.size()), texels.data(), texels.size());
-    if (rc != VT_OK) { vt_scene_free(mpScene); mpScene = nullptr; }
+    if (rc == VT_OK)                                        // the same tables for the host walk
+        rc = vt_host_scene_set_alpha(mpHostScene, attribs.data(), uint32_t(attribs.size()), mats.data(), uint32_t(mats.size()),
+                                     texels.data(), texels.size());
     return rc;
 }
 
@@ -163,8 +180,10 @@ TraceResult* AccelStruct::MakeResult(const vt_ray& ray, const vt_hit& hit, float
     const Triangle& tri = mTriangles[hit.prim];                          // :821
     static const Entity kNoEntity{};
     const Entity& ent = tri.entIdx < mEntities.size() ? mEntities[tri.entIdx] : kNoEntity;   // :822
+    static const Material kNoMaterial{};
+    const Material& mat = tri.material < mMaterials.size() ? mMaterials[tri.material] : kNoMaterial;   // :823
     return new TraceResult(Vec3{ray.dir[0], ray.dir[1], ray.dir[2]}, hit.t, coneWidth, coneAngle, tri, hit.prim,
-                           Vec2{hit.u, hit.v}, ent);                     // :825-831
+                           Vec2{hit.u, hit.v}, ent, mat);                // :825-831
 }
 
 int AccelStruct::Traverse(ILuaBase* LUA)
@@ -193,11 +212,14 @@ int AccelStruct::Traverse(ILuaBase* LUA)
 
     LUA->Pop(LUA->Top());
 
+    // One ray per call (the reference's `mpTraverser->traverse(ray, *mpIntersector)`, :818): walked on the host copy
+    // of the linearised scene -- 1-2 us against ~20 us for a launch-bound lone ray on the device (BASELINE config 1).
     const vt_ray ray{{origin.x, origin.y, origin.z}, {direction.x, direction.y, direction.z}, tMin, tMax};
     vt_hit hit;
-    if (vt_trace_closest(mpScene, &ray, 1, &hit) != VT_OK) {             // replaces :818
-        std::string msg = std::string("VisTrace: traversal failed: ") + vt_last_error();
-        LUA->ThrowError(msg.c_str());
+    if (vt_host_scene_trace_closest(mpHostScene, &ray, 1, &hit) != VT_OK) {
+        static thread_local char msg[512];
+        std::snprintf(msg, sizeof(msg), "VisTrace: traversal failed: %s", vt_last_error());
+        LUA->ThrowError(msg);
     }
     if (hit.prim != VT_MISS) {
         LUA->PushUserType_Value(MakeResult(ray, hit, coneWidth, coneAngle), TraceResult::id);
@@ -209,6 +231,19 @@ int AccelStruct::Traverse(ILuaBase* LUA)
 int AccelStruct::TraceClosest(const vt_ray* rays, uint64_t n, vt_hit* hits) const
 {
     if (!mAccelBuilt) return VT_ERR_INVALID_ARG;
+    // below the crossover a launch costs more than walking the rays on this thread (measured: tests/cpp --bench)
+    return n < kDeviceBatchMin ? TraceClosestHost(rays, n, hits) : TraceClosestDevice(rays, n, hits);
+}
+
+int AccelStruct::TraceClosestHost(const vt_ray* rays, uint64_t n, vt_hit* hits) const
+{
+    if (!mAccelBuilt) return VT_ERR_INVALID_ARG;
+    return vt_host_scene_trace_closest(mpHostScene, rays, n, hits);
+}
+
+int AccelStruct::TraceClosestDevice(const vt_ray* rays, uint64_t n, vt_hit* hits) const
+{
+    if (!mAccelBuilt) return VT_ERR_INVALID_ARG;
     return vt_trace_closest(mpScene, rays, n, hits);
 }
 
@@ -217,46 +252,55 @@ int AccelStruct::TraverseBatch(ILuaBase* LUA)
     if (!mAccelBuilt)
         LUA->ThrowError("Unable to perform traversal, acceleration structure invalid (use AccelStruct:Rebuild to rebuild it)");
     LUA->CheckType(2, Type::Table);
-    std::vector<vt_ray> rays;
-    // rays[i] = { origin, direction, tMin?, tMax? } with the defaults and checks of Traverse
-    LUA->PushNil();
-    while (LUA->Next(2) != 0) {
-        LUA->CheckType(-1, Type::Table);
-        const int rt = LUA->Top();
-        vt_ray r{{0, 0, 0}, {0, 0, 0}, 0.f, FLT_MAX};
-        int field = 0;
-        LUA->PushNil();
-        while (LUA->Next(rt) != 0) {
-            ++field;
-            if (field <= 2) {
-                LUA->CheckType(-1, Type::Vector);
-                const Vector v = LUA->GetVector(-1);
-                float* dst = field == 1 ? r.org : r.dir;
-                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z;
-            } else if (field == 3 && !LUA->IsType(-1, Type::Nil)) {
-                r.tmin = static_cast<float>(LUA->CheckNumber(-1));
-            } else if (field == 4 && !LUA->IsType(-1, Type::Nil)) {
-                r.tmax = static_cast<float>(LUA->CheckNumber(-1));
+    // rays[i] = { origin, direction, tMin?, tMax? } with the defaults and checks of Traverse.  Fields are read BY INDEX
+    // (rays[i][k]): lua_next skips nil values and promises no order, so {o, d, nil, tMax} must not shift tMax to field 3.
+    // First pass validates and counts (every raise happens before the ray array exists), second pass fills.
+    size_t count = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) mBatchRays.resize(count);
+        for (size_t i = 0;; ++i) {
+            LUA->PushNumber(double(i + 1));
+            LUA->GetTable(2);
+            if (LUA->IsType(-1, Type::Nil)) { LUA->Pop(); if (pass == 0) count = i; break; }
+            if (pass == 0) LUA->CheckType(-1, Type::Table);
+            const int rt = LUA->Top();
+            vt_ray r{{0, 0, 0}, {0, 0, 0}, 0.f, FLT_MAX};
+            for (int k = 1; k <= 4; ++k) {
+                LUA->PushNumber(double(k));
+                LUA->GetTable(rt);
+                if (k <= 2) {
+                    if (pass == 0 && !LUA->IsType(-1, Type::Vector))
+                        LUA->ThrowError("Each ray must be a table {origin, direction[, tMin[, tMax]]}");
+                    const Vector v = LUA->GetVector(-1);
+                    float* dst = k == 1 ? r.org : r.dir;
+                    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z;
+                } else if (!LUA->IsType(-1, Type::Nil)) {               // nil keeps the default, as in Traverse
+                    const float f = static_cast<float>(pass == 0 ? LUA->CheckNumber(-1) : LUA->GetNumber(-1));
+                    if (k == 3) r.tmin = f; else r.tmax = f;
+                }
+                LUA->Pop();
+            }
+            if (pass == 0) {
+                if (r.tmin < 0.f) LUA->ThrowError("tMin cannot be less than 0");
+                if (r.tmax <= r.tmin) LUA->ThrowError("tMax must be greater than tMin");
+            } else {
+                mBatchRays[i] = r;
             }
             LUA->Pop();
         }
-        if (field < 2) LUA->ThrowError("Each ray must be a table {origin, direction[, tMin[, tMax]]}");
-        if (r.tmin < 0.f) LUA->ThrowError("tMin cannot be less than 0");
-        if (r.tmax <= r.tmin) LUA->ThrowError("tMax must be greater than tMin");
-        rays.push_back(r);
-        LUA->Pop();
     }
     LUA->Pop(LUA->Top());
 
-    std::vector<vt_hit> hits(rays.size());
-    if (vt_trace_closest(mpScene, rays.data(), rays.size(), hits.data()) != VT_OK) {
-        std::string msg = std::string("VisTrace: traversal failed: ") + vt_last_error();
-        LUA->ThrowError(msg.c_str());
+    mBatchHits.resize(mBatchRays.size());
+    if (TraceClosest(mBatchRays.data(), mBatchRays.size(), mBatchHits.data()) != VT_OK) {
+        static thread_local char msg[512];
+        std::snprintf(msg, sizeof(msg), "VisTrace: traversal failed: %s", vt_last_error());
+        LUA->ThrowError(msg);
     }
     LUA->CreateTable();
-    for (size_t i = 0; i < hits.size(); ++i) {
+    for (size_t i = 0; i < mBatchHits.size(); ++i) {
         LUA->PushNumber(double(i + 1));
-        if (hits[i].prim != VT_MISS) LUA->PushUserType_Value(MakeResult(rays[i], hits[i], -1.f, -1.f), TraceResult::id);
+        if (mBatchHits[i].prim != VT_MISS) LUA->PushUserType_Value(MakeResult(mBatchRays[i], mBatchHits[i], -1.f, -1.f), TraceResult::id);
         else LUA->PushBool(false);
         LUA->SetTable(-3);
     }

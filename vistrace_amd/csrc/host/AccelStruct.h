@@ -33,8 +33,15 @@ public:
 
     const Material& GetMaterial(size_t i) const;
 
-    // Non-Lua batch entry for native callers (extensions): closest hits for n rays.
+    // Non-Lua batch entry for native callers (extensions): closest hits for n rays (host walk below
+    // kDeviceBatchMin rays, the device above).
     int TraceClosest(const vt_ray* rays, uint64_t n, vt_hit* hits) const;
+    // batches of fewer rays are walked on the host: a launch-bound tiny batch costs ~20 us on the device, a
+    // host-walked ray 1-2 us (tests/cpp/test_binding --bench prints both)
+    static constexpr uint64_t kDeviceBatchMin = 16;
+    // the two sides of that choice, callable directly (bench / tests)
+    int TraceClosestHost(const vt_ray* rays, uint64_t n, vt_hit* hits) const;
+    int TraceClosestDevice(const vt_ray* rays, uint64_t n, vt_hit* hits) const;
 
     static void SetEntityMeshSource(IEntityMeshSource* src);   // module-wide hook (see Scene.h)
     size_t TriangleCount() const { return mTriangles.size(); }
@@ -43,11 +50,16 @@ public:
 private:
     bool mAccelBuilt;
     vt_scene* mpScene;                      // device-resident linearised BVH + triangles
+    vt_host_scene* mpHostScene;             // the same records on the host: single rays are walked here (config 1)
+    std::vector<vt_ray> mBatchRays;         // TraverseBatch scratch (members: a Lua error must not skip a destructor)
+    std::vector<vt_hit> mBatchHits;
     std::vector<Triangle> mTriangles;
     std::vector<Entity>   mEntities;
     std::vector<Material> mMaterials;
 
     void ReleaseDevice();
+    void AppendEntity(void* entityUserData);
+    int  BuildAndUpload(vt_engine* eng);
     int  UploadAlphaTestData(const std::vector<uint8_t>& flags);
     TraceResult* MakeResult(const vt_ray& ray, const vt_hit& hit, float coneWidth, float coneAngle) const;
 };

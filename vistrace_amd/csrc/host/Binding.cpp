@@ -3,6 +3,10 @@
 // (AccelStruct, TraceResult) are the host classes in this directory.
 #include "Binding.h"
 
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
 #include "TraceResult.h"
 
 using namespace GarrysMod::Lua;
@@ -127,11 +131,23 @@ LUA_FUNCTION(TraceResult_Distance)                                     // VisTra
     return 1;
 }
 
-// The reference's TraceResult:Entity() (VisTrace.cpp:495-513) calls the engine's global
-// Entity(); the engine-independent part is the index it passes, exposed here.
-LUA_FUNCTION(TraceResult_EntIndex)
+LUA_FUNCTION(TraceResult_Entity)                                       // VisTrace.cpp:495-513
 {
-    LUA->PushNumber(Self(LUA)->entIdx);
+    TraceResult* pResult = Self(LUA);
+
+    LUA->PushSpecial(SPECIAL_GLOB);
+    LUA->GetField(-1, "Entity");
+    LUA->PushNumber(pResult->entIdx);
+    LUA->Call(1, 1);
+
+    // the entity behind that index may have been replaced since the build: hand out NULL instead
+    void* pEnt = LUA->GetUserdataRaw(-1, Type::Entity);
+    if (pEnt == nullptr || pEnt != pResult->rawEnt) {
+        LUA->GetField(-2, "Entity");
+        LUA->PushNumber(-1);
+        LUA->Call(1, 1);
+    }
+
     return 1;
 }
 
@@ -166,15 +182,67 @@ LUA_FUNCTION(TraceResult_SubMaterialIndex)                             // VisTra
     return 1;
 }
 
-LUA_FUNCTION(TraceResult_FrontFacing)
+LUA_FUNCTION(TraceResult_MaterialFlags)                                // VisTrace.cpp:613-619
+{
+    LUA->PushNumber(static_cast<double>(Self(LUA)->GetMaterialFlags()));
+    return 1;
+}
+
+LUA_FUNCTION(TraceResult_SurfaceFlags)                                 // VisTrace.cpp:620-626
+{
+    LUA->PushNumber(static_cast<double>(Self(LUA)->GetSurfFlags()));
+    return 1;
+}
+
+LUA_FUNCTION(TraceResult_HitSky)                                       // VisTrace.cpp:628-634
+{
+    LUA->PushBool(Self(LUA)->hitSky);
+    return 1;
+}
+
+LUA_FUNCTION(TraceResult_HitWater)                                     // VisTrace.cpp:635-641
+{
+    LUA->PushBool(Self(LUA)->HitWater());
+    return 1;
+}
+
+LUA_FUNCTION(TraceResult_FrontFacing)                                  // VisTrace.cpp:643-649
 {
     LUA->PushBool(Self(LUA)->frontFacing);
     return 1;
 }
 
-LUA_FUNCTION(TraceResult_tostring)
+LUA_FUNCTION(TraceResult_tostring)                                     // VisTrace.cpp:742-746
 {
-    LUA->PushString("TraceResult");
+    LUA->PushString("VisTraceResult");
+    return 1;
+}
+
+// ---- helpers ------------------------------------------------------------------------------------
+LUA_FUNCTION(vistrace_CalcRayOrigin)                                   // VisTrace.cpp:1478-1519
+{
+    LUA->CheckType(1, Type::Vector);
+    LUA->CheckType(2, Type::Vector);
+    const Vector p = LUA->GetVector(1), nrm = LUA->GetVector(2);
+    const float pos[3] = {p.x, p.y, p.z}, normal[3] = {nrm.x, nrm.y, nrm.z};
+
+    const float origin = 1.f / 32.f;
+    const float fScale = 1.f / 65536.f;
+    const float iScale = 256.f;
+
+    float out[3];
+    for (int k = 0; k < 3; ++k) {
+        // per-component integer offset to the bit representation of the fp32 position (:1500-1508)
+        const int32_t iOff = static_cast<int32_t>(normal[k] * iScale);
+        int32_t bits;
+        std::memcpy(&bits, &pos[k], 4);
+        bits += pos[k] < 0.f ? -iOff : iOff;
+        float iPos;
+        std::memcpy(&iPos, &bits, 4);
+        // small fixed offset near the origin, the variable one elsewhere (:1511-1516)
+        out[k] = std::fabs(pos[k]) < origin ? pos[k] + normal[k] * fScale : iPos;
+    }
+    LUA->PushVector(MakeVector(out[0], out[1], out[2]));
     return 1;
 }
 
@@ -187,30 +255,41 @@ static void Method(ILuaBase* LUA, const char* name, CFunc f)
 
 void RegisterTracingApi(ILuaBase* LUA)
 {
-    TraceResult::id = LUA->CreateMetaTable("VisTraceResult");
+    TraceResult::id = LUA->CreateMetaTable("VisTraceResult");          // :1685-1740 (the getters on this path)
     LUA->Push(-1);
     LUA->SetField(-2, "__index");
-    Method(LUA, "__gc", TraceResult_gc);
     Method(LUA, "__tostring", TraceResult_tostring);
+    Method(LUA, "__gc", TraceResult_gc);
     Method(LUA, "Pos", TraceResult_Pos);
     Method(LUA, "Incident", TraceResult_Incident);
     Method(LUA, "Distance", TraceResult_Distance);
-    Method(LUA, "EntIndex", TraceResult_EntIndex);
+    Method(LUA, "Entity", TraceResult_Entity);
     Method(LUA, "GeometricNormal", TraceResult_GeometricNormal);
     Method(LUA, "Barycentric", TraceResult_Barycentric);
     Method(LUA, "TextureUV", TraceResult_TextureUV);
     Method(LUA, "SubMaterialIndex", TraceResult_SubMaterialIndex);
+    Method(LUA, "MaterialFlags", TraceResult_MaterialFlags);
+    Method(LUA, "SurfaceFlags", TraceResult_SurfaceFlags);
+    Method(LUA, "HitSky", TraceResult_HitSky);
+    Method(LUA, "HitWater", TraceResult_HitWater);
     Method(LUA, "FrontFacing", TraceResult_FrontFacing);
     LUA->Pop();
 
-    AccelStruct_id = LUA->CreateMetaTable("AccelStruct");
+    AccelStruct_id = LUA->CreateMetaTable("AccelStruct");              // :1742-1752
     LUA->Push(-1);
     LUA->SetField(-2, "__index");
-    Method(LUA, "__gc", AccelStruct_gc);
     Method(LUA, "__tostring", AccelStruct_tostring);
-    Method(LUA, "Rebuild", AccelStruct_Rebuild);
+    Method(LUA, "__gc", AccelStruct_gc);
     Method(LUA, "Traverse", AccelStruct_Traverse);
-    Method(LUA, "TraverseBatch", AccelStruct_TraverseBatch);
+    Method(LUA, "Rebuild", AccelStruct_Rebuild);
+    Method(LUA, "TraverseBatch", AccelStruct_TraverseBatch);            // additive
+    LUA->Pop();
+
+    LUA->PushSpecial(SPECIAL_GLOB);                                    // :1817-1832 (the entries on this path)
+    LUA->CreateTable();
+    Method(LUA, "CreateAccel", vistrace_CreateAccel);
+    Method(LUA, "CalcRayOrigin", vistrace_CalcRayOrigin);
+    LUA->SetField(-2, "vistrace");
     LUA->Pop();
 }
 

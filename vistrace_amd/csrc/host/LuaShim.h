@@ -17,6 +17,9 @@ enum : int { None = -1, Nil = 0, Bool = 1, LightUserData = 2, Number = 3, String
              UserData = 7, Thread = 8, Entity = 9, Vector = 10, Angle = 11, Count = 44 /* first free user type */ };
 }
 
+// ILuaBase::PushSpecial arguments
+enum { SPECIAL_GLOB = 0, SPECIAL_ENV = 1, SPECIAL_REG = 2 };
+
 class ILuaBase;
 typedef int (*CFunc)(ILuaBase* LUA);
 
@@ -27,6 +30,10 @@ public:
     virtual void         Push(int stackPos) = 0;
     virtual void         Pop(int amount = 1) = 0;
     virtual void         CreateTable() = 0;
+    virtual void         PushSpecial(int type) = 0;                       // SPECIAL_GLOB: the global table
+    virtual void         GetField(int stackPos, const char* name) = 0;    // pushes t[name]
+    virtual void         GetTable(int stackPos) = 0;                      // pops a key, pushes t[key]
+    virtual void         Call(int nargs, int nresults) = 0;               // pops function + args, pushes the results
     virtual void         SetField(int stackPos, const char* name) = 0;    // t[name] = top; pops value
     virtual void         SetTable(int stackPos) = 0;                      // t[key] = value; pops both
     virtual void         SetMetaTable(int stackPos) = 0;                  // pops the metatable

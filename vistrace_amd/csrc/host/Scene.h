@@ -23,9 +23,15 @@ enum MaterialFlags : uint32_t {           // values of source/objects/Material.h
     MATFLAG_NOCULL    = 8192,             // Material.h:47
 };
 
+// BSPEnums::SURF bits (BSPParser is an absent submodule; values are the Source engine's bspflags.h): only SKY is
+// read on this path (source/objects/TraceResult.cpp:83)
+enum SurfFlags : uint32_t { SURF_NONE = 0, SURF_SKY = 0x4 };
+
 struct Material {
     std::string path;
     uint32_t    flags = MATFLAG_NONE;
+    uint32_t    surfFlags = SURF_NONE;                          // Material.h:120 (BSPEnums::SURF, set for world brushes: AccelStruct.cpp:392)
+    bool        water = false;                                  // Material.h (TraceResult::HitWater, TraceResult.cpp:311)
     // what the alpha test of Primitives.h:196-208 reads (Material.h:81-122).  The decoded mip-0 alpha plane of
     // the base texture stands in for `const IVTFTexture* baseTexture`: VTF decoding stays with the module.
     float    baseTexMat[2][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}};   // glm::mat2x4 baseTexMat: row r = transform[r]

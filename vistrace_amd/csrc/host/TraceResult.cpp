@@ -10,8 +10,9 @@ int TraceResult::id = -1;
 static inline float dot(const Vec3& a, const Vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
 TraceResult::TraceResult(const Vec3& direction, float dist, float cw, float ca, const Triangle& tri, size_t prim,
-                         const Vec2& uv, const Entity& ent)
-    : distance(dist), primitiveIndex(prim), coneWidth(cw), coneAngle(ca), mipOverride(cw < 0.f || ca <= 0.f)
+                         const Vec2& uv, const Entity& ent, const Material& mat)
+    : distance(dist), primitiveIndex(prim), coneWidth(cw), coneAngle(ca), mipOverride(cw < 0.f || ca <= 0.f),
+      materialFlags(mat.flags), surfFlags(mat.surfFlags), water(mat.water)
 {
     // caller passes glm::normalize(direction) in the reference (AccelStruct.cpp:826); wo = -direction (:56)
     const float inv = 1.0f / std::sqrt(dot(direction, direction));
@@ -37,6 +38,7 @@ TraceResult::TraceResult(const Vec3& direction, float dist, float cw, float ca, 
     entIdx = ent.id;                                                                // :76
     rawEnt = ent.rawEntity;
     submatIdx = uint32_t(tri.material);
+    hitSky = (mat.surfFlags & SURF_SKY) != SURF_NONE;                               // :83
     frontFacing = dot(wo, geometricNormal) >= 0.f;                                  // :85
 }
 

@@ -21,13 +21,19 @@ public:
     uint32_t entIdx;
     void*    rawEnt;
     uint32_t submatIdx;
+    bool     hitSky = false;              // (material.surfFlags & SURF::SKY) != NONE   (TraceResult.cpp:83)
     bool     frontFacing;
     size_t   primitiveIndex;              // hit->primitive_index (AccelStruct.cpp:821), kept for batch users
 
+    // `mat` = mMaterials[tri.material] (AccelStruct.cpp:823); the reference copies the whole Material, the getters
+    // on this path read three of its fields
     TraceResult(const Vec3& direction, float distance, float coneWidth, float coneAngle, const Triangle& tri,
-                size_t primitiveIndex, const Vec2& uv, const Entity& ent);
+                size_t primitiveIndex, const Vec2& uv, const Entity& ent, const Material& mat);
 
     const Vec3& GetPos();
+    uint32_t GetMaterialFlags() const { return materialFlags; }   // TraceResult.cpp:309
+    uint32_t GetSurfFlags() const { return surfFlags; }           // :310
+    bool     HitWater() const { return water; }                   // :311
 
 private:
     Vec3  v[3];
@@ -35,6 +41,8 @@ private:
     Vec3  pos;
     float coneWidth, coneAngle;
     bool  mipOverride;
+    uint32_t materialFlags, surfFlags;
+    bool  water;
 };
 
 } // namespace vistrace
