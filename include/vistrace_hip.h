@@ -156,6 +156,44 @@ int  vt_device_count(int* count);
 int  vt_engine_open(int device, vt_engine** out);
 void vt_engine_close(vt_engine* e);
 
+/* ---- multi-GPU: BVH replicated in every device's HBM, rays sharded, ONE RCCL gather of hits ----
+ * Rays never interact and the scene is read-only, so the path shards by independent units; the only exchange is the
+ * gather of the 16-byte hit records to the root device (ncclGather, rccl.h:745 -- N-1 direct xGMI sends into the root).
+ * The reference has nothing like it (one ray per call on one thread); this is the seam its C++ module would use.
+ *
+ * vt_engine_open_multi: ONE process, ndev devices.  The returned engine is the group's root (devices[0]):
+ *   - vt_scene_upload (and every later call that changes the scene: refit, skinning, attribs, alpha) applies to all
+ *     devices; vt_engine_set_option / vt_engine_synchronize / vt_engine_close act on the whole group;
+ *   - vt_trace_closest / vt_trace_any split a host ray array of >= 1 Mi rays into contiguous shards
+ *     (vt_shard_bounds) and run one staging pipeline per device side by side; results land in the caller's array;
+ *   - vt_trace_closest_gather_dev traces device-resident shards and gathers the hit records to the root device;
+ *   - the *_dev entry points keep working on the root device alone.
+ * RCCL is loaded on first use (dlopen librccl.so; override with VT_RCCL_LIB). */
+int vt_engine_open_multi(const int* devices, int ndev, vt_engine** out);
+int vt_engine_device_count(const vt_engine* e);          /* 1 for vt_engine_open */
+int vt_engine_device(const vt_engine* e, int g);         /* HIP device of group member g (0 = root), -1 if out of range */
+/* Contiguous sharding (keeps the coherence of primary rays inside a shard): capacity = ceil(n / ndev) rounded up to
+ * 64 rays, shard g = [g * capacity, min(n, (g + 1) * capacity)) -- the last shards may be short or empty. */
+uint64_t vt_shard_capacity(uint64_t n, int ndev);
+void     vt_shard_bounds(uint64_t n, int ndev, int g, uint64_t* lo, uint64_t* hi);
+/* d_rays[g] (on device g of the group) holds the rays of shard g of an n-ray batch.  Every device traces its shard
+ * (closest hit) on its own stream, then ONE ncclGather of `capacity` records per device brings the shards to the root
+ * device: d_hits_root (root device, ndev * capacity records) holds ray i's hit at record i.  Asynchronous: returns
+ * with traces and gather enqueued (the gather runs on a communication stream, so the next batch's traces overlap
+ * it; per-device send buffers are double-buffered) -- vt_engine_synchronize(root) waits for all of it. */
+int vt_trace_closest_gather_dev(vt_scene* s, const void* const* d_rays, uint64_t n, void* d_hits_root);
+/* One process per GPU (e.g. under torch.distributed.run): the same gather with one communicator per process.
+ * Rank 0 calls vt_comm_unique_id (128 bytes) and distributes it (any transport); every rank then calls
+ * vt_engine_comm_init_rank on its single-device engine.  vt_gather_hits_dev: `count` records from d_send of every rank
+ * into d_recv_root on `root` (nranks * count records, rank r's at r * count); the records must have been produced on
+ * `stream`; the gather itself runs on the engine's communication stream.  vt_gather_wait(e, 1, stream): make
+ * `stream` wait until at most ONE gather is still in flight (call it before overwriting the older of two alternating
+ * send buffers); vt_gather_wait(e, 0, NULL): host-wait for every gather. */
+int vt_comm_unique_id(void* id128);
+int vt_engine_comm_init_rank(vt_engine* e, int nranks, int rank, const void* id128);
+int vt_gather_hits_dev(vt_engine* e, const void* d_send, uint64_t count, void* d_recv_root, int root, void* stream);
+int vt_gather_wait(vt_engine* e, int batches_in_flight, void* stream);
+
 /* Upload once per Rebuild (north star: "uploaded once per Rebuild"). */
 int  vt_scene_upload(vt_engine* e, const vt_host_scene* hs, vt_scene** out);
 void vt_scene_free(vt_scene* s);
@@ -215,7 +253,7 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
  *   "reserved_limit"     blocks of the grid a reserved CU still keeps (2: measured to leave room for one
  *                        256-thread workgroup with the footprint of RCCL's kernel, 280 VGPRs + 20 KB LDS --
  *                        3 does not; 0 = keep the CU empty).  Later arrivals on a full reserved CU exit at once.
- * Read-only: "cu_count", "device", "last_persistent", "last_fetch_dma" (what the last launch used).
+ * Read-only: "cu_count", "device", "device_count", "last_persistent", "last_fetch_dma" (what the last launch used).
  * Results never depend on these, only speed does. */
 int vt_engine_set_option(vt_engine* e, const char* key, int64_t value);
 int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value);

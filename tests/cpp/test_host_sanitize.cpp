@@ -37,13 +37,52 @@ static void run(uint32_t n, unsigned seed, bool clustered)
     const vt_tri64* lt = vt_host_scene_tris(hs);
     for (uint32_t i = 0; i < n; ++i) { CHECK(lt[i].prim < n); if (lt[i].prim < n) seen[lt[i].prim]++; }
     for (uint32_t i = 0; i < n; ++i) CHECK(seen[i] == 1);
+    // the host walk (single-ray latency path) over the same scene: brute force agrees on t, and the walk stays in bounds
+    if (n > 0) {
+        std::vector<vt_ray> rays(256);
+        for (auto& r : rays) r = vt_ray{{U(rng), U(rng), 150.f}, {S(rng) * 0.3f, S(rng) * 0.3f, -1.f}, 0.f, 3.0e38f};
+        std::vector<vt_hit> hits(rays.size());
+        std::vector<uint8_t> occ(rays.size());
+        CHECK(vt_host_scene_trace_closest(hs, rays.data(), rays.size(), hits.data()) == VT_OK);
+        CHECK(vt_host_scene_trace_any(hs, rays.data(), rays.size(), occ.data()) == VT_OK);
+        for (size_t i = 0; i < rays.size(); ++i) {
+            CHECK((hits[i].prim != VT_MISS) == (occ[i] != 0));
+            CHECK(hits[i].prim == VT_MISS || hits[i].prim < n);
+        }
+    }
     vt_host_scene_free(hs);
     vt_bvh_free(bvh);
+}
+
+// shard bounds of the multi-GPU path: contiguous, disjoint, cover [0, n), shard g starts at g * capacity
+static void shards()
+{
+    for (uint64_t n : {0ull, 1ull, 63ull, 64ull, 65ull, 1000ull, 1048576ull, 16777216ull, 134217728ull, 134217729ull})
+        for (int ndev : {1, 2, 3, 4, 7, 8}) {
+            const uint64_t cap = vt_shard_capacity(n, ndev);
+            CHECK(cap % 64 == 0 && cap * uint64_t(ndev) >= n);
+            uint64_t expect = 0;
+            for (int g = 0; g < ndev; ++g) {
+                uint64_t lo = 1, hi = 0;
+                vt_shard_bounds(n, ndev, g, &lo, &hi);
+                CHECK(lo == expect && hi >= lo && hi - lo <= cap);
+                CHECK(lo == (cap * uint64_t(g) < n ? cap * uint64_t(g) : n));
+                expect = hi;
+            }
+            CHECK(expect == n);
+            uint64_t lo = 1, hi = 0;
+            vt_shard_bounds(n, ndev, ndev, &lo, &hi);       // out of range: empty
+            CHECK(lo == hi);
+            vt_shard_bounds(n, ndev, -1, &lo, &hi);
+            CHECK(lo == hi);
+        }
+    CHECK(vt_shard_capacity(100, 0) == 0);
 }
 
 int main()
 {
     for (uint32_t n : {0u, 1u, 2u, 3u, 17u, 1000u, 20000u}) { run(n, 7 + n, false); run(n, 11 + n, true); }
+    shards();
     vt_bvh* b = nullptr;
     CHECK(vt_bvh_build(nullptr, 5, 0, &b) != VT_OK && vt_last_error()[0] != 0);   // NULL input is an error, not a crash
     std::printf("host sanitize: %d failed\n", fails);

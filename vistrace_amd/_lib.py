@@ -75,6 +75,16 @@ SYMBOLS = {
     "vt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "vt_engine_open": (C.c_int, [C.c_int, _pp]),
     "vt_engine_close": (None, [_vp]),
+    "vt_engine_open_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, _pp]),
+    "vt_engine_device_count": (C.c_int, [_vp]),
+    "vt_engine_device": (C.c_int, [_vp, C.c_int]),
+    "vt_shard_capacity": (_u64, [_u64, C.c_int]),
+    "vt_shard_bounds": (None, [_u64, C.c_int, C.c_int, C.POINTER(_u64), C.POINTER(_u64)]),
+    "vt_trace_closest_gather_dev": (C.c_int, [_vp, C.POINTER(C.c_void_p), _u64, _vp]),
+    "vt_comm_unique_id": (C.c_int, [_vp]),
+    "vt_engine_comm_init_rank": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "vt_gather_hits_dev": (C.c_int, [_vp, _vp, _u64, _vp, C.c_int, _vp]),
+    "vt_gather_wait": (C.c_int, [_vp, C.c_int, _vp]),
     "vt_scene_upload": (C.c_int, [_vp, _vp, _pp]),
     "vt_scene_free": (None, [_vp]),
     "vt_scene_device_bytes": (_u64, [_vp]),

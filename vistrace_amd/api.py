@@ -155,12 +155,53 @@ def device_count() -> int:
     return n.value
 
 
+def shard_capacity(n: int, ndev: int) -> int:
+    return int(lib.vt_shard_capacity(n, ndev))
+
+
+def shard_bounds(n: int, ndev: int, g: int):
+    """Contiguous shard [lo, hi) of an n-ray batch for device g of ndev (vt_shard_bounds)."""
+    lo, hi = C.c_uint64(0), C.c_uint64(0)
+    lib.vt_shard_bounds(n, ndev, g, C.byref(lo), C.byref(hi))
+    return int(lo.value), int(hi.value)
+
+
+def comm_unique_id() -> bytes:
+    """128-byte RCCL id for vt_engine_comm_init_rank (rank 0 creates it, the launcher distributes it)."""
+    buf = (C.c_char * 128)()
+    check(lib.vt_comm_unique_id(buf))
+    return bytes(buf)
+
+
 class Engine:
-    def __init__(self, device: int = 0):
+    def __init__(self, device=0):
+        """device: a HIP device index, or a list of them = one single-process multi-GPU group (root = first)."""
         h = C.c_void_p()
-        check(lib.vt_engine_open(device, C.byref(h)))
+        if isinstance(device, (list, tuple)):
+            arr = (C.c_int * len(device))(*device)
+            check(lib.vt_engine_open_multi(arr, len(device), C.byref(h)))
+            self.devices = list(device)
+            device = device[0]
+        else:
+            check(lib.vt_engine_open(device, C.byref(h)))
+            self.devices = [device]
         self._h = h
         self.device = device
+
+    @property
+    def device_count(self) -> int:
+        return int(lib.vt_engine_device_count(self._h))
+
+    # one process per GPU: native RCCL gather of hit records (vt_gather_hits_dev)
+    def comm_init_rank(self, nranks: int, rank: int, unique_id: bytes) -> None:
+        assert len(unique_id) == 128
+        check(lib.vt_engine_comm_init_rank(self._h, nranks, rank, unique_id))
+
+    def gather_hits_dev(self, d_send: int, count: int, d_recv_root: int, root: int = 0, stream: int = 0) -> None:
+        check(lib.vt_gather_hits_dev(self._h, d_send, count, d_recv_root or None, root, stream or None))
+
+    def gather_wait(self, batches_in_flight: int = 0, stream: int = 0) -> None:
+        check(lib.vt_gather_wait(self._h, batches_in_flight, stream or None))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -254,6 +295,13 @@ class Scene:
     def trace_closest_dev(self, d_rays: int, n: int, d_hits: int, stream: int = 0) -> None:
         check(lib.vt_trace_closest_dev(self._h, d_rays, n, d_hits, stream or None))
 
+    def trace_closest_gather_dev(self, d_rays_per_device, n: int, d_hits_root: int) -> None:
+        """Multi-GPU group: d_rays_per_device[g] = address (on device g) of shard g's rays; the hit records of all
+        shards are gathered to d_hits_root on the root device (ndev * shard_capacity records, ray i at record i).
+        Asynchronous; engine.synchronize() waits for traces and gather."""
+        arr = (C.c_void_p * len(d_rays_per_device))(*[C.c_void_p(p or None) for p in d_rays_per_device])
+        check(lib.vt_trace_closest_gather_dev(self._h, arr, n, d_hits_root))
+
     def bounce_loop_dev(self, d_rays: int, n: int, depth: int, seed: int, d_hits: int, stream: int = 0) -> list:
         """Device-resident bounce loop: depth x n hit records (row d = hits of bounce d, indexed by path).
         Returns the number of live paths traced at each depth."""
@@ -324,5 +372,6 @@ def build_scene(engine: Engine, verts: np.ndarray, flags: Optional[np.ndarray] =
 
 
 __all__ = ["Engine", "Scene", "HostBvh", "HostScene", "tris_setup", "build_scene", "make_rays", "device_count",
+           "shard_capacity", "shard_bounds", "comm_unique_id",
            "RAY", "HIT", "TRI64", "BVH_NODE", "NODE_PAIR", "RAY_STATS", "HIT_ATTRS", "TRI_ATTRIBS", "HIT_SHADE", "SKIN_VERTEX", "ALPHA_MATERIAL",
            "FLT_MAX", "_lib"]

@@ -17,142 +17,11 @@
 #include <string>
 #include <vector>
 
-#include "trace_kernels.h"
-#include "vt_internal.h"
+#include "engine_internal.h"
 
 using namespace vt;
 
-#define VT_HIP(call)                                                                              \
-    do {                                                                                          \
-        hipError_t err__ = (call);                                                                \
-        if (err__ != hipSuccess)                                                                  \
-            return fail(VT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(err__));        \
-    } while (0)
-
-struct vt_engine {
-    int         device = 0;
-    hipStream_t stream = nullptr;
-    int         cu_count = 0;
-    size_t      lds_per_block_max = 0;
-    size_t      lds_per_cu = 160 * 1024;
-
-    // launch configuration (vt_engine_set_option)
-    int      persistent       = 2;    // 0 static (one ray per lane), 1 persistent waves, 2 auto by batch size
-    uint32_t coherent_detect  = 1;    // persistent DMA kernel: per-wave coherence probe (see trace_kernels.hip)
-    uint32_t static_overflow_mb = 256; // static kernel: largest per-lane stack overflow area (else full LDS stack)
-    uint32_t auto_static_factor = 2;  // auto: static when n <= factor * (CUs * 8 blocks * 256 lanes)
-    uint32_t lds_entries      = 10;   // stack entries per lane in LDS (rest spills to global)
-    uint32_t blocks_per_cu    = 8;    // persistent grid = cu_count * blocks_per_cu
-    uint32_t block_rays       = 128;  // consecutive rays handed to a wave at a time (128: primary rays -4 %, bounce rays unchanged)
-    uint32_t refill_threshold = 8;    // idle lanes that trigger a re-fill
-    uint32_t tri_threshold    = 4;    // lanes with pending triangles that trigger the TRI branch
-    int      fetch_dma        = 1;    // quad-cooperative global->LDS record fetch (persistent mode)
-    uint32_t max_claim        = 0;    // persistent mode: ray blocks one cursor atomic may claim while plenty are left (0 = auto)
-    int      xcd_cursors      = 0;    // persistent mode: one ray-block cursor per XCD over its own eighth of the batch (opt-in)
-    int      spin_wait        = 1;    // tiny host batches: watch the pinned result slots instead of a stream sync
-    uint32_t reserved_cus     = 0;    // CUs on which the persistent grid leaves room (for a concurrent collective's kernels)
-    uint32_t reserved_limit   = 2;    // blocks of the grid a reserved CU still keeps
-    uint32_t* d_reserved      = nullptr; // 1024-bit set of the reserved CUs' __smid() values, then 1024 per-CU counters
-
-    // Per-launch scratch: a ring of launch slots, rotated per launch, so that traces in flight on different
-    // streams (or enqueued back to back on one) never share a ray cursor, reserved-CU counters or a stack
-    // overflow area.  A slot is reused kLaunchSlots launches later; the new launch then waits (on the device,
-    // hipStreamWaitEvent) for the event recorded behind the slot's previous launch.
-    static constexpr uint32_t kLaunchSlots = 16;
-    static constexpr size_t   kSlotCtlBytes = 8192;   // 512 B of cursors (8 x 64 B), then 4 KB of reserved-CU counters
-    struct LaunchSlot {
-        uint32_t*  d_ctl = nullptr;          // into d_slot_ctl
-        uint32_t*  d_overflow = nullptr;     // grown on demand, per slot
-        size_t     overflow_words = 0;
-        hipEvent_t done = nullptr;
-        bool       used = false;
-    };
-    LaunchSlot slots[kLaunchSlots];
-    char*      d_slot_ctl = nullptr;
-    uint32_t   next_slot = 0;
-    std::mutex launch_mu;                    // slot rotation + enqueue (host threads may share an engine)
-    std::mutex host_mu;                      // the host-pointer entry points share the staging buffers
-    hipEvent_t ev_loop = nullptr;            // behind the last vt_bounce_loop_dev (its queues are engine-wide)
-    bool       loop_used = false;
-
-    // staging for the host-pointer entry points
-    void*  d_rays = nullptr;  size_t d_rays_bytes = 0;
-    void*  d_out  = nullptr;  size_t d_out_bytes = 0;
-    // large host batches: pinned double buffers + copy streams, so that H2D, trace and D2H of successive
-    // chunks overlap (pageable hipMemcpyAsync serialises on the host)
-    static constexpr uint64_t kHostChunk = uint64_t(1) << 20;   // rays per pipelined chunk
-    char* h_stage_in[2]  = {nullptr, nullptr};
-    char* h_stage_out[2] = {nullptr, nullptr};
-    hipStream_t s_in = nullptr, s_out = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-    // bounce loop: two ray queues, two path-id queues, the queue's hit records, block offsets, live counter
-    void*  d_loop = nullptr;  size_t d_loop_bytes = 0;
-    uint32_t* h_live = nullptr;           // pinned read-back of the live-path count
-    // single-ray / tiny-batch path: pinned, device-mapped host memory the kernel reads and writes in
-    // place (no copy calls: one launch + one stream sync per Traverse)
-    static constexpr uint32_t kTinyRays = 256;
-    vt_ray* h_tiny_rays = nullptr;  void* d_tiny_rays = nullptr;
-    char*   h_tiny_out  = nullptr;  void* d_tiny_out  = nullptr;
-
-    // timing
-    int        timing = 0;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool       ev_valid = false;
-
-    // scenes uploaded through this engine: closing the engine releases their device memory and detaches them
-    std::vector<vt_scene*> scenes;
-
-    // last launch geometry
-    uint32_t last_blocks = 0, last_threads = 0, last_lds = 0;
-    int      last_persistent = 0, last_dma = 0;
-};
-
-struct vt_scene {
-    vt_engine*    engine = nullptr;
-    char*         d_records = nullptr; // pairs, then (128-B aligned) the leaf-ordered triangles
-    vt_tri64*     d_tris = nullptr;    // = d_records + tri_base * 64
-    uint32_t      tri_base = 0;
-    uint32_t*     d_prim_to_slot = nullptr;
-    vt_tri_attribs* d_attribs = nullptr;   // optional side table, original triangle order
-    // refit: pair indices sorted by depth (deepest level first) and where each level starts
-    uint32_t*     d_level_pairs = nullptr;
-    std::vector<uint32_t> level_begin;     // level_begin[k] .. level_begin[k+1]) = k-th deepest level
-    // skinning inputs (vt_scene_set_skin) and the per-frame matrix table
-    float*          d_bind_verts = nullptr;
-    vt_skin_vertex* d_skin = nullptr;
-    uint32_t*       d_matrix_base = nullptr;
-    float*          d_skin_mats = nullptr;   // 3 x mats_cap matrices: bones | binds | products
-    uint32_t        mats_cap = 0;
-    // alpha test: set when a triangle carries VT_TRI_ALPHATEST; materials + alpha planes from vt_scene_set_alpha
-    bool               has_alpha = false;
-    vt_alpha_material* d_alpha_mats = nullptr;
-    uint8_t*           d_alpha_texels = nullptr;
-    uint32_t           n_alpha_mats = 0;
-    // refit / skinning with non-finite vertices: NaN boxes pass every slab test, so a poisoned subtree is walked by
-    // every ray -- the scene is refused until it has been refitted with finite data
-    float           coherent_radius2 = 0.f;   // (2 % of the scene's diagonal)^2: how far apart the origins of a ray packet may lie
-    uint32_t*       d_bad = nullptr;
-    bool            poisoned = false;
-    hipGraphExec_t  refit_graph = nullptr;   // the level-by-level refit launches, captured once (launch-bound: ~30 tiny kernels)
-    uint32_t      npairs = 0, ntris = 0, max_depth = 0, root_leaf_count = 0;
-    uint64_t      bytes = 0;
-};
-
-namespace {
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev)
-    {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard()
-    {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
+namespace vt {
 
 int ensure_bytes(void** ptr, size_t* have, size_t need)
 {
@@ -163,6 +32,10 @@ int ensure_bytes(void** ptr, size_t* have, size_t need)
     *have = cap;
     return VT_OK;
 }
+
+} // namespace vt
+
+namespace {
 
 struct LaunchPlan {
     bool     persistent;
@@ -438,8 +311,11 @@ static void release_scene_device(vt_scene* s);
 void vt_engine_close(vt_engine* e)
 {
     if (!e) return;
+    for (vt_engine* p : e->peers) vt_engine_close(p);   // a group's root owns the engines of the other devices
+    e->peers.clear();
     DeviceGuard guard(e->device);
     (void)hipDeviceSynchronize();               // launches on caller streams may still use the cursor / overflow areas
+    multi_release(e);
     for (vt_scene* sc : e->scenes) {            // scenes that outlive their engine become inert shells
         release_scene_device(sc);
         sc->engine = nullptr;
@@ -476,6 +352,7 @@ void vt_engine_close(vt_engine* e)
 int vt_engine_set_option(vt_engine* e, const char* key, int64_t value)
 {
     if (!e || !key) return fail(VT_ERR_INVALID_ARG, "vt_engine_set_option: NULL");
+    for (vt_engine* p : e->peers) { const int rc = vt_engine_set_option(p, key, value); if (rc != VT_OK) return rc; }
     const std::string k(key);
     if (k == "persistent" && value >= 0 && value <= 2) e->persistent = int(value);
     else if (k == "auto_static_factor" && value >= 0 && value <= 1024) e->auto_static_factor = uint32_t(value);
@@ -519,6 +396,7 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
     else if (k == "last_persistent") *value = e->last_persistent;
     else if (k == "last_fetch_dma") *value = e->last_dma;
     else if (k == "device") *value = e->device;
+    else if (k == "device_count") *value = int64_t(e->peers.size()) + 1;
     else return fail(VT_ERR_INVALID_ARG, "vt_engine_get_option: unknown key: " + k);
     return VT_OK;
 }
@@ -589,6 +467,13 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
         return fail(VT_ERR_HIP, std::string("vt_scene_upload: ") + hipGetErrorString(err));
     }
     e->scenes.push_back(s);
+    // a group's scene lives on every device: the BVH is replicated, rays are what is sharded
+    for (vt_engine* p : e->peers) {
+        vt_scene* rep = nullptr;
+        const int rc = vt_scene_upload(p, hsw, &rep);
+        if (rc != VT_OK) { vt_scene_free(s); return rc; }
+        s->replicas.push_back(rep);
+    }
     *out = s;
     return VT_OK;
 }
@@ -614,6 +499,8 @@ static void release_scene_device(vt_scene* s)
 void vt_scene_free(vt_scene* s)
 {
     if (!s) return;
+    for (vt_scene* rep : s->replicas) vt_scene_free(rep);
+    s->replicas.clear();
     if (vt_engine* e = s->engine) {             // NULL once the engine was closed: only the shell is left
         DeviceGuard guard(e->device);
         (void)hipDeviceSynchronize();           // traces of this scene may be in flight on caller streams
@@ -740,11 +627,13 @@ static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, si
 
 int vt_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_hit* hits)
 {
+    if (s && !s->replicas.empty() && n >= kMultiHostMin) return multi_trace_host(s, rays, n, hits, sizeof(vt_hit), false);
     return trace_host(s, rays, n, hits, sizeof(vt_hit), false);
 }
 
 int vt_trace_any(vt_scene* s, const vt_ray* rays, uint64_t n, uint8_t* occluded)
 {
+    if (s && !s->replicas.empty() && n >= kMultiHostMin) return multi_trace_host(s, rays, n, occluded, sizeof(uint8_t), true);
     return trace_host(s, rays, n, occluded, sizeof(uint8_t), true);
 }
 
@@ -925,6 +814,7 @@ static int refit_levels(vt_scene* s)
 
 int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32_t n)
 {
+    if (s) for (vt_scene* rep : s->replicas) { const int rc = vt_scene_refit(rep, verts, flags, n); if (rc != VT_OK) return rc; }
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: scene is NULL");
     if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: the scene\'s engine has been closed");
     if (n != s->ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: n differs from the scene's triangle count");
@@ -958,6 +848,7 @@ int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32
 
 int vt_scene_set_skin(vt_scene* s, const float* bind_verts, const vt_skin_vertex* skin, const uint32_t* matrix_base, uint32_t n)
 {
+    if (s) for (vt_scene* rep : s->replicas) { const int rc = vt_scene_set_skin(rep, bind_verts, skin, matrix_base, n); if (rc != VT_OK) return rc; }
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_skin: scene is NULL");
     if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_skin: the scene\'s engine has been closed");
     if (n != s->ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_skin: n differs from the scene's triangle count");
@@ -987,6 +878,7 @@ int vt_scene_set_skin(vt_scene* s, const float* bind_verts, const vt_skin_vertex
 
 int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uint32_t nmat)
 {
+    if (s) for (vt_scene* rep : s->replicas) { const int rc = vt_scene_skin_refit(rep, bones, binds, nmat); if (rc != VT_OK) return rc; }
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: scene is NULL");
     if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: the scene\'s engine has been closed");
     if (s->ntris == 0) return VT_OK;
@@ -1030,6 +922,7 @@ int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_o
 
 int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_t n)
 {
+    if (s) for (vt_scene* rep : s->replicas) { const int rc = vt_scene_set_tri_attribs(rep, attribs, n); if (rc != VT_OK) return rc; }
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_tri_attribs: scene is NULL");
     if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_tri_attribs: the scene\'s engine has been closed");
     if (n != s->ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_tri_attribs: n differs from the scene's triangle count");
@@ -1048,6 +941,7 @@ int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_
 
 int vt_scene_set_alpha(vt_scene* s, const vt_alpha_material* mats, uint32_t nmats, const uint8_t* texels, uint64_t ntexels)
 {
+    if (s) for (vt_scene* rep : s->replicas) { const int rc = vt_scene_set_alpha(rep, mats, nmats, texels, ntexels); if (rc != VT_OK) return rc; }
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_alpha: scene is NULL");
     if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_alpha: the scene\'s engine has been closed");
     if (nmats == 0 || !mats) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_alpha: no materials");
@@ -1117,8 +1011,10 @@ int vt_gen_bounce_dev(vt_engine* e, const void* d_attrs, uint64_t n, uint64_t se
 int vt_engine_synchronize(vt_engine* e)
 {
     if (!e) return fail(VT_ERR_INVALID_ARG, "vt_engine_synchronize: NULL");
+    for (vt_engine* p : e->peers) { const int rc = vt_engine_synchronize(p); if (rc != VT_OK) return rc; }
     DeviceGuard guard(e->device);
     VT_HIP(hipStreamSynchronize(e->stream));
+    if (e->s_comm) VT_HIP(hipStreamSynchronize(e->s_comm));      // gathers in flight (multi_gpu.hip)
     return VT_OK;
 }
 
@@ -1150,3 +1046,18 @@ int vt_engine_launch_info(vt_engine* e, uint32_t* blocks, uint32_t* threads, uin
 }
 
 } // extern "C"
+
+namespace vt {
+
+int engine_launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_occ, void* d_stats, bool any_hit, bool stats,
+                  hipStream_t stream)
+{
+    return launch(s, d_rays, n, d_hits, d_occ, d_stats, any_hit, stats, stream);
+}
+
+int engine_trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, size_t out_elem, bool any_hit)
+{
+    return trace_host(s, rays, n, out, out_elem, any_hit);
+}
+
+} // namespace vt

@@ -1,0 +1,179 @@
+// engine_internal.h -- what engine.hip and multi_gpu.hip share: the objects behind the opaque vt_engine / vt_scene
+// handles of include/vistrace_hip.h and the two internal entry points every trace goes through.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "trace_kernels.h"
+#include "vt_internal.h"
+
+#define VT_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t err__ = (call);                                                                \
+        if (err__ != hipSuccess)                                                                  \
+            return fail(VT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(err__));        \
+    } while (0)
+
+struct vt_engine {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    int         cu_count = 0;
+    size_t      lds_per_block_max = 0;
+    size_t      lds_per_cu = 160 * 1024;
+
+    // launch configuration (vt_engine_set_option)
+    int      persistent       = 2;    // 0 static (one ray per lane), 1 persistent waves, 2 auto by batch size
+    uint32_t coherent_detect  = 1;    // persistent DMA kernel: per-wave coherence probe (see trace_kernels.hip)
+    uint32_t static_overflow_mb = 256; // static kernel: largest per-lane stack overflow area (else full LDS stack)
+    uint32_t auto_static_factor = 2;  // auto: static when n <= factor * (CUs * 8 blocks * 256 lanes)
+    uint32_t lds_entries      = 10;   // stack entries per lane in LDS (rest spills to global)
+    uint32_t blocks_per_cu    = 8;    // persistent grid = cu_count * blocks_per_cu
+    uint32_t block_rays       = 128;  // consecutive rays handed to a wave at a time (128: primary rays -4 %, bounce rays unchanged)
+    uint32_t refill_threshold = 8;    // idle lanes that trigger a re-fill
+    uint32_t tri_threshold    = 4;    // lanes with pending triangles that trigger the TRI branch
+    int      fetch_dma        = 1;    // quad-cooperative global->LDS record fetch (persistent mode)
+    uint32_t max_claim        = 0;    // persistent mode: ray blocks one cursor atomic may claim while plenty are left (0 = auto)
+    int      xcd_cursors      = 0;    // persistent mode: one ray-block cursor per XCD over its own eighth of the batch (opt-in)
+    int      spin_wait        = 1;    // tiny host batches: watch the pinned result slots instead of a stream sync
+    uint32_t reserved_cus     = 0;    // CUs on which the persistent grid leaves room (for a concurrent collective's kernels)
+    uint32_t reserved_limit   = 2;    // blocks of the grid a reserved CU still keeps
+    uint32_t* d_reserved      = nullptr; // 1024-bit set of the reserved CUs' __smid() values, then 1024 per-CU counters
+
+    // Per-launch scratch: a ring of launch slots, rotated per launch, so that traces in flight on different
+    // streams (or enqueued back to back on one) never share a ray cursor, reserved-CU counters or a stack
+    // overflow area.  A slot is reused kLaunchSlots launches later; the new launch then waits (on the device,
+    // hipStreamWaitEvent) for the event recorded behind the slot's previous launch.
+    static constexpr uint32_t kLaunchSlots = 16;
+    static constexpr size_t   kSlotCtlBytes = 8192;   // 512 B of cursors (8 x 64 B), then 4 KB of reserved-CU counters
+    struct LaunchSlot {
+        uint32_t*  d_ctl = nullptr;          // into d_slot_ctl
+        uint32_t*  d_overflow = nullptr;     // grown on demand, per slot
+        size_t     overflow_words = 0;
+        hipEvent_t done = nullptr;
+        bool       used = false;
+    };
+    LaunchSlot slots[kLaunchSlots];
+    char*      d_slot_ctl = nullptr;
+    uint32_t   next_slot = 0;
+    std::mutex launch_mu;                    // slot rotation + enqueue (host threads may share an engine)
+    std::mutex host_mu;                      // the host-pointer entry points share the staging buffers
+    hipEvent_t ev_loop = nullptr;            // behind the last vt_bounce_loop_dev (its queues are engine-wide)
+    bool       loop_used = false;
+
+    // staging for the host-pointer entry points
+    void*  d_rays = nullptr;  size_t d_rays_bytes = 0;
+    void*  d_out  = nullptr;  size_t d_out_bytes = 0;
+    // large host batches: pinned double buffers + copy streams, so that H2D, trace and D2H of successive
+    // chunks overlap (pageable hipMemcpyAsync serialises on the host)
+    static constexpr uint64_t kHostChunk = uint64_t(1) << 20;   // rays per pipelined chunk
+    char* h_stage_in[2]  = {nullptr, nullptr};
+    char* h_stage_out[2] = {nullptr, nullptr};
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    // bounce loop: two ray queues, two path-id queues, the queue's hit records, block offsets, live counter
+    void*  d_loop = nullptr;  size_t d_loop_bytes = 0;
+    uint32_t* h_live = nullptr;           // pinned read-back of the live-path count
+    // single-ray / tiny-batch path: pinned, device-mapped host memory the kernel reads and writes in
+    // place (no copy calls: one launch + one stream sync per Traverse)
+    static constexpr uint32_t kTinyRays = 256;
+    vt_ray* h_tiny_rays = nullptr;  void* d_tiny_rays = nullptr;
+    char*   h_tiny_out  = nullptr;  void* d_tiny_out  = nullptr;
+
+    // timing
+    int        timing = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool       ev_valid = false;
+
+    // scenes uploaded through this engine: closing the engine releases their device memory and detaches them
+    std::vector<vt_scene*> scenes;
+
+    // last launch geometry
+    uint32_t last_blocks = 0, last_threads = 0, last_lds = 0;
+    int      last_persistent = 0, last_dma = 0;
+
+    // ---- multi-GPU (multi_gpu.hip) ------------------------------------------------------------------------------
+    // vt_engine_open_multi: this engine is the ROOT of a single-process group (its device = devices[0]); `peers`
+    // serve devices[1..] and are owned by it.  vt_engine_comm_init_rank: this engine is one rank of a
+    // one-process-per-GPU job.  Either way `comm` is this device's RCCL communicator.
+    std::vector<vt_engine*> peers;
+    vt_engine*  root = nullptr;               // on a peer: its root
+    void*       comm = nullptr;               // ncclComm_t
+    int         comm_rank = 0, comm_size = 1;
+    hipStream_t s_comm = nullptr;             // the gather of batch b runs here, beside the trace of batch b+1
+    hipEvent_t  ev_traced = nullptr;          // trace stream -> comm stream
+    hipEvent_t  ev_sent[2] = {nullptr, nullptr};   // comm stream: the gather that read send buffer b has completed
+    bool        sent_used[2] = {false, false};
+    void*       d_send[2] = {nullptr, nullptr};    // peers: this device's shard of hit records, double-buffered across batches
+    size_t      d_send_bytes[2] = {0, 0};
+    uint64_t    gather_batches = 0;
+};
+
+struct vt_scene {
+    vt_engine*    engine = nullptr;
+    char*         d_records = nullptr; // pairs, then (128-B aligned) the leaf-ordered triangles
+    vt_tri64*     d_tris = nullptr;    // = d_records + tri_base * 64
+    uint32_t      tri_base = 0;
+    uint32_t*     d_prim_to_slot = nullptr;
+    vt_tri_attribs* d_attribs = nullptr;   // optional side table, original triangle order
+    // refit: pair indices sorted by depth (deepest level first) and where each level starts
+    uint32_t*     d_level_pairs = nullptr;
+    std::vector<uint32_t> level_begin;     // level_begin[k] .. level_begin[k+1]) = k-th deepest level
+    // skinning inputs (vt_scene_set_skin) and the per-frame matrix table
+    float*          d_bind_verts = nullptr;
+    vt_skin_vertex* d_skin = nullptr;
+    uint32_t*       d_matrix_base = nullptr;
+    float*          d_skin_mats = nullptr;   // 3 x mats_cap matrices: bones | binds | products
+    uint32_t        mats_cap = 0;
+    // alpha test: set when a triangle carries VT_TRI_ALPHATEST; materials + alpha planes from vt_scene_set_alpha
+    bool               has_alpha = false;
+    vt_alpha_material* d_alpha_mats = nullptr;
+    uint8_t*           d_alpha_texels = nullptr;
+    uint32_t           n_alpha_mats = 0;
+    // refit / skinning with non-finite vertices: NaN boxes pass every slab test, so a poisoned subtree is walked by
+    // every ray -- the scene is refused until it has been refitted with finite data
+    float           coherent_radius2 = 0.f;   // (2 % of the scene's diagonal)^2: how far apart the origins of a ray packet may lie
+    uint32_t*       d_bad = nullptr;
+    bool            poisoned = false;
+    hipGraphExec_t  refit_graph = nullptr;   // the level-by-level refit launches, captured once (launch-bound: ~30 tiny kernels)
+    uint32_t      npairs = 0, ntris = 0, max_depth = 0, root_leaf_count = 0;
+    uint64_t      bytes = 0;
+    // multi-GPU group: the same scene on every peer device (replicas[g-1] lives on engine->peers[g-1]); owned by this scene
+    std::vector<vt_scene*> replicas;
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+namespace vt {
+
+int ensure_bytes(void** ptr, size_t* have, size_t need);
+// enqueue one trace of n device-resident rays on `stream` (per-launch scratch from the engine's slot ring)
+int engine_launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_occ, void* d_stats, bool any_hit, bool stats,
+                  hipStream_t stream);
+// the host-pointer path of ONE device: staging copies + launch(es) + copy-out, synchronous
+int engine_trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, size_t out_elem, bool any_hit);
+
+// multi_gpu.hip
+// a host ray array split into contiguous shards, one per device of the scene's group, traced side by side
+int multi_trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, size_t out_elem, bool any_hit);
+// communicator, comm stream, events and send buffers of one engine
+void multi_release(vt_engine* e);
+// host batches below this many rays stay on the root device (a second device's staging pipeline does not pay)
+constexpr uint64_t kMultiHostMin = uint64_t(1) << 20;
+
+} // namespace vt

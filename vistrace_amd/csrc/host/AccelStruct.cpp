@@ -21,12 +21,29 @@ IEntityMeshSource* g_meshSource = nullptr;
 vt_engine* g_engine = nullptr;
 
 // one engine per process, opened on first use (device from VISTRACE_DEVICE, default 0)
+// One engine per process, opened on first use.  VISTRACE_DEVICES="0,1,2,3" forms a single-process multi-GPU group
+// (BVH replicated on every device, TraverseBatch's rays sharded across them); otherwise one device, VISTRACE_DEVICE
+// (default 0).
 vt_engine* Engine(ILuaBase* LUA)
 {
     if (!g_engine) {
-        int dev = 0;
-        if (const char* e = std::getenv("VISTRACE_DEVICE")) dev = std::atoi(e);
-        if (vt_engine_open(dev, &g_engine) != VT_OK) {
+        int devs[64];
+        int ndev = 0;
+        if (const char* list = std::getenv("VISTRACE_DEVICES")) {
+            for (const char* p = list; *p && ndev < 64;) {
+                char* end = nullptr;
+                const long v = std::strtol(p, &end, 10);
+                if (end == p) break;
+                devs[ndev++] = int(v);
+                p = (*end == ',') ? end + 1 : end;
+            }
+        }
+        if (ndev == 0) {
+            const char* one = std::getenv("VISTRACE_DEVICE");
+            devs[ndev++] = one ? std::atoi(one) : 0;
+        }
+        const int rc = ndev > 1 ? vt_engine_open_multi(devs, ndev, &g_engine) : vt_engine_open(devs[0], &g_engine);
+        if (rc != VT_OK) {
             g_engine = nullptr;
             static thread_local char msg[512];
             std::snprintf(msg, sizeof(msg), "VisTrace: cannot open the HIP device: %s", vt_last_error());

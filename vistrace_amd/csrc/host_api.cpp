@@ -44,6 +44,24 @@ extern "C" {
 const char* vt_last_error(void) { return g_last_error.c_str(); }
 int vt_abi_version(void) { return VT_ABI_VERSION; }
 
+// ---- ray sharding of the multi-GPU path: contiguous shards, every one but the tail of equal size, so
+// that shard g of the rays and shard g of the gathered hit records both start at g * capacity ---------------------
+uint64_t vt_shard_capacity(uint64_t n, int ndev)
+{
+    if (ndev <= 0) return 0;
+    const uint64_t per = (n + uint64_t(ndev) - 1) / uint64_t(ndev);
+    return (per + 63) / 64 * 64;                       // whole 64-ray wave blocks: shard boundaries never split one
+}
+
+void vt_shard_bounds(uint64_t n, int ndev, int g, uint64_t* lo, uint64_t* hi)
+{
+    const uint64_t cap = vt_shard_capacity(n, ndev);
+    const bool valid = g >= 0 && g < ndev;
+    const uint64_t a = valid ? std::min(n, cap * uint64_t(g)) : n;
+    if (lo) *lo = a;
+    if (hi) *hi = valid ? std::min(n, a + cap) : a;
+}
+
 int vt_tris_setup(const float* verts, const uint8_t* flags, uint32_t n, vt_tri64* out)
 {
     if (n != 0 && (!verts || !out)) return fail(VT_ERR_INVALID_ARG, "vt_tris_setup: NULL argument");

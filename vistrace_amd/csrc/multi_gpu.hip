@@ -1,0 +1,367 @@
+// multi_gpu.hip -- multi-GPU behind the C ABI: replicated scene, sharded rays, ONE RCCL gather of hit records.
+//
+// rays never interact and the scene is read-only, so the path shards by independent units -- every
+// device holds a full replica of the linearised BVH in its own HBM (1 M triangles = 104 MB, 10 M = 1.04 GB of 288 GB),
+// traces a contiguous shard of the ray array, and the only exchange is the gather of the 16-byte hit records to the
+// root device (`ncclGather`, /opt/rocm/include/rccl/rccl.h:745; RCCL implements it as N-1 direct sends into the root,
+// one per xGMI link).  No all-reduce, no all-to-all.  Two ways to form the group:
+//   * vt_engine_open_multi(devices, ndev): ONE process drives all devices (what the reference's C++ module would do:
+//     a Lua state is one thread of one process) -- `ncclCommInitAll`, the gather calls of all devices in one group;
+//   * vt_engine_comm_init_rank(e, nranks, rank, id): one process per GPU (bench.py under torch.distributed.run) --
+//     `ncclCommInitRank` with an id from vt_comm_unique_id that the launcher distributes.
+// The gather of batch b runs on a communication stream beside the trace of batch b+1 (send buffers are double-buffered;
+// engine option "reserved_cus" keeps room on the CUs for RCCL's kernels while a persistent trace grid is resident).
+//
+// RCCL is loaded with dlopen on first use: a single-GPU user never needs the library, and a process that already
+// holds a copy (PyTorch bundles one) keeps using that one.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <type_traits>
+#include <vector>
+
+#include "engine_internal.h"
+
+using namespace vt;
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId)    GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank)   CommInitRank = nullptr;
+    decltype(&ncclCommInitAll)    CommInitAll = nullptr;
+    decltype(&ncclCommDestroy)    CommDestroy = nullptr;
+    decltype(&ncclGather)         Gather = nullptr;
+    decltype(&ncclGroupStart)     GroupStart = nullptr;
+    decltype(&ncclGroupEnd)       GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+
+RcclApi& rccl_state()
+{
+    static RcclApi api;
+    return api;
+}
+
+RcclApi* rccl()
+{
+    RcclApi& api = rccl_state();
+    static std::once_flag once;
+    std::call_once(once, [&api] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        const char* env = std::getenv("VT_RCCL_LIB");
+        if (env && *env) api.handle = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+        for (const char* n : names) {
+            if (api.handle) break;
+            api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!api.handle) { api.error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found"); return; }
+        bool ok = true;
+        auto sym = [&](auto& fn, const char* name) {
+            fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(api.handle, name));
+            if (!fn) { ok = false; api.error = std::string("librccl.so lacks ") + name; }
+        };
+        sym(api.GetUniqueId, "ncclGetUniqueId");
+        sym(api.CommInitRank, "ncclCommInitRank");
+        sym(api.CommInitAll, "ncclCommInitAll");
+        sym(api.CommDestroy, "ncclCommDestroy");
+        sym(api.Gather, "ncclGather");
+        sym(api.GroupStart, "ncclGroupStart");
+        sym(api.GroupEnd, "ncclGroupEnd");
+        sym(api.GetErrorString, "ncclGetErrorString");
+        if (!ok) { api.handle = nullptr; }
+    });
+    return api.handle ? &api : nullptr;
+}
+
+int rccl_fail(const char* what, ncclResult_t r)
+{
+    RcclApi* R = rccl();
+    return fail(VT_ERR_HIP, std::string(what) + ": " + (R ? R->GetErrorString(r) : "RCCL not loaded"));
+}
+
+#define VT_NCCL(call)                                                     \
+    do {                                                                  \
+        ncclResult_t r__ = (call);                                        \
+        if (r__ != ncclSuccess) return rccl_fail(#call, r__);             \
+    } while (0)
+
+// comm stream + events of one engine (its device is current)
+int ensure_comm_side(vt_engine* e)
+{
+    if (e->s_comm) return VT_OK;
+    VT_HIP(hipStreamCreateWithFlags(&e->s_comm, hipStreamNonBlocking));
+    VT_HIP(hipEventCreateWithFlags(&e->ev_traced, hipEventDisableTiming));
+    for (int b = 0; b < 2; ++b) VT_HIP(hipEventCreateWithFlags(&e->ev_sent[b], hipEventDisableTiming));
+    return VT_OK;
+}
+
+// the devices of a group in group order: root first
+std::vector<vt_engine*> group_of(vt_engine* root)
+{
+    std::vector<vt_engine*> g{root};
+    g.insert(g.end(), root->peers.begin(), root->peers.end());
+    return g;
+}
+
+// single-process group: one communicator per device, created together on first use
+int ensure_group_comms(vt_engine* root)
+{
+    if (root->comm) return VT_OK;
+    RcclApi* R = rccl();
+    if (!R) return fail(VT_ERR_HIP, "multi-GPU gather: " + rccl_state().error);
+    const std::vector<vt_engine*> g = group_of(root);
+    std::vector<int> devs;
+    for (vt_engine* e : g) devs.push_back(e->device);
+    std::vector<ncclComm_t> comms(g.size(), nullptr);
+    VT_NCCL(R->CommInitAll(comms.data(), int(g.size()), devs.data()));
+    for (size_t k = 0; k < g.size(); ++k) {
+        g[k]->comm = comms[k];
+        g[k]->comm_rank = int(k);
+        g[k]->comm_size = int(g.size());
+        DeviceGuard guard(g[k]->device);
+        const int rc = ensure_comm_side(g[k]);
+        if (rc != VT_OK) return rc;
+    }
+    return VT_OK;
+}
+
+} // namespace
+
+namespace vt {
+
+void multi_release(vt_engine* e)
+{
+    if (e->comm) {
+        if (RcclApi* R = rccl()) (void)R->CommDestroy(static_cast<ncclComm_t>(e->comm));
+        e->comm = nullptr;
+    }
+    for (int b = 0; b < 2; ++b) {
+        if (e->d_send[b]) (void)hipFree(e->d_send[b]);
+        e->d_send[b] = nullptr; e->d_send_bytes[b] = 0;
+        if (e->ev_sent[b]) (void)hipEventDestroy(e->ev_sent[b]);
+        e->ev_sent[b] = nullptr;
+    }
+    if (e->ev_traced) (void)hipEventDestroy(e->ev_traced);
+    e->ev_traced = nullptr;
+    if (e->s_comm) (void)hipStreamDestroy(e->s_comm);
+    e->s_comm = nullptr;
+}
+
+// Host ray array -> contiguous shards -> one staging pipeline per device, side by side (one host thread each: the
+// pipelines are synchronous per device).  Results land in the caller's array directly, so no collective is needed here.
+int multi_trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, size_t out_elem, bool any_hit)
+{
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_trace: the scene's engine has been closed");
+    if (!rays || !out) return fail(VT_ERR_INVALID_ARG, "vt_trace: NULL buffer");
+    std::vector<vt_scene*> scenes{s};
+    scenes.insert(scenes.end(), s->replicas.begin(), s->replicas.end());
+    const int ndev = int(scenes.size());
+    std::vector<int> rcs(size_t(ndev), VT_OK);
+    std::vector<std::string> errs(static_cast<size_t>(ndev));
+    std::vector<std::thread> workers;
+    for (int g = 0; g < ndev; ++g) {
+        uint64_t lo = 0, hi = 0;
+        vt_shard_bounds(n, ndev, g, &lo, &hi);
+        if (hi <= lo) continue;
+        workers.emplace_back([&, g, lo, hi] {
+            rcs[size_t(g)] = engine_trace_host(scenes[size_t(g)], rays + lo, hi - lo, static_cast<char*>(out) + lo * out_elem, out_elem, any_hit);
+            if (rcs[size_t(g)] != VT_OK) errs[size_t(g)] = vt_last_error();      // the error string is thread-local
+        });
+    }
+    for (std::thread& t : workers) t.join();
+    for (int g = 0; g < ndev; ++g)
+        if (rcs[size_t(g)] != VT_OK) return fail(rcs[size_t(g)], "device " + std::to_string(scenes[size_t(g)]->engine ? scenes[size_t(g)]->engine->device : -1) + ": " + errs[size_t(g)]);
+    return VT_OK;
+}
+
+} // namespace vt
+
+extern "C" {
+
+int vt_engine_open_multi(const int* devices, int ndev, vt_engine** out)
+{
+    if (!out) return fail(VT_ERR_INVALID_ARG, "vt_engine_open_multi: out is NULL");
+    *out = nullptr;
+    if (!devices || ndev <= 0) return fail(VT_ERR_INVALID_ARG, "vt_engine_open_multi: no devices");
+    for (int a = 0; a < ndev; ++a)
+        for (int b = a + 1; b < ndev; ++b)
+            if (devices[a] == devices[b]) return fail(VT_ERR_INVALID_ARG, "vt_engine_open_multi: a device is listed twice");
+    vt_engine* root = nullptr;
+    int rc = vt_engine_open(devices[0], &root);
+    if (rc != VT_OK) return rc;
+    for (int k = 1; k < ndev; ++k) {
+        vt_engine* p = nullptr;
+        rc = vt_engine_open(devices[k], &p);
+        if (rc != VT_OK) { vt_engine_close(root); return rc; }
+        p->root = root;
+        root->peers.push_back(p);
+    }
+    *out = root;
+    return VT_OK;
+}
+
+int vt_engine_device_count(const vt_engine* e) { return e ? int(e->peers.size()) + 1 : 0; }
+
+int vt_engine_device(const vt_engine* e, int g)
+{
+    if (!e || g < 0 || g > int(e->peers.size())) return -1;
+    return g == 0 ? e->device : e->peers[size_t(g) - 1]->device;
+}
+
+// ---- device-resident shards + the gather --------------------------------------------------------------------------
+
+int vt_trace_closest_gather_dev(vt_scene* s, const void* const* d_rays, uint64_t n, void* d_hits_root)
+{
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_trace_closest_gather_dev: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_trace_closest_gather_dev: the scene's engine has been closed");
+    if (n == 0) return VT_OK;
+    if (!d_rays || !d_hits_root) return fail(VT_ERR_INVALID_ARG, "vt_trace_closest_gather_dev: NULL argument");
+    vt_engine* root = s->engine;
+    if (root->root) return fail(VT_ERR_INVALID_ARG, "vt_trace_closest_gather_dev: call it on the group's root scene");
+    int rc = ensure_group_comms(root);
+    if (rc != VT_OK) return rc;
+    RcclApi* R = rccl();
+    const std::vector<vt_engine*> g = group_of(root);
+    std::vector<vt_scene*> scenes{s};
+    scenes.insert(scenes.end(), s->replicas.begin(), s->replicas.end());
+    if (scenes.size() != g.size()) return fail(VT_ERR_INVALID_ARG, "vt_trace_closest_gather_dev: the scene is not replicated over the group");
+    const int ndev = int(g.size());
+    const uint64_t cap = vt_shard_capacity(n, ndev);
+    const int buf = int(root->gather_batches & 1);
+
+    // 1. every device traces its shard into its send buffer (the root: straight into its slice of the result)
+    std::vector<void*> send(static_cast<size_t>(ndev), nullptr);
+    for (int k = 0; k < ndev; ++k) {
+        vt_engine* e = g[size_t(k)];
+        DeviceGuard guard(e->device);
+        if (!guard.ok) return fail(VT_ERR_HIP, "vt_trace_closest_gather_dev: hipSetDevice failed");
+        uint64_t lo = 0, hi = 0;
+        vt_shard_bounds(n, ndev, k, &lo, &hi);
+        if (k == 0) {
+            send[0] = d_hits_root;                     // in place: sendbuff == recvbuff + rank * sendcount
+        } else {
+            // the gather that last read this buffer (two batches ago) must be over before it is overwritten
+            if (e->sent_used[buf]) VT_HIP(hipStreamWaitEvent(e->stream, e->ev_sent[buf], 0));
+            if (e->d_send_bytes[buf] < cap * sizeof(vt_hit)) {
+                if (e->sent_used[buf]) VT_HIP(hipEventSynchronize(e->ev_sent[buf]));
+                rc = ensure_bytes(&e->d_send[buf], &e->d_send_bytes[buf], cap * sizeof(vt_hit));
+                if (rc != VT_OK) return rc;
+            }
+            send[size_t(k)] = e->d_send[buf];
+        }
+        if (hi > lo) {
+            if (!d_rays[k]) return fail(VT_ERR_INVALID_ARG, "vt_trace_closest_gather_dev: d_rays[" + std::to_string(k) + "] is NULL");
+            rc = engine_launch(scenes[size_t(k)], d_rays[k], hi - lo, send[size_t(k)], nullptr, nullptr, false, false, e->stream);
+            if (rc != VT_OK) return rc;
+        }
+        VT_HIP(hipEventRecord(e->ev_traced, e->stream));
+        VT_HIP(hipStreamWaitEvent(e->s_comm, e->ev_traced, 0));
+    }
+    // 2. ONE gather: cap records from every device into the root's buffer, shard g at record g * cap -- ray order
+    VT_NCCL(R->GroupStart());
+    for (int k = 0; k < ndev; ++k) {
+        vt_engine* e = g[size_t(k)];
+        const ncclResult_t r = R->Gather(send[size_t(k)], d_hits_root, cap * sizeof(vt_hit), ncclUint8, 0, static_cast<ncclComm_t>(e->comm), e->s_comm);
+        if (r != ncclSuccess) { (void)R->GroupEnd(); return rccl_fail("ncclGather", r); }
+    }
+    VT_NCCL(R->GroupEnd());
+    for (int k = 0; k < ndev; ++k) {
+        vt_engine* e = g[size_t(k)];
+        DeviceGuard guard(e->device);
+        VT_HIP(hipEventRecord(e->ev_sent[buf], e->s_comm));
+        e->sent_used[buf] = true;
+    }
+    ++root->gather_batches;
+    return VT_OK;
+}
+
+// ---- one process per GPU ---------------------------------------------------------------------------------------
+
+int vt_comm_unique_id(void* id128)
+{
+    if (!id128) return fail(VT_ERR_INVALID_ARG, "vt_comm_unique_id: NULL");
+    RcclApi* R = rccl();
+    if (!R) return fail(VT_ERR_HIP, "vt_comm_unique_id: " + rccl_state().error);
+    static_assert(sizeof(ncclUniqueId) == 128, "vt_comm_unique_id hands out 128 bytes");
+    ncclUniqueId id;
+    VT_NCCL(R->GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+    return VT_OK;
+}
+
+int vt_engine_comm_init_rank(vt_engine* e, int nranks, int rank, const void* id128)
+{
+    if (!e || !id128) return fail(VT_ERR_INVALID_ARG, "vt_engine_comm_init_rank: NULL");
+    if (nranks <= 0 || rank < 0 || rank >= nranks) return fail(VT_ERR_INVALID_ARG, "vt_engine_comm_init_rank: bad rank");
+    if (!e->peers.empty() || e->root) return fail(VT_ERR_INVALID_ARG, "vt_engine_comm_init_rank: the engine belongs to a single-process group");
+    if (e->comm) return fail(VT_ERR_INVALID_ARG, "vt_engine_comm_init_rank: already initialised");
+    RcclApi* R = rccl();
+    if (!R) return fail(VT_ERR_HIP, "vt_engine_comm_init_rank: " + rccl_state().error);
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_engine_comm_init_rank: hipSetDevice failed");
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm = nullptr;
+    VT_NCCL(R->CommInitRank(&comm, nranks, id, rank));
+    e->comm = comm;
+    e->comm_rank = rank;
+    e->comm_size = nranks;
+    return ensure_comm_side(e);
+}
+
+int vt_gather_hits_dev(vt_engine* e, const void* d_send, uint64_t count, void* d_recv_root, int root, void* stream_)
+{
+    if (!e || !d_send) return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_dev: NULL");
+    if (!e->comm || !e->peers.empty() || e->root) return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_dev: call vt_engine_comm_init_rank first");
+    if (root < 0 || root >= e->comm_size) return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_dev: bad root");
+    if (e->comm_rank == root && !d_recv_root) return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_dev: the root needs a receive buffer");
+    if (count == 0) return VT_OK;
+    RcclApi* R = rccl();
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_gather_hits_dev: hipSetDevice failed");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // the records were produced on `stream`; the gather runs on the engine's comm stream so that the next trace on
+    // `stream` does not queue behind it
+    VT_HIP(hipEventRecord(e->ev_traced, stream));
+    VT_HIP(hipStreamWaitEvent(e->s_comm, e->ev_traced, 0));
+    VT_NCCL(R->Gather(d_send, d_recv_root, count * sizeof(vt_hit), ncclUint8, root, static_cast<ncclComm_t>(e->comm), e->s_comm));
+    const int buf = int(e->gather_batches & 1);
+    VT_HIP(hipEventRecord(e->ev_sent[buf], e->s_comm));
+    e->sent_used[buf] = true;
+    ++e->gather_batches;
+    return VT_OK;
+}
+
+int vt_gather_wait(vt_engine* e, int batches_in_flight, void* stream_)
+{
+    if (!e) return fail(VT_ERR_INVALID_ARG, "vt_gather_wait: NULL");
+    if (!e->s_comm || e->gather_batches == 0) return VT_OK;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_gather_wait: hipSetDevice failed");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (batches_in_flight <= 0) {                       // everything: host wait
+        VT_HIP(hipStreamSynchronize(e->s_comm));
+        return VT_OK;
+    }
+    // allow one gather in flight: the one before the latest must be over before `stream` continues (its send buffer
+    // is the one the next batch writes)
+    if (e->gather_batches >= 2) {
+        const int buf = int((e->gather_batches - 2) & 1);
+        if (e->sent_used[buf]) VT_HIP(hipStreamWaitEvent(stream, e->ev_sent[buf], 0));
+    }
+    return VT_OK;
+}
+
+} // extern "C"
