@@ -5,30 +5,48 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (config.workload = "S1M_bounce16M", BASELINE.json configs[2]): scene S1M
-(1 000 300 triangles), 16 777 216 incoherent cosine-hemisphere bounce rays generated from
-the 4096x4096 primary hits of one camera, closest hit.  One "step" = one pass of the hot
-path (vt_trace_closest_dev) over the whole ray batch, rays and hits resident in HBM.
-With N > 1 ranks the BVH is replicated, every rank traces its own 16 Mi-ray batch (camera =
-rank; weak scaling) and the hit records are gathered to rank 0 over RCCL inside the step.
+Default workload (config.workload = "S1M_bounce16777216", BASELINE.json configs[2]): scene S1M (1 000 300
+triangles), 16 777 216 incoherent cosine-hemisphere bounce rays generated from the 4096x4096 primary hits of one
+camera, closest hit.  One "step" = one pass of the hot path (vt_trace_closest_dev) over the whole ray batch, rays and
+hits resident in HBM.  With N > 1 ranks the BVH is replicated and
+  --scaling weak   (default) every rank traces its own 16 Mi-ray batch (camera = rank);
+  --scaling strong BASELINE configs[4] verbatim with `--scene S10M`: 128 tiles of 1024x1024 primary rays from 128
+                   seeded camera poses = 134 217 728 rays in total, split contiguously over the ranks;
+either way the hit records are gathered to rank 0 over RCCL (xGMI) inside the step -- the single exchange of the path.
 
 The printed JSON line also carries
-  roofline     -- algorithmic bytes (32+16+64*steps+64*tests per ray, counters from the
-                  device stats kernel, cross-checked with the CPU oracle on the sample)
-                  / mean kernel time (HIP events on the launch stream) vs the 8 TB/s HBM peak;
-  cpu_baseline -- the CPU oracle (oracle/, a port: the reference itself cannot be built
-                  here) on all host cores over a bounded sample of the same rays.
+  roofline     -- the dominant kernel against the HBM roofline: `traffic` = fabric-side bytes per launch from
+                  rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; collected live by re-running this workload in a child
+                  process under the profiler, or read from profiles/r<N>/ when the kernel sources are unchanged),
+                  `achieved` = traffic / mean launch duration (HIP events on the launch stream over the timed region),
+                  `frac` = achieved / 8 TB/s.  The algorithmic figure of SURVEY.md 8(d) (32 + 16 + 64 * steps + 64 *
+                  tests bytes per ray, counters from the device stats kernel) is `alg_achieved` / `alg_over_peak`: it
+                  exceeds the peak because records are served by L1 / L2 / Infinity Cache.  `bound_actual` says what
+                  the kernel is bound by instead (VALU issue), from an SQ counter pass of the same launch;
+  cpu_baseline -- the CPU oracle (oracle/, a port: the reference itself cannot be built here) on the host's cores over
+                  a bounded sample of the same rays: -O3 x86-64-v3 build, threads pinned, one tree replica per NUMA node.
 Data is synthetic (seeded generator, vistrace_amd/workloads.py); nothing reads /root/reference.
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
+import signal
+import subprocess
 import sys
+import tempfile
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    # the cpu_baseline leg: pin the oracle's OpenMP threads (must be set before libgomp initialises)
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -36,7 +54,14 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured streaming copy)
+ROUND = "r2"
+KERNEL_SOURCES = ("vistrace_amd/csrc/trace_kernels.hip", "vistrace_amd/csrc/trace_kernels.h", "vistrace_amd/csrc/engine.hip",
+                  "vistrace_amd/csrc/engine_internal.h", "vistrace_amd/csrc/Makefile")
+# issue cost per wave-instruction and SIMD in cycles, measured on this part (scripts/ubench_valu.hip, profiles/r1/notes.md)
+ISSUE_COST = {"MUL_F32": 2.4, "ADD_F32": 2.4, "FMA_F32": 4.2, "TRANS_F32": 8.2, "INT32": 3.2, "OTHER": 4.2}
+SIMDS = 1024               # 256 CUs x 4
+CLOCK_GHZ = 2.4
 
 
 def log(*a):
@@ -44,64 +69,16 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scene", default="S1M")
-    ap.add_argument("--side", type=int, default=4096, help="primary image side; rays per GPU = side*side")
-    ap.add_argument("--kind", default="bounce", choices=["bounce", "primary"])
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--builder", default="ploc", choices=["ploc", "sah"],
-                    help="ploc = the reference's build pipeline (default); sah = opt-in binned SAH (not the headline)")
-    ap.add_argument("--gen", default="device", choices=["device", "host"], help="where the synthetic rays are generated")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL (one GPU per rank); gloo = test mode: ranks may share a GPU, hits gathered via host")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="dev: run the N > 1 control flow (process group, gather pipeline, barriers) even with one rank")
-    ap.add_argument("--reserve-cus", type=int, default=32,
-                    help="N > 1: CUs (one per shader engine of every XCD) on which the persistent trace grid leaves room "
-                         "for the RCCL gather's kernels, so that the transfer of batch b overlaps the trace of batch b+1; "
-                         "0 = off (the gather then only starts when the resident grid drains)")
-    ap.add_argument("--chunks", type=int, default=1,
-                    help="N > 1: launches per batch in the trace/gather pipeline (1 = whole batch per launch: every extra "
-                         "launch costs ~0.27 ms of ramp-up and end-of-queue tail; batches are double-buffered either way)")
-    ap.add_argument("--mode", default=None, choices=[None, "persistent", "static"])
-    args = ap.parse_args()
+def kernel_sources_sha() -> str:
+    h = hashlib.sha1()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
-    import torch
-    import torch.distributed as dist
 
-    import vistrace_amd as va
-    from vistrace_amd import torch_plumbing as tp
-    from vistrace_amd.distributed import HitGatherPipeline
-    from vistrace_amd import workloads as W
-    from vistrace_amd._lib import HIT, HIT_ATTRS, RAY, RAY_STATS
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (the traversal has no CPU path)")
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, ndev)
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    dist_on = world > 1 or args.force_dist
-    if dist_on:
-        if args.force_dist and "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group("gloo")
-
-    # ---- scene: CPU build once, upload once (Rebuild) -----------------------------------
+# ---- workload -----------------------------------------------------------------------------------------------------
+def build_scene(args, va, W, dev_index, world):
     t0 = time.time()
     verts = W.make_scene(args.scene)
     tris = va.tris_setup(verts)
@@ -117,13 +94,32 @@ def main() -> None:
     t3 = time.time()
     log(f"[bench] scene {args.scene}: {len(tris)} tris, {host_scene.pair_count} pairs, depth {host_scene.max_depth}, "
         f"{scene.device_bytes / 1e6:.1f} MB on device; gen {t1 - t0:.2f}s build {t2 - t1:.2f}s upload {t3 - t2:.2f}s")
+    return tris, bvh, host_scene, engine, scene, host_threads
 
-    # ---- rays: primary pass on the GPU, bounce rays from its hit records ----------------
+
+def make_rays(args, rank, world, va, W, tp, engine, scene, device):
+    """This rank's device-resident rays.  Returns (d_rays, n_local, n_total, workload name, host copy or None)."""
+    import torch
+    from vistrace_amd._lib import HIT_ATTRS, RAY
+    stream0 = tp.current_stream_handle(device)
+    if args.scaling == "strong":
+        # BASELINE configs[4]: `tiles` camera poses x 1024^2 pixel-centre rays, split contiguously over the ranks
+        tile = 1024 * 1024
+        per = (args.tiles + world - 1) // world
+        lo_t, hi_t = min(args.tiles, rank * per), min(args.tiles, (rank + 1) * per)
+        n_local = (hi_t - lo_t) * tile
+        d_rays = tp.empty_records(max(n_local, 1), RAY, device)
+        for t in range(lo_t, hi_t):
+            pos, fwd = W.camera_pose(args.scene, t)
+            engine.gen_primary_dev(1024, 1024, d_rays.data_ptr() + (t - lo_t) * tile * RAY.itemsize, pos=tuple(float(x) for x in pos),
+                                   forward=tuple(float(x) for x in fwd), stream=stream0)
+        torch.cuda.synchronize(device)
+        log(f"[bench] strong scaling: {args.tiles} tiles of 1024x1024 primary rays, rank {rank} traces tiles [{lo_t}, {hi_t})")
+        return d_rays, n_local, args.tiles * tile, f"{args.scene}_primary_{args.tiles}x1048576_tiles", None
     side = args.side
     n = side * side
     cams = W.camera_positions(args.scene)
     cam = cams[rank % len(cams)]
-    stream0 = tp.current_stream_handle(device)
     rays_host = None
     if args.gen == "host":
         prim_rays = W.primary_rays(side, side, pos=cam)
@@ -149,10 +145,237 @@ def main() -> None:
         del d_attrs, d_hits0, d_prim
         log(f"[bench] bounce rays: {n} from {side}x{side} primary hits ({miss} primary misses"
             f"{' re-filled' if args.gen == 'host' else ' -> null rays'}), generated on the {args.gen}")
-    d_hits = tp.empty_records(n, HIT, device)
-    pipe = HitGatherPipeline(n, device, nchunks=args.chunks, via_host=args.backend == "gloo") if dist_on else None
+    torch.cuda.synchronize(device)
+    return d_rays, n, n * world, f"{args.scene}_{args.kind}{n}", rays_host
+
+
+# ---- PMC: fabric-side traffic and SQ counters of the dominant kernel ------------------------------------------------
+PMC_PASSES = {
+    "fetch": ["FETCH_SIZE"],
+    "write": ["WRITE_SIZE"],
+    "sq": ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+           "SQ_ACTIVE_INST_ANY", "SQ_WAVES"],
+    "mix": ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
+            "SQ_INSTS_VALU_INT32", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD"],
+}
+
+
+def under_profiler() -> bool:
+    return any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")) or \
+        "ROCPROFILER_LIBRARY_CTOR" in os.environ
+
+
+def child_workload_args(args) -> list:
+    a = ["--scene", args.scene, "--side", str(args.side), "--kind", args.kind, "--builder", args.builder, "--gen", "device",
+         "--scaling", args.scaling, "--tiles", str(args.tiles)]
+    if args.mode is not None:
+        a += ["--mode", args.mode]
+    return a
+
+
+def collect_pmc_live(args, passes) -> dict:
+    """Re-run this workload's dominant launch in a child process under `rocprofv3 --pmc` (one pass per counter group;
+    never combined with other trace domains) and return {counter: value of the last dispatch of the trace kernel}."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        log("[bench] rocprofv3 not found: no live PMC pass")
+        return {}
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for name in passes:
+        tmp = tempfile.mkdtemp(prefix=f"vt_pmc_{name}_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", *PMC_PASSES[name], "--output-format", "csv", "-d", tmp, "--",
+               "python3", os.path.join(ROOT, "bench.py"), "--pmc-child", *child_workload_args(args)]
+        t0 = time.time()
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=args.pmc_timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                log(f"[bench] PMC pass {name}: timed out after {args.pmc_timeout}s")
+                shutil.rmtree(tmp, ignore_errors=True)
+                break
+            got = {}
+            for f in glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    kn = r.get("Kernel_Name", "")
+                    if "trace_kernel<false, false" in kn or "trace_kernel<false,false" in kn:
+                        got[r["Counter_Name"]] = float(r["Counter_Value"])     # rows are in dispatch order: keep the last
+            log(f"[bench] PMC pass {name}: rc {rc}, {len(got)} counters, {time.time() - t0:.1f}s")
+            out.update(got)
+        except OSError as exc:
+            log(f"[bench] PMC pass {name} failed: {exc}")
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def committed_pmc(workload: str, sha: str) -> dict:
+    """profiles/r<N>/pmc_<workload>.json, only if it was taken from exactly these kernel sources."""
+    path = os.path.join(ROOT, "profiles", ROUND, f"pmc_{workload}.json")
+    try:
+        with open(path) as f:
+            tj = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    if tj.get("workload") != workload or tj.get("kernel_sources_sha") != sha:
+        log(f"[bench] {path} is stale (kernel sources changed): not used")
+        return {}
+    return dict(tj.get("counters", {}), _source=os.path.relpath(path, ROOT))
+
+
+def bound_actual(pmc: dict, kernel_ms: float) -> dict | None:
+    if "SQ_INSTS_VALU" not in pmc:
+        return None
+    valu = pmc["SQ_INSTS_VALU"]
+    out = {"kind": "valu_issue", "sq_insts_valu": valu, "sq_insts_salu": pmc.get("SQ_INSTS_SALU"),
+           "lane_utilisation": round(pmc["SQ_THREAD_CYCLES_VALU"] / (valu * 64.0), 4) if pmc.get("SQ_THREAD_CYCLES_VALU") else None}
+    if "SQ_WAVE_CYCLES" in pmc and pmc["SQ_WAVE_CYCLES"]:
+        wc = pmc["SQ_WAVE_CYCLES"]
+        out["wave_time_split"] = {k: round(pmc.get(c, 0.0) / wc, 3) for k, c in
+                                  (("executing", "SQ_ACTIVE_INST_ANY"), ("waiting_memory_or_barrier", "SQ_WAIT_ANY"), ("waiting_to_issue", "SQ_WAIT_INST_ANY"))}
+    if "SQ_INSTS_VALU_MUL_F32" in pmc:
+        named = {k: pmc.get(f"SQ_INSTS_VALU_{k}", 0.0) for k in ("MUL_F32", "ADD_F32", "FMA_F32", "TRANS_F32", "INT32")}
+        other = max(0.0, valu - sum(named.values()))
+        cycles = sum(named[k] * ISSUE_COST[k] for k in named) + other * ISSUE_COST["OTHER"]
+        per_simd = cycles / SIMDS
+        out["valu_issue_cycles_per_simd"] = round(per_simd)
+        out["kernel_cycles"] = round(kernel_ms * 1e-3 * CLOCK_GHZ * 1e9)
+        out["valu_busy_frac"] = round(per_simd / (kernel_ms * 1e-3 * CLOCK_GHZ * 1e9), 3)
+        out["issue_cost_source"] = "scripts/ubench_valu.hip (cycles per wave-instruction and SIMD: mul/add 2.4, int 3.2, fma/select/minmax 4.2, rcp 8.2)"
+        out["branches"] = pmc.get("SQ_INSTS_BRANCH")
+    return out
+
+
+# ---- N > 1: gather of the hit records to rank 0 ---------------------------------------------------------------------
+class NativeGather:
+    """vt_gather_hits_dev (ncclGather from libvistrace_hip.so on its own communication stream), double-buffered: batch b
+    traces into hits[b % 2] and lands in recv[b % 2] on rank 0 while batch b + 1 is traced."""
+
+    def __init__(self, engine, n, world, rank, device, dist):
+        import torch
+        import vistrace_amd as va
+        ids = [va.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        engine.comm_init_rank(world, rank, ids[0])
+        self.engine, self.n, self.rank = engine, n, rank
+        self.hits = [torch.empty(n * 16, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = [torch.empty(world * n * 16, dtype=torch.uint8, device=device) if rank == 0 else None for _ in range(2)]
+        self.batch = 0
+
+    def submit(self, trace, stream):
+        b = self.batch % 2
+        self.engine.gather_wait(1, stream)                      # the gather that read hits[b] two batches ago is over
+        trace(self.hits[b])
+        self.engine.gather_hits_dev(self.hits[b].data_ptr(), self.n, self.recv[b].data_ptr() if self.rank == 0 else 0, 0, stream)
+        self.batch += 1
+        return b
+
+    def drain(self):
+        self.engine.gather_wait(0)
+
+
+def verify_gather(dist, rank, world, n, local_hits, recv, device, backend):
+    """Every rank's hit shard must have arrived on rank 0 unchanged: 64-bit word sums per shard, compared on rank 0."""
+    import torch
+    mine = local_hits.view(torch.int64).sum().reshape(1)
+    sums = [torch.zeros(1, dtype=torch.int64, device=mine.device) for _ in range(world)]
+    dist.all_gather(sums, mine)
+    ok = True
+    if rank == 0:
+        got = recv.view(torch.int64).view(world, -1).sum(dim=1)
+        ok = bool((got == torch.cat(sums)).all())
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+    dist.broadcast(flag, src=0)
+    return bool(flag.item())
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scene", default="S1M")
+    ap.add_argument("--side", type=int, default=4096, help="primary image side; rays per GPU = side*side (weak scaling)")
+    ap.add_argument("--kind", default="bounce", choices=["bounce", "primary"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank traces its own side*side batch; strong: BASELINE configs[4] -- `--tiles` camera tiles of "
+                         "1024x1024 primary rays split over the ranks (use with --scene S10M)")
+    ap.add_argument("--tiles", type=int, default=128, help="strong scaling: camera tiles (1024x1024 rays each) in the whole job")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the live rocprofv3 PMC passes (traffic then comes from profiles/ or is null)")
+    ap.add_argument("--pmc-passes", default="fetch,write,sq,mix")
+    ap.add_argument("--pmc-timeout", type=float, default=240.0)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--builder", default="ploc", choices=["ploc", "sah"],
+                    help="ploc = the reference's build pipeline (default); sah = opt-in binned SAH (not the headline)")
+    ap.add_argument("--gen", default="device", choices=["device", "host"], help="where the synthetic rays are generated")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (one GPU per rank); gloo = test mode: ranks may share a GPU, hits gathered via host")
+    ap.add_argument("--gather", default="native", choices=["native", "torch"],
+                    help="N > 1: native = vt_gather_hits_dev (ncclGather issued by libvistrace_hip.so, verified in the warm-up, "
+                         "falls back to torch on any error); torch = torch.distributed.gather")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="dev: run the N > 1 control flow (process group, gather pipeline, barriers) even with one rank")
+    ap.add_argument("--reserve-cus", type=int, default=32,
+                    help="N > 1: CUs (one per shader engine of every XCD) on which the persistent trace grid leaves room "
+                         "for the RCCL gather's kernels, so that the transfer of batch b overlaps the trace of batch b+1; "
+                         "0 = off (the gather then only starts when the resident grid drains)")
+    ap.add_argument("--chunks", type=int, default=1, help="torch gather: launches per batch in the trace/gather pipeline")
+    ap.add_argument("--mode", default=None, choices=[None, "persistent", "static"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import vistrace_amd as va
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd.distributed import HitGatherPipeline
+    from vistrace_amd import workloads as W
+    from vistrace_amd._lib import HIT, RAY, RAY_STATS
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the traversal has no CPU path)")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, ndev)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+
+    # ---- child of a PMC pass: the dominant launch a few times, nothing else ------------------------------------------
+    if args.pmc_child:
+        tris, bvh, host_scene, engine, scene, _ = build_scene(args, va, W, dev_index, 1)
+        d_rays, n, _, _, _ = make_rays(args, 0, 1, va, W, tp, engine, scene, device)
+        d_hits = tp.empty_records(n, HIT, device)
+        for _ in range(3):
+            tp.trace_closest(scene, d_rays, n, d_hits)
+        torch.cuda.synchronize(device)
+        return
+
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
+        if args.force_dist and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+
+    # ---- scene: CPU build once, upload once (Rebuild) -----------------------------------
+    t3 = time.time()
+    tris, bvh, host_scene, engine, scene, host_threads = build_scene(args, va, W, dev_index, world)
+    d_rays, n, n_total, workload, rays_host = make_rays(args, rank, world, va, W, tp, engine, scene, device)
+    d_hits = tp.empty_records(max(n, 1), HIT, device)
     t4 = time.time()
-    log(f"[bench] ray set-up {t4 - t3:.2f}s")
+    log(f"[bench] scene + ray set-up {t4 - t3:.2f}s; workload {workload}, {n} rays on this rank, {n_total} in the job")
 
     # ---- algorithmic bytes: exact counters from the stats kernel (untimed) --------------
     _, d_stats = tp.trace_stats(scene, d_rays, n)
@@ -162,7 +385,7 @@ def main() -> None:
     tot_tests = int(stats["tests"].sum(dtype=np.uint64))
     del d_stats
     alg_bytes = n * (32 + 16) + 64 * (tot_steps + tot_tests)
-    log(f"[bench] steps/ray {tot_steps / n:.2f} tests/ray {tot_tests / n:.2f} -> {alg_bytes / n:.0f} B/ray algorithmic")
+    log(f"[bench] steps/ray {tot_steps / max(n, 1):.2f} tests/ray {tot_tests / max(n, 1):.2f} -> {alg_bytes / max(n, 1):.0f} B/ray algorithmic")
 
     # ---- timed region -------------------------------------------------------------------
     engine.set_timing(True)
@@ -172,48 +395,94 @@ def main() -> None:
             engine.set_option("reserved_cus", args.reserve_cus)
         except Exception as exc:   # never lose the run over an optimisation: trace without the reservation
             log(f"[bench] reserved_cus not available ({exc}); the gather will not overlap the resident trace grid")
-        log(f"[bench] {engine.get_option('reserved_cus')} CUs keep room for the collective "
-            f"({engine.get_option('reserved_limit')} trace blocks each instead of {engine.launch_info()['blocks'] // max(1, engine.get_option('cu_count'))})")
 
     stream = tp.current_stream_handle(device)
+    gather_kind = None
+    pipe = native = None
+    if dist_on:
+        # weak: every rank sends n records; strong: shards are equal (tiles divide evenly) or padded to the largest
+        n_send = n if args.scaling == "weak" else ((args.tiles + world - 1) // world) * 1024 * 1024
+        if args.gather == "native" and args.backend == "nccl":
+            try:
+                native = NativeGather(engine, n_send, world, rank, device, dist)
+                gather_kind = "native ncclGather (vt_gather_hits_dev, own communication stream)"
+            except Exception as exc:
+                log(f"[bench] native gather unavailable ({exc}); using torch.distributed.gather")
+                native = None
+        if native is None:
+            pipe = HitGatherPipeline(n_send, device, nchunks=args.chunks, via_host=args.backend == "gloo")
+            gather_kind = "torch.distributed.gather" + (" via host (gloo test mode)" if args.backend == "gloo" else " (RCCL)")
 
-    def trace_chunk(hits_buf, lo, hi):
-        scene.trace_closest_dev(d_rays.data_ptr() + lo * RAY.itemsize, hi - lo, hits_buf.data_ptr() + lo * HIT.itemsize, stream)
+    def trace_into(hits_buf, lo=0, hi=None):
+        hi = n if hi is None else min(hi, n)
+        if hi > lo:
+            scene.trace_closest_dev(d_rays.data_ptr() + lo * RAY.itemsize, hi - lo, hits_buf.data_ptr() + lo * HIT.itemsize, stream)
 
     def step():
         if not dist_on:
             tp.trace_closest(scene, d_rays, n, d_hits)
+        elif native is not None:
+            native.submit(trace_into, stream)
         else:
-            # the single exchange of the path: hit records -> rank 0 (RCCL gather over xGMI).  Chunked and
-            # double-buffered: the gather of one chunk/batch overlaps the tracing of the next
-            pipe.submit(trace_chunk)
+            # chunked and double-buffered: the gather of one chunk/batch overlaps the tracing of the next
+            pipe.submit(trace_into)
 
-    # dominant-kernel time for the roofline: whole-batch launches bracketed by HIP events
-    pre_ms = []
-    for _ in range(2):
-        tp.trace_closest(scene, d_rays, n, d_hits)
-        pre_ms.append(engine.last_kernel_ms())
-    for _ in range(args.warmup):
+    def drain():
+        if native is not None:
+            native.drain()
+        elif pipe is not None:
+            pipe.drain()
+
+    # warm-up; with N > 1 also the proof that the gather delivers every rank's records to rank 0 unchanged
+    for _ in range(max(args.warmup, 2 if dist_on else 0)):
         step()
-    if pipe is not None:
-        pipe.drain()
-    kernel_ms = []
+    drain()
+    torch.cuda.synchronize(device)
+    gather_verified = None
+    if native is not None:
+        b = (native.batch - 1) % 2
+        try:
+            gather_verified = verify_gather(dist, rank, world, n_send, native.hits[b], native.recv[b], device, args.backend)
+        except Exception as exc:
+            log(f"[bench] gather verification failed to run: {exc}")
+            gather_verified = False
+        if not gather_verified:
+            log("[bench] native gather did NOT deliver the records intact: falling back to torch.distributed.gather")
+            native = None
+            pipe = HitGatherPipeline(n_send, device, nchunks=args.chunks, via_host=False)
+            gather_kind = "torch.distributed.gather (RCCL; native gather failed verification)"
+            for _ in range(2):
+                step()
+            drain()
+    elif pipe is not None and args.backend == "nccl":
+        b = (pipe.batch - 1) % 2
+        recv = torch.cat(pipe.recv[b]) if rank == 0 else None
+        gather_verified = verify_gather(dist, rank, world, n_send, pipe.hits[b], recv, device, args.backend)
+        del recv
+
+    # single-launch durations (HIP events on the launch stream around one launch each)
+    single_ms = []
+    if n > 0:
+        for _ in range(3):
+            tp.trace_closest(scene, d_rays, n, d_hits)
+            single_ms.append(engine.last_kernel_ms())
     torch.cuda.synchronize(device)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start = time.perf_counter()
+    ev0.record()                                       # on the launch stream (torch's current stream)
     for _ in range(args.steps):
         step()
-        if not dist_on:
-            kernel_ms.append(engine.last_kernel_ms())  # HIP events on the launch stream
-    if pipe is not None:
-        pipe.drain()                                   # every hit record has reached rank 0
+    ev1.record()
+    drain()                                            # every hit record has reached rank 0
     torch.cuda.synchronize(device)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - start
+    region_ms = ev0.elapsed_time(ev1)                  # launch-stream time of the K steps
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -221,21 +490,42 @@ def main() -> None:
     engine.set_timing(False)
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * n * args.steps / elapsed / 1e6
-    k_ms = float(np.mean(kernel_ms)) if kernel_ms else float(pre_ms[-1])
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    value = n_total * args.steps / elapsed / 1e6
+    k_ms = region_ms / args.steps                      # mean launch duration over the timed region (memset + kernel)
+    alg_achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
+    # ---- fabric-side traffic + SQ counters of that launch (rank 0, N = 1) -------------------------------------------
+    sha = kernel_sources_sha()
+    pmc, pmc_source = {}, None
+    if rank == 0 and world == 1 and not args.force_dist:
+        if not args.no_pmc and not under_profiler():
+            pmc = collect_pmc_live(args, [p for p in args.pmc_passes.split(",") if p in PMC_PASSES])
+            if "FETCH_SIZE" in pmc:
+                pmc_source = "live: rocprofv3 --pmc passes of this workload in a child process of this run (last dispatch of the kernel)"
+                try:
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    with open(os.path.join(ROOT, "gpurun_out", f"pmc_{workload}.json"), "w") as f:
+                        json.dump({"workload": workload, "kernel_sources_sha": sha, "counters": pmc,
+                                   "note": "last dispatch of vt::trace_kernel<false,false,...> in separate rocprofv3 --pmc passes "
+                                           "(FETCH_SIZE, WRITE_SIZE in KB; factor 1.000 for 64-B record fetches: profiles/r1/calib_fetch.txt)"}, f, indent=1)
+                except OSError:
+                    pass
+        if "FETCH_SIZE" not in pmc:
+            com = committed_pmc(workload, sha)
+            if "FETCH_SIZE" in com:
+                pmc_source = com.pop("_source") + " (kernel sources unchanged since that pass)"
+                pmc = com
     traffic = None
-    try:   # HBM-side bytes per launch from the committed rocprofv3 PMC pass of this same command
-        with open(os.path.join(ROOT, "profiles", "r1", "traffic.json")) as f:
-            tj = json.load(f)
-        if tj.get("workload") == f"{args.scene}_{args.kind}{n}" and args.builder == "ploc":
-            traffic = tj.get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
+    if "FETCH_SIZE" in pmc:
+        # FETCH_SIZE / WRITE_SIZE are in KB; x1024 IS the byte count for this kernel's 64-B record fetches (calibrated,
+        # profiles/r1/calib_fetch.txt) -- the x2 correction of MI355X_MICROARCH.md applies to wide streaming reads only
+        traffic = int(pmc["FETCH_SIZE"] * 1024 + pmc.get("WRITE_SIZE", 0.0) * 1024)
+    achieved = traffic / (k_ms * 1e-3) / 1e9 if traffic else None
 
+    persistent = bool(engine.get_option("last_persistent"))
+    dma = bool(engine.get_option("last_fetch_dma"))
     result = {
-        "metric": "Mrays/s closest-hit, 1M-triangle scene",
+        "metric": "Mrays/s closest-hit, 1M-triangle scene" if args.scene == "S1M" else f"Mrays/s closest-hit, scene {args.scene}",
         "value": round(value, 2),
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -243,68 +533,90 @@ def main() -> None:
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic (seeded; rays generated on the %s)" % args.gen,
         "config": {
-            "workload": f"{args.scene}_{args.kind}{n}",
+            "workload": workload,
             "scene_triangles": int(len(tris)),
             "bvh_builder": "PLOC r=14 + SAH leaf collapse (reference pipeline)" if args.builder == "ploc" else "binned SAH (opt-in)",
             "rays_per_gpu": n,
+            "rays_total": n_total,
             "query": "closest-hit",
-            "ray_kind": "cosine-hemisphere bounce (incoherent)" if args.kind == "bounce" else "pinhole primary",
-            "parallelism": f"rays sharded x{world}, BVH replicated" + (f", RCCL gather of hits to rank 0 ({args.chunks} chunks per batch, double-buffered, overlapped with tracing; {engine.get_option('reserved_cus')} CUs keep room for its kernels)" if world > 1 else ""),
-            "kernel_mode": ("persistent" + ("+lds-dma-fetch" if engine.get_option("last_fetch_dma") else "")) if engine.get_option("last_persistent") else "static",
+            "ray_kind": "pinhole primary" if (args.kind == "primary" or args.scaling == "strong") else "cosine-hemisphere bounce (incoherent)",
+            "parallelism": f"rays sharded x{world}, BVH replicated" + (
+                f", hits gathered to rank 0 inside the step: {gather_kind}, double-buffered and overlapped with tracing; "
+                f"{engine.get_option('reserved_cus')} CUs keep room for its kernels" if dist_on else ""),
+            "gather_verified": gather_verified,
+            "kernel_mode": ("persistent" + ("+lds-dma-fetch" if dma else "")) if persistent else "static",
             "launch_options": {k: engine.get_option(k) for k in ("lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold", "reserved_cus", "reserved_limit")},
             "launch": engine.launch_info(),
         },
         "roofline": {
             "bound": "hbm",
-            "achieved": round(achieved, 1),
+            "achieved": round(achieved, 1) if achieved else None,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
             "traffic": traffic,
-            "traffic_source": "profiles/r1/traffic.json: FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass of this command (factor calibrated: profiles/r1/calib_fetch.txt)" if traffic else None,
-            "kernel": "vt::trace_kernel<false,false,%s,%s,false>" % (   # <ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>
-                "true" if engine.get_option("last_persistent") else "false",
-                "true" if engine.get_option("last_fetch_dma") else "false"),
+            "traffic_source": pmc_source,
+            "traffic_note": "FETCH_SIZE + WRITE_SIZE (fabric side of L2, x1024 B; Infinity-Cache hits are counted, so true HBM traffic is lower still)",
+            "alg_achieved": round(alg_achieved, 1),
+            "alg_over_peak": round(alg_achieved / HBM_PEAK_GBS, 4),
+            "alg_note": "algorithmic bytes (SURVEY 8(d)) / launch duration; > peak because records are served by L1/L2/Infinity Cache",
+            "traffic_over_alg": round(traffic / alg_bytes, 4) if traffic else None,
+            "compulsory_bytes": int(n * 48 + scene.device_bytes),
+            "kernel": "vt::trace_kernel<false,false,%s,%s,false>" % ("true" if persistent else "false", "true" if dma else "false"),   # <ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>
             "kernel_ms": round(k_ms, 4),
-            "alg_bytes_per_ray": round(alg_bytes / n, 1),
-            "steps_per_ray": round(tot_steps / n, 2),
-            "tests_per_ray": round(tot_tests / n, 2),
+            "kernel_ms_how": "HIP events on the launch stream around the K timed steps / K (cursor memset + kernel); single launches: %s ms" % (
+                ", ".join(f"{x:.3f}" for x in single_ms)),
+            "alg_bytes_per_ray": round(alg_bytes / max(n, 1), 1),
+            "steps_per_ray": round(tot_steps / max(n, 1), 2),
+            "tests_per_ray": round(tot_tests / max(n, 1), 2),
+            "bound_actual": bound_actual(pmc, k_ms),
+            "kernel_sources_sha": sha,
         },
     }
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) -------------------
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and n > 0:
         from oracle import binding as O
         if rays_host is None:
             rays_host = tp.to_host(d_rays, RAY)
         nodes = bvh.nodes().view(O.NODE)
         pidx = bvh.prim_indices()
         otris = O.tris_from_tri64(tris)
-        pilot = min(n, 1 << 17)
-        # the CPU gets its best thread count: all logical CPUs or one per physical core (SMT often hurts this walk)
+        pilot = min(n, 1 << 19)
+        # the checker's own check: the -O3 x86-64-v3 build used for timing must equal the baseline build bit for bit
+        ctx = O.BatchContext(nodes, pidx, otris, nthreads=host_threads, fast=True)
+        chk = min(n, 1 << 16)
+        a = ctx.traverse(rays_host[:chk], want_stats=True)
+        b = O.traverse_batch(nodes, pidx, otris, rays_host[:chk], want_stats=True)
+        fast_equal = bool((a[0].view(np.uint8) == b[0].view(np.uint8)).all() and (a[1] == b[1]).all())
+        if not fast_equal:
+            log("[bench] the -O3 oracle build differs from the baseline build: timing the baseline build instead")
+            ctx.close()
+            ctx = O.BatchContext(nodes, pidx, otris, nthreads=host_threads, fast=False)
+        # the CPU gets its best thread count: all logical CPUs or one per physical core (SMT can hurt or help this walk)
         rate, cpu_threads = 0.0, host_threads
         for cand in sorted({host_threads, max(1, host_threads // 2)}, reverse=True):
-            O.traverse_batch(nodes, pidx, otris, rays_host[:pilot], nthreads=cand)           # warm-up
+            ctx.traverse(rays_host[:pilot], nthreads=cand)                               # warm-up
             tp0 = time.perf_counter()
-            O.traverse_batch(nodes, pidx, otris, rays_host[:pilot], nthreads=cand)
+            ctx.traverse(rays_host[:pilot], nthreads=cand)
             r = pilot / (time.perf_counter() - tp0)
             if r > rate:
                 rate, cpu_threads = r, cand
         sample = int(min(n, max(pilot, rate * args.cpu_seconds)))
         sample = max(4096, (sample // 4096) * 4096) if n >= 4096 else n
         tc0 = time.perf_counter()
-        ref, ref_stats, s_steps, s_tests, threads = O.traverse_batch(nodes, pidx, otris, rays_host[:sample], want_stats=True,
-                                                                    nthreads=cpu_threads)
+        ref, ref_stats, s_steps, s_tests, threads = ctx.traverse(rays_host[:sample], want_stats=True, nthreads=cpu_threads)
         cpu_s = time.perf_counter() - tc0
         # one host thread: the closest analogue of what a GLua script gets today (one ray per call, serial)
+        one_n = min(pilot, 1 << 17)
         t10 = time.perf_counter()
-        O.traverse_batch(nodes, pidx, otris, rays_host[:pilot], nthreads=1)
-        one_thread = pilot / (time.perf_counter() - t10) / 1e6
+        ctx.traverse(rays_host[:one_n], nthreads=1)
+        one_thread = one_n / (time.perf_counter() - t10) / 1e6
         gpu = tp.to_host(d_hits[: sample * HIT.itemsize], HIT)
         same_prim = bool((gpu["prim"] == ref["prim"]).all())
         same_tuv = all(bool((gpu[k].view(np.uint32) == ref[k].view(np.uint32)).all()) for k in ("t", "u", "v"))
@@ -325,10 +637,17 @@ def main() -> None:
             "kind": "port",
             "sample": f"first {sample} rays of the same batch, same tree, OpenMP schedule(dynamic,4096), {cpu_s:.1f}s",
             "cpu": cpu_model,
+            "logical_cpus": host_threads,
+            "build": ("gcc -O3 -march=x86-64-v3 -ffp-contract=off (bit-identical to the -O2 baseline-x86-64 build: checked on %d rays)" % chk)
+                     if ctx.fast else "gcc -O2 -ffp-contract=off (baseline x86-64)",
+            "threads_pinned": f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}",
+            "numa_replicas": ctx.replicas,
             "one_thread_value": round(one_thread, 4),
+            "scaling_vs_one_thread": round(sample / cpu_s / 1e6 / one_thread, 1) if one_thread > 0 else None,
         }
         result["parity_sample"] = {"rays": sample, "prim_bit_exact": same_prim, "tuv_bit_exact": same_tuv,
                                    "counters_equal": same_stats}
+        ctx.close()
         if not (same_prim and same_tuv):
             log("[bench] PARITY FAILURE on the sample")
     if rank == 0:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 1
+#define VT_ABI_VERSION 2   /* 2: launch-slot ring, host walk, multi-GPU entries (additive over 1) */
 
 enum vt_status {
     VT_OK              = 0,

@@ -14,6 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libvt_oracle.so")
+FAST_LIB_PATH = os.path.join(_HERE, "_build", "libvt_oracle_fast.so")   # -O3 -march=x86-64-v3: bench.py's timed leg only
 
 MISS = 0xFFFFFFFF
 RAY = np.dtype([("org", "<f4", 3), ("dir", "<f4", 3), ("tmin", "<f4"), ("tmax", "<f4")])
@@ -31,12 +32,84 @@ class _Stats(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    if force or not os.path.exists(LIB_PATH):
+    if force or not os.path.exists(LIB_PATH) or not os.path.exists(FAST_LIB_PATH):
         subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
     return LIB_PATH
 
 
 _lib = None
+_fast = None
+
+
+def _bind_ctx(L):
+    vp, u64 = C.c_void_p, C.c_uint64
+    L.vto_batch_ctx_create.argtypes = [vp, u64, vp, u64, vp, u64, C.c_int]
+    L.vto_batch_ctx_create.restype = vp
+    L.vto_batch_ctx_replicas.argtypes = [vp]
+    L.vto_batch_ctx_replicas.restype = C.c_int
+    L.vto_batch_ctx_destroy.argtypes = [vp]
+    L.vto_traverse_batch_ctx.argtypes = [vp, vp, u64, C.c_int, vp, vp, vp, C.c_int]
+    L.vto_traverse_batch_ctx.restype = C.c_int
+
+
+def _cpu_has_avx2() -> bool:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    fl = line.split(":", 1)[1].split()
+                    return "avx2" in fl and "bmi2" in fl and "fma" in fl
+    except OSError:
+        pass
+    return False
+
+
+def fast_lib():
+    """The -O3 -march=x86-64-v3 build of the same source (timed cpu_baseline leg); None if the host CPU lacks AVX2."""
+    global _fast
+    if _fast is None:
+        build()
+        if not _cpu_has_avx2():
+            return None
+        L = C.CDLL(FAST_LIB_PATH)
+        _bind_ctx(L)
+        _fast = L
+    return _fast
+
+
+class BatchContext:
+    """NUMA-aware batch driver of the timed CPU baseline: one replica of the tree per NUMA node (first-touched there),
+    every worker walks its node's replica.  `fast` picks the -O3 x86-64-v3 build.  Results equal traverse_batch's."""
+
+    def __init__(self, nodes: np.ndarray, prim_indices: np.ndarray, tris: np.ndarray, nthreads: int = 0, fast: bool = True):
+        assert nodes.dtype == NODE and tris.dtype == TRI
+        self._L = (fast_lib() if fast else None) or lib()
+        self.fast = self._L is not lib()
+        nodes = np.ascontiguousarray(nodes)
+        prim_indices = np.ascontiguousarray(prim_indices, np.uint32)
+        tris = np.ascontiguousarray(tris)
+        self._h = self._L.vto_batch_ctx_create(nodes.ctypes.data, len(nodes), prim_indices.ctypes.data, len(prim_indices),
+                                               tris.ctypes.data, len(tris), nthreads)
+        if not self._h:
+            raise MemoryError("vto_batch_ctx_create failed")
+        self.replicas = int(self._L.vto_batch_ctx_replicas(self._h))
+
+    def traverse(self, rays: np.ndarray, any_hit: bool = False, want_stats: bool = False, nthreads: int = 0):
+        rays = np.ascontiguousarray(rays)
+        hits = np.zeros(len(rays), HIT)
+        st = np.zeros((len(rays), 2), np.uint32) if want_stats else None
+        tot = _Stats()
+        used = self._L.vto_traverse_batch_ctx(self._h, rays.ctypes.data, len(rays), int(any_hit), hits.ctypes.data,
+                                              st.ctypes.data if st is not None else None, C.addressof(tot), nthreads)
+        return hits, st, int(tot.steps), int(tot.tests), used
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vto_batch_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
 
 
 def lib() -> C.CDLL:
@@ -55,6 +128,7 @@ def lib() -> C.CDLL:
         L.vto_traverse.restype = C.c_int
         L.vto_traverse_batch.argtypes = [vp, vp, vp, vp, u64, C.c_int, vp, vp, vp, C.c_int]
         L.vto_traverse_batch.restype = C.c_int
+        _bind_ctx(L)
         L.vto_hit_attrs.argtypes = [vp, vp, C.c_float, C.c_float, vp]
         L.vto_hit_shade.argtypes = [C.c_float, C.c_float, vp, vp, vp, vp]
         L.vto_calc_ray_origin.argtypes = [vp, vp, vp]

@@ -351,6 +351,110 @@ int vto_traverse_batch(const vto_node* nodes, const uint32_t* prim_indices,
     return nthreads;
 }
 
+/* ---- NUMA-aware batch driver (bench.py's cpu_baseline leg only) -------------------------------------------
+ * The tree of the 1 M-triangle scene (nodes 64 MB + triangles 52 MB) is allocated by one thread of the caller, so it
+ * sits on ONE socket's memory; on a two-socket host every thread of the other socket then chases pointers across
+ * the inter-socket link.  A context holds one replica per NUMA node, each first-touched by a thread running there;
+ * every worker walks the replica of the node it runs on (threads should be pinned: OMP_PROC_BIND).  Same arithmetic,
+ * same results. */
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <sys/syscall.h>
+
+#define VTO_MAX_NUMA 16
+struct vto_batch_ctx {
+    vto_node* nodes[VTO_MAX_NUMA];
+    uint32_t* prim_indices[VTO_MAX_NUMA];
+    vto_tri*  tris[VTO_MAX_NUMA];
+    int       replicas;
+};
+
+static int current_numa_node(void)
+{
+    unsigned cpu = 0, node = 0;
+#ifdef SYS_getcpu
+    if (syscall(SYS_getcpu, &cpu, &node, NULL) != 0) node = 0;
+#endif
+    return (int)(node < VTO_MAX_NUMA ? node : 0);
+}
+
+vto_batch_ctx* vto_batch_ctx_create(const vto_node* nodes, uint64_t nnodes, const uint32_t* prim_indices, uint64_t nprims,
+                                    const vto_tri* tris, uint64_t ntris, int nthreads)
+{
+    vto_batch_ctx* c = (vto_batch_ctx*)calloc(1, sizeof(*c));
+    if (!c) return NULL;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+    int claimed[VTO_MAX_NUMA] = {0};
+#pragma omp parallel num_threads(nthreads)
+    {
+        const int node = current_numa_node();
+        int mine = 0;
+#pragma omp critical(vto_ctx_claim)
+        { if (!claimed[node]) { claimed[node] = 1; mine = 1; } }
+        if (mine) {                       /* first thread seen on this node: allocate + copy here (first touch) */
+            vto_node* n = (vto_node*)malloc((size_t)(nnodes ? nnodes : 1) * sizeof(vto_node));
+            uint32_t* p = (uint32_t*)malloc((size_t)(nprims ? nprims : 1) * sizeof(uint32_t));
+            vto_tri*  t = (vto_tri*)malloc((size_t)(ntris ? ntris : 1) * sizeof(vto_tri));
+            if (n && p && t) {
+                memcpy(n, nodes, (size_t)nnodes * sizeof(vto_node));
+                memcpy(p, prim_indices, (size_t)nprims * sizeof(uint32_t));
+                memcpy(t, tris, (size_t)ntris * sizeof(vto_tri));
+                c->nodes[node] = n; c->prim_indices[node] = p; c->tris[node] = t;
+            } else { free(n); free(p); free(t); }
+        }
+    }
+    for (int k = 0; k < VTO_MAX_NUMA; ++k) c->replicas += c->nodes[k] != NULL;
+    if (c->replicas == 0) { free(c); return NULL; }
+    return c;
+}
+
+int vto_batch_ctx_replicas(const vto_batch_ctx* c) { return c ? c->replicas : 0; }
+
+void vto_batch_ctx_destroy(vto_batch_ctx* c)
+{
+    if (!c) return;
+    for (int k = 0; k < VTO_MAX_NUMA; ++k) { free(c->nodes[k]); free(c->prim_indices[k]); free(c->tris[k]); }
+    free(c);
+}
+
+int vto_traverse_batch_ctx(const vto_batch_ctx* c, const vto_ray* rays, uint64_t nrays, int any_hit, vto_hit* hits,
+                           uint32_t* per_ray_stats, vto_stats* total, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+    int first = 0;
+    while (first < VTO_MAX_NUMA && !c->nodes[first]) ++first;
+    uint64_t tsteps = 0, ttests = 0;
+#pragma omp parallel num_threads(nthreads) reduction(+ : tsteps, ttests)
+    {
+        int node = current_numa_node();
+        if (!c->nodes[node]) node = first;
+        const vto_node* nodes = c->nodes[node];
+        const uint32_t* pidx = c->prim_indices[node];
+        const vto_tri* tris = c->tris[node];
+#pragma omp for schedule(dynamic, 4096)
+        for (int64_t i = 0; i < (int64_t)nrays; ++i) {
+            vto_stats st;
+            vto_traverse(nodes, pidx, tris, &rays[i], any_hit, &hits[i], &st);
+            if (per_ray_stats) {
+                per_ray_stats[2 * i]     = (uint32_t)st.steps;
+                per_ray_stats[2 * i + 1] = (uint32_t)st.tests;
+            }
+            tsteps += st.steps; ttests += st.tests;
+        }
+    }
+    if (total) { total->steps = tsteps; total->tests = ttests; }
+    return nthreads;
+}
+
 /* ---- TraceResult.cpp:45-86, 255-262 ---------------------------------------*/
 void vto_hit_attrs(const vto_tri* tri, const float dir[3], float u, float v, vto_attrs* out)
 {

@@ -107,6 +107,16 @@ int vto_traverse_batch(const vto_node* nodes, const uint32_t* prim_indices,
                        int any_hit, vto_hit* hits, uint32_t* per_ray_stats,
                        vto_stats* total, int nthreads);
 
+/* NUMA-aware variant for the timed CPU baseline (bench.py): one replica of the tree per NUMA node, first-touched
+ * there; each worker walks the replica of the node it runs on.  Results identical to vto_traverse_batch. */
+typedef struct vto_batch_ctx vto_batch_ctx;
+vto_batch_ctx* vto_batch_ctx_create(const vto_node* nodes, uint64_t nnodes, const uint32_t* prim_indices, uint64_t nprims,
+                                    const vto_tri* tris, uint64_t ntris, int nthreads);
+int  vto_batch_ctx_replicas(const vto_batch_ctx* ctx);
+void vto_batch_ctx_destroy(vto_batch_ctx* ctx);
+int  vto_traverse_batch_ctx(const vto_batch_ctx* ctx, const vto_ray* rays, uint64_t nrays, int any_hit, vto_hit* hits,
+                            uint32_t* per_ray_stats, vto_stats* total, int nthreads);
+
 /* TraceResult.cpp:45-86 + GetPos :255-262 for hit {prim,u,v} of ray dir */
 void vto_hit_attrs(const vto_tri* tri, const float dir[3], float u, float v, vto_attrs* out);
 

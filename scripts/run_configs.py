@@ -93,15 +93,12 @@ def main():
             del d
         elif cfg == "5":
             # one rank's contiguous shard of the 128-tile ray array (N/G with G = 8 -> 16 tiles), one launch
-            cams = W.camera_positions("S10M")
             tile = 1024 * 1024
             d_rays = tp.empty_records(args.tiles * tile, va.RAY, dev)
             for t in range(args.tiles):
-                fwd = cams[(t + 1) % len(cams)] - cams[t] if t else np.array([1.0, 0, 0])
-                if np.linalg.norm(fwd) == 0:
-                    fwd = np.array([1.0, 0, 0])
-                engine.gen_primary_dev(1024, 1024, d_rays.data_ptr() + t * tile * va.RAY.itemsize, pos=tuple(cams[t]),
-                                       forward=tuple(fwd), stream=tp.current_stream_handle(dev))
+                pos, fwd = W.camera_pose("S10M", t)
+                engine.gen_primary_dev(1024, 1024, d_rays.data_ptr() + t * tile * va.RAY.itemsize, pos=tuple(float(x) for x in pos),
+                                       forward=tuple(float(x) for x in fwd), stream=tp.current_stream_handle(dev))
             torch.cuda.synchronize()
             r = measure(5, "S10M", d_rays, args.tiles * tile, reps=3)
             r["tiles"] = args.tiles

@@ -1,0 +1,310 @@
+"""BASELINE.json configs at full size, stream concurrency, the host walk against the device, and the multi-GPU ABI.
+
+Complements tests/test_gpu_parity.py (which runs every case against both kernel modes): the cases here are the big
+ones and run once, on the engine's default (auto) configuration -- what a caller gets.
+
+  config 4  64 Mi any-hit shadow rays into S1M                      test_config4_full_size_64mi_shadow_rays
+  config 5  one of 8 ranks' shard (16 tiles of 1024^2) into S10M    test_config5_s10m_primary_shard
+            + 16 Mi incoherent bounce rays into S10M (scene beyond the Infinity Cache)
+Parity bar as everywhere: primitive index bit-exact, t/u/v bit-identical (oracle on a slice that it finishes in
+seconds; size-independent properties on the whole batch).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+O_MISS = 0xFFFFFFFF
+
+
+def assert_hits_equal(got, ref):
+    assert (got["prim"] == ref["prim"]).all(), f"{int((got['prim'] != ref['prim']).sum())} primitive indices differ"
+    for k in ("t", "u", "v"):
+        assert (got[k].view(np.uint32) == ref[k].view(np.uint32)).all(), f"{k} not bit-identical"
+
+
+def check_hit_properties(b, rays, hits, closed_room=True):
+    """Size-independent properties of a whole batch: ranges, barycentrics, the hit point lies on the triangle."""
+    hit = hits["prim"] != O_MISS
+    assert (hits["t"][~hit] == 0).all() and (hits["u"][~hit] == 0).all() and (hits["v"][~hit] == 0).all()
+    if closed_room:
+        assert hit.mean() > 0.99
+    h, r = hits[hit], rays[hit]
+    assert (h["t"] >= r["tmin"]).all() and (h["t"] <= r["tmax"]).all()
+    assert (h["u"] >= 0).all() and (h["v"] >= 0).all() and (h["u"] + h["v"] <= 1 + 1e-6).all()
+    assert h["prim"].max() < len(b.tris)
+    step = max(1, len(h) // (1 << 21))               # the plane check on ~2 Mi samples keeps the host side quick
+    h, r = h[::step], r[::step]
+    T = b.tris[h["prim"]]
+    w = 1.0 - h["u"].astype(np.float64) - h["v"]
+    pos_tri = (w[:, None] * T["p0"] + h["u"][:, None] * (T["p0"].astype(np.float64) - T["e1"]) +
+               h["v"][:, None] * (T["p0"].astype(np.float64) + T["e2"]))
+    pos_ray = r["org"].astype(np.float64) + h["t"][:, None].astype(np.float64) * r["dir"]
+    err = np.abs(pos_tri - pos_ray).max(axis=1)
+    assert np.percentile(err, 99.9) < 0.05 and err.max() < 2.0
+
+
+@pytest.fixture(scope="module")
+def eng(va):
+    e = va.Engine(0)
+    yield e
+    e.close()
+
+
+def test_config5_s10m_primary_shard(va, eng, make_bundle):
+    """BASELINE config 5, one of 8 ranks' contiguous shard: 16 tiles of 1024x1024 primary rays from the seeded camera
+    poses into the 10 M-triangle scene (1.04 GB of records: beyond L2 and the Infinity Cache), one launch.  Oracle on
+    a 1 Mi-ray slice spread over the tiles; the whole batch through the property block; persistent / one-ray-per-lane
+    / direct-fetch kernels byte-identical.  Then 16 Mi incoherent bounce rays into the same scene."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10M")
+    scene = va.Scene(eng, b.host_scene)
+    assert scene.device_bytes > 1.0e9
+    dev = torch.device("cuda", 0)
+    tile, tiles = 1024 * 1024, 16
+    n = tile * tiles
+    d_rays = tp.empty_records(n, va.RAY, dev)
+    for t in range(tiles):
+        pos, fwd = W.camera_pose("S10M", t)
+        eng.gen_primary_dev(1024, 1024, d_rays.data_ptr() + t * tile * va.RAY.itemsize, pos=tuple(float(x) for x in pos),
+                            forward=tuple(float(x) for x in fwd), stream=tp.current_stream_handle(dev))
+    hits = tp.to_host(tp.trace_closest(scene, d_rays, n), va.HIT)
+    assert eng.get_option("last_persistent") == 1 and eng.get_option("last_fetch_dma") == 1
+    rays = tp.to_host(d_rays, va.RAY)
+    idx = np.concatenate([np.arange(t * tile + 37 * t, t * tile + 37 * t + 65536) for t in range(tiles)])   # 1 Mi rays, every tile
+    assert_hits_equal(hits[idx], b.oracle(rays[idx]))
+    check_hit_properties(b, rays, hits)
+    saved = {k: eng.get_option(k) for k in ("persistent", "fetch_dma")}
+    try:
+        for cfg in (dict(persistent=0), dict(persistent=1, fetch_dma=0)):
+            for k, v in cfg.items():
+                eng.set_option(k, v)
+            again = tp.to_host(tp.trace_closest(scene, d_rays, n), va.HIT)
+            assert (again.view(np.uint8) == hits.view(np.uint8)).all(), cfg
+    finally:
+        for k, v in saved.items():
+            eng.set_option(k, v)
+    occ = tp.trace_any(scene, d_rays, n).cpu().numpy()
+    assert (occ == (hits["prim"] != O_MISS)).all()
+
+    # 16 Mi incoherent bounce rays from the first camera's 4096^2 primary hits: the cache-exceeding regime
+    side = 4096
+    n2 = side * side
+    d_prim = tp.empty_records(n2, va.RAY, dev)
+    eng.gen_primary_dev(side, side, d_prim.data_ptr(), stream=tp.current_stream_handle(dev))
+    d_h0 = tp.trace_closest(scene, d_prim, n2)
+    d_attrs = tp.hit_attrs(scene, d_prim, d_h0, n2)
+    d_b = tp.empty_records(n2, va.RAY, dev)
+    eng.gen_bounce_dev(d_attrs.data_ptr(), n2, W.SEED + 3, d_b.data_ptr(), stream=tp.current_stream_handle(dev))
+    del d_prim, d_h0, d_attrs
+    bh = tp.to_host(tp.trace_closest(scene, d_b, n2), va.HIT)
+    br = tp.to_host(d_b, va.RAY)
+    sl = slice(5 << 20, 6 << 20)
+    assert_hits_equal(bh[sl], b.oracle(br[sl]))
+    check_hit_properties(b, br, bh)
+    scene.free()
+
+
+def test_config4_full_size_64mi_shadow_rays(va, eng, make_bundle):
+    """BASELINE config 4 at its full size: 67 108 864 any-hit shadow rays (4 per 4096^2 primary hit, 16 seeded lights,
+    tMax = dist * (1 - 1e-4)) into S1M: occluded <=> the closest-hit kernel finds a hit in the same interval, on the
+    whole batch; the oracle's any-hit walk on a 512 Ki slice."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S1M")
+    scene = va.Scene(eng, b.host_scene)
+    dev = torch.device("cuda", 0)
+    side = 4096
+    n0 = side * side
+    d_prim = tp.empty_records(n0, va.RAY, dev)
+    eng.gen_primary_dev(side, side, d_prim.data_ptr(), stream=tp.current_stream_handle(dev))
+    d_h = tp.trace_closest(scene, d_prim, n0)
+    attrs = tp.to_host(tp.hit_attrs(scene, d_prim, d_h, n0), va.HIT_ATTRS)
+    del d_prim, d_h
+    rays = W.shadow_rays(attrs, W.light_positions("S1M"), W.SEED + 4, per_hit=4)
+    del attrs
+    n = len(rays)
+    assert n == 64 * 1024 * 1024
+    d_rays = tp.to_device(rays, dev)                          # 2 GiB of rays
+    d_occ = tp.trace_any(scene, d_rays, n)
+    d_hits = tp.trace_closest(scene, d_rays, n)
+    hit = (d_hits.view(torch.int32).view(n, 4)[:, 0] != -1)
+    assert bool((d_occ.bool() == hit).all())                  # 64 Mi comparisons on the device
+    frac = float(hit.float().mean())
+    assert 0.05 < frac < 0.95                                 # lights are both visible and hidden
+    sl = slice(20 << 20, (20 << 20) + (1 << 19))
+    ref = b.oracle(rays[sl], any_hit=True)
+    occ_sl = d_occ[sl].cpu().numpy()
+    assert (occ_sl == (ref["prim"] != O_MISS)).all()
+    hits_sl = tp.to_host(d_hits[sl.start * 16: sl.stop * 16], va.HIT)
+    assert_hits_equal(hits_sl, b.oracle(rays[sl]))
+    scene.free()
+
+
+def test_concurrent_launches_on_two_streams(va, eng, make_bundle):
+    """Two different ray sets traced at the same time on two caller streams of one engine (each launch owns a slot of
+    the scratch ring: cursor, reserved-CU counters, overflow area), many times over, in both kernel modes: both bit-equal
+    to the oracle.  Then 40 back-to-back launches on alternating streams wrap the 16-slot ring."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S100k")
+    scene = va.Scene(eng, b.host_scene)
+    dev = torch.device("cuda", 0)
+    n = 1 << 20
+    rays_a = W.sphere_rays(n, 77, origin=(10.0, -20.0, 30.0))
+    rays_b = W.primary_rays(1024, 1024, pos=(-300.0, 200.0, 50.0))
+    ref_a, ref_b = b.oracle(rays_a), b.oracle(rays_b)
+    d_a, d_b = tp.to_device(rays_a, dev), tp.to_device(rays_b, dev)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    saved = eng.get_option("persistent")
+    try:
+        for mode in (1, 0, 2):
+            eng.set_option("persistent", mode)
+            outs = []
+            torch.cuda.synchronize()
+            for rep in range(6):
+                ha, hb = tp.empty_records(n, va.HIT, dev), tp.empty_records(n, va.HIT, dev)
+                scene.trace_closest_dev(d_a.data_ptr(), n, ha.data_ptr(), s1.cuda_stream)
+                scene.trace_closest_dev(d_b.data_ptr(), n, hb.data_ptr(), s2.cuda_stream)
+                outs.append((ha, hb))
+            torch.cuda.synchronize()
+            for ha, hb in outs:
+                assert_hits_equal(tp.to_host(ha, va.HIT), ref_a)
+                assert_hits_equal(tp.to_host(hb, va.HIT), ref_b)
+        eng.set_option("persistent", 1)
+        outs = []
+        for rep in range(40):                                  # > 16 launches in flight: slots are re-used behind their events
+            h = tp.empty_records(n, va.HIT, dev)
+            scene.trace_closest_dev((d_a if rep % 2 == 0 else d_b).data_ptr(), n, h.data_ptr(), (s1 if rep % 3 else s2).cuda_stream)
+            outs.append(h)
+        torch.cuda.synchronize()
+        for rep, h in enumerate(outs):
+            assert_hits_equal(tp.to_host(h, va.HIT), ref_a if rep % 2 == 0 else ref_b)
+        # a host-pointer call (engine's own stream) while device launches are in flight on another stream
+        h = tp.empty_records(n, va.HIT, dev)
+        scene.trace_closest_dev(d_a.data_ptr(), n, h.data_ptr(), s1.cuda_stream)
+        host = scene.trace_closest(rays_b[:300000])
+        torch.cuda.synchronize()
+        assert_hits_equal(host, ref_b[:300000])
+        assert_hits_equal(tp.to_host(h, va.HIT), ref_a)
+    finally:
+        eng.set_option("persistent", saved)
+    scene.free()
+
+
+def test_refit_while_traces_are_in_flight(va, eng, O):
+    """vt_scene_skin_refit / vt_scene_refit rewrite records in place: they wait for traces still running on caller
+    streams, so the natural per-frame loop (trace_dev on a stream, then refit) never lets rays see half-updated boxes."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    verts = W.make_scene("S100k")
+    tris = va.tris_setup(verts)
+    bvh = va.HostBvh(tris)
+    scene = va.Scene(eng, va.HostScene(bvh))
+    dev = torch.device("cuda", 0)
+    n = 1 << 21
+    rays = W.sphere_rays(n, 5, origin=(1.0, 2.0, 3.0))
+    d_rays = tp.to_device(rays, dev)
+    s1 = torch.cuda.Stream(dev)
+    otris = O.tris_from_tri64(tris)
+    ref0 = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays[:200000])[0]
+    moved = (verts * np.float32(1.25)).astype(np.float32)
+    for frame in range(3):
+        h = tp.empty_records(n, va.HIT, dev)
+        scene.trace_closest_dev(d_rays.data_ptr(), n, h.data_ptr(), s1.cuda_stream)     # asynchronous ...
+        scene.refit(moved if frame % 2 == 0 else verts)                                  # ... refit right behind it
+        got = tp.to_host(h, va.HIT)[:200000]
+        if frame % 2 == 0:
+            assert_hits_equal(got, ref0)                       # the trace saw the scene as it was before this refit
+    scene.free()
+
+
+def test_host_walk_equals_device(va, eng, make_bundle):
+    """BASELINE config 1 closed into a triangle: the product's host walk (what accel:Traverse runs) == the device
+    kernels == the oracle, bit for bit, on 10 k single-ray calls into S10k and on weird rays."""
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    scene = va.Scene(eng, b.host_scene)
+    rays = W.sphere_rays(10000, W.SEED + 1)
+    ref = b.oracle(rays)
+    single_host = np.concatenate([b.host_scene.trace_closest_host(rays[i:i + 1]) for i in range(len(rays))])
+    assert_hits_equal(single_host, ref)
+    assert_hits_equal(scene.trace_closest(rays), single_host)
+    single_dev = np.concatenate([scene.trace_closest(rays[i:i + 1]) for i in range(200)])     # tiny-batch device path
+    assert_hits_equal(single_dev, single_host[:200])
+    assert (scene.trace_any(rays) == b.host_scene.trace_any_host(rays)).all()
+    weird = np.concatenate([rays[:512]] * 4)
+    weird["dir"][0:512, 0] = 0.0
+    weird["dir"][512:1024, 1] = 1e-9
+    weird["tmax"][1024:1536] = np.nan
+    weird["org"][1536:, 2] = np.inf
+    assert_hits_equal(scene.trace_closest(weird), b.host_scene.trace_closest_host(weird))
+    scene.free()
+
+
+def test_multi_gpu_abi_with_one_device(va, make_bundle):
+    """The multi-GPU entry points through a group of ONE device (what this box has): vt_engine_open_multi, scene
+    replication, host-ray sharding, and vt_trace_closest_gather_dev = trace + ncclGather (RCCL, one rank) into the root
+    buffer at ray order, two batches back to back (double-buffered).  N > 1 needs the driver's multi-GPU node; the
+    shard arithmetic is covered on the CPU (tests/cpp, tests/test_multigpu_gloo.py)."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    eng = va.Engine([0])
+    assert eng.device_count == 1 and eng.get_option("device_count") == 1
+    scene = va.Scene(eng, b.host_scene)
+    dev = torch.device("cuda", 0)
+    n = (1 << 20) + 77
+    rays = W.sphere_rays(n, 3, origin=(4.0, 5.0, 6.0))
+    ref = b.oracle(rays)
+    assert_hits_equal(scene.trace_closest(rays), ref)             # host rays through the group (one shard here)
+    cap = va.shard_capacity(n, 1)
+    assert cap >= n and cap % 64 == 0 and va.shard_bounds(n, 1, 0) == (0, n)
+    d_rays = tp.to_device(rays, dev)
+    outs = [torch.zeros(cap * 16, dtype=torch.uint8, device=dev) for _ in range(3)]
+    for o in outs:
+        scene.trace_closest_gather_dev([d_rays.data_ptr()], n, o.data_ptr())
+    eng.synchronize()
+    for o in outs:
+        assert_hits_equal(tp.to_host(o[: n * 16], va.HIT), ref)
+    scene.free()
+    eng.close()
+
+
+def test_native_gather_single_rank(va, make_bundle):
+    """One process per GPU form: vt_comm_unique_id + vt_engine_comm_init_rank (world of one) + vt_gather_hits_dev on
+    the communication stream, alternating send buffers with vt_gather_wait."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    eng = va.Engine(0)
+    scene = va.Scene(eng, b.host_scene)
+    dev = torch.device("cuda", 0)
+    n = 1 << 18
+    rays = W.sphere_rays(n, 8)
+    ref = b.oracle(rays)
+    d_rays = tp.to_device(rays, dev)
+    eng.comm_init_rank(1, 0, va.comm_unique_id())
+    stream = tp.current_stream_handle(dev)
+    send = [tp.empty_records(n, va.HIT, dev) for _ in range(2)]
+    recv = [torch.zeros(n * 16, dtype=torch.uint8, device=dev) for _ in range(2)]
+    for batch in range(5):
+        k = batch % 2
+        eng.gather_wait(1, stream)
+        scene.trace_closest_dev(d_rays.data_ptr(), n, send[k].data_ptr(), stream)
+        eng.gather_hits_dev(send[k].data_ptr(), n, recv[k].data_ptr(), 0, stream)
+    eng.gather_wait(0)
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert_hits_equal(tp.to_host(recv[k], va.HIT), ref)
+    scene.free()
+    eng.close()

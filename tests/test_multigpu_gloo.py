@@ -121,3 +121,18 @@ def test_two_rank_shard_and_gather(tmp_path, n):
     port = 29500 + (os.getpid() + n) % 2000
     mp.spawn(_worker, args=(2, port, n, str(result)), nprocs=2, join=True)
     assert result.read_text() == "ok"
+
+
+def test_abi_shard_bounds_cover_and_align(va):
+    """vt_shard_bounds / vt_shard_capacity (what vt_trace_closest and vt_trace_closest_gather_dev shard by): contiguous,
+    disjoint, 64-ray aligned starts, shard g starts at g * capacity -- so gathered hit records land in ray order."""
+    for n in (0, 1, 63, 64, 65, 1000, 1 << 20, (1 << 24) + 5, 1 << 27):
+        for ndev in (1, 2, 3, 4, 8):
+            cap = va.shard_capacity(n, ndev)
+            assert cap % 64 == 0 and cap * ndev >= n
+            expect = 0
+            for g in range(ndev):
+                lo, hi = va.shard_bounds(n, ndev, g)
+                assert lo == expect == min(n, g * cap) and lo <= hi <= lo + cap
+                expect = hi
+            assert expect == n

@@ -95,6 +95,17 @@ def camera_positions(name: str, count: int = 128) -> np.ndarray:
     return pos
 
 
+def camera_pose(name: str, t: int, count: int = 128):
+    """(position, forward) of seeded camera pose t: BASELINE config 5 renders one 1024x1024 tile per pose.
+    Pose 0 looks along +x from the room centre; pose t looks from camera t towards camera t+1."""
+    cams = camera_positions(name, count)
+    pos = cams[t % count]
+    fwd = cams[(t + 1) % count] - pos if t % count else np.array([1.0, 0.0, 0.0], np.float32)
+    if np.linalg.norm(fwd) == 0:
+        fwd = np.array([1.0, 0.0, 0.0], np.float32)
+    return pos, fwd.astype(np.float32)
+
+
 def light_positions(name: str, count: int = 16) -> np.ndarray:
     u = uniform01(SEED + 200 + SCENE_IDS[name], 0, 3 * count).reshape(count, 3)
     return (u * 1600.0 - 800.0).astype(np.float32)
