@@ -317,7 +317,7 @@ int vt_scene_set_alpha(vt_scene* s, const vt_alpha_material* mats, uint32_t nmat
 /* ---- host side: the single-ray latency path (BASELINE config 1) -------------------------------
  * What one `accel:Traverse(origin, dir)` call from GLua does (source/objects/AccelStruct.cpp:810-820): ONE ray.  A
  * lone ray on the GPU is launch bound (~20 us) while the same walk takes 1-2 us on a host core, so the host class
- * keeps the vt_host_scene it uploaded and answers single rays and batches below the crossover (~16 rays) here: the
+ * keeps the vt_host_scene it uploaded and answers single rays and batches below the crossover (~128 rays) here: the
  * reference's scalar walk (bvh v1 SingleRayTraverser + FastNodeIntersector + the in-tree triangle test) on the
  * linearised records, bit-identical to the device kernels' results.  This is a separate, explicitly named path, NOT
  * a fallback: vt_trace_* and the *_dev entries never run on the CPU, and without a HIP device no vt_scene exists.

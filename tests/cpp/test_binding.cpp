@@ -349,7 +349,7 @@ static void test_gpu_side()
                 delete a; delete b;
             }
         }
-        CHECK(nhit > 100 && nhit < 400);
+        CHECK(nhit > 10 && nhit < 400);
         L.Pop(L.Top());
     }
 

@@ -36,9 +36,10 @@ public:
     // Non-Lua batch entry for native callers (extensions): closest hits for n rays (host walk below
     // kDeviceBatchMin rays, the device above).
     int TraceClosest(const vt_ray* rays, uint64_t n, vt_hit* hits) const;
-    // batches of fewer rays are walked on the host: a launch-bound tiny batch costs ~20 us on the device, a
-    // host-walked ray 1-2 us (tests/cpp/test_binding --bench prints both)
-    static constexpr uint64_t kDeviceBatchMin = 16;
+    // batches of fewer rays are walked on the host: a launch-bound tiny batch costs 45-60 us on the device (idle
+    // clocks, dependent fetches), a host-walked ray 0.5 us -- measured crossover ~110 rays on S10k-sized scenes
+    // (tests/cpp/test_binding --bench prints both sides for 1 .. 4096 rays)
+    static constexpr uint64_t kDeviceBatchMin = 128;
     // the two sides of that choice, callable directly (bench / tests)
     int TraceClosestHost(const vt_ray* rays, uint64_t n, vt_hit* hits) const;
     int TraceClosestDevice(const vt_ray* rays, uint64_t n, vt_hit* hits) const;
