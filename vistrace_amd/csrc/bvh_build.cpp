@@ -122,9 +122,6 @@ void collapse_leaves(std::vector<vt_bvh_node>& nodes, std::vector<uint32_t>& pri
     const size_t nc = nodes.size();
     if (nc == 0 || nodes[0].prim_count != 0) return;
 
-    // experiments only: VT_EXP_COLLAPSE_COST overrides the reference's traversal_cost of 1 (<= -1e9: never collapse)
-    float traversal_cost = kTraversalCost;
-    if (const char* e = std::getenv("VT_EXP_COLLAPSE_COST")) traversal_cost = float(std::atof(e));
     std::vector<uint32_t> pcount(nc);      // > 0: (collapsed) leaf with that many prims
     std::vector<uint8_t>  removed(nc, 0);
     for (size_t k = nc; k-- > 0;) {
@@ -134,7 +131,7 @@ void collapse_leaves(std::vector<vt_bvh_node>& nodes, std::vector<uint32_t>& pri
         pcount[k] = 0;
         if (pcount[l] > 0 && pcount[r] > 0) {
             const float total = float(pcount[l] + pcount[r]);
-            const float collapse_cost = half_area(node_box(nd)) * (total - traversal_cost);
+            const float collapse_cost = half_area(node_box(nd)) * (total - kTraversalCost);
             const float base_cost = half_area(node_box(nodes[l])) * float(pcount[l]) +
                                     half_area(node_box(nodes[r])) * float(pcount[r]);
             if (collapse_cost <= base_cost) {
