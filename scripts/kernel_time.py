@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--reps", type=int, default=15)
     ap.add_argument("--opt", action="append", default=[], help="key=value engine options")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--builder", default="ploc")
     args = ap.parse_args()
 
     import torch
@@ -42,7 +43,7 @@ def main():
             for o in args.opt:
                 k, v = o.split("=")
                 eng.set_option(k, int(v))
-            scenes[name] = (eng, va.Scene(eng, va.HostScene(va.HostBvh(tris, nthreads=16))))
+            scenes[name] = (eng, va.Scene(eng, va.HostScene(va.HostBvh(tris, nthreads=16, builder=args.builder))))
         eng, scene = scenes[name]
         n = args.side * args.side
         stream = tp.current_stream_handle(dev)
@@ -68,7 +69,14 @@ def main():
         ms = ms[2:]
         torch.cuda.synchronize()
         chk = int(d_hits.view(torch.int64).sum().item()) & 0xFFFFFFFFFFFFFFFF
-        print(f"{args.tag or os.path.basename(os.environ.get('VISTRACE_HIP_LIB', 'default'))} {item}: median {np.median(ms):.4f} min {min(ms):.4f} ms  chk {chk:016x}", flush=True)
+        if kind != "any":
+            d_s = tp.trace_stats(scene, d_rays, n)[1]
+            st = d_s.view(torch.int32).view(n, 2).sum(dim=0, dtype=torch.int64).cpu().numpy() / n
+            extra = f" steps {st[0]:.2f} tests {st[1]:.2f} depth {scene.host_scene.max_depth}"
+            del d_s
+        else:
+            extra = ""
+        print(f"{args.tag or os.path.basename(os.environ.get('VISTRACE_HIP_LIB', 'default'))} {item}: median {np.median(ms):.4f} min {min(ms):.4f} ms  chk {chk:016x}{extra}", flush=True)
         del d_rays, d_hits, d_prim
 
 
