@@ -313,6 +313,9 @@ def main() -> None:
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--builder", default="ploc", choices=["ploc", "sah"],
                     help="ploc = the reference's build pipeline (default); sah = opt-in binned SAH (not the headline)")
+    ap.add_argument("--alt-builder", default="sah", choices=["sah", "none"],
+                    help="N = 1: also time the same workload on the opt-in binned-SAH tree and report it as `alt_builder` "
+                         "(kernel time is proportional to the steps per ray; the headline `value` stays on the reference pipeline's tree)")
     ap.add_argument("--gen", default="device", choices=["device", "host"], help="where the synthetic rays are generated")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (one GPU per rank); gloo = test mode: ranks may share a GPU, hits gathered via host")
@@ -578,6 +581,38 @@ def main() -> None:
             "kernel_sources_sha": sha,
         },
     }
+
+    # ---- the same workload on the opt-in binned-SAH tree (N = 1): what the tree is worth ----------------------------------
+    if rank == 0 and world == 1 and not dist_on and args.alt_builder != "none" and args.builder == "ploc" and n > 0:
+        try:
+            alt_args = argparse.Namespace(**vars(args))
+            alt_args.builder = args.alt_builder
+            a_tris, a_bvh, a_hs, a_engine, a_scene, _ = build_scene(alt_args, va, W, dev_index, world)
+            a_rays, a_n, _, _, _ = make_rays(alt_args, rank, world, va, W, tp, a_engine, a_scene, device)
+            a_hits = tp.empty_records(a_n, HIT, device)
+            _, a_stats = tp.trace_stats(a_scene, a_rays, a_n)
+            a_st = a_stats.view(torch.int32).view(a_n, 2).sum(dim=0, dtype=torch.int64).cpu().numpy() / a_n
+            del a_stats
+            for _ in range(3):
+                tp.trace_closest(a_scene, a_rays, a_n, a_hits)
+            torch.cuda.synchronize(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            alt_steps = max(10, min(args.steps, 50))
+            e0.record()
+            for _ in range(alt_steps):
+                tp.trace_closest(a_scene, a_rays, a_n, a_hits)
+            e1.record()
+            torch.cuda.synchronize(device)
+            a_ms = e0.elapsed_time(e1) / alt_steps
+            result["alt_builder"] = {
+                "bvh_builder": "binned SAH, 16 bins (opt-in VT_BUILDER_BINNED_SAH; NOT the reference's build pipeline)",
+                "value": round(a_n / (a_ms * 1e-3) / 1e6, 2), "unit": "Mrays/s", "kernel_ms": round(a_ms, 4),
+                "steps_per_ray": round(float(a_st[0]), 2), "tests_per_ray": round(float(a_st[1]), 2),
+                "note": "same rays procedure, same kernel; kernel time is proportional to steps per ray (profiles/r2/notes.md)",
+            }
+            del a_rays, a_hits, a_scene, a_engine
+        except Exception as exc:   # a secondary figure must never cost the headline line
+            log(f"[bench] alt_builder leg failed: {exc}")
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) -------------------
     if rank == 0 and world == 1 and not args.no_cpu and n > 0:

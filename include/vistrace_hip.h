@@ -230,14 +230,8 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
  *   "blocks_per_cu"      cap on resident 256-thread blocks per CU (8; the occupancy query decides below it)
  *   "block_rays"         consecutive rays handed to a wave at a time (128)
  *   "refill_threshold"   idle lanes that trigger a re-fill (8);  "tri_threshold": waiting lanes that
- *                        trigger the triangle branch (0 = auto: 4);  "static_overflow_mb": overflow-area cap of the
+ *                        trigger the triangle branch (4);  "static_overflow_mb": overflow-area cap of the
  *                        one-ray-per-lane kernel (256)
- *   "defer_leaves"       persistent DMA kernels (no alpha test): deferred triangle tests (default 0).  A lane whose pending
- *                        leaf still waits for a triangle pass keeps walking and parks the next leaves it finds; triangle
- *                        passes then run for ~14 instead of ~7 of 64 lanes.  Exact (triangles are still tested in the
- *                        reference's order against the reference's tmax: see vt::trace_kernel); VALU instructions -10 %,
- *                        lane utilisation 0.52 -> 0.61 on the headline workload, kernel time +1.4 % -- kept as an option.
- *                        "tri_threshold" 0 (default) = 4 lanes, or 10 with defer_leaves.
  *   "max_claim"          persistent kernel: ray blocks one atomic on the cursor may claim while plenty are left (guided
  *                        self-scheduling; single blocks near the end).  The cursor is ONE word and serves ~90 M
  *                        claims per second, i.e. at most 5.8 Grays/s with 64-ray claims: rays into small scenes are

@@ -1,4 +1,5 @@
-N=$PWD/vistrace_amd/lib/variants/libvistrace_hip_nodefer.so
-for b in ploc sah; do for e in 10 12 14; do
-VISTRACE_HIP_LIB=$N python scripts/kernel_time.py --work "S1M:bounce" --builder $b --opt lds_entries=$e --tag ${b}_e$e 2>&1 | grep -E "median|rror"
+for r in 1 2 3; do
+for v in orig base; do
+if [ $v = base ]; then L=$PWD/vistrace_amd/lib/libvistrace_hip.so; else L=$PWD/vistrace_amd/lib/variants/libvistrace_hip_$v.so; fi
+VISTRACE_HIP_LIB=$L python scripts/kernel_time.py --work "S1M:bounce,S1M:primary" --tag $v 2>&1 | grep -E "median|rror"
 done; done

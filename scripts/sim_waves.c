@@ -10,6 +10,8 @@
 //             its current tmax; queued leaves are tested in order in dense TRI passes (fired when >= fire lanes hold
 //             work or a lane is blocked), each entry re-checked against the tmax of that moment (first <= min(second,
 //             tmax)) -- exact by the containment argument in profiles/r2/notes.md
+//   policy 2  the form a kernel can hold in registers: the live pending range as today + ONE parked group (the sibling
+//             leaves of one step); a lane that tested does not step in the same iteration (one record per lane)
 //
 //   gcc -O2 -fopenmp -ffp-contract=off scripts/sim_waves.c -o /tmp/sim_waves -lm && /tmp/sim_waves <dir with *.bin> <policy> [params]
 #include "../oracle/vt_oracle.c"

@@ -309,63 +309,3 @@ def test_native_gather_single_rank(va, make_bundle):
     scene.free()
     eng.close()
 
-
-def test_deferred_leaves_equal_oracle(va, make_bundle):
-    """Engine option defer_leaves (deferred triangle tests in the persistent DMA kernels): same hits, bit for bit, as
-    the oracle and as the default kernels -- small scenes with every tie-break in play, cull flags, any-hit, and the
-    whole 16 Mi-ray headline batch."""
-    import torch
-    from vistrace_amd import torch_plumbing as tp
-    from vistrace_amd import workloads as W
-    eng = va.Engine(0)
-    eng.set_option("persistent", 1)
-    eng.set_option("defer_leaves", 1)
-    dev = torch.device("cuda", 0)
-    for name in ("S1k", "S10k", "terrain"):
-        b = make_bundle(name)
-        scene = va.Scene(eng, b.host_scene)
-        rays = np.concatenate([W.primary_rays(256, 256), W.sphere_rays(200000, 5, origin=(3.0, -4.0, 20.0)),
-                               W.sphere_rays(100000, 6, origin=(30.0, 40.0, -30.0))])
-        rays["tmin"][1000:3000] = 5.0
-        rays["tmax"][3000:6000] = 60.0
-        for thr in (0, 1, 4, 24, 64):
-            eng.set_option("tri_threshold", thr)
-            assert_hits_equal(scene.trace_closest(rays), b.oracle(rays))
-            assert eng.get_option("last_persistent") == 1 and eng.get_option("last_fetch_dma") == 1
-        eng.set_option("tri_threshold", 0)
-        occ = scene.trace_any(rays)
-        assert (occ == (b.oracle(rays, any_hit=True)["prim"] != O_MISS)).all()
-        scene.free()
-    # coincident triangles: the later visited one must still win
-    tri = np.array([[[10, -5, -5], [10, 5, -5], [10, 0, 5]]], np.float32)
-    verts = np.concatenate([tri] * 7 + [tri + np.float32(0.5)] * 3)
-    tris = va.tris_setup(verts)
-    bvh = va.HostBvh(tris)
-    scene = va.Scene(eng, va.HostScene(bvh))
-    rays = np.concatenate([va.make_rays([[0, 0, 0]], [[1, 0, 0]])] * 300 + [W.sphere_rays(5000, 2)])
-    from oracle import binding as O
-    ref = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris), rays)[0]
-    assert_hits_equal(scene.trace_closest(rays), ref)
-    scene.free()
-    # the headline batch: byte-identical to the default kernels
-    b = make_bundle("S1M")
-    scene = va.Scene(eng, b.host_scene)
-    side = 4096
-    n = side * side
-    d_prim = tp.empty_records(n, va.RAY, dev)
-    eng.gen_primary_dev(side, side, d_prim.data_ptr(), stream=tp.current_stream_handle(dev))
-    d_h0 = tp.trace_closest(scene, d_prim, n)
-    d_attrs = tp.hit_attrs(scene, d_prim, d_h0, n)
-    d_rays = tp.empty_records(n, va.RAY, dev)
-    eng.gen_bounce_dev(d_attrs.data_ptr(), n, W.SEED + 3, d_rays.data_ptr(), stream=tp.current_stream_handle(dev))
-    deferred = tp.trace_closest(scene, d_rays, n)
-    deferred_any = tp.trace_any(scene, d_rays, n)
-    eng.set_option("defer_leaves", 0)
-    plain = tp.trace_closest(scene, d_rays, n)
-    plain_any = tp.trace_any(scene, d_rays, n)
-    assert bool((deferred == plain).all()) and bool((deferred_any == plain_any).all())
-    sl = slice(3 << 20, (3 << 20) + (1 << 18))
-    rays_h = tp.to_host(d_rays[sl.start * 32: sl.stop * 32], va.RAY)
-    assert_hits_equal(tp.to_host(deferred[sl.start * 16: sl.stop * 16], va.HIT), b.oracle(rays_h))
-    scene.free()
-    eng.close()

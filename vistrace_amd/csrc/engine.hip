@@ -149,8 +149,7 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
         a.block_rays = uint32_t(std::max<uint64_t>(64, std::min(br, std::max<uint64_t>(fair, 64))));
     }
     a.refill_threshold = std::min(std::max(e->refill_threshold, 1u), 64u);
-    a.defer_leaves = e->defer_leaves != 0 && p.persistent && p.fetch_dma && !stats && !s->has_alpha;
-    a.tri_threshold = e->tri_threshold ? std::min(e->tri_threshold, 64u) : (a.defer_leaves ? 10u : 4u);
+    a.tri_threshold = std::min(std::max(e->tri_threshold, 1u), 64u);
     a.coherent_detect = e->coherent_detect;
     a.coherent_radius2 = s->coherent_radius2;
     a.attribs = s->d_attribs;
@@ -363,8 +362,7 @@ int vt_engine_set_option(vt_engine* e, const char* key, int64_t value)
     else if (k == "blocks_per_cu" && value >= 1 && value <= 64) e->blocks_per_cu = uint32_t(value);
     else if (k == "block_rays" && value >= 64 && value <= (1 << 24)) e->block_rays = uint32_t(value);
     else if (k == "refill_threshold" && value >= 1 && value <= 64) e->refill_threshold = uint32_t(value);
-    else if (k == "tri_threshold" && value >= 0 && value <= 64) e->tri_threshold = uint32_t(value);
-    else if (k == "defer_leaves") e->defer_leaves = value != 0;
+    else if (k == "tri_threshold" && value >= 1 && value <= 64) e->tri_threshold = uint32_t(value);
     else if (k == "fetch_dma") e->fetch_dma = value != 0;
     else if (k == "spin_wait") e->spin_wait = value != 0;
     else if (k == "xcd_cursors") e->xcd_cursors = value != 0;
@@ -388,7 +386,6 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
     else if (k == "static_overflow_mb") *value = e->static_overflow_mb;
     else if (k == "coherent_detect") *value = e->coherent_detect;
     else if (k == "tri_threshold") *value = e->tri_threshold;
-    else if (k == "defer_leaves") *value = e->defer_leaves;
     else if (k == "fetch_dma") *value = e->fetch_dma;
     else if (k == "spin_wait") *value = e->spin_wait;
     else if (k == "xcd_cursors") *value = e->xcd_cursors;

@@ -34,8 +34,7 @@ struct vt_engine {
     uint32_t blocks_per_cu    = 8;    // persistent grid = cu_count * blocks_per_cu
     uint32_t block_rays       = 128;  // consecutive rays handed to a wave at a time (128: primary rays -4 %, bounce rays unchanged)
     uint32_t refill_threshold = 8;    // idle lanes that trigger a re-fill
-    uint32_t tri_threshold    = 0;    // lanes with pending triangles that trigger the TRI branch (0 = auto: 4, or 10 with defer_leaves)
-    int      defer_leaves     = 0;    // persistent DMA kernels: deferred triangle tests (exact; fewer VALU, not faster: profiles/r2/notes.md)
+    uint32_t tri_threshold    = 4;    // lanes with pending triangles that trigger the TRI branch
     int      fetch_dma        = 1;    // quad-cooperative global->LDS record fetch (persistent mode)
     uint32_t max_claim        = 0;    // persistent mode: ray blocks one cursor atomic may claim while plenty are left (0 = auto)
     int      xcd_cursors      = 0;    // persistent mode: one ray-block cursor per XCD over its own eighth of the batch (opt-in)

@@ -41,7 +41,6 @@ struct TraceArgs {
     const uint32_t*     reserved_cus;     // persistent mode: 1024-bit set of __smid() values of the reserved CUs, or NULL
     uint32_t*           cu_slots;         // 1024 counters (zeroed per launch): blocks that asked to stay on a reserved CU
     uint32_t            reserved_limit;   // blocks a reserved CU keeps (0 = none)
-    uint32_t            defer_leaves;     // persistent DMA kernels: park leaves behind the pending range (see trace_kernel)
 };
 
 struct HitAttrsArgs {

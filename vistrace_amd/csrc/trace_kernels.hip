@@ -121,11 +121,6 @@ struct Lane {
     uint32_t tri_cur, tri_end; // pending leaf triangles
     uint32_t sp;               // stack entries in use
     uint32_t steps, tests;
-    // deferred leaves (DEFER kernels): the sibling leaves found by ONE node step while [tri_cur, tri_end) was still being
-    // tested.  q_counts = left count | right count << 16 (0: nothing queued); q_fl / q_fr = the slab entry distances of
-    // the two leaves; their triangles start at record q_start (left leaf first, the right one behind it).
-    uint32_t q_start, q_counts;
-    float q_fl, q_fr;
 };
 
 typedef __attribute__((address_space(1))) const void* global_cptr;
@@ -184,26 +179,9 @@ __device__ __forceinline__ bool alpha_pass(const TraceArgs& a, uint32_t prim, fl
     return !(alpha < M.alpha_ref);                                                       // :205
 }
 
-template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA, bool DEFER_LEAVES>
+template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA>
 __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
 {
-    // Deferred triangle tests (engine option "defer_leaves", off by default; never in the STATS kernels, which must
-    // reproduce the reference's step counts).  The walk is eight node steps to one triangle test, so a wave that tests a
-    // leaf the moment a lane finds it runs its triangle code for ~7 of 64 lanes (measured).  With the option a lane whose
-    // pending range is still waiting for a triangle pass keeps walking -- with the tmax it has -- and parks the next
-    // leaves it finds (one group: the sibling leaves of one node step, with their slab entry distances); the triangle
-    // pass runs when enough lanes hold work.  When the parked group's turn comes, every earlier triangle of the ray has
-    // been tested, so tmax is exactly what the reference had when IT slab-tested those leaves: the group is re-checked
-    // against it (`first <= tmax`; first <= min(exit) already held, and second = min(exit, tmax)) and a leaf that fails
-    // is dropped -- the reference never entered it.  Node steps taken with a stale (larger) tmax only enter extra
-    // subtrees; a child box lies inside its parent's (bounds are exact min/max of the triangle vertices) and entry /
-    // exit times are monotone in the bounds, so everything below a node the reference culled fails its own slab test or
-    // re-check and adds no candidate.  Triangles are therefore tested in the reference's order against the reference's
-    // tmax: same hits, same tie-breaks (scripts/sim_waves.c replays the scheme on the CPU with the oracle's arithmetic:
-    // 0 mismatches; tests/test_gpu_configs.py::test_deferred_leaves_equal_oracle).  Measured on S1M bounce rays
-    // (profiles/r2/notes.md): VALU instructions -10.5 %, lane utilisation 0.52 -> 0.61, kernel time +1.4 % -- the wave's
-    // own dependent chain, not VALU issue, sets the iteration time at 6 waves per SIMD, hence off by default.
-    constexpr bool DEFER = DEFER_LEAVES && !STATS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
@@ -269,7 +247,6 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
         L.sx = -L.ox * L.ix; L.sy = -L.oy * L.iy; L.sz = -L.oz * L.iz;
         L.prim = VT_MISS; L.u = 0.f; L.v = 0.f;
         L.sp = 0; L.steps = 0; L.tests = 0;
-        L.q_counts = 0; L.q_start = 0; L.q_fl = 0.f; L.q_fr = 0.f;
         if (a.root_leaf_count != 0) {        // the root is a leaf: no slab test at all
             L.node = kDone; L.tri_cur = 0; L.tri_end = a.root_leaf_count;
         } else {
@@ -414,20 +391,11 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
 
         // ---- which record does this lane need? ----------------------------------------------
         const bool want_tri  = has_ray && L.tri_cur < L.tri_end;
-        // who may step a node: without deferral a lane whose pending range is empty (node != kDone is implied, else it
-        // has finished); with it, every lane whose walk is still going and that has no parked group
-        const bool can_step = DEFER ? (has_ray && L.node != kDone && L.q_counts == 0) : (has_ray && !want_tri);
-        // the TRI branch runs only when enough lanes wait for it, or nobody can step a node -- or (DEFER) a quarter of
-        // the wave's rays can do nothing else
+        const bool want_node = has_ray && !want_tri;       // node != kDone is implied (else finished)
+        // the TRI branch runs only when enough lanes wait for it, or nobody can step a node
         const uint64_t tri_mask = __ballot(want_tri);
-        const uint64_t step_mask = __ballot(can_step);
-        bool run_tri = tri_mask != 0 && (uint32_t(__popcll(tri_mask)) >= a.tri_threshold || step_mask == 0);
-        if constexpr (DEFER) {
-            const uint32_t stuck = uint32_t(__popcll(tri_mask & ~step_mask));
-            run_tri = run_tri || (tri_mask != 0 && 4u * stuck >= uint32_t(__popcll(__ballot(has_ray))));
-        }
+        const bool run_tri = tri_mask != 0 && (uint32_t(__popcll(tri_mask)) >= a.tri_threshold || __ballot(want_node) == 0);
         const bool do_tri = want_tri && run_tri;
-        const bool want_node = can_step && !do_tri;        // one record per lane and iteration: test OR step
         // idle lanes (no ray, or waiting for the TRI branch) fetch record 0 in the DMA form: an always-valid
         // address keeps the four DMA loads branch-free; the direct form skips them instead
         const uint32_t rec = do_tri ? a.tri_base + L.tri_cur : (want_node ? L.node : (FETCH_DMA ? 0u : kNoFetch));
@@ -510,18 +478,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
             }
             if (hit) {
                 L.prim = tprim; L.u = u; L.v = v; L.tmax = t;
-                if constexpr (ANY_HIT) { L.tri_cur = L.tri_end; L.node = kDone; L.q_counts = 0; }
-            }
-            if constexpr (DEFER) {
-                // the pending range is done: the parked group takes its place, re-checked against the tmax of this moment
-                if (L.tri_cur >= L.tri_end && L.q_counts != 0) {
-                    const uint32_t cl = L.q_counts & 0xFFFFu, cr = L.q_counts >> 16;
-                    const bool live_l = cl != 0 && L.q_fl <= L.tmax;
-                    const bool live_r = cr != 0 && L.q_fr <= L.tmax;
-                    L.tri_cur = L.q_start + (live_l ? 0u : cl);
-                    L.tri_end = L.q_start + cl + (live_r ? cr : 0u);
-                    L.q_counts = 0;
-                }
+                if constexpr (ANY_HIT) { L.tri_cur = L.tri_end; L.node = kDone; }
             }
         } else if (want_node) {
             // ---- NODE: one iteration of SingleRayTraverser::traverse -------------------
@@ -556,21 +513,10 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
 
             // leaves that were hit become the pending triangle range, left before right;
             // two leaf siblings are contiguous in the leaf-ordered triangle array
-            if constexpr (!DEFER) {
-                uint32_t tc = 0, te = 0;
-                if (hit_l && leaf_l) { tc = lfirst; te = lfirst + lcount; }
-                if (hit_r && leaf_r) { if (te == 0) tc = rfirst; te = rfirst + rcount; }
-                L.tri_cur = tc; L.tri_end = te;
-            } else {
-                const bool lh = hit_l && leaf_l, rh = hit_r && leaf_r;
-                const uint32_t cl = lh ? lcount : 0u, cr = rh ? rcount : 0u;
-                const uint32_t start = lh ? lfirst : rfirst;         // only read when cl + cr != 0
-                const bool busy = L.tri_cur < L.tri_end;             // the previous leaves still wait for their triangle pass
-                L.q_start = start; L.q_fl = fl; L.q_fr = fr;
-                L.q_counts = busy ? (cl | (cr << 16)) : 0u;          // park the group behind them, unchecked ...
-                L.tri_cur = busy ? L.tri_cur : start;                // ... or make it the pending range (tmax has not moved
-                L.tri_end = busy ? L.tri_end : start + cl + cr;      //     since the slab test: nothing to re-check)
-            }
+            uint32_t tc = 0, te = 0;
+            if (hit_l && leaf_l) { tc = lfirst; te = lfirst + lcount; }
+            if (hit_r && leaf_r) { if (te == 0) tc = rfirst; te = rfirst + rcount; }
+            L.tri_cur = tc; L.tri_end = te;
 
             const bool go_l = hit_l && !leaf_l, go_r = hit_r && !leaf_r;
             uint32_t next;
@@ -919,10 +865,10 @@ __global__ __launch_bounds__(kBlockThreads) void refit_level_kernel(RefitLevelAr
 }
 
 // ---- launchers ---------------------------------------------------------------------------
-template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA, bool DEFER>
+template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA>
 static hipError_t launch_one(const TraceArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA, DEFER>), grid, dim3(kBlockThreads), lds_bytes,
+    hipLaunchKernelGGL((trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>), grid, dim3(kBlockThreads), lds_bytes,
                        stream, a);
     return hipGetLastError();
 }
@@ -943,40 +889,31 @@ namespace {
 
 // one entry per compiled variant: launch it, or ask how many blocks fit on a CU
 template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA>
-hipError_t variant_op(const TraceArgs* a, dim3 grid, size_t lds_bytes, hipStream_t stream, int* blocks_per_cu, bool defer)
+hipError_t variant_op(const TraceArgs* a, dim3 grid, size_t lds_bytes, hipStream_t stream, int* blocks_per_cu)
 {
-    // the deferred-leaves form exists for the persistent DMA kernels without alpha test (the headline path)
-    if constexpr (PERSISTENT && FETCH_DMA && !STATS && !ALPHA) {
-        if (defer) {
-            if (blocks_per_cu)
-                return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                    blocks_per_cu, trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA, true>, int(kBlockThreads), lds_bytes);
-            return launch_one<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA, true>(*a, grid, lds_bytes, stream);
-        }
-    }
     if (blocks_per_cu)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            blocks_per_cu, trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA, false>, int(kBlockThreads), lds_bytes);
-    return launch_one<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA, false>(*a, grid, lds_bytes, stream);
+            blocks_per_cu, trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>, int(kBlockThreads), lds_bytes);
+    return launch_one<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>(*a, grid, lds_bytes, stream);
 }
 
 template <bool ALPHA>
 hipError_t dispatch(const TraceArgs* a, bool any_hit, bool stats, bool persistent, bool fetch_dma, dim3 grid,
-                    size_t lds_bytes, hipStream_t stream, int* occ, bool defer)
+                    size_t lds_bytes, hipStream_t stream, int* occ)
 {
     if (persistent && fetch_dma) {
-        if (any_hit) return variant_op<true, false, true, true, ALPHA>(a, grid, lds_bytes, stream, occ, defer);
-        if (stats)   return variant_op<false, true, true, true, ALPHA>(a, grid, lds_bytes, stream, occ, defer);
-        return variant_op<false, false, true, true, ALPHA>(a, grid, lds_bytes, stream, occ, defer);
+        if (any_hit) return variant_op<true, false, true, true, ALPHA>(a, grid, lds_bytes, stream, occ);
+        if (stats)   return variant_op<false, true, true, true, ALPHA>(a, grid, lds_bytes, stream, occ);
+        return variant_op<false, false, true, true, ALPHA>(a, grid, lds_bytes, stream, occ);
     }
     if (persistent) {
-        if (any_hit) return variant_op<true, false, true, false, ALPHA>(a, grid, lds_bytes, stream, occ, defer);
-        if (stats)   return variant_op<false, true, true, false, ALPHA>(a, grid, lds_bytes, stream, occ, defer);
-        return variant_op<false, false, true, false, ALPHA>(a, grid, lds_bytes, stream, occ, defer);
+        if (any_hit) return variant_op<true, false, true, false, ALPHA>(a, grid, lds_bytes, stream, occ);
+        if (stats)   return variant_op<false, true, true, false, ALPHA>(a, grid, lds_bytes, stream, occ);
+        return variant_op<false, false, true, false, ALPHA>(a, grid, lds_bytes, stream, occ);
     }
-    if (any_hit) return variant_op<true, false, false, false, ALPHA>(a, grid, lds_bytes, stream, occ, defer);
-    if (stats)   return variant_op<false, true, false, false, ALPHA>(a, grid, lds_bytes, stream, occ, defer);
-    return variant_op<false, false, false, false, ALPHA>(a, grid, lds_bytes, stream, occ, defer);
+    if (any_hit) return variant_op<true, false, false, false, ALPHA>(a, grid, lds_bytes, stream, occ);
+    if (stats)   return variant_op<false, true, false, false, ALPHA>(a, grid, lds_bytes, stream, occ);
+    return variant_op<false, false, false, false, ALPHA>(a, grid, lds_bytes, stream, occ);
 }
 
 } // namespace
@@ -984,15 +921,14 @@ hipError_t dispatch(const TraceArgs* a, bool any_hit, bool stats, bool persisten
 hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, bool fetch_dma, bool alpha,
                         uint32_t grid_blocks, size_t lds_bytes, hipStream_t stream)
 {
-    const bool defer = a.defer_leaves != 0;
-    return alpha ? dispatch<true>(&a, any_hit, stats, persistent, fetch_dma, dim3(grid_blocks), lds_bytes, stream, nullptr, defer)
-                 : dispatch<false>(&a, any_hit, stats, persistent, fetch_dma, dim3(grid_blocks), lds_bytes, stream, nullptr, defer);
+    return alpha ? dispatch<true>(&a, any_hit, stats, persistent, fetch_dma, dim3(grid_blocks), lds_bytes, stream, nullptr)
+                 : dispatch<false>(&a, any_hit, stats, persistent, fetch_dma, dim3(grid_blocks), lds_bytes, stream, nullptr);
 }
 
 hipError_t trace_blocks_per_cu(bool any_hit, bool stats, bool persistent, bool fetch_dma, bool alpha, size_t lds_bytes, int* out)
 {
-    return alpha ? dispatch<true>(nullptr, any_hit, stats, persistent, fetch_dma, dim3(1), lds_bytes, nullptr, out, false)
-                 : dispatch<false>(nullptr, any_hit, stats, persistent, fetch_dma, dim3(1), lds_bytes, nullptr, out, false);
+    return alpha ? dispatch<true>(nullptr, any_hit, stats, persistent, fetch_dma, dim3(1), lds_bytes, nullptr, out)
+                 : dispatch<false>(nullptr, any_hit, stats, persistent, fetch_dma, dim3(1), lds_bytes, nullptr, out);
 }
 
 __global__ __launch_bounds__(kBlockThreads) void cu_probe_kernel(uint32_t* seen)
