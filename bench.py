@@ -6,8 +6,9 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Default workload (config.workload = "S1M_bounce16777216", BASELINE.json configs[2]): scene S1M (1 000 300
-triangles), 16 777 216 incoherent cosine-hemisphere bounce rays generated from the 4096x4096 primary hits of one
-camera, closest hit.  One "step" = one pass of the hot path (vt_trace_closest_dev) over the whole ray batch, rays and
+triangles; tree from the product's default builder, binned SAH -- `alt_builder` repeats the measurement on the
+reference-algorithm PLOC tree), 16 777 216 incoherent cosine-hemisphere bounce rays generated from the 4096x4096
+primary hits of one camera, closest hit.  One "step" = one pass of the hot path (vt_trace_closest_dev) over the whole ray batch, rays and
 hits resident in HBM.  With N > 1 ranks the BVH is replicated and
   --scaling weak   (default) every rank traces its own 16 Mi-ray batch (camera = rank);
   --scaling strong BASELINE configs[4] verbatim with `--scene S10M`: 128 tiles of 1024x1024 primary rays from 128
@@ -60,6 +61,8 @@ KERNEL_SOURCES = ("vistrace_amd/csrc/trace_kernels.hip", "vistrace_amd/csrc/trac
                   "vistrace_amd/csrc/engine_internal.h", "vistrace_amd/csrc/Makefile")
 # issue cost per wave-instruction and SIMD in cycles, measured on this part (scripts/ubench_valu.hip, profiles/r1/notes.md)
 ISSUE_COST = {"MUL_F32": 2.4, "ADD_F32": 2.4, "FMA_F32": 4.2, "TRANS_F32": 8.2, "INT32": 3.2, "OTHER": 4.2}
+BUILDER_NAMES = {"sah": "binned SAH, 16 bins, task-parallel (VT_BUILDER_BINNED_SAH: the default of vt_bvh_build)",
+                 "ploc": "PLOC r=14 + SAH leaf collapse (VT_BUILDER_PLOC: the reference's algorithm; the tree of round 1)"}
 SIMDS = 1024               # 256 CUs x 4
 CLOCK_GHZ = 2.4
 
@@ -213,15 +216,15 @@ def collect_pmc_live(args, passes) -> dict:
     return out
 
 
-def committed_pmc(workload: str, sha: str) -> dict:
-    """profiles/r<N>/pmc_<workload>.json, only if it was taken from exactly these kernel sources."""
-    path = os.path.join(ROOT, "profiles", ROUND, f"pmc_{workload}.json")
+def committed_pmc(workload: str, builder: str, sha: str) -> dict:
+    """profiles/r<N>/pmc_<workload>_<builder>.json, only if it was taken from exactly these kernel sources."""
+    path = os.path.join(ROOT, "profiles", ROUND, f"pmc_{workload}_{builder}.json")
     try:
         with open(path) as f:
             tj = json.load(f)
     except (OSError, ValueError):
         return {}
-    if tj.get("workload") != workload or tj.get("kernel_sources_sha") != sha:
+    if tj.get("workload") != workload or tj.get("builder") != builder or tj.get("kernel_sources_sha") != sha:
         log(f"[bench] {path} is stale (kernel sources changed): not used")
         return {}
     return dict(tj.get("counters", {}), _source=os.path.relpath(path, ROOT))
@@ -311,11 +314,12 @@ def main() -> None:
     ap.add_argument("--pmc-passes", default="fetch,write,sq,mix")
     ap.add_argument("--pmc-timeout", type=float, default=240.0)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--builder", default="ploc", choices=["ploc", "sah"],
-                    help="ploc = the reference's build pipeline (default); sah = opt-in binned SAH (not the headline)")
-    ap.add_argument("--alt-builder", default="sah", choices=["sah", "none"],
-                    help="N = 1: also time the same workload on the opt-in binned-SAH tree and report it as `alt_builder` "
-                         "(kernel time is proportional to the steps per ray; the headline `value` stays on the reference pipeline's tree)")
+    ap.add_argument("--builder", default="sah", choices=["ploc", "sah"],
+                    help="sah = binned SAH, the product's default builder (vt_bvh_build); ploc = the reference's algorithm "
+                         "(PLOC r=14 + leaf collapse)")
+    ap.add_argument("--alt-builder", default="ploc", choices=["ploc", "sah", "none"],
+                    help="N = 1: also time the same workload on the other builder's tree and report it as `alt_builder` "
+                         "(default: the reference-algorithm PLOC tree, the one round 1 was measured on)")
     ap.add_argument("--gen", default="device", choices=["device", "host"], help="where the synthetic rays are generated")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (one GPU per rank); gloo = test mode: ranks may share a GPU, hits gathered via host")
@@ -507,14 +511,14 @@ def main() -> None:
                 pmc_source = "live: rocprofv3 --pmc passes of this workload in a child process of this run (last dispatch of the kernel)"
                 try:
                     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-                    with open(os.path.join(ROOT, "gpurun_out", f"pmc_{workload}.json"), "w") as f:
-                        json.dump({"workload": workload, "kernel_sources_sha": sha, "counters": pmc,
+                    with open(os.path.join(ROOT, "gpurun_out", f"pmc_{workload}_{args.builder}.json"), "w") as f:
+                        json.dump({"workload": workload, "builder": args.builder, "kernel_sources_sha": sha, "counters": pmc,
                                    "note": "last dispatch of vt::trace_kernel<false,false,...> in separate rocprofv3 --pmc passes "
                                            "(FETCH_SIZE, WRITE_SIZE in KB; factor 1.000 for 64-B record fetches: profiles/r1/calib_fetch.txt)"}, f, indent=1)
                 except OSError:
                     pass
         if "FETCH_SIZE" not in pmc:
-            com = committed_pmc(workload, sha)
+            com = committed_pmc(workload, args.builder, sha)
             if "FETCH_SIZE" in com:
                 pmc_source = com.pop("_source") + " (kernel sources unchanged since that pass)"
                 pmc = com
@@ -543,7 +547,7 @@ def main() -> None:
         "config": {
             "workload": workload,
             "scene_triangles": int(len(tris)),
-            "bvh_builder": "PLOC r=14 + SAH leaf collapse (reference pipeline)" if args.builder == "ploc" else "binned SAH (opt-in)",
+            "bvh_builder": BUILDER_NAMES[args.builder],
             "rays_per_gpu": n,
             "rays_total": n_total,
             "query": "closest-hit",
@@ -582,8 +586,8 @@ def main() -> None:
         },
     }
 
-    # ---- the same workload on the opt-in binned-SAH tree (N = 1): what the tree is worth ----------------------------------
-    if rank == 0 and world == 1 and not dist_on and args.alt_builder != "none" and args.builder == "ploc" and n > 0:
+    # ---- the same workload on the other builder's tree (N = 1): what the tree is worth ------------------------------------
+    if rank == 0 and world == 1 and not dist_on and args.alt_builder not in ("none", args.builder) and n > 0:
         try:
             alt_args = argparse.Namespace(**vars(args))
             alt_args.builder = args.alt_builder
@@ -605,7 +609,7 @@ def main() -> None:
             torch.cuda.synchronize(device)
             a_ms = e0.elapsed_time(e1) / alt_steps
             result["alt_builder"] = {
-                "bvh_builder": "binned SAH, 16 bins (opt-in VT_BUILDER_BINNED_SAH; NOT the reference's build pipeline)",
+                "bvh_builder": BUILDER_NAMES[args.alt_builder],
                 "value": round(a_n / (a_ms * 1e-3) / 1e6, 2), "unit": "Mrays/s", "kernel_ms": round(a_ms, 4),
                 "steps_per_ray": round(float(a_st[0]), 2), "tests_per_ray": round(float(a_st[1]), 2),
                 "note": "same rays procedure, same kernel; kernel time is proportional to steps per ray (profiles/r2/notes.md)",

@@ -1,5 +1,3 @@
-for r in 1 2 3; do
-for v in orig base; do
-if [ $v = base ]; then L=$PWD/vistrace_amd/lib/libvistrace_hip.so; else L=$PWD/vistrace_amd/lib/variants/libvistrace_hip_$v.so; fi
-VISTRACE_HIP_LIB=$L python scripts/kernel_time.py --work "S1M:bounce,S1M:primary" --tag $v 2>&1 | grep -E "median|rror"
-done; done
+for b in ploc sah retop; do
+python scripts/kernel_time.py --work "S1M:bounce,S1M:primary,S100k:bounce,S100k:primary" --builder $b --tag $b 2>&1 | grep -E "median|rror"
+done

@@ -24,7 +24,7 @@ from vistrace_amd import workloads as W  # noqa: E402
 def main():
     verts = W.make_scene("S1k")
     tris = va.tris_setup(verts)
-    bvh = va.HostBvh(tris)
+    bvh = va.HostBvh(tris, builder="ploc")      # the fixtures pin the reference-algorithm tree
     nodes, pidx = bvh.nodes(), bvh.prim_indices()
     otris = O.tris_from_tri64(tris)
 
@@ -58,7 +58,7 @@ def main():
     # ---- second fixture: one-sided heightfield (cull flag set), rays from above and below, windows ----
     tverts, tflags = W.make_terrain(16)
     ttris = va.tris_setup(tverts, tflags)
-    tbvh = va.HostBvh(ttris)
+    tbvh = va.HostBvh(ttris, builder="ploc")
     tnodes, tpidx, totris = tbvh.nodes(), tbvh.prim_indices(), O.tris_from_tri64(ttris)
     trays = np.concatenate([W.sphere_rays(1024, W.SEED + 21, origin=(0.0, 0.0, 60.0)),
                             W.sphere_rays(1024, W.SEED + 22, origin=(3.0, -4.0, -30.0))])

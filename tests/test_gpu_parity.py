@@ -41,7 +41,7 @@ def stats_on_device(va, scene, rays):
 def test_golden_vectors(va, engine):
     gold = np.load(GOLDEN)
     tris = va.tris_setup(gold["verts"])
-    scene = va.Scene(engine, va.HostScene(va.HostBvh(tris)))
+    scene = va.Scene(engine, va.HostScene(va.HostBvh(tris, builder="ploc")))
     rays = gold["rays"].view(va.RAY)
     assert_hits_equal(scene.trace_closest(rays), gold["hits"].view(va.HIT))
     assert (scene.trace_any(rays) == gold["occluded"]).all()
@@ -51,7 +51,7 @@ def test_golden_vectors(va, engine):
 
 def test_terrain_golden_vectors(va, engine):
     gold = np.load(os.path.join(os.path.dirname(GOLDEN), "terrain_golden.npz"))
-    scene = va.Scene(engine, va.HostScene(va.HostBvh(va.tris_setup(gold["verts"], gold["flags"]))))
+    scene = va.Scene(engine, va.HostScene(va.HostBvh(va.tris_setup(gold["verts"], gold["flags"]), builder="ploc")))
     rays = gold["rays"].view(va.RAY)
     assert_hits_equal(scene.trace_closest(rays), gold["hits"].view(va.HIT))
     _, st = stats_on_device(va, scene, rays)
@@ -478,11 +478,12 @@ def test_config4_shadow_rays_any_hit(va, engine, make_bundle):
     assert (hits["t"][hits["prim"] != O_MISS] <= rays["tmax"][hits["prim"] != O_MISS]).all()
 
 
-def test_sah_tree_on_device(va, engine, O):
-    """The kernels are tree-agnostic: on the opt-in binned-SAH tree the device still equals the oracle."""
+def test_ploc_tree_on_device(va, engine, O):
+    """The kernels are tree-agnostic: on the reference-algorithm PLOC tree (every other scene test runs on the default
+    binned-SAH tree; the golden-vector tests on the PLOC tree too) the device equals the oracle, counters included."""
     from vistrace_amd import workloads as W
     tris = va.tris_setup(W.make_scene("S10k"))
-    bvh = va.HostBvh(tris, builder="sah")
+    bvh = va.HostBvh(tris, builder="ploc")
     scene = va.Scene(engine, va.HostScene(bvh))
     rays = np.concatenate([W.primary_rays(96, 64), W.sphere_rays(6000, 12, origin=(-200.0, 30.0, 10.0))])
     ref, ref_st, _, _, _ = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris), rays, want_stats=True)

@@ -75,23 +75,25 @@ def check_linearised(hs, bvh, tris):
         assert (ltris[k] == src[k]).all()
 
 
+@pytest.mark.parametrize("builder", ["sah", "ploc"])
 @pytest.mark.parametrize("name", ["S1k", "S10k"])
-def test_scene_trees(va, name):
+def test_scene_trees(va, name, builder):
     from vistrace_amd import workloads as W
     tris = va.tris_setup(W.make_scene(name))
-    bvh = va.HostBvh(tris)
+    bvh = va.HostBvh(tris, builder=builder)
     check_tree(va, tris, bvh)
     check_linearised(va.HostScene(bvh), bvh, tris)
     counts = bvh.nodes()["prim_count"]
-    assert counts.max() <= 16 and (counts > 1).any()          # leaf collapse produced multi-triangle leaves
+    assert counts.max() <= 16 and (counts > 1).any()          # multi-triangle leaves (SAH termination / PLOC leaf collapse)
 
 
+@pytest.mark.parametrize("builder", ["sah", "ploc"])
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 64, 257])
-def test_small_and_empty(va, n):
+def test_small_and_empty(va, n, builder):
     rng = np.random.default_rng(n)
     verts = rng.uniform(-10, 10, (n, 3, 3)).astype(np.float32)
     tris = va.tris_setup(verts)
-    bvh = va.HostBvh(tris)
+    bvh = va.HostBvh(tris, builder=builder)
     check_tree(va, tris, bvh)
     hs = va.HostScene(bvh)
     check_linearised(hs, bvh, tris)
@@ -104,9 +106,10 @@ def test_degenerate_inputs(va):
     same = np.tile(np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32), (100, 1, 1))
     for verts in (same, np.concatenate([same, same + np.array([3, 0, 0], np.float32)])):
         tris = va.tris_setup(verts)
-        bvh = va.HostBvh(tris)
-        check_tree(va, tris, bvh)
-        check_linearised(va.HostScene(bvh), bvh, tris)
+        for builder in ("sah", "ploc"):
+            bvh = va.HostBvh(tris, builder=builder)
+            check_tree(va, tris, bvh)
+            check_linearised(va.HostScene(bvh), bvh, tris)
 
 
 def test_flags_travel_to_records(va):
@@ -120,28 +123,62 @@ def test_flags_travel_to_records(va):
     assert (lt["flags"] == flags[lt["prim"]]).all()
 
 
-@pytest.mark.parametrize("name", ["S1k", "S10k"])
-def test_optional_sah_builder(va, O, name):
-    """Opt-in binned-SAH builder: same structural invariants, deterministic, and the oracle finds the
-    same t,u,v on it as on the default PLOC tree (only tie-broken indices may differ)."""
+@pytest.mark.parametrize("name", ["S1k", "S10k", "S100k"])
+def test_both_builders(va, O, name):
+    """Default binned-SAH builder (task-parallel) and the reference-algorithm PLOC builder: same structural invariants,
+    both deterministic for any thread count (S100k is large enough for the SAH builder's parallel top + subtree tasks),
+    and the oracle finds the same t,u,v on both trees (only tie-broken indices may differ)."""
     from vistrace_amd import workloads as W
     tris = va.tris_setup(W.make_scene(name))
     sah = va.HostBvh(tris, builder="sah")
+    assert (va.HostBvh(tris).nodes().view(np.uint8) == sah.nodes().view(np.uint8)).all()      # "sah" IS the default
     check_tree(va, tris, sah)
     check_linearised(va.HostScene(sah), sah, tris)
-    again = va.HostBvh(tris, nthreads=1, builder="sah")
-    assert (again.nodes().view(np.uint8) == sah.nodes().view(np.uint8)).all()
-    ploc = va.HostBvh(tris)
+    for nt in (1, 3):
+        again = va.HostBvh(tris, nthreads=nt, builder="sah")
+        assert (again.nodes().view(np.uint8) == sah.nodes().view(np.uint8)).all()
+        assert (again.prim_indices() == sah.prim_indices()).all()
+    ploc = va.HostBvh(tris, builder="ploc")
+    check_tree(va, tris, ploc)
+    assert (va.HostBvh(tris, nthreads=1, builder="ploc").nodes().view(np.uint8) == ploc.nodes().view(np.uint8)).all()
     rays = np.concatenate([W.primary_rays(48, 48), W.sphere_rays(2000, 4, origin=(100.0, -50.0, 20.0))])
     ot = O.tris_from_tri64(tris)
-    a, _, _, _, _ = O.traverse_batch(sah.nodes().view(O.NODE), sah.prim_indices(), ot, rays)
-    b, _, _, _, _ = O.traverse_batch(ploc.nodes().view(O.NODE), ploc.prim_indices(), ot, rays)
+    a, _, sa, _, _ = O.traverse_batch(sah.nodes().view(O.NODE), sah.prim_indices(), ot, rays)
+    b, _, sb, _, _ = O.traverse_batch(ploc.nodes().view(O.NODE), ploc.prim_indices(), ot, rays)
     for k in ("t", "u", "v"):
         same = a["prim"] == b["prim"]
         assert (a[k][same].view(np.uint32) == b[k][same].view(np.uint32)).all()
     assert (a["t"].view(np.uint32) == b["t"].view(np.uint32)).all()
+    if name == "S100k":
+        assert sa < 0.85 * sb                                  # fewer traversal steps on the SAH tree from 100 k triangles up: why it is the default
     with pytest.raises(KeyError):
         va.HostBvh(tris, builder="nope")
+
+
+def test_vt_builder_environment_override(va):
+    """vt_bvh_build (what the host class calls) follows VT_BUILDER=ploc / sah; vt_bvh_build_ex names the builder."""
+    import ctypes as C
+    import os
+    from vistrace_amd import workloads as W
+    tris = va.tris_setup(W.make_scene("S1k"))
+    lib = va._lib.lib
+
+    def build_default():
+        h = C.c_void_p()
+        va._lib.check(lib.vt_bvh_build(va._lib.ptr(tris), len(tris), 0, C.byref(h)))
+        n = lib.vt_bvh_node_count(h)
+        lib.vt_bvh_free(h)
+        return n
+    old = os.environ.pop("VT_BUILDER", None)
+    try:
+        n_default = build_default()
+        assert n_default == len(va.HostBvh(tris, builder="sah").nodes())
+        os.environ["VT_BUILDER"] = "ploc"
+        assert build_default() == len(va.HostBvh(tris, builder="ploc").nodes())
+    finally:
+        os.environ.pop("VT_BUILDER", None)
+        if old is not None:
+            os.environ["VT_BUILDER"] = old
 
 
 def test_host_refit_keeps_topology_and_bounds_the_moved_triangles(va):

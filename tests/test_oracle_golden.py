@@ -48,10 +48,10 @@ def test_golden_matches_brute_force(O, gold):
 
 def test_builder_rebuilds_golden_tree(va, gold):
     tris = va.tris_setup(gold["verts"])
-    bvh = va.HostBvh(tris)
+    bvh = va.HostBvh(tris, builder="ploc")                     # the fixture holds the PLOC tree
     assert (bvh.nodes().view(np.uint8) == gold["nodes"].view(np.uint8)).all()
     assert (bvh.prim_indices() == gold["prim_indices"]).all()
-    bvh1 = va.HostBvh(tris, nthreads=1)                          # thread count must not change the tree
+    bvh1 = va.HostBvh(tris, nthreads=1, builder="ploc")                          # thread count must not change the tree
     assert (bvh1.nodes().view(np.uint8) == gold["nodes"].view(np.uint8)).all()
 
 
@@ -77,5 +77,5 @@ def test_terrain_golden_cull_flags(va, O):
         assert (hits[k].view(np.uint32) == ref[k].view(np.uint32)).all()
     n_above = int((ref["prim"][:1024] != O.MISS).sum()); n_below = int((ref["prim"][1024:2048] != O.MISS).sum())
     assert n_above != n_below and n_above > 0 and n_below > 0        # the cull bit changes the answer
-    bvh = va.HostBvh(va.tris_setup(g["verts"], g["flags"]))
+    bvh = va.HostBvh(va.tris_setup(g["verts"], g["flags"]), builder="ploc")
     assert (bvh.nodes().view(np.uint8) == g["nodes"].view(np.uint8)).all()

@@ -1,5 +1,5 @@
 """Property test of the oracle's BVH walk (bvh v1 semantics) against its own brute-force
-intersector on random small scenes, built by the product's PLOC builder: for every ray the walk returns the
+intersector on random small scenes, built by the product's builders (default SAH and PLOC): for every ray the walk returns the
 minimum t bit for bit (the slab test never prunes the closest triangle), the reported index lies in the set of
 triangles attaining it, any-hit agrees, and the walk never tests more triangles than there are.  CPU only."""
 import numpy as np
@@ -20,7 +20,7 @@ def test_walk_equals_brute_force(va, O, seed, ntris, scale, cull, window):
         verts[2, 1] = verts[2, 0]                             # zero-area triangle
     flags = (rng.integers(0, 2, ntris).astype(np.uint8) if cull else None)
     tris = va.tris_setup(verts, flags)
-    bvh = va.HostBvh(tris)
+    bvh = va.HostBvh(tris, builder="ploc" if seed % 2 else "sah")
     otris = O.tris_from_tri64(tris)
     nr = 300
     org = rng.normal(scale=2.0 * scale, size=(nr, 3)).astype(np.float32)

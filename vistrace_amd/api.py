@@ -58,8 +58,8 @@ class HostBvh:
 
     BUILDERS = {"ploc": 0, "sah": 1}
 
-    def __init__(self, tris: np.ndarray, nthreads: int = 0, builder: str = "ploc"):
-        """builder: "ploc" = the reference's pipeline (PLOC + leaf collapse), "sah" = opt-in binned SAH."""
+    def __init__(self, tris: np.ndarray, nthreads: int = 0, builder: str = "sah"):
+        """builder: "sah" = binned SAH (the default of vt_bvh_build), "ploc" = the reference's algorithm (PLOC + leaf collapse)."""
         assert tris.dtype == TRI64
         self._tris = np.ascontiguousarray(tris)
         h = C.c_void_p()
@@ -366,7 +366,7 @@ class Scene:
 
 
 def build_scene(engine: Engine, verts: np.ndarray, flags: Optional[np.ndarray] = None, nthreads: int = 0) -> Scene:
-    """verts (n,3,3) -> setup -> PLOC build -> linearise -> upload."""
+    """verts (n,3,3) -> setup -> build (default builder) -> linearise -> upload."""
     tris = tris_setup(verts, flags)
     return Scene(engine, HostScene(HostBvh(tris, nthreads)))
 
