@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--reps", type=int, default=15)
     ap.add_argument("--opt", action="append", default=[], help="key=value engine options")
     ap.add_argument("--tag", default="")
-    ap.add_argument("--builder", default="ploc")
+    ap.add_argument("--builder", default="sah")
     args = ap.parse_args()
 
     import torch
