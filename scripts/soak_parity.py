@@ -18,7 +18,7 @@ bad = 0
 t0 = time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    n = int(rng.integers(1, 20000))
+    n = int(rng.integers(1, 20000)) if seed % 7 else int(rng.integers(20000, 90000))   # the larger ones reach the SAH builder's parallel subtree tasks
     spread = 10.0 ** rng.uniform(0, 3)
     centre = rng.uniform(-spread, spread, (n, 1, 3))
     scale = 10.0 ** rng.uniform(-4, 2, (n, 1, 1))
@@ -35,12 +35,17 @@ for seed in range(first, first + count):
         rig[1]["uv"][::11] *= np.float32(1e6)                 # absurd texture coordinates
         rig[1]["uv"][5::23, 0, 0] = np.nan
     tris = va.tris_setup(verts, flags)
-    bvh = va.HostBvh(tris, builder="sah" if seed % 5 == 0 else "ploc")
-    scene = va.Scene(eng, va.HostScene(bvh))
+    if seed % 11 == 0 and n > 50:                             # a few non-finite triangles: never hit, must not derail a builder
+        verts[1::max(2, n // 7), rng.integers(0, 3), rng.integers(0, 3)] = [np.nan, np.inf, -np.inf][seed % 3]
+        tris = va.tris_setup(verts, flags)
+    bvh = va.HostBvh(tris, nthreads=int(rng.integers(1, 9)), builder="ploc" if seed % 2 else "sah")
+    host_scene = va.HostScene(bvh)
+    scene = va.Scene(eng, host_scene)
     otris = O.tris_from_tri64(tris)
     if rig is not None:
         scene.set_tri_attribs(rig[1].view(va.TRI_ATTRIBS))
         scene.set_alpha(rig[2].view(va.ALPHA_MATERIAL), rig[3])
+        host_scene.set_alpha_host(rig[1].view(va.TRI_ATTRIBS), rig[2].view(va.ALPHA_MATERIAL), rig[3])
         O.set_alpha(otris, rig[1]["uv"].reshape(n, 6), rig[1]["material"], rig[2].view(O.ALPHA_MATERIAL), rig[3])
     else:
         O.set_alpha()
@@ -58,6 +63,12 @@ for seed in range(first, first + count):
     rays = va.make_rays(org, d, tmin, tmax)
     ref, ref_st, _, _, _ = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays, want_stats=True)
     any_ref = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays, any_hit=True)[0]
+    # the single-ray latency path (host walk) against the same reference
+    hk = min(m, 3000)
+    if not ((host_scene.trace_closest_host(rays[:hk]).view(np.uint8) == ref[:hk].view(np.uint8)).all()
+            and (host_scene.trace_any_host(rays[:hk]) == (any_ref["prim"][:hk] != O.MISS)).all()):
+        bad += 1
+        print(f"HOST WALK MISMATCH seed {seed} n {n}", flush=True)
     for mode in (1, 0, 2):
         eng.set_option("persistent", mode)
         d_rays = tp.to_device(rays, dev)
@@ -72,6 +83,15 @@ for seed in range(first, first + count):
             kk = min(k, m)
             ok = ok and (scene.trace_closest(rays[:kk]).view(np.uint8) == ref[:kk].view(np.uint8)).all()
             ok = ok and (scene.trace_any(rays[-kk:]) == (any_ref["prim"][-kk:] != O.MISS)).all()
+        if mode == 1 and seed % 4 == 1:                       # two launches in flight on two streams (scratch ring)
+            s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+            h1, h2 = tp.empty_records(m, va.HIT, dev), tp.empty_records(m, va.HIT, dev)
+            torch.cuda.synchronize()
+            for _ in range(3):
+                scene.trace_closest_dev(d_rays.data_ptr(), m, h1.data_ptr(), s1.cuda_stream)
+                scene.trace_closest_dev(d_rays.data_ptr(), m, h2.data_ptr(), s2.cuda_stream)
+            torch.cuda.synchronize()
+            ok = ok and (tp.to_host(h1, va.HIT).view(np.uint8) == ref.view(np.uint8)).all() and (tp.to_host(h2, va.HIT).view(np.uint8) == ref.view(np.uint8)).all()
         if mode == 1 and seed % 3 == 0:
             eng.set_option("reserved_cus", 32)
             ok = ok and (scene.trace_closest(rays).view(np.uint8) == ref.view(np.uint8)).all()

@@ -364,7 +364,20 @@ int build_binned_sah(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out)
     std::vector<float> centers(size_t(n) * 3);
     std::vector<uint32_t> idx(n);
 #pragma omp parallel for schedule(static) num_threads(nthreads)
-    for (int64_t i = 0; i < int64_t(n); ++i) { tri_box_center(tris[i], boxes[i], &centers[size_t(i) * 3]); idx[i] = uint32_t(i); }
+    for (int64_t i = 0; i < int64_t(n); ++i) {
+        tri_box_center(tris[i], boxes[i], &centers[size_t(i) * 3]);
+        // A triangle with a NaN / infinite vertex can never be hit (Primitives.h:173-189 yields NaN or -inf), but its box
+        // would poison every box above it (NaN slab terms drop out of the reference's test, so rays would walk into it):
+        // it gets the empty box (neutral in every union, fails every slab test) and a harmless centre.
+        bool finite = true;
+        for (int k = 0; k < 3; ++k)
+            finite = finite && std::fabs(boxes[i].lo[k]) <= FLT_MAX && std::fabs(boxes[i].hi[k]) <= FLT_MAX;
+        if (!finite) {
+            boxes[i] = Box{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+            centers[size_t(i) * 3] = centers[size_t(i) * 3 + 1] = centers[size_t(i) * 3 + 2] = 0.0f;
+        }
+        idx[i] = uint32_t(i);
+    }
     const SahCtx ctx{boxes.data(), centers.data(), idx.data(), nthreads};
 
     // top of the tree on this thread; subtrees of <= kTaskPrims triangles as tasks, in creation order
