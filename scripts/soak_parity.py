@@ -35,7 +35,8 @@ for seed in range(first, first + count):
         rig[1]["uv"][::11] *= np.float32(1e6)                 # absurd texture coordinates
         rig[1]["uv"][5::23, 0, 0] = np.nan
     tris = va.tris_setup(verts, flags)
-    if seed % 11 == 0 and n > 50:                             # a few non-finite triangles: never hit, must not derail a builder
+    poisoned = seed % 11 == 0 and n > 50
+    if poisoned:                             # a few non-finite triangles: never hit, must not derail a builder
         verts[1::max(2, n // 7), rng.integers(0, 3), rng.integers(0, 3)] = [np.nan, np.inf, -np.inf][seed % 3]
         tris = va.tris_setup(verts, flags)
     bvh = va.HostBvh(tris, nthreads=int(rng.integers(1, 9)), builder="ploc" if seed % 2 else "sah")
@@ -99,7 +100,7 @@ for seed in range(first, first + count):
         if not ok:
             bad += 1
             print(f"MISMATCH seed {seed} mode {mode} n {n} m {m}", flush=True)
-    if seed % 5 == 1 and rig is None:                         # device refit against the host pipeline, then trace parity
+    if seed % 5 == 1 and rig is None and not poisoned:                         # device refit against the host pipeline, then trace parity
         moved = (verts + rng.normal(scale=0.05 * spread, size=verts.shape)).astype(np.float32)
         scene.refit(moved, flags)
         mtris = va.tris_setup(moved, flags)
