@@ -10,7 +10,7 @@ triangles; tree from the product's default builder, binned SAH -- `alt_builder` 
 reference-algorithm PLOC tree), 16 777 216 incoherent cosine-hemisphere bounce rays generated from the 4096x4096
 primary hits of one camera, closest hit.  One "step" = one pass of the hot path (vt_trace_closest_dev) over the whole ray batch, rays and
 hits resident in HBM.  With N > 1 ranks the BVH is replicated and
-  --scaling weak   (default) every rank traces its own 16 Mi-ray batch (camera = rank);
+  --scaling weak   (default) every rank traces its own 16 Mi-ray batch (same camera, the rank's own bounce seed);
   --scaling strong BASELINE configs[4] verbatim with `--scene S10M`: 128 tiles of 1024x1024 primary rays from 128
                    seeded camera poses = 134 217 728 rays in total, split contiguously over the ranks;
 either way the hit records are gathered to rank 0 over RCCL (xGMI) inside the step -- the single exchange of the path.
@@ -121,8 +121,9 @@ def make_rays(args, rank, world, va, W, tp, engine, scene, device):
         return d_rays, n_local, args.tiles * tile, f"{args.scene}_primary_{args.tiles}x1048576_tiles", None
     side = args.side
     n = side * side
-    cams = W.camera_positions(args.scene)
-    cam = cams[rank % len(cams)]
+    # weak scaling: every rank gets a batch of the SAME difficulty -- the camera of the N = 1 workload, its own bounce seed
+    # (different seeded cameras see 10-20 % more or fewer steps per ray, which would show up as scaling loss or gain)
+    cam = W.camera_positions(args.scene)[0]
     rays_host = None
     if args.gen == "host":
         prim_rays = W.primary_rays(side, side, pos=cam)

@@ -1,3 +1,5 @@
-for o in "lds_entries=10" "lds_entries=8" "lds_entries=7" "lds_entries=6" "tri_threshold=2" "tri_threshold=6" "refill_threshold=4" "refill_threshold=12" "block_rays=64" "block_rays=256"; do
-python scripts/kernel_time.py --work "S1M:bounce" --opt $o --tag $o 2>&1 | grep -E "median|rror" | cut -c1-90
-done
+for r in 1 2 3; do
+for v in base pipe; do
+if [ $v = base ]; then L=$PWD/vistrace_amd/lib/libvistrace_hip.so; else L=$PWD/vistrace_amd/lib/variants/libvistrace_hip_$v.so; fi
+VISTRACE_HIP_LIB=$L python scripts/kernel_time.py --work "S1M:bounce,S1M:primary" --tag $v 2>&1 | grep -E "median|rror" | cut -c1-100
+done; done
