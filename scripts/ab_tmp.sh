@@ -1,5 +1,3 @@
-for r in 1 2 3; do
-for v in base pipe; do
-if [ $v = base ]; then L=$PWD/vistrace_amd/lib/libvistrace_hip.so; else L=$PWD/vistrace_amd/lib/variants/libvistrace_hip_$v.so; fi
-VISTRACE_HIP_LIB=$L python scripts/kernel_time.py --work "S1M:bounce,S1M:primary" --tag $v 2>&1 | grep -E "median|rror" | cut -c1-100
-done; done
+for o in "lds_entries=10" "lds_entries=8" "lds_entries=6" "xcd_cursors=1" "block_rays=64" "refill_threshold=12"; do
+python scripts/kernel_time.py --work "S10M:bounce,S10M:primary" --reps 8 --opt $o --tag $o 2>&1 | grep -E "median|rror" | cut -c1-110
+done
