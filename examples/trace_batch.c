@@ -1,5 +1,7 @@
 /* trace_batch.c -- the C ABI of include/vistrace_hip.h used from plain C (no C++, no Python):
- * set up a two-triangle scene, build + linearise on the CPU, upload, trace a small batch, read the hits.
+ * set up a two-triangle scene, build + linearise on the CPU, open ALL devices as one group (vt_engine_open_multi: the
+ * scene is replicated, big host batches are sharded), upload, trace a small batch, read the hits; then the single-ray
+ * latency path (host walk) on the same records.
  *   gcc -std=c11 -Iinclude examples/trace_batch.c -Lvistrace_amd/lib -lvistrace_hip -Wl,-rpath,$PWD/vistrace_amd/lib
  * Exit code 0 = the expected hits came back; 2 = no HIP device (the library has no CPU fallback). */
 #include <float.h>
@@ -29,9 +31,13 @@ int main(void)
     CHECK(vt_tris_setup(verts, NULL, 2, recs));
     CHECK(vt_bvh_build(recs, 2, 0, &bvh));
     CHECK(vt_scene_linearise(bvh, recs, &hs));
-    CHECK(vt_engine_open(0, &eng));
+    int ndev = 0, devs[64];
+    CHECK(vt_device_count(&ndev));
+    if (ndev > 64) ndev = 64;
+    for (int i = 0; i < ndev; ++i) devs[i] = i;
+    if (ndev <= 0) { fprintf(stderr, "no HIP device (the library has no CPU fallback)\n"); return 2; }
+    CHECK(vt_engine_open_multi(devs, ndev, &eng));
     CHECK(vt_scene_upload(eng, hs, &scene));
-    vt_host_scene_free(hs);
     vt_bvh_free(bvh);
 
     const vt_ray rays[3] = {
@@ -48,8 +54,15 @@ int main(void)
     const int ok = hits[0].prim == 1 && hits[0].t == 4.f && hits[0].u == 0.25f && hits[0].v == 0.25f &&
                    hits[1].prim == 0 && hits[1].t == 5.f && hits[2].prim == VT_MISS && occluded[0] == 1 &&
                    occluded[1] == 1 && occluded[2] == 0;
+    /* what one accel:Traverse call does: the same walk on the host copy, bit-identical */
+    vt_hit hw[3];
+    CHECK(vt_host_scene_trace_closest(hs, rays, 3, hw));
+    int same = 1;
+    for (int i = 0; i < 3; ++i) same = same && hw[i].prim == hits[i].prim && hw[i].t == hits[i].t && hw[i].u == hits[i].u && hw[i].v == hits[i].v;
+    printf("devices in the group: %d; host walk %s the device\n", vt_engine_device_count(eng), same ? "equals" : "DIFFERS FROM");
+    vt_host_scene_free(hs);
     vt_scene_free(scene);
     vt_engine_close(eng);
-    printf(ok ? "ok\n" : "MISMATCH\n");
-    return ok ? 0 : 1;
+    printf(ok && same ? "ok\n" : "MISMATCH\n");
+    return ok && same ? 0 : 1;
 }

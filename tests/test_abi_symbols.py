@@ -48,3 +48,23 @@ def test_device_calls_fail_loudly_without_gpu(va):
     with pytest.raises(va._lib.VisTraceError) as e:
         va.Engine(0)
     assert e.value.code == va._lib.VT_ERR_HIP
+
+
+def test_multi_gpu_entry_points_validate_arguments(va):
+    """vt_engine_open_multi rejects an empty or duplicated device list before touching a device; without a GPU it fails
+    loudly like vt_engine_open; the per-rank communicator calls refuse an engine-less / uninitialised use."""
+    import ctypes as C
+    import torch
+    L = va._lib
+    h = C.c_void_p()
+    devs = (C.c_int * 2)(0, 0)
+    assert L.lib.vt_engine_open_multi(devs, 2, C.byref(h)) == L.VT_ERR_INVALID_ARG and b"twice" in L.lib.vt_last_error()
+    assert L.lib.vt_engine_open_multi(devs, 0, C.byref(h)) == L.VT_ERR_INVALID_ARG
+    assert L.lib.vt_engine_open_multi(None, 1, C.byref(h)) == L.VT_ERR_INVALID_ARG
+    assert L.lib.vt_engine_device_count(None) == 0 and L.lib.vt_engine_device(None, 0) == -1
+    assert L.lib.vt_gather_hits_dev(None, None, 1, None, 0, None) == L.VT_ERR_INVALID_ARG
+    assert L.lib.vt_engine_comm_init_rank(None, 1, 0, None) == L.VT_ERR_INVALID_ARG
+    assert L.lib.vt_gather_wait(None, 0, None) == L.VT_ERR_INVALID_ARG
+    if not torch.cuda.is_available():
+        one = (C.c_int * 1)(0)
+        assert L.lib.vt_engine_open_multi(one, 1, C.byref(h)) == L.VT_ERR_HIP
