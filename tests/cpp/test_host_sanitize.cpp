@@ -25,6 +25,16 @@ static void run(uint32_t n, unsigned seed, bool clustered)
     for (uint32_t i = 0; i < n; ++i) flags[i] = uint8_t(i & 1);
     std::vector<vt_tri64> recs(n);
     CHECK(vt_tris_setup(verts.data(), flags.data(), n, recs.data()) == VT_OK);
+    // both builders: the default (task-parallel binned SAH) and the reference's algorithm (PLOC + leaf collapse)
+    for (int builder : {int(VT_BUILDER_BINNED_SAH), int(VT_BUILDER_PLOC)}) {
+        vt_bvh* b2 = nullptr;
+        CHECK(vt_bvh_build_ex(recs.data(), n, 3, builder, &b2) == VT_OK && b2);
+        CHECK(vt_bvh_prim_count(b2) == n);
+        vt_host_scene* h2 = nullptr;
+        CHECK(vt_scene_linearise(b2, recs.data(), &h2) == VT_OK && h2 && vt_host_scene_tri_count(h2) == n);
+        vt_host_scene_free(h2);
+        vt_bvh_free(b2);
+    }
     vt_bvh* bvh = nullptr;
     CHECK(vt_bvh_build(recs.data(), n, 3, &bvh) == VT_OK && bvh);
     vt_host_scene* hs = nullptr;
@@ -81,7 +91,7 @@ static void shards()
 
 int main()
 {
-    for (uint32_t n : {0u, 1u, 2u, 3u, 17u, 1000u, 20000u}) { run(n, 7 + n, false); run(n, 11 + n, true); }
+    for (uint32_t n : {0u, 1u, 2u, 3u, 17u, 1000u, 20000u, 70000u}) { run(n, 7 + n, false); run(n, 11 + n, true); }
     shards();
     vt_bvh* b = nullptr;
     CHECK(vt_bvh_build(nullptr, 5, 0, &b) != VT_OK && vt_last_error()[0] != 0);   // NULL input is an error, not a crash
