@@ -262,9 +262,25 @@ class NativeGather:
     def __init__(self, engine, n, world, rank, device, dist):
         import torch
         import vistrace_amd as va
-        ids = [va.comm_unique_id() if rank == 0 else None]
+        # every rank takes the same decision: a failure on one rank must not leave the others waiting in a collective
+        ids = [None]
+        if rank == 0:
+            try:
+                ids[0] = va.comm_unique_id()
+            except Exception as exc:
+                ids[0] = f"error: {exc}"
         dist.broadcast_object_list(ids, src=0)
-        engine.comm_init_rank(world, rank, ids[0])
+        if isinstance(ids[0], str):
+            raise RuntimeError(f"rank 0 could not create the RCCL id ({ids[0]})")
+        err = None
+        try:
+            engine.comm_init_rank(world, rank, ids[0])
+        except Exception as exc:
+            err = exc
+        bad = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=device)
+        dist.all_reduce(bad)
+        if int(bad.item()) != 0:
+            raise RuntimeError(f"vt_engine_comm_init_rank failed on {int(bad.item())} rank(s)" + (f": {err}" if err else ""))
         self.engine, self.n, self.rank = engine, n, rank
         self.hits = [torch.empty(n * 16, dtype=torch.uint8, device=device) for _ in range(2)]
         self.recv = [torch.empty(world * n * 16, dtype=torch.uint8, device=device) if rank == 0 else None for _ in range(2)]
@@ -690,6 +706,15 @@ def main() -> None:
         ctx.close()
         if not (same_prim and same_tuv):
             log("[bench] PARITY FAILURE on the sample")
+    if dist_on:
+        # RCCL writes a version banner to the C stdout of rank 0; when stdout is a pipe it sits in the stdio buffer until
+        # exit and would land BEHIND the result.  Push it out first so that the JSON line is the last line of the run.
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        dist.barrier()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist_on:
