@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Long randomized parity soak on the GPU: many seeded triangle soups (degenerate / duplicate triangles, cull
 flags, extreme scales) x random rays (windows, zero components), device vs oracle bit for bit incl. counters,
-for the persistent, static and auto kernels.  Usage: python scripts/soak_parity.py [first_seed] [count]"""
+for the persistent, static and auto kernels.  Usage: python scripts/soak_parity.py [first_seed] [count] [seconds]
+(stops cleanly after `seconds`, prints a progress line every 100 seeds)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,11 +13,18 @@ from vistrace_amd import torch_plumbing as tp
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+budget = float(sys.argv[3]) if len(sys.argv) > 3 else float("inf")
 eng = va.Engine(0)
 dev = torch.device("cuda", 0)
 bad = 0
 t0 = time.time()
+done = 0
 for seed in range(first, first + count):
+    if time.time() - t0 > budget:
+        break
+    if done and done % 100 == 0:
+        print(f"soak: {done} seeds done, {bad} mismatches, {time.time() - t0:.0f}s", flush=True)
+    done += 1
     rng = np.random.default_rng(seed)
     n = int(rng.integers(1, 20000)) if seed % 7 else int(rng.integers(20000, 90000))   # the larger ones reach the SAH builder's parallel subtree tasks
     spread = 10.0 ** rng.uniform(0, 3)
@@ -113,5 +121,5 @@ for seed in range(first, first + count):
         if not ok:
             bad += 1
             print(f"REFIT MISMATCH seed {seed} n {n}", flush=True)
-print(f"soak: seeds {first}..{first + count - 1}, {bad} mismatches, {time.time() - t0:.0f}s")
+print(f"soak: seeds {first}..{first + done - 1}, {bad} mismatches, {time.time() - t0:.0f}s")
 sys.exit(1 if bad else 0)

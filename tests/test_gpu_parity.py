@@ -415,6 +415,14 @@ def test_device_ray_generation_matches_host(va, engine, make_bundle):
     ref = W.primary_rays(w, h, pos=cam, forward=(1.0, 0.2, -0.1))
     assert (got["org"] == ref["org"]).all() and (got["tmin"] == 0).all() and (got["tmax"] == ref["tmax"]).all()
     assert np.abs(got["dir"] - ref["dir"]).max() <= 1e-6
+    for rw, rh in ((97, 65), (1, 1), (2049, 3)):          # ragged against the 8 x 256 pixels a block generates
+        d_r = tp.empty_records(rw * rh + 1, va.RAY, dev)
+        d_r.zero_()
+        engine.gen_primary_dev(rw, rh, d_r.data_ptr(), pos=cam, forward=(1.0, 0.2, -0.1), stream=tp.current_stream_handle(dev))
+        g = tp.to_host(d_r, va.RAY)
+        r = W.primary_rays(rw, rh, pos=cam, forward=(1.0, 0.2, -0.1))
+        assert (g["org"][:-1] == r["org"]).all() and np.abs(g["dir"][:-1] - r["dir"]).max() <= 1e-6
+        assert g["tmax"][-1] == 0 and (g["dir"][-1] == 0).all()       # nothing written behind the image
     d_hits = tp.trace_closest(scene, d_prim, w * h)
     d_attrs = tp.hit_attrs(scene, d_prim, d_hits, w * h)
     attrs = tp.to_host(d_attrs, va.HIT_ATTRS)

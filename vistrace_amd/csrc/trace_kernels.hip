@@ -602,12 +602,12 @@ __global__ __launch_bounds__(kBlockThreads) void hit_shade_kernel(HitShadeArgs a
 }
 
 // ---- device-side ray generation (harness for wavefront callers) ----
+constexpr uint32_t kGenPixelsPerThread = 8;   // the camera basis (two sqrt, six divides, one tan in fp64) is set up once per thread
+
 __global__ __launch_bounds__(kBlockThreads) void gen_primary_kernel(GenPrimaryArgs a)
 {
-    const uint64_t i = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
     const uint32_t w = a.cam.width, h = a.cam.height;
-    if (i >= uint64_t(w) * h) return;
-    const uint32_t px = uint32_t(i % w), py = uint32_t(i / w);
+    const uint64_t n = uint64_t(w) * h;
     // double precision set-up, rounded once to fp32 (as the host generator does)
     double f[3] = {a.cam.forward[0], a.cam.forward[1], a.cam.forward[2]};
     double up[3] = {a.cam.up[0], a.cam.up[1], a.cam.up[2]};
@@ -618,14 +618,19 @@ __global__ __launch_bounds__(kBlockThreads) void gen_primary_kernel(GenPrimaryAr
     r[0] /= rl; r[1] /= rl; r[2] /= rl;
     const double u[3] = {r[1] * f[2] - r[2] * f[1], r[2] * f[0] - r[0] * f[2], r[0] * f[1] - r[1] * f[0]};
     const double th = tan(double(a.cam.vfov_deg) * 3.14159265358979323846 / 180.0 / 2.0);
-    const double sx = ((double(px) + 0.5) / w * 2.0 - 1.0) * th * (double(w) / h);
-    const double sy = (1.0 - (double(py) + 0.5) / h * 2.0) * th;
-    double d[3] = {f[0] + sx * r[0] + sy * u[0], f[1] + sx * r[1] + sy * u[1], f[2] + sx * r[2] + sy * u[2]};
-    const double dl = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    vt_ray ray;
-    for (int k = 0; k < 3; ++k) { ray.org[k] = a.cam.pos[k]; ray.dir[k] = float(d[k] / dl); }
-    ray.tmin = 0.f; ray.tmax = FLT_MAX;
-    a.rays[i] = ray;
+    // consecutive lanes write consecutive rays; a thread's pixels lie one block apart
+    uint64_t i = uint64_t(blockIdx.x) * (kBlockThreads * kGenPixelsPerThread) + threadIdx.x;
+    for (uint32_t k = 0; k < kGenPixelsPerThread && i < n; ++k, i += kBlockThreads) {
+        const uint32_t px = uint32_t(i % w), py = uint32_t(i / w);
+        const double sx = ((double(px) + 0.5) / w * 2.0 - 1.0) * th * (double(w) / h);
+        const double sy = (1.0 - (double(py) + 0.5) / h * 2.0) * th;
+        double d[3] = {f[0] + sx * r[0] + sy * u[0], f[1] + sx * r[1] + sy * u[1], f[2] + sx * r[2] + sy * u[2]};
+        const double dl = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        vt_ray ray;
+        for (int c = 0; c < 3; ++c) { ray.org[c] = a.cam.pos[c]; ray.dir[c] = float(d[c] / dl); }
+        ray.tmin = 0.f; ray.tmax = FLT_MAX;
+        a.rays[i] = ray;
+    }
 }
 
 __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t index)
@@ -962,8 +967,8 @@ hipError_t launch_gen_primary(const GenPrimaryArgs& a, hipStream_t stream)
 {
     const uint64_t n = uint64_t(a.cam.width) * a.cam.height;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(gen_primary_kernel, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0,
-                       stream, a);
+    const uint64_t per_block = uint64_t(kBlockThreads) * kGenPixelsPerThread;
+    hipLaunchKernelGGL(gen_primary_kernel, dim3(uint32_t((n + per_block - 1) / per_block)), dim3(kBlockThreads), 0, stream, a);
     return hipGetLastError();
 }
 
