@@ -293,6 +293,11 @@ int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uin
  * either pointer may be NULL.  For inspection and tests. */
 int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_out);
 
+/* After vt_scene_refit / vt_scene_skin_refit: bring the host copy that vt_host_scene_trace_* walk (the single-ray path of
+ * accel:Traverse, source/objects/AccelStruct.cpp:818) up to date with the device -- the records are read back into `hs`
+ * (S1M: 101 MB), which must be the host scene `s` was uploaded from.  Not thread safe against host walks of `hs`. */
+int vt_host_scene_sync(vt_host_scene* hs, vt_scene* s);
+
 /* Optional per-triangle side table (n must equal the scene's triangle count); copied to the device. */
 int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_t n);
 /* Alpha test inside the triangle test (source/objects/Primitives.h:196-208).  In tree and followed exactly: texUV

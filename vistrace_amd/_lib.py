@@ -72,6 +72,7 @@ SYMBOLS = {
     "vt_host_scene_trace_closest": (C.c_int, [_vp, _vp, _u64, _vp]),
     "vt_host_scene_trace_any": (C.c_int, [_vp, _vp, _u64, _vp]),
     "vt_host_scene_set_alpha": (C.c_int, [_vp, _vp, _u32, _vp, _u32, _vp, _u64]),
+    "vt_host_scene_sync": (C.c_int, [_vp, _vp]),
     "vt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "vt_engine_open": (C.c_int, [C.c_int, _pp]),
     "vt_engine_close": (None, [_vp]),

@@ -348,6 +348,10 @@ class Scene:
             raise ValueError("bones and binds must have the same shape")
         check(lib.vt_scene_skin_refit(self._h, ptr(bones) if len(bones) else None, ptr(binds) if len(binds) else None, len(bones)))
 
+    def sync_host_scene(self) -> None:
+        """After refit / skin_refit: read the device records back into the host scene the single-ray path walks."""
+        check(lib.vt_host_scene_sync(self.host_scene._h, self._h))
+
     def read_records(self):
         """(pairs, tris) as they currently are on the device."""
         pairs = np.zeros(self.host_scene.pair_count, dtype=NODE_PAIR)

@@ -920,6 +920,21 @@ int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_o
     return VT_OK;
 }
 
+int vt_host_scene_sync(vt_host_scene* hsw, vt_scene* s)
+{
+    if (!hsw || !s) return fail(VT_ERR_INVALID_ARG, "vt_host_scene_sync: NULL argument");
+    HostScene& hs = hsw->hs;
+    if (hs.pairs.size() != s->npairs || hs.tris.size() != s->ntris || hs.root_leaf_count != s->root_leaf_count)
+        return fail(VT_ERR_INVALID_ARG, "vt_host_scene_sync: the scene was not uploaded from this host scene");
+    if (s->poisoned) return fail(VT_ERR_INVALID_ARG, "vt_host_scene_sync: the last refit left non-finite triangles; refit with finite data first");
+    const int rc = vt_scene_read_records(s, hs.pairs.data(), hs.tris.data());
+    if (rc != VT_OK) return rc;
+    bool alpha = false;                                   // a refit may change the flags
+    for (const vt_tri64& t : hs.tris) alpha |= (t.flags & VT_TRI_ALPHATEST) != 0;
+    hs.has_alpha = alpha;
+    return VT_OK;
+}
+
 int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_t n)
 {
     if (s) for (vt_scene* rep : s->replicas) { const int rc = vt_scene_set_tri_attribs(rep, attribs, n); if (rc != VT_OK) return rc; }

@@ -66,7 +66,11 @@ RcclApi* rccl()
             if (api.handle) break;
             api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
-        if (!api.handle) { api.error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found"); return; }
+        if (!api.handle) {
+            const char* why = dlerror();                  // one call: dlerror() clears the message it returns
+            api.error = std::string("cannot load librccl.so: ") + (why ? why : "not found");
+            return;
+        }
         bool ok = true;
         auto sym = [&](auto& fn, const char* name) {
             fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(api.handle, name));
@@ -100,10 +104,10 @@ int rccl_fail(const char* what, ncclResult_t r)
 // comm stream + events of one engine (its device is current)
 int ensure_comm_side(vt_engine* e)
 {
-    if (e->s_comm) return VT_OK;
-    VT_HIP(hipStreamCreateWithFlags(&e->s_comm, hipStreamNonBlocking));
-    VT_HIP(hipEventCreateWithFlags(&e->ev_traced, hipEventDisableTiming));
-    for (int b = 0; b < 2; ++b) VT_HIP(hipEventCreateWithFlags(&e->ev_sent[b], hipEventDisableTiming));
+    if (!e->s_comm) VT_HIP(hipStreamCreateWithFlags(&e->s_comm, hipStreamNonBlocking));
+    if (!e->ev_traced) VT_HIP(hipEventCreateWithFlags(&e->ev_traced, hipEventDisableTiming));
+    for (int b = 0; b < 2; ++b)
+        if (!e->ev_sent[b]) VT_HIP(hipEventCreateWithFlags(&e->ev_sent[b], hipEventDisableTiming));
     return VT_OK;
 }
 
@@ -118,20 +122,24 @@ std::vector<vt_engine*> group_of(vt_engine* root)
 // single-process group: one communicator per device, created together on first use
 int ensure_group_comms(vt_engine* root)
 {
-    if (root->comm) return VT_OK;
     RcclApi* R = rccl();
     if (!R) return fail(VT_ERR_HIP, "multi-GPU gather: " + rccl_state().error);
     const std::vector<vt_engine*> g = group_of(root);
-    std::vector<int> devs;
-    for (vt_engine* e : g) devs.push_back(e->device);
-    std::vector<ncclComm_t> comms(g.size(), nullptr);
-    VT_NCCL(R->CommInitAll(comms.data(), int(g.size()), devs.data()));
-    for (size_t k = 0; k < g.size(); ++k) {
-        g[k]->comm = comms[k];
-        g[k]->comm_rank = int(k);
-        g[k]->comm_size = int(g.size());
-        DeviceGuard guard(g[k]->device);
-        const int rc = ensure_comm_side(g[k]);
+    if (!root->comm) {
+        std::vector<int> devs;
+        for (vt_engine* e : g) devs.push_back(e->device);
+        std::vector<ncclComm_t> comms(g.size(), nullptr);
+        VT_NCCL(R->CommInitAll(comms.data(), int(g.size()), devs.data()));
+        for (size_t k = 0; k < g.size(); ++k) {
+            g[k]->comm = comms[k];
+            g[k]->comm_rank = int(k);
+            g[k]->comm_size = int(g.size());
+        }
+    }
+    for (vt_engine* e : g) {                              // idempotent: a failure here is retried by the next call
+        DeviceGuard guard(e->device);
+        if (!guard.ok) return fail(VT_ERR_HIP, "multi-GPU gather: hipSetDevice failed");
+        const int rc = ensure_comm_side(e);
         if (rc != VT_OK) return rc;
     }
     return VT_OK;
