@@ -65,6 +65,7 @@ def test_multi_gpu_entry_points_validate_arguments(va):
     assert L.lib.vt_gather_hits_dev(None, None, 1, None, 0, None) == L.VT_ERR_INVALID_ARG
     assert L.lib.vt_engine_comm_init_rank(None, 1, 0, None) == L.VT_ERR_INVALID_ARG
     assert L.lib.vt_gather_wait(None, 0, None) == L.VT_ERR_INVALID_ARG
+    assert L.lib.vt_host_scene_sync(None, None) == L.VT_ERR_INVALID_ARG
     if not torch.cuda.is_available():
         one = (C.c_int * 1)(0)
         assert L.lib.vt_engine_open_multi(one, 1, C.byref(h)) == L.VT_ERR_HIP
