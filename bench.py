@@ -62,7 +62,8 @@ KERNEL_SOURCES = ("vistrace_amd/csrc/trace_kernels.hip", "vistrace_amd/csrc/trac
 # issue cost per wave-instruction and SIMD in cycles, measured on this part (scripts/ubench_valu.hip, profiles/r1/notes.md)
 ISSUE_COST = {"MUL_F32": 2.4, "ADD_F32": 2.4, "FMA_F32": 4.2, "TRANS_F32": 8.2, "INT32": 3.2, "OTHER": 4.2}
 BUILDER_NAMES = {"sah": "binned SAH, 16 bins, task-parallel (VT_BUILDER_BINNED_SAH: the default of vt_bvh_build)",
-                 "ploc": "PLOC r=14 + SAH leaf collapse (VT_BUILDER_PLOC: the reference's algorithm; the tree of round 1)"}
+                 "ploc": "PLOC r=14 + SAH leaf collapse (VT_BUILDER_PLOC: the reference's algorithm; the tree of round 1)",
+                 "sah_refined": "binned SAH + 2 passes of insertion-based optimisation (VT_BUILDER_BINNED_SAH_REFINED: opt-in, +25 % build time)"}
 SIMDS = 1024               # 256 CUs x 4
 CLOCK_GHZ = 2.4
 
@@ -331,10 +332,10 @@ def main() -> None:
     ap.add_argument("--pmc-passes", default="fetch,write,sq,mix")
     ap.add_argument("--pmc-timeout", type=float, default=240.0)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--builder", default="sah", choices=["ploc", "sah"],
+    ap.add_argument("--builder", default="sah", choices=["ploc", "sah", "sah_refined"],
                     help="sah = binned SAH, the product's default builder (vt_bvh_build); ploc = the reference's algorithm "
-                         "(PLOC r=14 + leaf collapse)")
-    ap.add_argument("--alt-builder", default="ploc", choices=["ploc", "sah", "none"],
+                         "(PLOC r=14 + leaf collapse); sah_refined = binned SAH + insertion-based optimisation (opt-in)")
+    ap.add_argument("--alt-builder", default="ploc", choices=["ploc", "sah", "sah_refined", "none"],
                     help="N = 1: also time the same workload on the other builder's tree and report it as `alt_builder` "
                          "(default: the reference-algorithm PLOC tree, the one round 1 was measured on)")
     ap.add_argument("--gen", default="device", choices=["device", "host"], help="where the synthetic rays are generated")

@@ -47,7 +47,7 @@ for seed in range(first, first + count):
     if poisoned:                             # a few non-finite triangles: never hit, must not derail a builder
         verts[1::max(2, n // 7), rng.integers(0, 3), rng.integers(0, 3)] = [np.nan, np.inf, -np.inf][seed % 3]
         tris = va.tris_setup(verts, flags)
-    bvh = va.HostBvh(tris, nthreads=int(rng.integers(1, 9)), builder="ploc" if seed % 2 else "sah")
+    bvh = va.HostBvh(tris, nthreads=int(rng.integers(1, 9)), builder=("sah", "ploc", "sah_refined")[seed % 3])
     host_scene = va.HostScene(bvh)
     scene = va.Scene(eng, host_scene)
     otris = O.tris_from_tri64(tris)

@@ -25,8 +25,8 @@ static void run(uint32_t n, unsigned seed, bool clustered)
     for (uint32_t i = 0; i < n; ++i) flags[i] = uint8_t(i & 1);
     std::vector<vt_tri64> recs(n);
     CHECK(vt_tris_setup(verts.data(), flags.data(), n, recs.data()) == VT_OK);
-    // both builders: the default (task-parallel binned SAH) and the reference's algorithm (PLOC + leaf collapse)
-    for (int builder : {int(VT_BUILDER_BINNED_SAH), int(VT_BUILDER_PLOC)}) {
+    // every builder: the default (task-parallel binned SAH), the reference's algorithm (PLOC + leaf collapse), SAH + re-insertion
+    for (int builder : {int(VT_BUILDER_BINNED_SAH), int(VT_BUILDER_PLOC), int(VT_BUILDER_BINNED_SAH_REFINED)}) {
         vt_bvh* b2 = nullptr;
         CHECK(vt_bvh_build_ex(recs.data(), n, 3, builder, &b2) == VT_OK && b2);
         CHECK(vt_bvh_prim_count(b2) == n);

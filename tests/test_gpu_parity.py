@@ -486,12 +486,14 @@ def test_config4_shadow_rays_any_hit(va, engine, make_bundle):
     assert (hits["t"][hits["prim"] != O_MISS] <= rays["tmax"][hits["prim"] != O_MISS]).all()
 
 
-def test_ploc_tree_on_device(va, engine, O):
+@pytest.mark.parametrize("builder", ["ploc", "sah_refined"])
+def test_other_trees_on_device(va, engine, O, builder):
     """The kernels are tree-agnostic: on the reference-algorithm PLOC tree (every other scene test runs on the default
-    binned-SAH tree; the golden-vector tests on the PLOC tree too) the device equals the oracle, counters included."""
+    binned-SAH tree; the golden-vector tests on the PLOC tree too) and on the opt-in refined SAH tree the device equals
+    the oracle, counters included."""
     from vistrace_amd import workloads as W
     tris = va.tris_setup(W.make_scene("S10k"))
-    bvh = va.HostBvh(tris, builder="ploc")
+    bvh = va.HostBvh(tris, builder=builder)
     scene = va.Scene(engine, va.HostScene(bvh))
     rays = np.concatenate([W.primary_rays(96, 64), W.sphere_rays(6000, 12, origin=(-200.0, 30.0, 10.0))])
     ref, ref_st, _, _, _ = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris), rays, want_stats=True)

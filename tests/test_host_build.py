@@ -75,7 +75,7 @@ def check_linearised(hs, bvh, tris):
         assert (ltris[k] == src[k]).all()
 
 
-@pytest.mark.parametrize("builder", ["sah", "ploc"])
+@pytest.mark.parametrize("builder", ["sah", "ploc", "sah_refined"])
 @pytest.mark.parametrize("name", ["S1k", "S10k"])
 def test_scene_trees(va, name, builder):
     from vistrace_amd import workloads as W
@@ -87,7 +87,7 @@ def test_scene_trees(va, name, builder):
     assert counts.max() <= 16 and (counts > 1).any()          # multi-triangle leaves (SAH termination / PLOC leaf collapse)
 
 
-@pytest.mark.parametrize("builder", ["sah", "ploc"])
+@pytest.mark.parametrize("builder", ["sah", "ploc", "sah_refined"])
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 64, 257])
 def test_small_and_empty(va, n, builder):
     rng = np.random.default_rng(n)
@@ -106,7 +106,7 @@ def test_degenerate_inputs(va):
     same = np.tile(np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32), (100, 1, 1))
     for verts in (same, np.concatenate([same, same + np.array([3, 0, 0], np.float32)])):
         tris = va.tris_setup(verts)
-        for builder in ("sah", "ploc"):
+        for builder in ("sah", "ploc", "sah_refined"):
             bvh = va.HostBvh(tris, builder=builder)
             check_tree(va, tris, bvh)
             check_linearised(va.HostScene(bvh), bvh, tris)
@@ -151,6 +151,19 @@ def test_both_builders(va, O, name):
     assert (a["t"].view(np.uint32) == b["t"].view(np.uint32)).all()
     if name == "S100k":
         assert sa < 0.85 * sb                                  # fewer traversal steps on the SAH tree from 100 k triangles up: why it is the default
+    # opt-in refinement (re-insertion of the worst inner nodes): same leaves and triangle order, a valid tree, the same
+    # for any thread count, same t,u,v -- and fewer steps where the tree is large enough for it to matter
+    ref = va.HostBvh(tris, builder="sah_refined")
+    check_tree(va, tris, ref)
+    check_linearised(va.HostScene(ref), ref, tris)
+    assert (ref.prim_indices() == sah.prim_indices()).all() and len(ref.nodes()) == len(sah.nodes())
+    assert (va.HostBvh(tris, nthreads=1, builder="sah_refined").nodes().view(np.uint8) == ref.nodes().view(np.uint8)).all()
+    leaves = lambda t: np.sort(t.nodes()[t.nodes()["prim_count"] > 0], order=["first"])
+    assert (leaves(ref).view(np.uint8) == leaves(sah).view(np.uint8)).all()
+    c, _, sc, _, _ = O.traverse_batch(ref.nodes().view(O.NODE), ref.prim_indices(), ot, rays)
+    assert (a["t"].view(np.uint32) == c["t"].view(np.uint32)).all()
+    if name == "S100k":
+        assert sc < 0.99 * sa
     with pytest.raises(KeyError):
         va.HostBvh(tris, builder="nope")
 
@@ -175,6 +188,8 @@ def test_vt_builder_environment_override(va):
         assert n_default == len(va.HostBvh(tris, builder="sah").nodes())
         os.environ["VT_BUILDER"] = "ploc"
         assert build_default() == len(va.HostBvh(tris, builder="ploc").nodes())
+        os.environ["VT_BUILDER"] = "sah_refined"
+        assert build_default() == len(va.HostBvh(tris, builder="sah_refined").nodes())
     finally:
         os.environ.pop("VT_BUILDER", None)
         if old is not None:

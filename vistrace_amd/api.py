@@ -56,10 +56,11 @@ def tris_setup(verts: np.ndarray, flags: Optional[np.ndarray] = None) -> np.ndar
 class HostBvh:
     """v1-layout tree (bvh::Bvh<float>): nodes[0] = root, siblings adjacent."""
 
-    BUILDERS = {"ploc": 0, "sah": 1}
+    BUILDERS = {"ploc": 0, "sah": 1, "sah_refined": 2}
 
     def __init__(self, tris: np.ndarray, nthreads: int = 0, builder: str = "sah"):
-        """builder: "sah" = binned SAH (the default of vt_bvh_build), "ploc" = the reference's algorithm (PLOC + leaf collapse)."""
+        """builder: "sah" = binned SAH (the default of vt_bvh_build), "ploc" = the reference's algorithm (PLOC + leaf collapse),
+        "sah_refined" = binned SAH + insertion-based optimisation (opt-in: slower build, fewer steps per ray)."""
         assert tris.dtype == TRI64
         self._tris = np.ascontiguousarray(tris)
         h = C.c_void_p()

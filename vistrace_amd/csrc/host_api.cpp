@@ -82,6 +82,7 @@ int vt_bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, vt_bvh** out)
     if (const char* e = std::getenv("VT_BUILDER")) {
         if (std::strcmp(e, "ploc") == 0) builder = VT_BUILDER_PLOC;
         else if (std::strcmp(e, "sah") == 0) builder = VT_BUILDER_BINNED_SAH;
+        else if (std::strcmp(e, "sah_refined") == 0) builder = VT_BUILDER_BINNED_SAH_REFINED;
     }
     return vt_bvh_build_ex(tris, n, nthreads, builder, out);
 }
