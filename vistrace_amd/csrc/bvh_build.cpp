@@ -437,7 +437,7 @@ int build_ploc(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out);
 constexpr int   kRefinePasses = 2;
 constexpr float kRefineFraction = 0.01f;
 
-void refine_by_reinsertion(Bvh& bvh)
+void refine_by_reinsertion(Bvh& bvh, int nthreads)
 {
     std::vector<vt_bvh_node>& N = bvh.nodes;
     const int nc = int(N.size());
@@ -446,7 +446,8 @@ void refine_by_reinsertion(Bvh& bvh)
     std::vector<int> parent(size_t(nc), -1), left(size_t(nc), -1), right(size_t(nc), -1);
     std::vector<Box> box(static_cast<size_t>(nc));
     std::vector<float> area(size_t(nc), 0.0f);
-    for (int k = 0; k < nc; ++k) {
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int k = 0; k < nc; ++k) {                        // every child has one parent: the writes are disjoint
         box[size_t(k)] = node_box(N[size_t(k)]);
         area[size_t(k)] = half_area(box[size_t(k)]);
         if (N[size_t(k)].prim_count == 0) {
@@ -491,20 +492,25 @@ void refine_by_reinsertion(Bvh& bvh)
     };
     std::vector<std::pair<float, int>> cand;
     std::vector<char> touched(static_cast<size_t>(nc));
+    std::vector<float> score(static_cast<size_t>(nc));
     const auto worse = [](const std::pair<float, int>& x, const std::pair<float, int>& y) {
         return x.first > y.first || (x.first == y.first && x.second < y.second);
     };
     for (int pass = 0; pass < kRefinePasses; ++pass) {
         cand.clear();
+#pragma omp parallel for schedule(static) num_threads(nthreads)
         for (int k = 0; k < nc; ++k) {
+            score[size_t(k)] = -1.0f;
             if (left[size_t(k)] < 0 || k == root || parent[size_t(k)] < 0 || parent[size_t(k)] == root) continue;
             const float a = area[size_t(k)], al = area[size_t(left[size_t(k)])], ar = area[size_t(right[size_t(k)])];
             const float mn = al < ar ? al : ar, mx = al < ar ? ar : al;
             // area x (area / smaller child) x (area / mean child): large boxes over small or lopsided content first
             const float pr = a * (a / mn) * (a / (0.5f * (al + ar)));
             if (!(mn > 0.0f) || !(mx <= FLT_MAX) || !(pr <= FLT_MAX)) continue;     // degenerate / empty boxes stay
-            cand.push_back({pr, k});
+            score[size_t(k)] = pr;
         }
+        for (int k = 0; k < nc; ++k)
+            if (score[size_t(k)] >= 0.0f) cand.push_back({score[size_t(k)], k});
         const size_t take = std::min(cand.size(), std::max<size_t>(1, size_t(float(cand.size()) * kRefineFraction)));
         if (take < cand.size()) std::nth_element(cand.begin(), cand.begin() + long(take), cand.end(), worse);
         cand.resize(take);
@@ -576,7 +582,7 @@ int bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, int builder, Bvh& 
     if (builder == VT_BUILDER_BINNED_SAH) return build_binned_sah(tris, n, nthreads, out);
     if (builder == VT_BUILDER_BINNED_SAH_REFINED) {
         const int rc = build_binned_sah(tris, n, nthreads, out);
-        if (rc == VT_OK) refine_by_reinsertion(out);
+        if (rc == VT_OK) refine_by_reinsertion(out, nthreads);
         return rc;
     }
     return fail(VT_ERR_INVALID_ARG, "vt_bvh_build_ex: unknown builder");
