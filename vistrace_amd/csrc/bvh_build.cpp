@@ -440,8 +440,8 @@ constexpr float kRefineFraction = 0.01f;
 void refine_by_reinsertion(Bvh& bvh, int nthreads)
 {
     std::vector<vt_bvh_node>& N = bvh.nodes;
+    if (N.size() < 7 || N.size() > size_t(0x3FFFFFFF) || N[0].prim_count != 0) return;   // node ids are ints here
     const int nc = int(N.size());
-    if (nc < 7 || N[0].prim_count != 0) return;
     const int root = 0;
     std::vector<int> parent(size_t(nc), -1), left(size_t(nc), -1), right(size_t(nc), -1);
     std::vector<Box> box(static_cast<size_t>(nc));
