@@ -317,7 +317,7 @@ def verify_gather(dist, rank, world, n, local_hits, recv, device, backend):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scene", default="S1M")
     ap.add_argument("--side", type=int, default=4096, help="primary image side; rays per GPU = side*side (weak scaling)")
