@@ -283,8 +283,9 @@ class NativeGather:
         if int(bad.item()) != 0:
             raise RuntimeError(f"vt_engine_comm_init_rank failed on {int(bad.item())} rank(s)" + (f": {err}" if err else ""))
         self.engine, self.n, self.rank = engine, n, rank
-        self.hits = [torch.empty(n * 16, dtype=torch.uint8, device=device) for _ in range(2)]
         self.recv = [torch.empty(world * n * 16, dtype=torch.uint8, device=device) if rank == 0 else None for _ in range(2)]
+        # the root traces straight into its slice of the result (ncclGather in place: sendbuff == recvbuff + rank * count)
+        self.hits = [self.recv[b][: n * 16] if rank == 0 else torch.empty(n * 16, dtype=torch.uint8, device=device) for b in range(2)]
         self.batch = 0
 
     def submit(self, trace, stream):

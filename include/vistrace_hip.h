@@ -193,7 +193,8 @@ int vt_trace_closest_gather_dev(vt_scene* s, const void* const* d_rays, uint64_t
  * Rank 0 calls vt_comm_unique_id (128 bytes) and distributes it (any transport); every rank then calls
  * vt_engine_comm_init_rank on its single-device engine.  vt_gather_hits_dev: `count` records from d_send of every rank
  * into d_recv_root on `root` (nranks * count records, rank r's at r * count); the records must have been produced on
- * `stream`; the gather itself runs on the engine's communication stream.  vt_gather_wait(e, 1, stream): make
+ * `stream`; the gather itself runs on the engine's communication stream.  The root may trace straight into its slice
+ * (d_send == d_recv_root + root * count records: in place, no local copy).  vt_gather_wait(e, 1, stream): make
  * `stream` wait until at most ONE gather is still in flight (call it before overwriting the older of two alternating
  * send buffers); vt_gather_wait(e, 0, NULL): host-wait for every gather. */
 int vt_comm_unique_id(void* id128);
