@@ -239,8 +239,10 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
     uint32_t claim_cur = 0, claim_end = 0;   // wave-uniform: ray blocks claimed but not yet started
 
     auto start_ray = [&](uint64_t idx) {
-        const float4* r4 = reinterpret_cast<const float4*>(a.rays + idx);
-        const float4 r0 = r4[0], r1 = r4[1];
+        // rays are read once and hits written once: non-temporal, so that 48 B per ray of streaming data do not push
+        // records out of L2 / Infinity Cache (S10M, whose records do not fit there: 5.97 -> 5.86 ms; S1M unchanged)
+        const f32x4* r4 = reinterpret_cast<const f32x4*>(a.rays + idx);
+        const f32x4 r0 = __builtin_nontemporal_load(r4), r1 = __builtin_nontemporal_load(r4 + 1);
         L.ox = r0.x; L.oy = r0.y; L.oz = r0.z; L.dx = r0.w;
         L.dy = r1.x; L.dz = r1.y; L.tmin = r1.z; L.tmax = r1.w;
         L.ix = safe_inverse(L.dx); L.iy = safe_inverse(L.dy); L.iz = safe_inverse(L.dz);
@@ -279,11 +281,11 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
         if constexpr (ANY_HIT) {
             a.occluded[ray_idx] = L.prim != VT_MISS ? 1 : 0;
         } else {
-            float4 h;
+            f32x4 h;
             h.x = __uint_as_float(L.prim);
             h.y = L.prim != VT_MISS ? L.tmax : 0.f;
             h.z = L.u; h.w = L.v;
-            reinterpret_cast<float4*>(a.hits)[ray_idx] = h;
+            __builtin_nontemporal_store(h, reinterpret_cast<f32x4*>(a.hits) + ray_idx);
         }
         if constexpr (STATS) {
             a.ray_stats[ray_idx] = vt_ray_stats{L.steps, L.tests};
