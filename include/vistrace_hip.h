@@ -120,14 +120,15 @@ int vt_tris_setup(const float* verts, const uint8_t* flags, uint32_t n, vt_tri64
  * Primitives.h:107-118; build; leaves of several triangles).  tris in ORIGINAL order.  n == 0 gives an empty tree (every
  * trace misses).  nthreads <= 0: min(OpenMP default, 16).  Two builders, same v1 node layout, same traversal, identical
  * t,u,v (only tie-broken indices can differ, as between any two trees):
- *   VT_BUILDER_BINNED_SAH  top-down binned SAH, task-parallel and deterministic for any thread count -- the DEFAULT of
- *                          vt_bvh_build: kernel time is proportional to the node steps per ray, and this tree needs 11 %
- *                          (incoherent rays) to 37 % (camera rays) fewer of them than the PLOC tree at the same Rebuild
+ *   VT_BUILDER_BINNED_SAH  top-down binned SAH, task-parallel and deterministic for any thread count, every subtree task
+ *                          refining its subtree by re-insertion (below) -- the DEFAULT of
+ *                          vt_bvh_build: kernel time is proportional to the node steps per ray, and this tree needs 14 %
+ *                          (incoherent rays) to 39 % (camera rays) fewer of them than the PLOC tree at the same Rebuild
  *                          time (1 M triangles, 8 threads: 0.42 s against 0.39 s; 10 M: 5.3 s against 6.4 s);
- *   VT_BUILDER_BINNED_SAH_REFINED  the same followed by two passes of insertion-based optimisation (Bittner et al. 2013: the
- *                          worst 1 % of the inner nodes are taken out and their subtrees re-inserted where they enlarge the
- *                          tree least).  Opt-in (VT_BUILDER=sah_refined) for scenes that are built once and traced a lot:
- *                          1 M triangles +0.09 s of build, 5 % fewer node steps, 3-5 % less kernel time;
+ *   VT_BUILDER_BINNED_SAH_REFINED  the same followed by two passes of insertion-based optimisation over the WHOLE tree (Bittner
+ *                          et al. 2013: the worst 1 % of the inner nodes are taken out and their subtrees re-inserted where they
+ *                          enlarge the tree least).  Opt-in (VT_BUILDER=sah_refined) for scenes that are built once and traced
+ *                          a lot: 1 M triangles +0.1 s of build, another 3 % fewer node steps;
  *   VT_BUILDER_PLOC        the reference's algorithm: Morton-32 sort, PLOC (search radius 14), SAH leaf collapse
  *                          (bvh v1 LocallyOrderedClusteringBuilder + LeafCollapser).  VT_BUILDER=ploc in the environment
  *                          makes vt_bvh_build use it. */

@@ -334,6 +334,14 @@ uint32_t sah_split_node(const SahCtx& c, vt_bvh_node& self, uint32_t begin, uint
     return mid;
 }
 
+void refine_nodes(std::vector<vt_bvh_node>& N, int nthreads, int passes, float fraction);
+
+// What a subtree task spends on its own subtree after building it (see refine_nodes): three passes over the worst 2 % of
+// its inner nodes.  The subtree is cache resident and the tasks run side by side, so this does not show in the build
+// time (1 M triangles, 8 threads: 0.41 s with and without), and it removes 3.3 % of the node steps per incoherent ray.
+constexpr int   kLocalRefinePasses = 3;
+constexpr float kLocalRefineFraction = 0.02f;
+
 // serial build of the subtree over [begin, end) into `out` (out[0] = its root, children behind their parents)
 void sah_build_subtree(const SahCtx& c, uint32_t begin, uint32_t end, std::vector<vt_bvh_node>& out)
 {
@@ -356,6 +364,7 @@ void sah_build_subtree(const SahCtx& c, uint32_t begin, uint32_t end, std::vecto
         }
         out[t.node] = self;
     }
+    refine_nodes(out, 1, kLocalRefinePasses, kLocalRefineFraction);
 }
 
 int build_binned_sah(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out)
@@ -426,20 +435,20 @@ int build_binned_sah(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out)
 
 int build_ploc(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out);
 
-// ---- opt-in refinement of a finished tree (VT_BUILDER_BINNED_SAH_REFINED) --------------------------------------------
+// ---- refinement by re-insertion: inside every subtree task of the SAH builder (above), and once more over the whole
+// ---- finished tree as the opt-in VT_BUILDER_BINNED_SAH_REFINED ------------------------------------------------------
 // Insertion-based optimisation after Bittner, Hapala, Havran, "Fast insertion-based optimization of bounding volume
 // hierarchies" (CGF 2013): the inner nodes whose boxes are largest for what they hold are taken out, and their two
 // subtrees are put back where they enlarge the tree least (branch-and-bound search over the tree; the cost of a
 // position = the area of the new parent + the growth of every box above it).  Leaves and the triangle order stay as
-// they are, only inner nodes move.  Two passes over the worst 1 % each: 1 M triangles +0.09 s, 5.4 % fewer node steps
-// per incoherent ray and 3-5 % less kernel time (profiles/r2/notes.md); more passes stop paying.  Serial and
-// deterministic.
+// they are, only inner nodes move.  Over the whole tree (two passes over the worst 1 % each; 1 M triangles +0.09 s, most of
+// it array set-up and the re-layout of all nodes) it reaches 5.4 % fewer node steps per incoherent ray; inside the builder's
+// subtree tasks it is free and reaches 3.3 % (profiles/r2/notes.md).  Serial per call and deterministic.
 constexpr int   kRefinePasses = 2;
 constexpr float kRefineFraction = 0.01f;
 
-void refine_by_reinsertion(Bvh& bvh, int nthreads)
+void refine_nodes(std::vector<vt_bvh_node>& N, int nthreads, int passes, float fraction)
 {
-    std::vector<vt_bvh_node>& N = bvh.nodes;
     if (N.size() < 7 || N.size() > size_t(0x3FFFFFFF) || N[0].prim_count != 0) return;   // node ids are ints here
     const int nc = int(N.size());
     const int root = 0;
@@ -496,7 +505,7 @@ void refine_by_reinsertion(Bvh& bvh, int nthreads)
     const auto worse = [](const std::pair<float, int>& x, const std::pair<float, int>& y) {
         return x.first > y.first || (x.first == y.first && x.second < y.second);
     };
-    for (int pass = 0; pass < kRefinePasses; ++pass) {
+    for (int pass = 0; pass < passes; ++pass) {
         cand.clear();
 #pragma omp parallel for schedule(static) num_threads(nthreads)
         for (int k = 0; k < nc; ++k) {
@@ -511,7 +520,7 @@ void refine_by_reinsertion(Bvh& bvh, int nthreads)
         }
         for (int k = 0; k < nc; ++k)
             if (score[size_t(k)] >= 0.0f) cand.push_back({score[size_t(k)], k});
-        const size_t take = std::min(cand.size(), std::max<size_t>(1, size_t(float(cand.size()) * kRefineFraction)));
+        const size_t take = std::min(cand.size(), std::max<size_t>(1, size_t(float(cand.size()) * fraction)));
         if (take < cand.size()) std::nth_element(cand.begin(), cand.begin() + long(take), cand.end(), worse);
         cand.resize(take);
         std::sort(cand.begin(), cand.end(), worse);
@@ -582,7 +591,7 @@ int bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, int builder, Bvh& 
     if (builder == VT_BUILDER_BINNED_SAH) return build_binned_sah(tris, n, nthreads, out);
     if (builder == VT_BUILDER_BINNED_SAH_REFINED) {
         const int rc = build_binned_sah(tris, n, nthreads, out);
-        if (rc == VT_OK) refine_by_reinsertion(out, nthreads);
+        if (rc == VT_OK) refine_nodes(out.nodes, nthreads, kRefinePasses, kRefineFraction);
         return rc;
     }
     return fail(VT_ERR_INVALID_ARG, "vt_bvh_build_ex: unknown builder");
