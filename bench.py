@@ -61,9 +61,9 @@ KERNEL_SOURCES = ("vistrace_amd/csrc/trace_kernels.hip", "vistrace_amd/csrc/trac
                   "vistrace_amd/csrc/engine_internal.h", "vistrace_amd/csrc/Makefile")
 # issue cost per wave-instruction and SIMD in cycles, measured on this part (scripts/ubench_valu.hip, profiles/r1/notes.md)
 ISSUE_COST = {"MUL_F32": 2.4, "ADD_F32": 2.4, "FMA_F32": 4.2, "TRANS_F32": 8.2, "INT32": 3.2, "OTHER": 4.2}
-BUILDER_NAMES = {"sah": "binned SAH, 16 bins, task-parallel (VT_BUILDER_BINNED_SAH: the default of vt_bvh_build)",
+BUILDER_NAMES = {"sah": "binned SAH, 16 bins, task-parallel, subtrees refined by re-insertion (VT_BUILDER_BINNED_SAH: the default of vt_bvh_build)",
                  "ploc": "PLOC r=14 + SAH leaf collapse (VT_BUILDER_PLOC: the reference's algorithm; the tree of round 1)",
-                 "sah_refined": "binned SAH + 2 passes of insertion-based optimisation (VT_BUILDER_BINNED_SAH_REFINED: opt-in, +25 % build time)"}
+                 "sah_refined": "the default tree + 2 re-insertion passes over the whole tree (VT_BUILDER_BINNED_SAH_REFINED: opt-in, +25 % build time)"}
 SIMDS = 1024               # 256 CUs x 4
 CLOCK_GHZ = 2.4
 
