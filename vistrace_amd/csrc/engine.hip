@@ -58,7 +58,7 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool 
     const uint64_t factor = s->npairs <= 200000u ? uint64_t(e->auto_static_factor) * 2 : (uint64_t(e->auto_static_factor) + 1) / 2;
     p.persistent = e->persistent == 1 || (e->persistent == 2 && n > factor * e->cu_count * 8 * kBlockThreads);
     // the DMA-fetch kernel addresses records as base + 32-bit byte offset: scenes below 4 GiB
-    const uint64_t rec_bytes = (uint64_t(s->tri_base) + s->ntris) * 64;
+    const uint64_t rec_bytes = (uint64_t(s->interleaved ? s->npairs : s->tri_base) + s->ntris) * 64;
     p.fetch_dma = p.persistent && e->fetch_dma != 0 && rec_bytes < (uint64_t(1) << 32);
     const uint64_t blocks_for_rays = (n + kBlockThreads - 1) / kBlockThreads;
     if (p.persistent) {
@@ -426,15 +426,52 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
         prim_to_slot[hs.tris[i].prim] = uint32_t(i);
     }
 
-    // one array of 64-B records: pairs first, triangles behind them on a 128-B boundary
-    s->tri_base = (s->npairs + 1u) & ~1u;
-    const size_t pair_bytes = hs.pairs.size() * sizeof(vt_node_pair);
-    const size_t tri_off = size_t(s->tri_base) * 64, tri_bytes = hs.tris.size() * sizeof(vt_tri64);
-    // never empty: idle lanes of the DMA-fetch kernel read record 0, so it must exist (zeros for an empty scene)
-    const size_t rec_bytes = std::max<size_t>(tri_off + tri_bytes, 128);
-    if (uint64_t(s->tri_base) + s->ntris >= 0xFFFFFFFFull) { delete s; return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: scene too large"); }
+    // Record layout.  Default: pairs first, triangles behind them on a 128-B boundary.  interleaved (measurement knob
+    // VT_LAYOUT_INTERLEAVE=1, profiles/r3/notes.md): the triangles of a pair's leaf children lie directly behind the
+    // pair's record -- [pair][left leaf][right leaf] --, so the first triangle a NODE step finds shares its 128-B line
+    // or the next one; child indices, prim_to_slot and the level lists then hold absolute record indices, tri_base = 0.
+    s->interleaved = env_long("VT_LAYOUT_INTERLEAVE", 0) != 0 && !hs.pairs.empty();
+    std::vector<uint32_t> pair_at;                       // interleaved: record index of pair i
     hipError_t err = hipSuccess;
-    if (rec_bytes != 0) {
+    if (uint64_t(s->npairs) + s->ntris + 2 >= 0xFFFFFFFFull) { delete s; return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: scene too large"); }
+    if (s->interleaved) {
+        std::vector<uint32_t> tri_at(hs.tris.size());
+        pair_at.resize(hs.pairs.size());
+        uint32_t cur = 0;
+        for (size_t i = 0; i < hs.pairs.size(); ++i) {
+            pair_at[i] = cur++;
+            for (int side = 0; side < 2; ++side) {
+                const vt_bvh_node& c = hs.pairs[i].child[side];
+                for (uint32_t q = 0; q < c.prim_count; ++q) tri_at[c.first + q] = cur++;
+            }
+        }
+        std::vector<vt_node_pair> recs(cur);
+        static_assert(sizeof(vt_node_pair) == sizeof(vt_tri64), "one record size");
+        for (size_t i = 0; i < hs.pairs.size(); ++i) {
+            vt_node_pair P = hs.pairs[i];
+            for (int side = 0; side < 2; ++side) {
+                vt_bvh_node& c = P.child[side];
+                c.first = c.prim_count != 0 ? tri_at[c.first] : pair_at[c.first];
+            }
+            recs[pair_at[i]] = P;
+        }
+        for (size_t j = 0; j < hs.tris.size(); ++j) {
+            std::memcpy(&recs[tri_at[j]], &hs.tris[j], sizeof(vt_tri64));
+            prim_to_slot[hs.tris[j].prim] = tri_at[j];
+        }
+        s->tri_base = 0;
+        const size_t rec_bytes = std::max<size_t>(recs.size() * 64, 128);
+        err = hipMalloc(reinterpret_cast<void**>(&s->d_records), rec_bytes);
+        if (err == hipSuccess) err = hipMemset(s->d_records, 0, rec_bytes);
+        if (err == hipSuccess) err = hipMemcpy(s->d_records, recs.data(), recs.size() * 64, hipMemcpyHostToDevice);
+        s->d_tris = reinterpret_cast<vt_tri64*>(s->d_records);
+        s->bytes += rec_bytes;
+    } else {
+        s->tri_base = (s->npairs + 1u) & ~1u;
+        const size_t pair_bytes = hs.pairs.size() * sizeof(vt_node_pair);
+        const size_t tri_off = size_t(s->tri_base) * 64, tri_bytes = hs.tris.size() * sizeof(vt_tri64);
+        // never empty: idle lanes of the DMA-fetch kernel read record 0, so it must exist (zeros for an empty scene)
+        const size_t rec_bytes = std::max<size_t>(tri_off + tri_bytes, 128);
         err = hipMalloc(reinterpret_cast<void**>(&s->d_records), rec_bytes);
         if (err == hipSuccess) err = hipMemset(s->d_records, 0, rec_bytes);
         if (err == hipSuccess && pair_bytes) err = hipMemcpy(s->d_records, hs.pairs.data(), pair_bytes, hipMemcpyHostToDevice);
@@ -457,7 +494,7 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
         uint32_t acc = 0;
         for (uint32_t d = hs.max_depth; d >= 1; --d) { start[d] = acc; acc += count[d]; s->level_begin.push_back(acc); }
         std::vector<uint32_t> order(hs.pairs.size());
-        for (uint32_t p = 0; p < hs.pairs.size(); ++p) order[start[hs.pair_depth[p]]++] = p;
+        for (uint32_t p = 0; p < hs.pairs.size(); ++p) order[start[hs.pair_depth[p]]++] = s->interleaved ? pair_at[p] : p;
         err = hipMalloc(reinterpret_cast<void**>(&s->d_level_pairs), order.size() * sizeof(uint32_t));
         if (err == hipSuccess) err = hipMemcpy(s->d_level_pairs, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         s->bytes += order.size() * sizeof(uint32_t);
@@ -915,6 +952,7 @@ int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_o
     DeviceGuard guard(s->engine->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_read_records: hipSetDevice failed");
     VT_HIP(hipStreamSynchronize(s->engine->stream));
+    if (s->interleaved) return fail(VT_ERR_UNSUPPORTED, "vt_scene_read_records: not available with VT_LAYOUT_INTERLEAVE");
     if (pairs_out && s->npairs) VT_HIP(hipMemcpy(pairs_out, s->d_records, size_t(s->npairs) * sizeof(vt_node_pair), hipMemcpyDeviceToHost));
     if (tris_out && s->ntris) VT_HIP(hipMemcpy(tris_out, s->d_tris, size_t(s->ntris) * sizeof(vt_tri64), hipMemcpyDeviceToHost));
     return VT_OK;

@@ -117,6 +117,7 @@ struct vt_scene {
     char*         d_records = nullptr; // pairs, then (128-B aligned) the leaf-ordered triangles
     vt_tri64*     d_tris = nullptr;    // = d_records + tri_base * 64
     uint32_t      tri_base = 0;
+    bool          interleaved = false; // measurement layout (VT_LAYOUT_INTERLEAVE): leaf triangles behind their pair, tri_base = 0
     uint32_t*     d_prim_to_slot = nullptr;
     vt_tri_attribs* d_attribs = nullptr;   // optional side table, original triangle order
     // refit: pair indices sorted by depth (deepest level first) and where each level starts

@@ -45,6 +45,14 @@
 
 #pragma clang fp contract(off)
 
+// measurement switches of profiles/r3/notes.md (make variant NAME=.. DEFS=-DVT_EXP_..=1); the product is built without
+#ifndef VT_EXP_PREFETCH
+#define VT_EXP_PREFETCH 0   // 1: a lane that pushes its far child loads one word of that record (pulls the line into L2)
+#endif
+#ifndef VT_EXP_DMA_AUX
+#define VT_EXP_DMA_AUX 0    // cache-policy bits of the record DMA: 1 = sc0, 2 = nt, 16 = sc1
+#endif
+
 namespace vt {
 
 namespace {
@@ -221,6 +229,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
     Lane L;
     uint64_t ray_idx = 0;
     bool has_ray = false;
+    [[maybe_unused]] uint32_t pf = 0;   // VT_EXP_PREFETCH: destination of the far-child prefetch, never read
 
     // wave-uniform block cursor (PERSISTENT)
     uint64_t blk_cur = 0, blk_end = 0;
@@ -427,13 +436,13 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
             const uint32_t r0 = quad_broadcast<0>(rec), r1 = quad_broadcast<1>(rec),
                            r2 = quad_broadcast<2>(rec), r3 = quad_broadcast<3>(rec);
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r0 << 6) | piece)),
-                                             (lds_ptr)(uintptr_t)(stage_lds + 0u * kStageRow), 16, 0, 0);
+                                             (lds_ptr)(uintptr_t)(stage_lds + 0u * kStageRow), 16, 0, VT_EXP_DMA_AUX);
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r1 << 6) | piece)),
-                                             (lds_ptr)(uintptr_t)(stage_lds + 1u * kStageRow), 16, 0, 0);
+                                             (lds_ptr)(uintptr_t)(stage_lds + 1u * kStageRow), 16, 0, VT_EXP_DMA_AUX);
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r2 << 6) | piece)),
-                                             (lds_ptr)(uintptr_t)(stage_lds + 2u * kStageRow), 16, 0, 0);
+                                             (lds_ptr)(uintptr_t)(stage_lds + 2u * kStageRow), 16, 0, VT_EXP_DMA_AUX);
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r3 << 6) | piece)),
-                                             (lds_ptr)(uintptr_t)(stage_lds + 3u * kStageRow), 16, 0, 0);
+                                             (lds_ptr)(uintptr_t)(stage_lds + 3u * kStageRow), 16, 0, VT_EXP_DMA_AUX);
             // Wait for the DMA rows, then read this lane's 64-B record back with four ds_read_b128
             // (conflict-free with the padded rows).  One asm statement holds the reads and their
             // waits, so hipcc can neither split the reads nor consume a destination early
@@ -451,6 +460,9 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                          : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
                          : "v"(my_rec)
                          : "memory");
+#if VT_EXP_PREFETCH
+            asm volatile("" :: "v"(pf));     // keeps the prefetch destination reserved until the wait above has covered it
+#endif
             q0 = make_float4(v0.x, v0.y, v0.z, v0.w); q1 = make_float4(v1.x, v1.y, v1.z, v1.w);
             q2 = make_float4(v2.x, v2.y, v2.z, v2.w); q3 = make_float4(v3.x, v3.y, v3.z, v3.w);
         } else if (!fetched) {
@@ -539,6 +551,11 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                 if (L.sp < a.lds_entries) st_lds[L.sp * 64] = far;
                 else st_ovf[size_t(L.sp - a.lds_entries) * gstride] = far;
                 ++L.sp;
+#if VT_EXP_PREFETCH
+                // issued behind the compiler's back: a load it knows of is waited for at the end of the block
+                if constexpr (FETCH_DMA && PERSISTENT && !STATS)
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf) : "v"(records + (size_t(far) << 6)));
+#endif
             } else if (go_l) {
                 next = lfirst;
             } else if (go_r) {
@@ -547,7 +564,13 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                 --L.sp;
                 // two separate loads on purpose: a pointer select would turn this into a flat_load
                 if (L.sp < a.lds_entries) next = st_lds[L.sp * 64];
+#if VT_EXP_PREFETCH
+                // waits inside the (rare) branch, so that the end of the iteration does not wait for the prefetch
+                else asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)"
+                                  : "=v"(next) : "v"(st_ovf + size_t(L.sp - a.lds_entries) * gstride) : "memory");
+#else
                 else next = st_ovf[size_t(L.sp - a.lds_entries) * gstride];
+#endif
             } else {
                 next = kDone;
             }
