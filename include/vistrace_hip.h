@@ -188,7 +188,16 @@ void     vt_shard_bounds(uint64_t n, int ndev, int g, uint64_t* lo, uint64_t* hi
  * (closest hit) on its own stream, then ONE ncclGather of `capacity` records per device brings the shards to the root
  * device: d_hits_root (root device, ndev * capacity records) holds ray i's hit at record i.  Asynchronous: returns
  * with traces and gather enqueued (the gather runs on a communication stream, so the next batch's traces overlap
- * it; per-device send buffers are double-buffered) -- vt_engine_synchronize(root) waits for all of it. */
+ * it; per-device send buffers are double-buffered) -- vt_engine_synchronize(root) waits for all of it.
+ * Ownership of d_hits_root: from this call until the batch's gather has completed (vt_engine_synchronize(root)) the
+ * buffer belongs to the engine -- the root device traces straight into its first `capacity` records (ncclGather in
+ * place) and the other shards arrive later.  To overlap batches pass a DIFFERENT buffer to the next call (alternate two)
+ * and consume a buffer only after a synchronisation that covers its batch; passing the same buffer again lets batch
+ * b + 1 overwrite shard 0 while batch b is still arriving.
+ * STATUS: experimental for ndev > 1 -- exercised on hardware with one device per group only (no multi-GPU node was
+ * available); the order of traces, waits and gathers is the one tests/cpp/test_gather_schedule.cpp checks on a
+ * simulated group of 2, 4 and 8 devices (vistrace_amd/csrc/gather_schedule.h).  The engine must come from
+ * vt_engine_open_multi: an engine whose communicator was made by vt_engine_comm_init_rank is refused. */
 int vt_trace_closest_gather_dev(vt_scene* s, const void* const* d_rays, uint64_t n, void* d_hits_root);
 /* One process per GPU (e.g. under torch.distributed.run): the same gather with one communicator per process.
  * Rank 0 calls vt_comm_unique_id (128 bytes) and distributes it (any transport); every rank then calls
@@ -197,11 +206,15 @@ int vt_trace_closest_gather_dev(vt_scene* s, const void* const* d_rays, uint64_t
  * `stream`; the gather itself runs on the engine's communication stream.  The root may trace straight into its slice
  * (d_send == d_recv_root + root * count records: in place, no local copy).  vt_gather_wait(e, 1, stream): make
  * `stream` wait until at most ONE gather is still in flight (call it before overwriting the older of two alternating
- * send buffers); vt_gather_wait(e, 0, NULL): host-wait for every gather. */
+ * send buffers); vt_gather_wait(e, 0, NULL): host-wait for every gather.  Engine option "gather_overlap" = 0 makes
+ * vt_gather_wait(e, 1, stream) wait for the latest gather too (diagnostic: step = trace + gather).  With
+ * vt_engine_set_timing on, vt_engine_last_gather_ms reports the duration of the latest gather on the communication
+ * stream (HIP events around the ncclGather). */
 int vt_comm_unique_id(void* id128);
 int vt_engine_comm_init_rank(vt_engine* e, int nranks, int rank, const void* id128);
 int vt_gather_hits_dev(vt_engine* e, const void* d_send, uint64_t count, void* d_recv_root, int root, void* stream);
 int vt_gather_wait(vt_engine* e, int batches_in_flight, void* stream);
+int vt_engine_last_gather_ms(vt_engine* e, float* ms);
 
 /* Upload once per Rebuild (north star: "uploaded once per Rebuild"). */
 int  vt_scene_upload(vt_engine* e, const vt_host_scene* hs, vt_scene** out);

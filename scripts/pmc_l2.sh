@@ -5,7 +5,7 @@
 TAG=$1; WORK=$2; LIB=${3:-vistrace_amd/lib/libvistrace_hip.so}; shift 3
 OUT=gpurun_out/l2_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 export VISTRACE_HIP_LIB=$PWD/$LIB
-for kv in "$@"; do export "$kv"; done
+for kv in "$@"; do case "$kv" in *=*) export "$kv";; esac; done
 pass() { local name=$1; shift
   timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 scripts/kernel_time.py --work $WORK --reps 2 > $OUT/pmc_$name.log 2>&1; }
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum

@@ -20,8 +20,19 @@ def test_shard_bounds_cover_exactly():
             spans = [shard_bounds(n, world, r) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
-            assert max(hi - lo for lo, hi in spans) <= shard_capacity(n, world)
-            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+            cap = shard_capacity(n, world)
+            assert cap % 64 == 0 and max(hi - lo for lo, hi in spans) <= cap
+            # one rule for the torch path and the native path: the C ABI's (shard g starts at g * capacity)
+            assert all(lo == min(n, r * cap) for r, (lo, hi) in enumerate(spans))
+
+
+def test_python_and_abi_shard_rules_are_the_same_function():
+    import vistrace_amd as va
+    from vistrace_amd import distributed as D
+    for n in (0, 65, 1000, (1 << 24) + 5):
+        for world in (1, 2, 3, 8):
+            assert D.shard_capacity(n, world) == va.shard_capacity(n, world)
+            assert [D.shard_bounds(n, world, r) for r in range(world)] == [va.shard_bounds(n, world, r) for r in range(world)]
 
 
 def _worker(rank, world, port, n, result_path):
@@ -136,3 +147,14 @@ def test_abi_shard_bounds_cover_and_align(va):
                 assert lo == expect == min(n, g * cap) and lo <= hi <= lo + cap
                 expect = hi
             assert expect == n
+
+
+def test_gather_schedule_on_a_simulated_group():
+    """The order of traces, event waits and gathers that multi_gpu.hip executes (vistrace_amd/csrc/gather_schedule.h),
+    run on a simulated group of 1, 2, 4 and 8 devices with randomly interleaved streams: no send buffer is re-written
+    under a gather, no gather starts before its trace, overlap happens (and does not with gather_overlap = 0)."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "schedule"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "_build", "test_gather_schedule")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all checks passed" in out.stdout

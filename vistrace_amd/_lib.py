@@ -86,6 +86,7 @@ SYMBOLS = {
     "vt_engine_comm_init_rank": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "vt_gather_hits_dev": (C.c_int, [_vp, _vp, _u64, _vp, C.c_int, _vp]),
     "vt_gather_wait": (C.c_int, [_vp, C.c_int, _vp]),
+    "vt_engine_last_gather_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "vt_scene_upload": (C.c_int, [_vp, _vp, _pp]),
     "vt_scene_free": (None, [_vp]),
     "vt_scene_device_bytes": (_u64, [_vp]),

@@ -204,6 +204,12 @@ class Engine:
     def gather_wait(self, batches_in_flight: int = 0, stream: int = 0) -> None:
         check(lib.vt_gather_wait(self._h, batches_in_flight, stream or None))
 
+    def last_gather_ms(self) -> float:
+        """Duration of the latest vt_gather_hits_dev on the communication stream (needs set_timing(True))."""
+        ms = C.c_float(0)
+        check(lib.vt_engine_last_gather_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
     def close(self):
         if getattr(self, "_h", None):
             lib.vt_engine_close(self._h)

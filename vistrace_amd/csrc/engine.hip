@@ -369,6 +369,7 @@ int vt_engine_set_option(vt_engine* e, const char* key, int64_t value)
     else if (k == "max_claim" && value >= 0 && value <= 1024) e->max_claim = uint32_t(value);
     else if (k == "reserved_cus" && value >= 0 && value <= e->cu_count / 2) return reserve_cus(e, uint32_t(value));
     else if (k == "reserved_limit" && value >= 0 && value <= 64) e->reserved_limit = uint32_t(value);
+    else if (k == "gather_overlap") e->sched.overlap = value != 0;
     else return fail(VT_ERR_INVALID_ARG, "vt_engine_set_option: unknown key or value out of range: " + k);
     return VT_OK;
 }
@@ -392,6 +393,7 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
     else if (k == "max_claim") *value = e->max_claim;
     else if (k == "reserved_cus") *value = e->reserved_cus;
     else if (k == "reserved_limit") *value = e->reserved_limit;
+    else if (k == "gather_overlap") *value = e->sched.overlap;
     else if (k == "cu_count") *value = e->cu_count;
     else if (k == "last_persistent") *value = e->last_persistent;
     else if (k == "last_fetch_dma") *value = e->last_dma;

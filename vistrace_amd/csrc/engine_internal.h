@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "gather_schedule.h"
 #include "trace_kernels.h"
 #include "vt_internal.h"
 
@@ -102,14 +103,16 @@ struct vt_engine {
     std::vector<vt_engine*> peers;
     vt_engine*  root = nullptr;               // on a peer: its root
     void*       comm = nullptr;               // ncclComm_t
+    bool        comm_from_init_all = false;   // made by ncclCommInitAll for the single-process group (not by vt_engine_comm_init_rank)
     int         comm_rank = 0, comm_size = 1;
     hipStream_t s_comm = nullptr;             // the gather of batch b runs here, beside the trace of batch b+1
     hipEvent_t  ev_traced = nullptr;          // trace stream -> comm stream
     hipEvent_t  ev_sent[2] = {nullptr, nullptr};   // comm stream: the gather that read send buffer b has completed
-    bool        sent_used[2] = {false, false};
+    hipEvent_t  ev_g0 = nullptr, ev_g1 = nullptr;  // comm stream, around the latest gather when `timing` is on
+    bool        gather_timed = false;
     void*       d_send[2] = {nullptr, nullptr};    // peers: this device's shard of hit records, double-buffered across batches
     size_t      d_send_bytes[2] = {0, 0};
-    uint64_t    gather_batches = 0;
+    vt::GatherSchedule sched;                      // batches issued + which sent events exist (group state lives on the root)
 };
 
 struct vt_scene {

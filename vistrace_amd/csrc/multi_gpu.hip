@@ -108,6 +108,8 @@ int ensure_comm_side(vt_engine* e)
     if (!e->ev_traced) VT_HIP(hipEventCreateWithFlags(&e->ev_traced, hipEventDisableTiming));
     for (int b = 0; b < 2; ++b)
         if (!e->ev_sent[b]) VT_HIP(hipEventCreateWithFlags(&e->ev_sent[b], hipEventDisableTiming));
+    if (!e->ev_g0) VT_HIP(hipEventCreate(&e->ev_g0));
+    if (!e->ev_g1) VT_HIP(hipEventCreate(&e->ev_g1));
     return VT_OK;
 }
 
@@ -125,6 +127,11 @@ int ensure_group_comms(vt_engine* root)
     RcclApi* R = rccl();
     if (!R) return fail(VT_ERR_HIP, "multi-GPU gather: " + rccl_state().error);
     const std::vector<vt_engine*> g = group_of(root);
+    // A communicator from vt_engine_comm_init_rank spans the ranks of a multi-process job, not this group: a gather on
+    // it would deliver comm_size x cap records into a buffer sized for the group (or hang in a mismatched collective).
+    if (root->comm && (!root->comm_from_init_all || root->comm_size != int(g.size())))
+        return fail(VT_ERR_INVALID_ARG, "multi-GPU gather: the engine's communicator was made by vt_engine_comm_init_rank "
+                                        "(one process per GPU); the single-process group needs its own engine (vt_engine_open_multi)");
     if (!root->comm) {
         std::vector<int> devs;
         for (vt_engine* e : g) devs.push_back(e->device);
@@ -132,6 +139,7 @@ int ensure_group_comms(vt_engine* root)
         VT_NCCL(R->CommInitAll(comms.data(), int(g.size()), devs.data()));
         for (size_t k = 0; k < g.size(); ++k) {
             g[k]->comm = comms[k];
+            g[k]->comm_from_init_all = true;
             g[k]->comm_rank = int(k);
             g[k]->comm_size = int(g.size());
         }
@@ -163,6 +171,10 @@ void multi_release(vt_engine* e)
     }
     if (e->ev_traced) (void)hipEventDestroy(e->ev_traced);
     e->ev_traced = nullptr;
+    if (e->ev_g0) (void)hipEventDestroy(e->ev_g0);
+    if (e->ev_g1) (void)hipEventDestroy(e->ev_g1);
+    e->ev_g0 = e->ev_g1 = nullptr;
+    e->gather_timed = false;
     if (e->s_comm) (void)hipStreamDestroy(e->s_comm);
     e->s_comm = nullptr;
 }
@@ -247,51 +259,69 @@ int vt_trace_closest_gather_dev(vt_scene* s, const void* const* d_rays, uint64_t
     if (scenes.size() != g.size()) return fail(VT_ERR_INVALID_ARG, "vt_trace_closest_gather_dev: the scene is not replicated over the group");
     const int ndev = int(g.size());
     const uint64_t cap = vt_shard_capacity(n, ndev);
-    const int buf = int(root->gather_batches & 1);
+    const int buf = root->sched.next_buf();
+    const bool buf_was_used = root->sched.sent_used[buf];
 
-    // 1. every device traces its shard into its send buffer (the root: straight into its slice of the result)
+    // send buffers of the non-root devices (the root traces straight into its slice of the result: ncclGather in place,
+    // sendbuff == recvbuff + rank * sendcount); growing one first waits for the gather that may still read it
     std::vector<void*> send(static_cast<size_t>(ndev), nullptr);
+    send[0] = d_hits_root;
     for (int k = 0; k < ndev; ++k) {
+        uint64_t lo = 0, hi = 0;
+        vt_shard_bounds(n, ndev, k, &lo, &hi);
+        if (hi > lo && !d_rays[k]) return fail(VT_ERR_INVALID_ARG, "vt_trace_closest_gather_dev: d_rays[" + std::to_string(k) + "] is NULL");
+        if (k == 0) continue;
         vt_engine* e = g[size_t(k)];
         DeviceGuard guard(e->device);
         if (!guard.ok) return fail(VT_ERR_HIP, "vt_trace_closest_gather_dev: hipSetDevice failed");
-        uint64_t lo = 0, hi = 0;
-        vt_shard_bounds(n, ndev, k, &lo, &hi);
-        if (k == 0) {
-            send[0] = d_hits_root;                     // in place: sendbuff == recvbuff + rank * sendcount
-        } else {
-            // the gather that last read this buffer (two batches ago) must be over before it is overwritten
-            if (e->sent_used[buf]) VT_HIP(hipStreamWaitEvent(e->stream, e->ev_sent[buf], 0));
-            if (e->d_send_bytes[buf] < cap * sizeof(vt_hit)) {
-                if (e->sent_used[buf]) VT_HIP(hipEventSynchronize(e->ev_sent[buf]));
-                rc = ensure_bytes(&e->d_send[buf], &e->d_send_bytes[buf], cap * sizeof(vt_hit));
-                if (rc != VT_OK) return rc;
-            }
-            send[size_t(k)] = e->d_send[buf];
-        }
-        if (hi > lo) {
-            if (!d_rays[k]) return fail(VT_ERR_INVALID_ARG, "vt_trace_closest_gather_dev: d_rays[" + std::to_string(k) + "] is NULL");
-            rc = engine_launch(scenes[size_t(k)], d_rays[k], hi - lo, send[size_t(k)], nullptr, nullptr, false, false, e->stream);
+        if (e->d_send_bytes[buf] < cap * sizeof(vt_hit)) {
+            if (buf_was_used) VT_HIP(hipEventSynchronize(e->ev_sent[buf]));
+            rc = ensure_bytes(&e->d_send[buf], &e->d_send_bytes[buf], cap * sizeof(vt_hit));
             if (rc != VT_OK) return rc;
         }
-        VT_HIP(hipEventRecord(e->ev_traced, e->stream));
-        VT_HIP(hipStreamWaitEvent(e->s_comm, e->ev_traced, 0));
+        send[size_t(k)] = e->d_send[buf];
     }
-    // 2. ONE gather: cap records from every device into the root's buffer, shard g at record g * cap -- ray order
-    VT_NCCL(R->GroupStart());
-    for (int k = 0; k < ndev; ++k) {
-        vt_engine* e = g[size_t(k)];
-        const ncclResult_t r = R->Gather(send[size_t(k)], d_hits_root, cap * sizeof(vt_hit), ncclUint8, 0, static_cast<ncclComm_t>(e->comm), e->s_comm);
-        if (r != ncclSuccess) { (void)R->GroupEnd(); return rccl_fail("ncclGather", r); }
-    }
-    VT_NCCL(R->GroupEnd());
-    for (int k = 0; k < ndev; ++k) {
-        vt_engine* e = g[size_t(k)];
+
+    // the batch, step by step, as gather_schedule.h plans it: per device [wait for the gather of two batches ago,] trace,
+    // hand over to the communication stream; then ONE gather -- cap records from every device into the root's buffer,
+    // shard g at record g * cap (ray order) --, all devices' calls in one group
+    bool in_group = false;
+    for (const GatherStep& st : root->sched.plan(ndev)) {
+        vt_engine* e = g[size_t(st.dev)];
         DeviceGuard guard(e->device);
-        VT_HIP(hipEventRecord(e->ev_sent[buf], e->s_comm));
-        e->sent_used[buf] = true;
+        if (!guard.ok) { if (in_group) (void)R->GroupEnd(); return fail(VT_ERR_HIP, "vt_trace_closest_gather_dev: hipSetDevice failed"); }
+        if (in_group && st.op != GatherOp::Gather) { in_group = false; VT_NCCL(R->GroupEnd()); }
+        switch (st.op) {
+        case GatherOp::WaitSent:
+            VT_HIP(hipStreamWaitEvent(e->stream, e->ev_sent[st.buf], 0));
+            break;
+        case GatherOp::Trace: {
+            uint64_t lo = 0, hi = 0;
+            vt_shard_bounds(n, ndev, st.dev, &lo, &hi);
+            if (hi > lo) {
+                rc = engine_launch(scenes[size_t(st.dev)], d_rays[st.dev], hi - lo, send[size_t(st.dev)], nullptr, nullptr, false, false, e->stream);
+                if (rc != VT_OK) return rc;
+            }
+            break;
+        }
+        case GatherOp::RecordTraced:
+            VT_HIP(hipEventRecord(e->ev_traced, e->stream));
+            break;
+        case GatherOp::WaitTraced:
+            VT_HIP(hipStreamWaitEvent(e->s_comm, e->ev_traced, 0));
+            break;
+        case GatherOp::Gather: {
+            if (!in_group) { VT_NCCL(R->GroupStart()); in_group = true; }
+            const ncclResult_t r = R->Gather(send[size_t(st.dev)], d_hits_root, cap * sizeof(vt_hit), ncclUint8, 0, static_cast<ncclComm_t>(e->comm), e->s_comm);
+            if (r != ncclSuccess) { (void)R->GroupEnd(); return rccl_fail("ncclGather", r); }
+            break;
+        }
+        case GatherOp::RecordSent:
+            VT_HIP(hipEventRecord(e->ev_sent[st.buf], e->s_comm));
+            break;
+        }
     }
-    ++root->gather_batches;
+    if (in_group) VT_NCCL(R->GroupEnd());
     return VT_OK;
 }
 
@@ -341,21 +371,38 @@ int vt_gather_hits_dev(vt_engine* e, const void* d_send, uint64_t count, void* d
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_gather_hits_dev: hipSetDevice failed");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     // the records were produced on `stream`; the gather runs on the engine's comm stream so that the next trace on
-    // `stream` does not queue behind it
-    VT_HIP(hipEventRecord(e->ev_traced, stream));
-    VT_HIP(hipStreamWaitEvent(e->s_comm, e->ev_traced, 0));
-    VT_NCCL(R->Gather(d_send, d_recv_root, count * sizeof(vt_hit), ncclUint8, root, static_cast<ncclComm_t>(e->comm), e->s_comm));
-    const int buf = int(e->gather_batches & 1);
-    VT_HIP(hipEventRecord(e->ev_sent[buf], e->s_comm));
-    e->sent_used[buf] = true;
-    ++e->gather_batches;
+    // `stream` does not queue behind it.  Steps as gather_schedule.h plans them for one rank; the wait and the trace in
+    // front of them are the caller's (vt_gather_wait + its own launch).
+    for (const GatherStep& st : e->sched.plan(1)) {
+        switch (st.op) {
+        case GatherOp::WaitSent: case GatherOp::Trace: break;
+        case GatherOp::RecordTraced: VT_HIP(hipEventRecord(e->ev_traced, stream)); break;
+        case GatherOp::WaitTraced:   VT_HIP(hipStreamWaitEvent(e->s_comm, e->ev_traced, 0)); break;
+        case GatherOp::Gather:
+            if (e->timing) VT_HIP(hipEventRecord(e->ev_g0, e->s_comm));
+            VT_NCCL(R->Gather(d_send, d_recv_root, count * sizeof(vt_hit), ncclUint8, root, static_cast<ncclComm_t>(e->comm), e->s_comm));
+            if (e->timing) { VT_HIP(hipEventRecord(e->ev_g1, e->s_comm)); e->gather_timed = true; }
+            break;
+        case GatherOp::RecordSent:   VT_HIP(hipEventRecord(e->ev_sent[st.buf], e->s_comm)); break;
+        }
+    }
+    return VT_OK;
+}
+
+int vt_engine_last_gather_ms(vt_engine* e, float* ms)
+{
+    if (!e || !ms) return fail(VT_ERR_INVALID_ARG, "vt_engine_last_gather_ms: NULL");
+    if (!e->gather_timed) return fail(VT_ERR_INVALID_ARG, "vt_engine_last_gather_ms: no timed gather yet (vt_engine_set_timing)");
+    DeviceGuard guard(e->device);
+    VT_HIP(hipEventSynchronize(e->ev_g1));
+    VT_HIP(hipEventElapsedTime(ms, e->ev_g0, e->ev_g1));
     return VT_OK;
 }
 
 int vt_gather_wait(vt_engine* e, int batches_in_flight, void* stream_)
 {
     if (!e) return fail(VT_ERR_INVALID_ARG, "vt_gather_wait: NULL");
-    if (!e->s_comm || e->gather_batches == 0) return VT_OK;
+    if (!e->s_comm || e->sched.batches == 0) return VT_OK;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_gather_wait: hipSetDevice failed");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -363,12 +410,11 @@ int vt_gather_wait(vt_engine* e, int batches_in_flight, void* stream_)
         VT_HIP(hipStreamSynchronize(e->s_comm));
         return VT_OK;
     }
-    // allow one gather in flight: the one before the latest must be over before `stream` continues (its send buffer
-    // is the one the next batch writes)
-    if (e->gather_batches >= 2) {
-        const int buf = int((e->gather_batches - 2) & 1);
-        if (e->sent_used[buf]) VT_HIP(hipStreamWaitEvent(stream, e->ev_sent[buf], 0));
-    }
+    // allow one gather in flight: the one that read the send buffer the NEXT batch writes (two batches ago) must be over
+    // before `stream` continues; with engine option gather_overlap = 0 the latest one too (diagnostic: no overlap)
+    const int buf = e->sched.next_buf();
+    if (e->sched.sent_used[buf]) VT_HIP(hipStreamWaitEvent(stream, e->ev_sent[buf], 0));
+    if (!e->sched.overlap && e->sched.sent_used[buf ^ 1]) VT_HIP(hipStreamWaitEvent(stream, e->ev_sent[buf ^ 1], 0));
     return VT_OK;
 }
 

@@ -49,6 +49,15 @@
 #ifndef VT_EXP_PREFETCH
 #define VT_EXP_PREFETCH 0   // 1: a lane that pushes its far child loads one word of that record (pulls the line into L2)
 #endif
+#ifndef VT_EXP_PREFETCH_ROOT
+#define VT_EXP_PREFETCH_ROOT 0   // with VT_EXP_PREFETCH: load record 0 instead (always an L1 hit): the instruction without the L2 request
+#endif
+#ifndef VT_EXP_DMA_DUP
+#define VT_EXP_DMA_DUP 0    // 1: every record DMA issued twice (the second one hits L1): front-end requests without L2 requests
+#endif
+#ifndef VT_EXP_DMA_MASK
+#define VT_EXP_DMA_MASK 0   // 1: lanes that need no record this round take no part in the DMA (no dummy fetch of record 0)
+#endif
 #ifndef VT_EXP_DMA_AUX
 #define VT_EXP_DMA_AUX 0    // cache-policy bits of the record DMA: 1 = sc0, 2 = nt, 16 = sc1
 #endif
@@ -435,6 +444,18 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
             const uint32_t piece = (lane & 3u) * 16u;
             const uint32_t r0 = quad_broadcast<0>(rec), r1 = quad_broadcast<1>(rec),
                            r2 = quad_broadcast<2>(rec), r3 = quad_broadcast<3>(rec);
+#if VT_EXP_DMA_MASK
+            const uint32_t need = (do_tri || want_node) ? 1u : 0u;
+            if (quad_broadcast<0>(need))
+                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r0 << 6) | piece)), (lds_ptr)(uintptr_t)(stage_lds + 0u * kStageRow), 16, 0, 0);
+            if (quad_broadcast<1>(need))
+                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r1 << 6) | piece)), (lds_ptr)(uintptr_t)(stage_lds + 1u * kStageRow), 16, 0, 0);
+            if (quad_broadcast<2>(need))
+                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r2 << 6) | piece)), (lds_ptr)(uintptr_t)(stage_lds + 2u * kStageRow), 16, 0, 0);
+            if (quad_broadcast<3>(need))
+                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r3 << 6) | piece)), (lds_ptr)(uintptr_t)(stage_lds + 3u * kStageRow), 16, 0, 0);
+#else
+            for (int rep = 0; rep < 1 + VT_EXP_DMA_DUP; ++rep) {
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r0 << 6) | piece)),
                                              (lds_ptr)(uintptr_t)(stage_lds + 0u * kStageRow), 16, 0, VT_EXP_DMA_AUX);
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r1 << 6) | piece)),
@@ -443,6 +464,8 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                                              (lds_ptr)(uintptr_t)(stage_lds + 2u * kStageRow), 16, 0, VT_EXP_DMA_AUX);
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r3 << 6) | piece)),
                                              (lds_ptr)(uintptr_t)(stage_lds + 3u * kStageRow), 16, 0, VT_EXP_DMA_AUX);
+            }
+#endif
             // Wait for the DMA rows, then read this lane's 64-B record back with four ds_read_b128
             // (conflict-free with the padded rows).  One asm statement holds the reads and their
             // waits, so hipcc can neither split the reads nor consume a destination early
@@ -554,7 +577,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
 #if VT_EXP_PREFETCH
                 // issued behind the compiler's back: a load it knows of is waited for at the end of the block
                 if constexpr (FETCH_DMA && PERSISTENT && !STATS)
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf) : "v"(records + (size_t(far) << 6)));
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf) : "v"(records + (VT_EXP_PREFETCH_ROOT ? size_t(0) : size_t(far) << 6)));
 #endif
             } else if (go_l) {
                 next = lfirst;

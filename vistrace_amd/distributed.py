@@ -18,15 +18,17 @@ HIT_BYTES = 16
 
 
 def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
-    """Contiguous shard [lo, hi) of n rays for `rank`; the first n % world ranks get one more.
-    Contiguous (not interleaved) shards keep the coherence of primary rays inside a shard."""
-    base, extra = divmod(n, world)
-    lo = rank * base + min(rank, extra)
-    return lo, lo + base + (1 if rank < extra else 0)
+    """Contiguous shard [lo, hi) of n rays for `rank`: THE shard rule of the C ABI (vt_shard_bounds) -- capacity =
+    ceil(n / world) rounded up to 64 rays, shard g = [g * capacity, min(n, (g + 1) * capacity)).  The torch path and the
+    native path (vt_trace_closest_gather_dev, vt_gather_hits_dev) therefore lay out the gathered array identically:
+    rank r's records start at record r * capacity, which is ray order."""
+    from .api import shard_bounds as abi_bounds
+    return abi_bounds(n, world, rank)
 
 
 def shard_capacity(n: int, world: int) -> int:
-    return (n + world - 1) // world
+    from .api import shard_capacity as abi_capacity
+    return abi_capacity(n, world)
 
 
 def gather_records(local: torch.Tensor, count: int, n_total: int, record_bytes: int = HIT_BYTES, dst: int = 0,
@@ -45,11 +47,8 @@ def gather_records(local: torch.Tensor, count: int, n_total: int, record_bytes: 
     if rank == dst:
         bufs = out if out is not None else [torch.empty(cap, dtype=torch.uint8, device=local.device) for _ in range(world)]
         dist.gather(send, bufs, dst=dst)
-        parts = []
-        for r in range(world):
-            lo, hi = shard_bounds(n_total, world, r)
-            parts.append(bufs[r][: (hi - lo) * record_bytes])
-        return torch.cat(parts)
+        # shard r starts at record r * capacity: the concatenation IS ray order, padding only behind the last ray
+        return torch.cat(bufs)[: n_total * record_bytes]
     dist.gather(send, None, dst=dst)
     return None
 
