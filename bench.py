@@ -56,7 +56,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured streaming copy)
-ROUND = "r2"
+ROUND = "r3"
 KERNEL_SOURCES = ("vistrace_amd/csrc/trace_kernels.hip", "vistrace_amd/csrc/trace_kernels.h", "vistrace_amd/csrc/engine.hip",
                   "vistrace_amd/csrc/engine_internal.h", "vistrace_amd/csrc/Makefile")
 # issue cost per wave-instruction and SIMD in cycles, measured on this part (scripts/ubench_valu.hip, profiles/r1/notes.md)
@@ -65,7 +65,8 @@ BUILDER_NAMES = {"sah": "binned SAH, 16 bins, task-parallel, subtrees refined by
                  "ploc": "PLOC r=14 + SAH leaf collapse (VT_BUILDER_PLOC: the reference's algorithm; the tree of round 1)",
                  "sah_refined": "the default tree + 2 re-insertion passes over the whole tree (VT_BUILDER_BINNED_SAH_REFINED: opt-in, +25 % build time)"}
 SIMDS = 1024               # 256 CUs x 4
-CLOCK_GHZ = 2.4
+CLOCK_GHZ = 2.4            # nominal; main() replaces it by the device's own shader clock (hipDeviceAttributeClockRate)
+CLOCK_SOURCE = "nominal 2.4 GHz (MI355X_MICROARCH.md)"
 
 
 def log(*a):
@@ -85,7 +86,9 @@ def kernel_sources_sha() -> str:
 def build_scene(args, va, W, dev_index, world):
     t0 = time.time()
     verts = W.make_scene(args.scene)
-    tris = va.tris_setup(verts)
+    # --alpha-frac F: that share of the triangles carries VT_TRI_ALPHATEST (Primitives.h:196-208): the ALPHA kernel variants
+    rig = W.alpha_test_rig(len(verts), alpha_fraction=args.alpha_frac) if args.alpha_frac > 0 else None
+    tris = va.tris_setup(verts, rig[0] if rig else None)
     t1 = time.time()
     host_threads = max(1, len(os.sched_getaffinity(0)) // max(1, world))   # explicit: launchers may export OMP_NUM_THREADS=1
     bvh = va.HostBvh(tris, nthreads=min(16, host_threads), builder=args.builder)   # ranks build side by side
@@ -95,6 +98,10 @@ def build_scene(args, va, W, dev_index, world):
     if args.mode is not None:
         engine.set_option("persistent", 1 if args.mode == "persistent" else 0)
     scene = va.Scene(engine, host_scene)
+    if rig:
+        scene.set_tri_attribs(rig[1].view(va.TRI_ATTRIBS))
+        scene.set_alpha(rig[2].view(va.ALPHA_MATERIAL), rig[3])
+    scene.alpha_rig = rig
     t3 = time.time()
     log(f"[bench] scene {args.scene}: {len(tris)} tris, {host_scene.pair_count} pairs, depth {host_scene.max_depth}, "
         f"{scene.device_bytes / 1e6:.1f} MB on device; gen {t1 - t0:.2f}s build {t2 - t1:.2f}s upload {t3 - t2:.2f}s")
@@ -136,6 +143,19 @@ def make_rays(args, rank, world, va, W, tp, engine, scene, device):
         d_rays = d_prim
         if args.gen == "host":
             rays_host = prim_rays
+    elif args.kind == "shadow":
+        # BASELINE configs[3]: `per_hit` shadow rays per primary hit towards 16 seeded point lights, tmax = dist (1 - 1e-4)
+        # (generated on the host: there is no device generator for them; 64 Mi rays take ~30 s of numpy)
+        d_hits0 = tp.trace_closest(scene, d_prim, n)
+        attrs = tp.to_host(tp.hit_attrs(scene, d_prim, d_hits0, n), HIT_ATTRS)
+        del d_hits0, d_prim
+        rays_host = W.shadow_rays(attrs, W.light_positions(args.scene), W.SEED + 4 + 1000 * rank, per_hit=args.shadow_per_hit)
+        del attrs
+        d_rays = tp.to_device(rays_host, device)
+        n = len(rays_host)
+        log(f"[bench] shadow rays: {n} = {args.shadow_per_hit} per primary hit of a {side}x{side} image, any-hit")
+        if n > (1 << 24):
+            rays_host = rays_host[: 1 << 24].copy()           # the CPU sample never needs more; keeps host memory bounded
     else:
         d_hits0 = tp.trace_closest(scene, d_prim, n)
         d_attrs = tp.hit_attrs(scene, d_prim, d_hits0, n)
@@ -151,7 +171,8 @@ def make_rays(args, rank, world, va, W, tp, engine, scene, device):
         log(f"[bench] bounce rays: {n} from {side}x{side} primary hits ({miss} primary misses"
             f"{' re-filled' if args.gen == 'host' else ' -> null rays'}), generated on the {args.gen}")
     torch.cuda.synchronize(device)
-    return d_rays, n, n * world, f"{args.scene}_{args.kind}{n}", rays_host
+    name = f"{args.scene}_{args.kind}{n}" + (f"_alpha{int(round(args.alpha_frac * 100))}" if args.alpha_frac > 0 else "")
+    return d_rays, n, n * world, name, rays_host
 
 
 # ---- PMC: fabric-side traffic and SQ counters of the dominant kernel ------------------------------------------------
@@ -162,6 +183,9 @@ PMC_PASSES = {
            "SQ_ACTIVE_INST_ANY", "SQ_WAVES"],
     "mix": ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
             "SQ_INSTS_VALU_INT32", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD"],
+    # the vector L1 (TCP) and the L2 (TCC): what the record gather costs (profiles/r3/notes.md)
+    "tcp": ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCC_READ_REQ_LATENCY_sum"],
+    "l2": ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "GRBM_GUI_ACTIVE"],
 }
 
 
@@ -172,10 +196,16 @@ def under_profiler() -> bool:
 
 def child_workload_args(args) -> list:
     a = ["--scene", args.scene, "--side", str(args.side), "--kind", args.kind, "--builder", args.builder, "--gen", "device",
-         "--scaling", args.scaling, "--tiles", str(args.tiles)]
+         "--scaling", args.scaling, "--tiles", str(args.tiles), "--alpha-frac", str(args.alpha_frac),
+         "--shadow-per-hit", str(args.shadow_per_hit)]
     if args.mode is not None:
         a += ["--mode", args.mode]
     return a
+
+
+def kernel_row_prefix(args) -> str:
+    """How the dominant kernel's rows start in rocprofv3's CSVs (spaces removed): trace_kernel<ANY_HIT,STATS,..."""
+    return "trace_kernel<%s,false," % ("true" if args.kind == "shadow" else "false")
 
 
 def collect_pmc_live(args, passes) -> dict:
@@ -208,7 +238,7 @@ def collect_pmc_live(args, passes) -> dict:
             for f in glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     kn = r.get("Kernel_Name", "")
-                    if "trace_kernel<false, false" in kn or "trace_kernel<false,false" in kn:
+                    if kernel_row_prefix(args) in kn.replace(" ", ""):
                         got[r["Counter_Name"]] = float(r["Counter_Value"])     # rows are in dispatch order: keep the last
             log(f"[bench] PMC pass {name}: rc {rc}, {len(got)} counters, {time.time() - t0:.1f}s")
             out.update(got)
@@ -250,8 +280,36 @@ def bound_actual(pmc: dict, kernel_ms: float) -> dict | None:
         out["valu_issue_cycles_per_simd"] = round(per_simd)
         out["kernel_cycles"] = round(kernel_ms * 1e-3 * CLOCK_GHZ * 1e9)
         out["valu_busy_frac"] = round(per_simd / (kernel_ms * 1e-3 * CLOCK_GHZ * 1e9), 3)
+        out["clock_ghz"] = round(CLOCK_GHZ, 3)
+        out["clock_source"] = CLOCK_SOURCE
         out["issue_cost_source"] = "scripts/ubench_valu.hip (cycles per wave-instruction and SIMD: mul/add 2.4, int 3.2, fma/select/minmax 4.2, rcp 8.2)"
         out["branches"] = pmc.get("SQ_INSTS_BRANCH")
+    return out
+
+
+def gather_path(pmc: dict, kernel_ms: float, cus: int) -> dict | None:
+    """What the record gather costs on the way in: the vector L1 (TCP) of every CU takes one access per 64-B record
+    (quad-cooperative DMA) and returns them in order, so its throughput is (entries in flight) / (latency of the L2 reads
+    among them).  MI355X_MICROARCH.md measures 66-73 GB/s per CU for L2-resident random gathers and 29-34 GB/s per CU
+    from the Infinity Cache; the figures below are this launch against that ceiling (profiles/r3/notes.md)."""
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" not in pmc or not cus:
+        return None
+    acc, req = pmc["TCP_TOTAL_CACHE_ACCESSES_sum"], pmc.get("TCP_TCC_READ_REQ_sum", 0.0)
+    out = {"tcp_accesses": acc, "tcp_l2_read_requests": req, "l1_hit_rate": round(1.0 - req / acc, 4) if acc else None,
+           "l1_gb_s_per_cu": round(acc * 64 / cus / (kernel_ms * 1e-3) / 1e9, 1),
+           "l2_to_l1_gb_s_per_cu": round(req * 64 / cus / (kernel_ms * 1e-3) / 1e9, 1),
+           "guide_ceiling_gb_s_per_cu": {"l2_resident_gather": [66, 73], "infinity_cache_gather": [29, 34]}}
+    if pmc.get("TCP_TCC_READ_REQ_LATENCY_sum") and req:
+        out["avg_l2_read_latency_cycles"] = round(pmc["TCP_TCC_READ_REQ_LATENCY_sum"] / req, 1)
+    if "GRBM_GUI_ACTIVE" in pmc:
+        cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0                                    # summed over the 8 XCDs
+        out["kernel_cycles"] = round(cyc)
+        out["effective_clock_ghz"] = round(cyc / (kernel_ms * 1e-3) / 1e9, 3)
+        out["tcp_accesses_per_cycle_per_cu"] = round(acc / cus / cyc, 3)
+        if "TCP_PENDING_STALL_CYCLES_sum" in pmc:
+            out["tcp_pending_stall_frac"] = round(pmc["TCP_PENDING_STALL_CYCLES_sum"] / cus / cyc, 3)
+    if "TCC_HIT_sum" in pmc and pmc.get("TCC_REQ_sum"):
+        out["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc.get("TCC_MISS_sum", 0.0)), 4)
     return out
 
 
@@ -322,7 +380,12 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scene", default="S1M")
     ap.add_argument("--side", type=int, default=4096, help="primary image side; rays per GPU = side*side (weak scaling)")
-    ap.add_argument("--kind", default="bounce", choices=["bounce", "primary"])
+    ap.add_argument("--kind", default="bounce", choices=["bounce", "primary", "shadow"],
+                    help="bounce = BASELINE configs[2] (the headline); primary with --scene S100k --side 1024 = configs[1]; "
+                         "shadow = configs[3]: any-hit occlusion rays, --shadow-per-hit per primary hit (side 4096 x 4 = 64 Mi)")
+    ap.add_argument("--shadow-per-hit", type=int, default=4)
+    ap.add_argument("--alpha-frac", type=float, default=0.0,
+                    help="share of the triangles that carry the alpha-test flag (Primitives.h:196-208): runs the ALPHA kernel variants")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank traces its own side*side batch; strong: BASELINE configs[4] -- `--tiles` camera tiles of "
                          "1024x1024 primary rays split over the ranks (use with --scene S10M)")
@@ -330,7 +393,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the live rocprofv3 PMC passes (traffic then comes from profiles/ or is null)")
-    ap.add_argument("--pmc-passes", default="fetch,write,sq,mix")
+    ap.add_argument("--pmc-passes", default="fetch,write,sq,mix,tcp,l2")
     ap.add_argument("--pmc-timeout", type=float, default=240.0)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--builder", default="sah", choices=["ploc", "sah", "sah_refined"],
@@ -343,8 +406,11 @@ def main() -> None:
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (one GPU per rank); gloo = test mode: ranks may share a GPU, hits gathered via host")
     ap.add_argument("--gather", default="native", choices=["native", "torch"],
-                    help="N > 1: native = vt_gather_hits_dev (ncclGather issued by libvistrace_hip.so, verified in the warm-up, "
-                         "falls back to torch on any error); torch = torch.distributed.gather")
+                    help="N > 1: native = vt_gather_hits_dev (ncclGather issued by libvistrace_hip.so, verified in the warm-up; any "
+                         "failure ends the run with a non-zero exit code -- a SCALE number is never silently a torch number); "
+                         "torch = torch.distributed.gather, on request only")
+    ap.add_argument("--overlap", default="on", choices=["on", "off"],
+                    help="N > 1: off = every trace waits for the previous batch's gather (diagnostic: step = trace + gather)")
     ap.add_argument("--force-dist", action="store_true",
                     help="dev: run the N > 1 control flow (process group, gather pipeline, barriers) even with one rank")
     ap.add_argument("--reserve-cus", type=int, default=32,
@@ -380,12 +446,28 @@ def main() -> None:
     if args.pmc_child:
         tris, bvh, host_scene, engine, scene, _ = build_scene(args, va, W, dev_index, 1)
         d_rays, n, _, _, _ = make_rays(args, 0, 1, va, W, tp, engine, scene, device)
-        d_hits = tp.empty_records(n, HIT, device)
-        for _ in range(3):
-            tp.trace_closest(scene, d_rays, n, d_hits)
+        if args.kind == "shadow":
+            d_occ = torch.empty(n, dtype=torch.uint8, device=device)
+            for _ in range(3):
+                tp.trace_any(scene, d_rays, n, d_occ)
+        else:
+            d_hits = tp.empty_records(n, HIT, device)
+            for _ in range(3):
+                tp.trace_closest(scene, d_rays, n, d_hits)
         torch.cuda.synchronize(device)
         return
 
+    global CLOCK_GHZ, CLOCK_SOURCE
+    try:
+        khz = int(torch.cuda.get_device_properties(device).clock_rate)       # hipDeviceAttributeClockRate, kHz
+        if khz > 0:
+            CLOCK_GHZ, CLOCK_SOURCE = khz / 1e6, "hipDeviceAttributeClockRate (the device's peak shader clock; it may hold less under load)"
+    except Exception:
+        pass
+
+    any_hit = args.kind == "shadow"
+    if any_hit and (world > 1 or args.force_dist or args.scaling == "strong"):
+        raise SystemExit("--kind shadow is a single-GPU workload (BASELINE configs[3])")
     dist_on = world > 1 or args.force_dist
     if dist_on:
         if args.force_dist and "MASTER_ADDR" not in os.environ:
@@ -399,18 +481,19 @@ def main() -> None:
     t3 = time.time()
     tris, bvh, host_scene, engine, scene, host_threads = build_scene(args, va, W, dev_index, world)
     d_rays, n, n_total, workload, rays_host = make_rays(args, rank, world, va, W, tp, engine, scene, device)
-    d_hits = tp.empty_records(max(n, 1), HIT, device)
+    d_hits = tp.empty_records(max(n, 1), HIT, device) if not any_hit else torch.empty(max(n, 1), dtype=torch.uint8, device=device)
     t4 = time.time()
     log(f"[bench] scene + ray set-up {t4 - t3:.2f}s; workload {workload}, {n} rays on this rank, {n_total} in the job")
 
     # ---- algorithmic bytes: exact counters from the stats kernel (untimed) --------------
-    _, d_stats = tp.trace_stats(scene, d_rays, n)
+    _, d_stats = tp.trace_any_stats(scene, d_rays, n) if any_hit else tp.trace_stats(scene, d_rays, n)
     torch.cuda.synchronize(device)
     stats = tp.to_host(d_stats, RAY_STATS)
     tot_steps = int(stats["steps"].sum(dtype=np.uint64))
     tot_tests = int(stats["tests"].sum(dtype=np.uint64))
     del d_stats
-    alg_bytes = n * (32 + 16) + 64 * (tot_steps + tot_tests)
+    out_bytes = 1 if any_hit else 16                     # 16-B hit record, 1 byte for any-hit
+    alg_bytes = n * (32 + out_bytes) + 64 * (tot_steps + tot_tests)
     log(f"[bench] steps/ray {tot_steps / max(n, 1):.2f} tests/ray {tot_tests / max(n, 1):.2f} -> {alg_bytes / max(n, 1):.0f} B/ray algorithmic")
 
     # ---- timed region -------------------------------------------------------------------
@@ -428,13 +511,17 @@ def main() -> None:
     if dist_on:
         # weak: every rank sends n records; strong: shards are equal (tiles divide evenly) or padded to the largest
         n_send = n if args.scaling == "weak" else ((args.tiles + world - 1) // world) * 1024 * 1024
+        if args.overlap == "off":
+            engine.set_option("gather_overlap", 0)
         if args.gather == "native" and args.backend == "nccl":
             try:
                 native = NativeGather(engine, n_send, world, rank, device, dist)
                 gather_kind = "native ncclGather (vt_gather_hits_dev, own communication stream)"
             except Exception as exc:
-                log(f"[bench] native gather unavailable ({exc}); using torch.distributed.gather")
-                native = None
+                # no silent downgrade: a scaling number must say what moved the records (ask for --gather torch explicitly)
+                print(f"[bench] FATAL rank {rank}: native gather unavailable ({exc}); re-run with --gather torch to measure "
+                      f"torch.distributed.gather instead", file=sys.stderr, flush=True)
+                sys.exit(3)
         if native is None:
             pipe = HitGatherPipeline(n_send, device, nchunks=args.chunks, via_host=args.backend == "gloo")
             gather_kind = "torch.distributed.gather" + (" via host (gloo test mode)" if args.backend == "gloo" else " (RCCL)")
@@ -445,7 +532,9 @@ def main() -> None:
             scene.trace_closest_dev(d_rays.data_ptr() + lo * RAY.itemsize, hi - lo, hits_buf.data_ptr() + lo * HIT.itemsize, stream)
 
     def step():
-        if not dist_on:
+        if any_hit:
+            tp.trace_any(scene, d_rays, n, d_hits)
+        elif not dist_on:
             tp.trace_closest(scene, d_rays, n, d_hits)
         elif native is not None:
             native.submit(trace_into, stream)
@@ -473,13 +562,9 @@ def main() -> None:
             log(f"[bench] gather verification failed to run: {exc}")
             gather_verified = False
         if not gather_verified:
-            log("[bench] native gather did NOT deliver the records intact: falling back to torch.distributed.gather")
-            native = None
-            pipe = HitGatherPipeline(n_send, device, nchunks=args.chunks, via_host=False)
-            gather_kind = "torch.distributed.gather (RCCL; native gather failed verification)"
-            for _ in range(2):
-                step()
-            drain()
+            print(f"[bench] FATAL rank {rank}: the native gather did NOT deliver every rank's records to rank 0 intact",
+                  file=sys.stderr, flush=True)
+            sys.exit(4)
     elif pipe is not None and args.backend == "nccl":
         b = (pipe.batch - 1) % 2
         recv = torch.cat(pipe.recv[b]) if rank == 0 else None
@@ -490,7 +575,10 @@ def main() -> None:
     single_ms = []
     if n > 0:
         for _ in range(3):
-            tp.trace_closest(scene, d_rays, n, d_hits)
+            if any_hit:
+                tp.trace_any(scene, d_rays, n, d_hits)
+            else:
+                tp.trace_closest(scene, d_rays, n, d_hits)
             single_ms.append(engine.last_kernel_ms())
     torch.cuda.synchronize(device)
     if dist_on:
@@ -513,9 +601,49 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- N > 1: where the step time goes (untimed diagnostic: a few synchronised steps behind the timed region) -------------
+    dist_breakdown = None
+    if dist_on and n > 0:
+        D = 6
+        buf = native.hits[0] if native is not None else (pipe.hits[0] if pipe is not None else d_hits)
+        tr, ga = [], []
+        for _ in range(D):                                   # the trace alone (reserved CUs included), no gather in flight
+            trace_into(buf)
+            torch.cuda.synchronize(device)
+            tr.append(engine.last_kernel_ms())
+        if native is not None:
+            for _ in range(D):                               # trace + gather, one batch at a time: the gather's own duration
+                native.submit(trace_into, stream)
+                native.drain()
+                torch.cuda.synchronize(device)
+                try:
+                    ga.append(engine.last_gather_ms())
+                except Exception:
+                    pass
+        t_mean, g_mean = float(np.mean(tr)), (float(np.mean(ga)) if ga else 0.0)
+        dev_t = device if args.backend == "nccl" else "cpu"
+        hi = torch.tensor([t_mean, g_mean], dtype=torch.float64, device=dev_t)
+        lo = hi.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        t_max, g_max = float(hi[0]), float(hi[1])
+        hidden = max(0.0, t_max + g_max - ms_per_step)
+        dist_breakdown = {
+            "trace_ms_per_rank": {"min": round(float(lo[0]), 4), "max": round(t_max, 4)},
+            "gather_ms_per_rank": ({"min": round(float(lo[1]), 4), "max": round(g_max, 4)} if ga else None),
+            "gather_ms_how": "HIP events on the communication stream around one ncclGather with no trace beside it (vt_engine_last_gather_ms)" if ga
+                             else "not measured (torch.distributed.gather path)",
+            "step_ms": round(ms_per_step, 4),
+            "overlap": args.overlap,
+            "overlap_frac": round(min(1.0, hidden / min(t_max, g_max)), 3) if ga and min(t_max, g_max) > 0 else None,
+            "overlap_note": "(trace + gather - step) / min(trace, gather): 1 = the shorter of the two is fully hidden, 0 = they run back to back",
+            "gather_kind": gather_kind,
+            "bytes_into_root_per_step": int((world - 1) * n_send * 16),
+        }
     engine.set_timing(False)
 
-    ms_per_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed / 1e6
     k_ms = region_ms / args.steps                      # mean launch duration over the timed region (memset + kernel)
     alg_achieved = alg_bytes / (k_ms * 1e-3) / 1e9
@@ -551,7 +679,7 @@ def main() -> None:
     persistent = bool(engine.get_option("last_persistent"))
     dma = bool(engine.get_option("last_fetch_dma"))
     result = {
-        "metric": "Mrays/s closest-hit, 1M-triangle scene" if args.scene == "S1M" else f"Mrays/s closest-hit, scene {args.scene}",
+        "metric": ("Mrays/s %s, 1M-triangle scene" if args.scene == "S1M" else "Mrays/s %%s, scene %s" % args.scene) % ("any-hit" if any_hit else "closest-hit"),
         "value": round(value, 2),
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -569,12 +697,15 @@ def main() -> None:
             "bvh_builder": BUILDER_NAMES[args.builder],
             "rays_per_gpu": n,
             "rays_total": n_total,
-            "query": "closest-hit",
-            "ray_kind": "pinhole primary" if (args.kind == "primary" or args.scaling == "strong") else "cosine-hemisphere bounce (incoherent)",
+            "query": "any-hit (shadow occlusion, tMax early-out)" if any_hit else "closest-hit",
+            "ray_kind": "pinhole primary" if (args.kind == "primary" or args.scaling == "strong") else
+                        ("shadow rays from primary hits towards 16 point lights" if any_hit else "cosine-hemisphere bounce (incoherent)"),
+            "alpha_tested_triangle_share": args.alpha_frac if args.alpha_frac > 0 else None,
             "parallelism": f"rays sharded x{world}, BVH replicated" + (
                 f", hits gathered to rank 0 inside the step: {gather_kind}, double-buffered and overlapped with tracing; "
                 f"{engine.get_option('reserved_cus')} CUs keep room for its kernels" if dist_on else ""),
             "gather_verified": gather_verified,
+            "dist_breakdown": dist_breakdown,
             "kernel_mode": ("persistent" + ("+lds-dma-fetch" if dma else "")) if persistent else "static",
             "launch_options": {k: engine.get_option(k) for k in ("lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold", "reserved_cus", "reserved_limit")},
             "launch": engine.launch_info(),
@@ -592,8 +723,9 @@ def main() -> None:
             "alg_over_peak": round(alg_achieved / HBM_PEAK_GBS, 4),
             "alg_note": "algorithmic bytes (SURVEY 8(d)) / launch duration; > peak because records are served by L1/L2/Infinity Cache",
             "traffic_over_alg": round(traffic / alg_bytes, 4) if traffic else None,
-            "compulsory_bytes": int(n * 48 + scene.device_bytes),
-            "kernel": "vt::trace_kernel<false,false,%s,%s,false>" % ("true" if persistent else "false", "true" if dma else "false"),   # <ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>
+            "compulsory_bytes": int(n * (32 + out_bytes) + scene.device_bytes),
+            "kernel": "vt::trace_kernel<%s,false,%s,%s,%s>" % ("true" if any_hit else "false", "true" if persistent else "false", "true" if dma else "false",
+                                                                "true" if args.alpha_frac > 0 else "false"),   # <ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>
             "kernel_ms": round(k_ms, 4),
             "kernel_ms_how": "HIP events on the launch stream around the K timed steps / K (cursor memset + kernel); single launches: %s ms" % (
                 ", ".join(f"{x:.3f}" for x in single_ms)),
@@ -601,12 +733,13 @@ def main() -> None:
             "steps_per_ray": round(tot_steps / max(n, 1), 2),
             "tests_per_ray": round(tot_tests / max(n, 1), 2),
             "bound_actual": bound_actual(pmc, k_ms),
+            "gather_path": gather_path(pmc, k_ms, engine.get_option("cu_count")),
             "kernel_sources_sha": sha,
         },
     }
 
     # ---- the same workload on the other builder's tree (N = 1): what the tree is worth ------------------------------------
-    if rank == 0 and world == 1 and not dist_on and args.alt_builder not in ("none", args.builder) and n > 0:
+    if rank == 0 and world == 1 and not dist_on and args.alt_builder not in ("none", args.builder) and n > 0 and not any_hit and args.alpha_frac == 0:
         try:
             alt_args = argparse.Namespace(**vars(args))
             alt_args.builder = args.alt_builder
@@ -645,39 +778,60 @@ def main() -> None:
         nodes = bvh.nodes().view(O.NODE)
         pidx = bvh.prim_indices()
         otris = O.tris_from_tri64(tris)
-        pilot = min(n, 1 << 19)
+        n_host = len(rays_host)                               # shadow batches keep the first 16 Mi rays on the host
+        pilot = min(n_host, 1 << 19)
+        rig = getattr(scene, "alpha_rig", None)
+        if rig:                                               # the alpha test lives in the baseline build of the oracle only
+            O.set_alpha(otris, rig[1]["uv"].reshape(len(otris), 6), rig[1]["material"], rig[2].view(O.ALPHA_MATERIAL), rig[3])
         # the checker's own check: the -O3 x86-64-v3 build used for timing must equal the baseline build bit for bit
-        ctx = O.BatchContext(nodes, pidx, otris, nthreads=host_threads, fast=True)
-        chk = min(n, 1 << 16)
-        a = ctx.traverse(rays_host[:chk], want_stats=True)
-        b = O.traverse_batch(nodes, pidx, otris, rays_host[:chk], want_stats=True)
+        if rig:
+            class _PlainCtx:                                  # vto_traverse_batch names alpha triangles by address: no NUMA replicas
+                fast, replicas = False, 1
+                def traverse(self, rays, any_hit=False, want_stats=False, nthreads=0):
+                    return O.traverse_batch(nodes, pidx, otris, rays, any_hit=any_hit, want_stats=want_stats, nthreads=nthreads)
+                def close(self):
+                    pass
+            ctx = _PlainCtx()
+        else:
+            ctx = O.BatchContext(nodes, pidx, otris, nthreads=host_threads, fast=True)
+        chk = min(n_host, 1 << 16)
+        a = ctx.traverse(rays_host[:chk], any_hit=any_hit, want_stats=True)
+        b = O.traverse_batch(nodes, pidx, otris, rays_host[:chk], any_hit=any_hit, want_stats=True)
         fast_equal = bool((a[0].view(np.uint8) == b[0].view(np.uint8)).all() and (a[1] == b[1]).all())
         if not fast_equal:
             log("[bench] the -O3 oracle build differs from the baseline build: timing the baseline build instead")
             ctx.close()
-            ctx = O.BatchContext(nodes, pidx, otris, nthreads=host_threads, fast=False)
+            if not rig:
+                ctx = O.BatchContext(nodes, pidx, otris, nthreads=host_threads, fast=False)
         # the CPU gets its best thread count: all logical CPUs or one per physical core (SMT can hurt or help this walk)
         rate, cpu_threads = 0.0, host_threads
         for cand in sorted({host_threads, max(1, host_threads // 2)}, reverse=True):
-            ctx.traverse(rays_host[:pilot], nthreads=cand)                               # warm-up
+            ctx.traverse(rays_host[:pilot], any_hit=any_hit, nthreads=cand)              # warm-up
             tp0 = time.perf_counter()
-            ctx.traverse(rays_host[:pilot], nthreads=cand)
+            ctx.traverse(rays_host[:pilot], any_hit=any_hit, nthreads=cand)
             r = pilot / (time.perf_counter() - tp0)
             if r > rate:
                 rate, cpu_threads = r, cand
-        sample = int(min(n, max(pilot, rate * args.cpu_seconds)))
-        sample = max(4096, (sample // 4096) * 4096) if n >= 4096 else n
+        sample = int(min(n_host, max(pilot, rate * args.cpu_seconds)))
+        sample = max(4096, (sample // 4096) * 4096) if n_host >= 4096 else n_host
         tc0 = time.perf_counter()
-        ref, ref_stats, s_steps, s_tests, threads = ctx.traverse(rays_host[:sample], want_stats=True, nthreads=cpu_threads)
+        ref, ref_stats, s_steps, s_tests, threads = ctx.traverse(rays_host[:sample], any_hit=any_hit, want_stats=True, nthreads=cpu_threads)
         cpu_s = time.perf_counter() - tc0
-        # one host thread: the closest analogue of what a GLua script gets today (one ray per call, serial)
-        one_n = min(pilot, 1 << 17)
+        # one host thread: the closest analogue of what a GLua script gets today (one ray per call, serial).
+        # Timed like the multi-thread leg: a slice of the same sample, walked once to warm the caches, then timed.
+        one_n = min(sample, 1 << 17)
+        ctx.traverse(rays_host[:one_n], any_hit=any_hit, nthreads=1)
         t10 = time.perf_counter()
-        ctx.traverse(rays_host[:one_n], nthreads=1)
+        ctx.traverse(rays_host[:one_n], any_hit=any_hit, nthreads=1)
         one_thread = one_n / (time.perf_counter() - t10) / 1e6
-        gpu = tp.to_host(d_hits[: sample * HIT.itemsize], HIT)
-        same_prim = bool((gpu["prim"] == ref["prim"]).all())
-        same_tuv = all(bool((gpu[k].view(np.uint32) == ref[k].view(np.uint32)).all()) for k in ("t", "u", "v"))
+        if any_hit:
+            occ = d_hits[:sample].cpu().numpy()
+            same_prim = bool((occ == (ref["prim"] != 0xFFFFFFFF)).all())
+            same_tuv = True                                   # any-hit reports one byte
+        else:
+            gpu = tp.to_host(d_hits[: sample * HIT.itemsize], HIT)
+            same_prim = bool((gpu["prim"] == ref["prim"]).all())
+            same_tuv = all(bool((gpu[k].view(np.uint32) == ref[k].view(np.uint32)).all()) for k in ("t", "u", "v"))
         same_stats = bool((stats[:sample]["steps"] == ref_stats[:, 0]).all() and (stats[:sample]["tests"] == ref_stats[:, 1]).all())
         cpu_model = ""
         try:
@@ -701,11 +855,14 @@ def main() -> None:
             "threads_pinned": f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}",
             "numa_replicas": ctx.replicas,
             "one_thread_value": round(one_thread, 4),
-            "scaling_vs_one_thread": round(sample / cpu_s / 1e6 / one_thread, 1) if one_thread > 0 else None,
+            "scaling_vs_one_thread": round(sample / cpu_s / 1e6 / one_thread, 2) if one_thread > 0 else None,
+            "one_thread_how": f"{one_n} rays of the same sample on one pinned thread, second of two consecutive walks",
         }
-        result["parity_sample"] = {"rays": sample, "prim_bit_exact": same_prim, "tuv_bit_exact": same_tuv,
+        result["parity_sample"] = {"rays": sample, ("occluded_equal" if any_hit else "prim_bit_exact"): same_prim, "tuv_bit_exact": same_tuv,
                                    "counters_equal": same_stats}
         ctx.close()
+        if rig:
+            O.set_alpha()
         if not (same_prim and same_tuv):
             log("[bench] PARITY FAILURE on the sample")
     if dist_on:

@@ -238,6 +238,10 @@ int vt_trace_any_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_occlud
 /* Closest hit + per-ray counters (diagnostic kernel; same visitation order). */
 int vt_trace_stats_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits,
                        void* d_ray_stats, void* stream);
+/* Any hit + per-ray counters: the node steps and triangle tests the reference's AnyPrimitiveIntersector walk performs
+ * up to its early-out (what SURVEY.md 8(d)'s algorithmic bytes of a shadow-ray batch are counted from). */
+int vt_trace_any_stats_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_occluded,
+                           void* d_ray_stats, void* stream);
 /* TraceResult batch materialisation from hits (d_attrs: n x vt_hit_attrs). */
 int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64_t n,
                      void* d_attrs, void* stream);

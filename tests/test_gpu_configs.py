@@ -5,6 +5,7 @@ ones and run once, on the engine's default (auto) configuration -- what a caller
 
   config 4  64 Mi any-hit shadow rays into S1M                      test_config4_full_size_64mi_shadow_rays
   config 5  one of 8 ranks' shard (16 tiles of 1024^2) into S10M    test_config5_s10m_primary_shard
+            the whole job (128 tiles = 134 217 728 rays) in ONE call   test_config5_full_size_128_tiles_one_call
             + 16 Mi incoherent bounce rays into S10M (scene beyond the Infinity Cache)
 Parity bar as everywhere: primitive index bit-exact, t/u/v bit-identical (oracle on a slice that it finishes in
 seconds; size-independent properties on the whole batch).
@@ -309,3 +310,83 @@ def test_native_gather_single_rank(va, make_bundle):
     scene.free()
     eng.close()
 
+
+
+def test_config5_full_size_128_tiles_one_call(va, make_bundle):
+    """BASELINE configs[4] at its full size in ONE job on one GPU: 128 tiles x 1024^2 = 134 217 728 primary rays from the 128
+    seeded camera poses into S10M, through vt_engine_open_multi([0]) + ONE vt_trace_closest_gather_dev call (4 GiB of
+    rays, 2 GiB of hit records: byte offsets beyond 2^32, capacity x ndev arithmetic, the in-place ncclGather of a
+    one-device group).  Oracle on 1 Mi rays spread over all 128 tiles; size-independent properties on the whole batch,
+    evaluated on the device (no 6 GiB host copies); any-hit <=> closest-hit on the whole batch."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10M")
+    eng = va.Engine([0])
+    scene = va.Scene(eng, b.host_scene)
+    dev = torch.device("cuda", 0)
+    tile, tiles = 1024 * 1024, 128
+    n = tile * tiles
+    assert n == 134217728 and n * va.RAY.itemsize > (1 << 32)
+    d_rays = tp.empty_records(n, va.RAY, dev)
+    for t in range(tiles):
+        pos, fwd = W.camera_pose("S10M", t)
+        eng.gen_primary_dev(1024, 1024, d_rays.data_ptr() + t * tile * va.RAY.itemsize, pos=tuple(float(x) for x in pos),
+                            forward=tuple(float(x) for x in fwd), stream=tp.current_stream_handle(dev))
+    torch.cuda.synchronize()
+    cap = va.shard_capacity(n, 1)
+    assert cap == n
+    d_hits = torch.empty(cap * 16, dtype=torch.uint8, device=dev)
+    scene.trace_closest_gather_dev([d_rays.data_ptr()], n, d_hits.data_ptr())          # ONE call
+    eng.synchronize()
+    H = d_hits.view(torch.int32).view(n, 4)
+    R = d_rays.view(torch.float32).view(n, 8)
+    hit = H[:, 0] != -1
+    assert float(hit.float().mean()) > 0.99                                             # closed room
+    t, u, v = (H[:, k].view(torch.float32) for k in (1, 2, 3))
+    assert bool((t[~hit] == 0).all() and (u[~hit] == 0).all() and (v[~hit] == 0).all())
+    assert bool((t[hit] >= R[:, 6][hit]).all() and (t[hit] <= R[:, 7][hit]).all())
+    assert bool((u[hit] >= 0).all() and (v[hit] >= 0).all() and ((u[hit] + v[hit]) <= 1 + 1e-6).all())
+    assert int(H[:, 0][hit].max()) < len(b.tris)
+    # every tile produced hits of its own (a shard or offset error would leave tiles empty or duplicated)
+    per_tile = hit.view(tiles, tile).float().mean(dim=1)
+    assert float(per_tile.min()) > 0.9
+    first = H.view(tiles, tile, 4)[:, :4096, :].contiguous()
+    assert len({bytes(first[k].cpu().numpy().tobytes()) for k in range(tiles)}) == tiles
+    # oracle: 8192 consecutive rays from each of the 128 tiles = 1 Mi rays, bit-exact
+    idx = torch.cat([torch.arange(k * tile + 4099 * k, k * tile + 4099 * k + 8192, device=dev) for k in range(tiles)])
+    rays_s = tp.to_host(d_rays.view(torch.uint8).view(n, 32)[idx].contiguous().view(-1), va.RAY)
+    hits_s = tp.to_host(d_hits.view(n, 16)[idx].contiguous().view(-1), va.HIT)
+    assert len(rays_s) == 1 << 20
+    assert_hits_equal(hits_s, b.oracle(rays_s))
+    # the hit point lies on the reported triangle (host side, on the 1 Mi sample)
+    check_hit_properties(b, rays_s, hits_s)
+    # any-hit over the same 128 Mi rays agrees with closest-hit everywhere
+    d_occ = tp.trace_any(scene, d_rays, n)
+    assert bool((d_occ.bool() == hit).all())
+    # and the plain single-device entry point gives the same bytes as the group call
+    d_h2 = tp.trace_closest(scene, d_rays, n)
+    assert bool((d_h2.view(torch.int64) == d_hits.view(torch.int64)).all())
+    scene.free()
+    eng.close()
+
+
+def test_group_gather_refuses_a_per_rank_communicator(va, make_bundle):
+    """An engine whose communicator came from vt_engine_comm_init_rank (one process per GPU) must not be used for the
+    single-process group gather: ncclGather would deliver comm_size x capacity records into a buffer sized for the group."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S1k")
+    eng = va.Engine(0)
+    scene = va.Scene(eng, b.host_scene)
+    eng.comm_init_rank(1, 0, va.comm_unique_id())
+    dev = torch.device("cuda", 0)
+    rays = W.sphere_rays(4096, 2)
+    d_rays = tp.to_device(rays, dev)
+    out = torch.zeros(va.shard_capacity(4096, 1) * 16, dtype=torch.uint8, device=dev)
+    with pytest.raises(va._lib.VisTraceError) as err:
+        scene.trace_closest_gather_dev([d_rays.data_ptr()], 4096, out.data_ptr())
+    assert "vt_engine_comm_init_rank" in str(err.value)
+    scene.free()
+    eng.close()

@@ -127,8 +127,16 @@ def test_scene_parity_with_counters(va, engine, make_bundle, name):
     assert (st["steps"] == ref_st[:, 0]).all() and (st["tests"] == ref_st[:, 1]).all()
     occ = scene.trace_any(rays)
     assert (occ == (ref["prim"] != O_MISS)).all()
-    any_ref = b.oracle(rays, any_hit=True)
+    any_ref, any_st = b.oracle(rays, any_hit=True, want_stats=True)
     assert (occ == (any_ref["prim"] != O_MISS)).all()
+    # any-hit counters (vt_trace_any_stats_dev): the steps and tests of the reference's walk up to its early-out
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    d_occ, d_st = tp.trace_any_stats(scene, tp.to_device(rays, torch.device("cuda", 0)), len(rays))
+    torch.cuda.synchronize()
+    st_any = tp.to_host(d_st, va.RAY_STATS)
+    assert (d_occ.cpu().numpy() == occ).all()
+    assert (st_any["steps"] == any_st[:, 0]).all() and (st_any["tests"] == any_st[:, 1]).all()
 
 
 O_MISS = 0xFFFFFFFF

@@ -95,6 +95,7 @@ SYMBOLS = {
     "vt_trace_closest_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
     "vt_trace_any_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
     "vt_trace_stats_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
+    "vt_trace_any_stats_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "vt_hit_attrs_dev": (C.c_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     "vt_scene_refit": (C.c_int, [_vp, _vp, _vp, _u32]),
     "vt_scene_set_alpha": (C.c_int, [_vp, _vp, _u32, _vp, _u64]),

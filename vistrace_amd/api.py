@@ -322,6 +322,9 @@ class Scene:
     def trace_stats_dev(self, d_rays: int, n: int, d_hits: int, d_stats: int, stream: int = 0) -> None:
         check(lib.vt_trace_stats_dev(self._h, d_rays, n, d_hits, d_stats, stream or None))
 
+    def trace_any_stats_dev(self, d_rays: int, n: int, d_occ: int, d_stats: int, stream: int = 0) -> None:
+        check(lib.vt_trace_any_stats_dev(self._h, d_rays, n, d_occ, d_stats, stream or None))
+
     def hit_attrs_dev(self, d_rays: int, d_hits: int, n: int, d_attrs: int, stream: int = 0) -> None:
         check(lib.vt_hit_attrs_dev(self._h, d_rays, d_hits, n, d_attrs, stream or None))
 

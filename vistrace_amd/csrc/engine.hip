@@ -57,6 +57,7 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool 
     // up to half of it: scripts/sweep.py tables in profiles/r1/notes.md)
     const uint64_t factor = s->npairs <= 200000u ? uint64_t(e->auto_static_factor) * 2 : (uint64_t(e->auto_static_factor) + 1) / 2;
     p.persistent = e->persistent == 1 || (e->persistent == 2 && n > factor * e->cu_count * 8 * kBlockThreads);
+    if (any_hit && stats) p.persistent = false;        // the any-hit counters kernel exists as the one-ray-per-lane variant only
     // the DMA-fetch kernel addresses records as base + 32-bit byte offset: scenes below 4 GiB
     const uint64_t rec_bytes = (uint64_t(s->interleaved ? s->npairs : s->tri_base) + s->ntris) * 64;
     p.fetch_dma = p.persistent && e->fetch_dma != 0 && rec_bytes < (uint64_t(1) << 32);
@@ -703,6 +704,12 @@ int vt_trace_stats_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits
 {
     if (!d_ray_stats) return fail(VT_ERR_INVALID_ARG, "vt_trace_stats_dev: d_ray_stats is NULL");
     return trace_dev(s, d_rays, n, d_hits, nullptr, d_ray_stats, false, true, stream);
+}
+
+int vt_trace_any_stats_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_occluded, void* d_ray_stats, void* stream)
+{
+    if (!d_ray_stats) return fail(VT_ERR_INVALID_ARG, "vt_trace_any_stats_dev: d_ray_stats is NULL");
+    return trace_dev(s, d_rays, n, nullptr, d_occluded, d_ray_stats, true, true, stream);
 }
 
 int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64_t n, void* d_attrs, void* stream)

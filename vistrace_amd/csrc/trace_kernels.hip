@@ -444,7 +444,25 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
             const uint32_t piece = (lane & 3u) * 16u;
             const uint32_t r0 = quad_broadcast<0>(rec), r1 = quad_broadcast<1>(rec),
                            r2 = quad_broadcast<2>(rec), r3 = quad_broadcast<3>(rec);
-#if VT_EXP_DMA_MASK
+#if VT_EXP_DMA_MASK == 2
+            // EXEC of DMA k = the quads whose lane k needs a record, formed on the scalar unit: no dummy accesses
+            const uint64_t needm = __ballot(do_tri || want_node);
+            const uint64_t nib = 0x1111111111111111ull;
+            uint64_t e0 = needm & nib, e1 = (needm >> 1) & nib, e2 = (needm >> 2) & nib, e3 = (needm >> 3) & nib;
+            e0 = (e0 << 4) - e0; e1 = (e1 << 4) - e1; e2 = (e2 << 4) - e2; e3 = (e3 << 4) - e3;
+            uint64_t save;
+            asm volatile("s_mov_b64 %[sv], exec\n\t"
+                         "s_mov_b32 m0, %[l0]\n\ts_mov_b64 exec, %[e0]\n\tglobal_load_lds_dwordx4 %[a0], %[base]\n\t"
+                         "s_mov_b32 m0, %[l1]\n\ts_mov_b64 exec, %[e1]\n\tglobal_load_lds_dwordx4 %[a1], %[base]\n\t"
+                         "s_mov_b32 m0, %[l2]\n\ts_mov_b64 exec, %[e2]\n\tglobal_load_lds_dwordx4 %[a2], %[base]\n\t"
+                         "s_mov_b32 m0, %[l3]\n\ts_mov_b64 exec, %[e3]\n\tglobal_load_lds_dwordx4 %[a3], %[base]\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [sv] "=&s"(save)
+                         : [a0] "v"((r0 << 6) | piece), [a1] "v"((r1 << 6) | piece), [a2] "v"((r2 << 6) | piece), [a3] "v"((r3 << 6) | piece),
+                           [base] "s"(records), [l0] "s"(stage_lds), [l1] "s"(stage_lds + kStageRow), [l2] "s"(stage_lds + 2u * kStageRow),
+                           [l3] "s"(stage_lds + 3u * kStageRow), [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [e3] "s"(e3)
+                         : "memory", "m0");
+#elif VT_EXP_DMA_MASK
             const uint32_t need = (do_tri || want_node) ? 1u : 0u;
             if (quad_broadcast<0>(need))
                 __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r0 << 6) | piece)), (lds_ptr)(uintptr_t)(stage_lds + 0u * kStageRow), 16, 0, 0);
@@ -963,6 +981,8 @@ template <bool ALPHA>
 hipError_t dispatch(const TraceArgs* a, bool any_hit, bool stats, bool persistent, bool fetch_dma, dim3 grid,
                     size_t lds_bytes, hipStream_t stream, int* occ)
 {
+    // any-hit counters (vt_trace_any_stats_dev): one variant, one ray per lane -- counters do not depend on the schedule
+    if (any_hit && stats) return variant_op<true, true, false, false, ALPHA>(a, grid, lds_bytes, stream, occ);
     if (persistent && fetch_dma) {
         if (any_hit) return variant_op<true, false, true, true, ALPHA>(a, grid, lds_bytes, stream, occ);
         if (stats)   return variant_op<false, true, true, true, ALPHA>(a, grid, lds_bytes, stream, occ);

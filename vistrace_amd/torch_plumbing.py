@@ -50,6 +50,14 @@ def trace_stats(scene, d_rays: torch.Tensor, n: int):
     return d_hits, d_stats
 
 
+def trace_any_stats(scene, d_rays: torch.Tensor, n: int):
+    d_occ = torch.empty(n, dtype=torch.uint8, device=d_rays.device)
+    d_stats = empty_records(n, RAY_STATS, d_rays.device)
+    scene.trace_any_stats_dev(d_rays.data_ptr(), n, d_occ.data_ptr(), d_stats.data_ptr(),
+                              current_stream_handle(d_rays.device))
+    return d_occ, d_stats
+
+
 def hit_attrs(scene, d_rays: torch.Tensor, d_hits: torch.Tensor, n: int) -> torch.Tensor:
     d_attrs = empty_records(n, HIT_ATTRS, d_rays.device)
     scene.hit_attrs_dev(d_rays.data_ptr(), d_hits.data_ptr(), n, d_attrs.data_ptr(),
@@ -65,4 +73,4 @@ def bounce_loop(scene, d_rays: torch.Tensor, n: int, depth: int, seed: int):
 
 
 __all__ = ["to_device", "to_host", "empty_records", "current_stream_handle", "trace_closest", "trace_any",
-           "trace_stats", "hit_attrs", "bounce_loop", "RAY", "HIT"]
+           "trace_stats", "trace_any_stats", "hit_attrs", "bounce_loop", "RAY", "HIT"]
