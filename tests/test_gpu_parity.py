@@ -705,6 +705,46 @@ def test_alpha_test_in_kernel(va, engine, O):
     assert_hits_equal(got, ref)
     assert (st["steps"] == ref_st[:, 0]).all() and (st["tests"] == ref_st[:, 1]).all()
     assert_hits_equal(scene.trace_closest(rays[:200]), ref[:200])        # tiny host batch, one ray per lane
+    # every kernel form runs the alpha test as lane states (parked candidate -> AlphaRec -> texels): same bytes
+    saved = {k: engine.get_option(k) for k in ("persistent", "fetch_dma")}
+    try:
+        for cfg in (dict(persistent=0), dict(persistent=1, fetch_dma=0), dict(persistent=1, fetch_dma=1)):
+            for k, v in cfg.items():
+                engine.set_option(k, v)
+            assert_hits_equal(scene.trace_closest(rays), ref)
+            assert (scene.trace_any(rays) == (any_ref["prim"] != O_MISS)).all()
+    finally:
+        for k, v in saved.items():
+            engine.set_option(k, v)
+    # materials beyond the table: the reference's test is skipped for them, the geometric hit stands
+    attribs2 = attribs.copy()
+    attribs2["material"][::3] = len(mats) + 5
+    scene.set_tri_attribs(attribs2.view(va.TRI_ATTRIBS))
+    try:
+        O.set_alpha(otris, attribs2["uv"].reshape(n, 6), attribs2["material"], mats.view(O.ALPHA_MATERIAL), texels)
+        ref2 = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays)[0]
+    finally:
+        O.set_alpha()
+    assert int((ref2["prim"] != ref["prim"]).sum()) > 100
+    assert_hits_equal(scene.trace_closest(rays), ref2)
+    scene.free()
+    # a scene uploaded WITHOUT flagged triangles whose refit switches the test on (the record array grows once)
+    tris0 = va.tris_setup(verts)
+    bvh0 = va.HostBvh(tris0)
+    scene0 = va.Scene(engine, va.HostScene(bvh0))
+    scene0.set_tri_attribs(attribs.view(va.TRI_ATTRIBS))
+    scene0.set_alpha(mats.view(va.ALPHA_MATERIAL), texels)
+    assert_hits_equal(scene0.trace_closest(rays), plain)
+    scene0.refit(verts, flags)
+    otris0 = O.tris_from_tri64(tris0)
+    otris0["flags"] = flags
+    try:
+        O.set_alpha(otris0, attribs["uv"].reshape(n, 6), attribs["material"], mats.view(O.ALPHA_MATERIAL), texels)
+        ref0 = O.traverse_batch(bvh0.nodes().view(O.NODE), bvh0.prim_indices(), otris0, rays)[0]
+    finally:
+        O.set_alpha()
+    assert_hits_equal(scene0.trace_closest(rays), ref0)
+    scene0.free()
 
 
 def test_scene_outliving_its_engine_is_inert(va, make_bundle):

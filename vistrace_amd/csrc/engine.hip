@@ -59,7 +59,7 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool 
     p.persistent = e->persistent == 1 || (e->persistent == 2 && n > factor * e->cu_count * 8 * kBlockThreads);
     if (any_hit && stats) p.persistent = false;        // the any-hit counters kernel exists as the one-ray-per-lane variant only
     // the DMA-fetch kernel addresses records as base + 32-bit byte offset: scenes below 4 GiB
-    const uint64_t rec_bytes = (uint64_t(s->interleaved ? s->npairs : s->tri_base) + s->ntris) * 64;
+    const uint64_t rec_bytes = uint64_t(s->record_capacity) * 64;
     p.fetch_dma = p.persistent && e->fetch_dma != 0 && rec_bytes < (uint64_t(1) << 32);
     const uint64_t blocks_for_rays = (n + kBlockThreads - 1) / kBlockThreads;
     if (p.persistent) {
@@ -102,7 +102,7 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     if (n == 0) return VT_OK;
     if (s->poisoned)
         return fail(VT_ERR_INVALID_ARG, "the scene was last refitted with non-finite vertex positions; refit it with finite data");
-    if (s->has_alpha && (!s->d_attribs || !s->d_alpha_mats))
+    if (s->has_alpha && (!s->d_attribs || !s->d_alpha_mats || !s->alpha_ready))
         return fail(VT_ERR_UNSUPPORTED, "the scene holds alpha-tested triangles (Primitives.h:196-208): call "
                                         "vt_scene_set_tri_attribs and vt_scene_set_alpha before tracing");
     LaunchPlan p;
@@ -153,10 +153,8 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     a.tri_threshold = std::min(std::max(e->tri_threshold, 1u), 64u);
     a.coherent_detect = e->coherent_detect;
     a.coherent_radius2 = s->coherent_radius2;
-    a.attribs = s->d_attribs;
-    a.alpha_mats = s->d_alpha_mats;
+    a.alpha_base = s->alpha_base;
     a.alpha_texels = s->d_alpha_texels;
-    a.n_alpha_mats = s->n_alpha_mats;
     a.reserved_cus = p.persistent && e->reserved_cus ? e->d_reserved : nullptr;
     a.cu_slots = d_cu_slots;
     a.reserved_limit = e->reserved_limit;
@@ -240,6 +238,39 @@ float packet_radius2(const vt_node_pair& root)
         if (ext == ext && ext > 0.f && ext < 1e18f) d2 += ext * ext;
     }
     return 0.02f * 0.02f * d2;
+}
+
+// The AlphaRecs of a scene with alpha-tested triangles (trace_kernels.h): room for them behind the triangles (the record
+// array is re-allocated once if the scene was uploaded without any flagged triangle), then one kernel over the slots.
+// The engine's device is current and idle (the callers synchronise first).
+int build_alpha_records(vt_scene* s)
+{
+    s->alpha_ready = false;
+    if (!s->has_alpha || !s->d_attribs || !s->d_alpha_mats || s->ntris == 0) return VT_OK;
+    if (s->interleaved) return fail(VT_ERR_UNSUPPORTED, "alpha-tested triangles are not available with VT_LAYOUT_INTERLEAVE");
+    vt_engine* e = s->engine;
+    if (s->alpha_base == 0) {
+        const uint32_t base = (s->tri_base + s->ntris + 1u) & ~1u;
+        const size_t cap = size_t(base) + s->ntris;
+        char* grown = nullptr;
+        VT_HIP(hipMalloc(reinterpret_cast<void**>(&grown), cap * 64));
+        hipError_t err = hipMemset(grown, 0, cap * 64);
+        if (err == hipSuccess) err = hipMemcpy(grown, s->d_records, s->record_capacity * 64, hipMemcpyDeviceToDevice);
+        if (err != hipSuccess) { (void)hipFree(grown); return fail(VT_ERR_HIP, std::string("alpha records: ") + hipGetErrorString(err)); }
+        (void)hipFree(s->d_records);
+        s->bytes += (cap - s->record_capacity) * 64;
+        s->d_records = grown;
+        s->d_tris = reinterpret_cast<vt_tri64*>(grown + size_t(s->tri_base) * 64);
+        s->record_capacity = cap;
+        s->alpha_base = base;
+        if (s->refit_graph) { (void)hipGraphExecDestroy(s->refit_graph); s->refit_graph = nullptr; }   // it captured the old pointers
+    }
+    AlphaRecArgs a{s->d_tris, s->d_attribs, s->d_alpha_mats, s->n_alpha_mats,
+                   reinterpret_cast<AlphaRec*>(s->d_records + size_t(s->alpha_base) * 64), s->ntris};
+    VT_HIP(launch_alpha_records(a, e->stream));
+    VT_HIP(hipStreamSynchronize(e->stream));
+    s->alpha_ready = true;
+    return VT_OK;
 }
 
 long env_long(const char* name, long dflt)
@@ -436,7 +467,7 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
     s->interleaved = env_long("VT_LAYOUT_INTERLEAVE", 0) != 0 && !hs.pairs.empty();
     std::vector<uint32_t> pair_at;                       // interleaved: record index of pair i
     hipError_t err = hipSuccess;
-    if (uint64_t(s->npairs) + s->ntris + 2 >= 0xFFFFFFFFull) { delete s; return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: scene too large"); }
+    if (uint64_t(s->npairs) + 2 * uint64_t(s->ntris) + 4 >= 0xFFFFFFFFull) { delete s; return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: scene too large"); }
     if (s->interleaved) {
         std::vector<uint32_t> tri_at(hs.tris.size());
         pair_at.resize(hs.pairs.size());
@@ -463,6 +494,7 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
             prim_to_slot[hs.tris[j].prim] = tri_at[j];
         }
         s->tri_base = 0;
+        s->record_capacity = std::max<size_t>(recs.size(), 2);
         const size_t rec_bytes = std::max<size_t>(recs.size() * 64, 128);
         err = hipMalloc(reinterpret_cast<void**>(&s->d_records), rec_bytes);
         if (err == hipSuccess) err = hipMemset(s->d_records, 0, rec_bytes);
@@ -473,8 +505,12 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
         s->tri_base = (s->npairs + 1u) & ~1u;
         const size_t pair_bytes = hs.pairs.size() * sizeof(vt_node_pair);
         const size_t tri_off = size_t(s->tri_base) * 64, tri_bytes = hs.tris.size() * sizeof(vt_tri64);
+        // a scene with alpha-tested triangles keeps one AlphaRec per triangle slot behind the triangles (filled once
+        // vt_scene_set_tri_attribs and vt_scene_set_alpha have both been called)
+        if (has_alpha) s->alpha_base = (s->tri_base + s->ntris + 1u) & ~1u;
+        s->record_capacity = std::max<size_t>(has_alpha ? size_t(s->alpha_base) + s->ntris : size_t(s->tri_base) + s->ntris, 2);
         // never empty: idle lanes of the DMA-fetch kernel read record 0, so it must exist (zeros for an empty scene)
-        const size_t rec_bytes = std::max<size_t>(tri_off + tri_bytes, 128);
+        const size_t rec_bytes = s->record_capacity * 64;
         err = hipMalloc(reinterpret_cast<void**>(&s->d_records), rec_bytes);
         if (err == hipSuccess) err = hipMemset(s->d_records, 0, rec_bytes);
         if (err == hipSuccess && pair_bytes) err = hipMemcpy(s->d_records, hs.pairs.data(), pair_bytes, hipMemcpyHostToDevice);
@@ -889,6 +925,7 @@ int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32
                      s->d_prim_to_slot, s->d_tris, n, s->d_bad};
     VT_HIP(launch_refit_tris(ta, e->stream));
     rc = refit_levels(s);
+    if (rc == VT_OK && flags && s->has_alpha && !s->alpha_ready) rc = build_alpha_records(s);   // the flags switched the test on
     return rc != VT_OK ? rc : end_finite_check(s, "vt_scene_refit");
 }
 
@@ -997,8 +1034,9 @@ int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_
         VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_attribs), bytes));
         s->bytes += bytes;
     }
+    VT_HIP(hipDeviceSynchronize());                  // traces in flight may read the AlphaRecs derived from the old table
     VT_HIP(hipMemcpy(s->d_attribs, attribs, bytes, hipMemcpyHostToDevice));
-    return VT_OK;
+    return build_alpha_records(s);
 }
 
 int vt_scene_set_alpha(vt_scene* s, const vt_alpha_material* mats, uint32_t nmats, const uint8_t* texels, uint64_t ntexels)
@@ -1013,6 +1051,9 @@ int vt_scene_set_alpha(vt_scene* s, const vt_alpha_material* mats, uint32_t nmat
         if ((m.width == 0) != (m.height == 0)) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_alpha: width and height must both be 0 or both be set");
         if (m.width && (m.offset > ntexels || uint64_t(m.width) * m.height > ntexels - m.offset || !texels))
             return fail(VT_ERR_INVALID_ARG, "vt_scene_set_alpha: an alpha plane lies outside the texel array");
+        // what one 64-B AlphaRec can hold (trace_kernels.h): 16-bit plane sides, 31-bit texel offsets
+        if (m.width > 65535u || m.height > 65535u || (m.width && m.offset >= (uint64_t(1) << 31)))
+            return fail(VT_ERR_UNSUPPORTED, "vt_scene_set_alpha: alpha planes are limited to 65535 x 65535 texels and 2 GiB of texels in all");
     }
     vt_engine* e = s->engine;
     DeviceGuard guard(e->device);
@@ -1026,7 +1067,7 @@ int vt_scene_set_alpha(vt_scene* s, const vt_alpha_material* mats, uint32_t nmat
     if (ntexels) VT_HIP(hipMemcpy(s->d_alpha_texels, texels, ntexels, hipMemcpyHostToDevice));
     s->n_alpha_mats = nmats;
     s->bytes += size_t(nmats) * sizeof(vt_alpha_material) + ntexels;
-    return VT_OK;
+    return build_alpha_records(s);
 }
 
 int vt_hit_shade_dev(vt_scene* s, const void* d_hits, uint64_t n, void* d_out, void* stream)

@@ -137,6 +137,11 @@ struct vt_scene {
     vt_alpha_material* d_alpha_mats = nullptr;
     uint8_t*           d_alpha_texels = nullptr;
     uint32_t           n_alpha_mats = 0;
+    // ... and what the kernels read: one 64-B AlphaRec per triangle slot behind the triangles in d_records (built from
+    // the two side tables by alpha_records_kernel whenever either changes; trace_kernels.h)
+    uint32_t           alpha_base = 0;        // record index of slot 0's AlphaRec; 0 = no room reserved yet
+    bool               alpha_ready = false;
+    size_t             record_capacity = 0;   // 64-B records allocated at d_records
     // refit / skinning with non-finite vertices: NaN boxes pass every slab test, so a poisoned subtree is walked by
     // every ray -- the scene is refused until it has been refitted with finite data
     float           coherent_radius2 = 0.f;   // (2 % of the scene's diagonal)^2: how far apart the origins of a ray packet may lie

@@ -29,11 +29,9 @@ struct TraceArgs {
     uint32_t            tri_threshold;    // run the TRI branch once this many lanes wait for it
     uint32_t            coherent_detect;  // DMA kernel: per-wave octant probe -> direct fetch, whole-wave re-fill
     float               coherent_radius2; // ... only for rays whose origins lie within this squared distance of the first
-    // alpha test (ALPHA variants only): per-triangle uvs + material (original order), materials, alpha planes
-    const vt_tri_attribs*     attribs;
-    const vt_alpha_material*  alpha_mats;
+    // alpha test (ALPHA variants only): record index of the AlphaRec of triangle slot 0, the alpha planes
+    uint32_t                  alpha_base;
     const uint8_t*            alpha_texels;
-    uint32_t                  n_alpha_mats;
     uint32_t            xcd_cursors;      // persistent mode: 1 = one cursor per XCD (block_cursor[16 * xcd]), each over its own
                                           // eighth of the ray blocks, with stealing; 0 = one global cursor
     uint32_t            nblocks;          // ray blocks in the batch
@@ -42,6 +40,21 @@ struct TraceArgs {
     uint32_t*           cu_slots;         // 1024 counters (zeroed per launch): blocks that asked to stay on a reserved CU
     uint32_t            reserved_limit;   // blocks a reserved CU keeps (0 = none)
 };
+
+// One per triangle slot of a scene with alpha-tested triangles, in the scene's record array behind the triangles (so
+// the walk fetches it like any other record): what Primitives.h:196-208 needs of the triangle and of its material.
+struct AlphaRec {
+    float    uv[3][2];        // vt_tri_attribs::uv
+    float    m[2][3];         // per row of Material::baseTexMat: [0], [1], [2] + [3]
+    float    tex_scale, alpha_ref;
+    uint32_t dims;            // width | height << 16; 0 = no texture (alpha 1); kAlphaAlwaysPass = material out of range
+    uint32_t offset_filter;   // first texel of the plane (31 bits) | filter << 31
+};
+static_assert(sizeof(AlphaRec) == 64, "an AlphaRec is one 64-B record");
+constexpr uint32_t kAlphaAlwaysPass = 0xFFFFFFFFu;
+struct AlphaRecArgs { const vt_tri64* tris; const vt_tri_attribs* attribs; const vt_alpha_material* mats; uint32_t n_mats;
+                      AlphaRec* out; uint32_t n; };
+hipError_t launch_alpha_records(const AlphaRecArgs& a, hipStream_t stream);
 
 struct HitAttrsArgs {
     const vt_tri64* tris;

@@ -138,6 +138,11 @@ struct Lane {
     uint32_t tri_cur, tri_end; // pending leaf triangles
     uint32_t sp;               // stack entries in use
     uint32_t steps, tests;
+    // ALPHA variants: a parked candidate hit (Primitives.h:196-208 decides whether it counts)
+    uint32_t astate;           // 0 none, 1 = wants its triangle's AlphaRec, 2 = texels requested
+    uint32_t cprim;  float cu, cv, ct;
+    float ax, ay, aref;        // state 2: bilinear weights (ax < 0: nearest, one texel) and the material's reference
+    uint32_t tx0, tx1, tx2, tx3;   // state 2: destinations of the texel loads in flight
 };
 
 typedef __attribute__((address_space(1))) const void* global_cptr;
@@ -154,46 +159,40 @@ constexpr uint32_t kStageBytes = 4 * kStageRow;  // the four rows start on diffe
 // ---- alpha test inside intersect(): Primitives.h:196-208, TransformTexcoord Utils.h:65-72 -------------------
 // The texel lookup (IVTFTexture::Sample lives in the absent VTFParser submodule) is the one defined in
 // include/vistrace_hip.h at vt_alpha_material: mip 0 alpha plane, repeat addressing, nearest or bilinear.
+// In the ALPHA kernel variants the test is two more states of a lane instead of a call inside the triangle test: a
+// candidate hit on a flagged triangle is parked, the lane's next record is the triangle's 64-B AlphaRec (uvs + the
+// material's transform, through the same fetch as every other record), the texels are requested when it arrives and
+// judged one round later -- the wave never waits for one lane's dependent loads (profiles/r3/notes.md).
 __device__ __forceinline__ uint32_t wrap_index(float f, uint32_t n)
 {
-    const long long i = (long long)f;            // f is integral and |f| < 1e9
-    const long long m = i % (long long)n;
-    return uint32_t(m < 0 ? m + (long long)n : m);
+    const int i = int(f);                        // f is integral and |f| < 1e9: fits; n <= 65535
+    const int m = i % int(n);
+    return uint32_t(m < 0 ? m + int(n) : m);
 }
 
-__device__ __forceinline__ bool alpha_pass(const TraceArgs& a, uint32_t prim, float u, float v)
+// one thread per triangle slot: the AlphaRec of the triangle in that slot from the caller's side tables
+__global__ __launch_bounds__(kBlockThreads) void alpha_records_kernel(AlphaRecArgs a)
 {
+    const uint32_t slot = blockIdx.x * kBlockThreads + threadIdx.x;
+    if (slot >= a.n) return;
+    const uint32_t prim = a.tris[slot].prim;
     const vt_tri_attribs A = a.attribs[prim];
-    if (A.material >= a.n_alpha_mats) return true;
-    const vt_alpha_material M = a.alpha_mats[A.material];
-    const float w = 1.0f - u - v;                                                       // :198
-    const float tx = (w * A.uv[0][0] + u * A.uv[1][0]) + v * A.uv[2][0];
-    const float ty = (w * A.uv[0][1] + u * A.uv[1][1]) + v * A.uv[2][1];
-    const float s = ((tx * M.tex_mat[0][0] + ty * M.tex_mat[0][1]) + (M.tex_mat[0][2] + M.tex_mat[0][3])) * M.tex_scale;
-    const float t = ((tx * M.tex_mat[1][0] + ty * M.tex_mat[1][1]) + (M.tex_mat[1][2] + M.tex_mat[1][3])) * M.tex_scale;
-    float alpha = 1.0f;
-    if (M.width != 0 && M.height != 0) {
-        const uint8_t* img = a.alpha_texels + M.offset;
-        float x = s * float(M.width), y = t * float(M.height);
-        if (!(fabsf(x) < 1.0e9f)) x = 0.0f;
-        if (!(fabsf(y) < 1.0e9f)) y = 0.0f;
-        if (M.filter == 0) {
-            const uint32_t xi = wrap_index(floorf(x), M.width), yi = wrap_index(floorf(y), M.height);
-            alpha = float(img[size_t(yi) * M.width + xi]) / 255.0f;
-        } else {
-            const float fx = x - 0.5f, fy = y - 0.5f;
-            const float x0 = floorf(fx), y0 = floorf(fy);
-            const float ax = fx - x0, ay = fy - y0;
-            const uint32_t i0 = wrap_index(x0, M.width), i1 = wrap_index(x0 + 1.0f, M.width);
-            const uint32_t j0 = wrap_index(y0, M.height), j1 = wrap_index(y0 + 1.0f, M.height);
-            const float a00 = float(img[size_t(j0) * M.width + i0]), a10 = float(img[size_t(j0) * M.width + i1]);
-            const float a01 = float(img[size_t(j1) * M.width + i0]), a11 = float(img[size_t(j1) * M.width + i1]);
-            const float top = a00 * (1.0f - ax) + a10 * ax;
-            const float bot = a01 * (1.0f - ax) + a11 * ax;
-            alpha = (top * (1.0f - ay) + bot * ay) / 255.0f;
+    AlphaRec r;
+    for (int k = 0; k < 3; ++k) { r.uv[k][0] = A.uv[k][0]; r.uv[k][1] = A.uv[k][1]; }
+    if (A.material >= a.n_mats) {                // no such material: the reference's test is skipped, the hit stands
+        for (int q = 0; q < 2; ++q) r.m[q][0] = r.m[q][1] = r.m[q][2] = 0.0f;
+        r.tex_scale = 0.0f; r.alpha_ref = 0.0f; r.dims = kAlphaAlwaysPass; r.offset_filter = 0;
+    } else {
+        const vt_alpha_material M = a.mats[A.material];
+        for (int q = 0; q < 2; ++q) {
+            r.m[q][0] = M.tex_mat[q][0]; r.m[q][1] = M.tex_mat[q][1];
+            r.m[q][2] = M.tex_mat[q][2] + M.tex_mat[q][3];           // the sum TransformTexcoord forms first (Utils.h:65-72)
         }
+        r.tex_scale = M.tex_scale; r.alpha_ref = M.alpha_ref;
+        r.dims = M.width | (M.height << 16);
+        r.offset_filter = uint32_t(M.offset) | (M.filter << 31);
     }
-    return !(alpha < M.alpha_ref);                                                       // :205
+    a.out[slot] = r;
 }
 
 template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA>
@@ -236,6 +235,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
     }
 
     Lane L;
+    if constexpr (ALPHA) { L.astate = 0; L.tx0 = L.tx1 = L.tx2 = L.tx3 = 0; L.ax = L.ay = L.aref = 0.f; L.cprim = 0; L.cu = L.cv = L.ct = 0.f; }
     uint64_t ray_idx = 0;
     bool has_ray = false;
     [[maybe_unused]] uint32_t pf = 0;   // VT_EXP_PREFETCH: destination of the far-child prefetch, never read
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
         L.sx = -L.ox * L.ix; L.sy = -L.oy * L.iy; L.sz = -L.oz * L.iz;
         L.prim = VT_MISS; L.u = 0.f; L.v = 0.f;
         L.sp = 0; L.steps = 0; L.tests = 0;
+        if constexpr (ALPHA) L.astate = 0;
         if (a.root_leaf_count != 0) {        // the root is a leaf: no slab test at all
             L.node = kDone; L.tri_cur = 0; L.tri_end = a.root_leaf_count;
         } else {
@@ -416,21 +417,25 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
         }
 
         // ---- which record does this lane need? ----------------------------------------------
-        const bool want_tri  = has_ray && L.tri_cur < L.tri_end;
-        const bool want_node = has_ray && !want_tri;       // node != kDone is implied (else finished)
+        bool alpha1 = false, alpha2 = false;                // ALPHA: the lane's parked candidate waits for its AlphaRec / its texels
+        if constexpr (ALPHA) { alpha1 = has_ray && L.astate == 1; alpha2 = has_ray && L.astate == 2; }
+        const bool want_tri  = has_ray && !alpha1 && !alpha2 && L.tri_cur < L.tri_end;
+        const bool want_node = has_ray && !alpha1 && !alpha2 && !want_tri;       // node != kDone is implied (else finished)
         // the TRI branch runs only when enough lanes wait for it, or nobody can step a node
         const uint64_t tri_mask = __ballot(want_tri);
         const bool run_tri = tri_mask != 0 && (uint32_t(__popcll(tri_mask)) >= a.tri_threshold || __ballot(want_node) == 0);
         const bool do_tri = want_tri && run_tri;
         // idle lanes (no ray, or waiting for the TRI branch) fetch record 0 in the DMA form: an always-valid
         // address keeps the four DMA loads branch-free; the direct form skips them instead
-        const uint32_t rec = do_tri ? a.tri_base + L.tri_cur : (want_node ? L.node : (FETCH_DMA ? 0u : kNoFetch));
+        // (ALPHA: the AlphaRec of the triangle just tested sits at alpha_base + its slot; tri_cur is already past it)
+        const uint32_t rec = do_tri ? a.tri_base + L.tri_cur
+                                    : (want_node ? L.node : (alpha1 ? a.alpha_base + L.tri_cur - 1u : (FETCH_DMA ? 0u : kNoFetch)));
 
         float4 q0, q1, q2, q3;   // the record
         bool fetched = false;
         if constexpr (FETCH_DMA) {
             if (coherent) {      // wave-uniform
-                if (do_tri || want_node) {
+                if (do_tri || want_node || alpha1) {
                     const float4* g = reinterpret_cast<const float4*>(records + (size_t(rec) << 6));
                     q0 = g[0]; q1 = g[1]; q2 = g[2]; q3 = g[3];
                 }
@@ -538,11 +543,79 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
             bool hit = !culled && u >= 0.0f && v >= 0.0f && w >= 0.0f &&               // :187
                        t >= L.tmin && t <= L.tmax;                                     // :189
             if constexpr (ALPHA) {                                                     // :196-208
-                if (hit && (tflags & VT_TRI_ALPHATEST)) hit = alpha_pass(a, tprim, u, v);
+                if (hit && (tflags & VT_TRI_ALPHATEST)) {        // the candidate is parked until its alpha is known
+                    L.astate = 1; L.cprim = tprim; L.cu = u; L.cv = v; L.ct = t;
+                    hit = false;
+                }
             }
             if (hit) {
                 L.prim = tprim; L.u = u; L.v = v; L.tmax = t;
                 if constexpr (ANY_HIT) { L.tri_cur = L.tri_end; L.node = kDone; }
+            }
+        } else if (ALPHA && (alpha1 || alpha2)) {
+            if constexpr (ALPHA) {
+                bool decided = false, pass = false;
+                if (alpha2) {
+                    // ---- ALPHA 2: the texels requested one round ago: alpha, then :205.  (In program order BEFORE the block
+                    // that issues new texel loads, so the wait below never waits for loads of this round; with the DMA fetch
+                    // it is already satisfied -- the record wait of this round covered the older texel loads.)
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(L.tx0), "+v"(L.tx1), "+v"(L.tx2), "+v"(L.tx3) : : "memory");
+                    float alpha;
+                    if (L.ax < 0.0f) {
+                        alpha = float(L.tx0) / 255.0f;
+                    } else {
+                        const float a00 = float(L.tx0), a10 = float(L.tx1), a01 = float(L.tx2), a11 = float(L.tx3);
+                        const float top = a00 * (1.0f - L.ax) + a10 * L.ax;
+                        const float bot = a01 * (1.0f - L.ax) + a11 * L.ax;
+                        alpha = (top * (1.0f - L.ay) + bot * L.ay) / 255.0f;
+                    }
+                    decided = true; pass = !(alpha < L.aref);
+                }
+                if (alpha1) {
+                    // ---- ALPHA 1: the triangle's AlphaRec has arrived: texUV (:198), TransformTexcoord, texel addresses
+                    const float w = 1.0f - L.cu - L.cv;
+                    const float tx = (w * q0.x + L.cu * q0.z) + L.cv * q1.x;
+                    const float ty = (w * q0.y + L.cu * q0.w) + L.cv * q1.y;
+                    const float ss = ((tx * q1.z + ty * q1.w) + q2.x) * q3.x;
+                    const float tt = ((tx * q2.y + ty * q2.z) + q2.w) * q3.x;
+                    const uint32_t dims = __float_as_uint(q3.z), of = __float_as_uint(q3.w);
+                    L.aref = q3.y;
+                    if (dims == kAlphaAlwaysPass) { decided = true; pass = true; }
+                    else if (dims == 0u) { decided = true; pass = !(1.0f < L.aref); }         // no texture: alpha 1
+                    else {
+                        const uint32_t W = dims & 0xFFFFu, H = dims >> 16;
+                        const uint8_t* img = a.alpha_texels + (of & 0x7FFFFFFFu);
+                        float x = ss * float(W), y = tt * float(H);
+                        if (!(fabsf(x) < 1.0e9f)) x = 0.0f;
+                        if (!(fabsf(y) < 1.0e9f)) y = 0.0f;
+                        // the loads are issued behind the compiler's back (a load it knows of is waited for at the end of the
+                        // block): their destinations stay reserved until ALPHA 2 reads them one round later
+                        if ((of >> 31) == 0u) {
+                            const uint32_t xi = wrap_index(floorf(x), W), yi = wrap_index(floorf(y), H);
+                            asm volatile("global_load_ubyte %0, %1, off" : "=v"(L.tx0) : "v"(img + (size_t(yi) * W + xi)));
+                            L.ax = -1.0f; L.ay = 0.0f;
+                        } else {
+                            const float fx = x - 0.5f, fy = y - 0.5f;
+                            const float x0 = floorf(fx), y0 = floorf(fy);
+                            L.ax = fx - x0; L.ay = fy - y0;
+                            const uint32_t i0 = wrap_index(x0, W), i1 = wrap_index(x0 + 1.0f, W);
+                            const uint32_t j0 = wrap_index(y0, H), j1 = wrap_index(y0 + 1.0f, H);
+                            asm volatile("global_load_ubyte %0, %4, off\n\tglobal_load_ubyte %1, %5, off\n\t"
+                                         "global_load_ubyte %2, %6, off\n\tglobal_load_ubyte %3, %7, off"
+                                         : "=&v"(L.tx0), "=&v"(L.tx1), "=&v"(L.tx2), "=&v"(L.tx3)
+                                         : "v"(img + (size_t(j0) * W + i0)), "v"(img + (size_t(j0) * W + i1)),
+                                           "v"(img + (size_t(j1) * W + i0)), "v"(img + (size_t(j1) * W + i1)));
+                        }
+                        L.astate = 2;
+                    }
+                }
+                if (decided) {
+                    L.astate = 0;
+                    if (pass) {
+                        L.prim = L.cprim; L.u = L.cu; L.v = L.cv; L.tmax = L.ct;
+                        if constexpr (ANY_HIT) { L.tri_cur = L.tri_end; L.node = kDone; }
+                    }
+                }
             }
         } else if (want_node) {
             // ---- NODE: one iteration of SingleRayTraverser::traverse -------------------
@@ -617,7 +690,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
             }
             L.node = next;
         }
-        if (has_ray && L.node == kDone && L.tri_cur >= L.tri_end) finish_ray();
+        if (has_ray && L.node == kDone && L.tri_cur >= L.tri_end && (!ALPHA || L.astate == 0)) finish_ray();
     }
 }
 
@@ -1029,6 +1102,13 @@ hipError_t launch_cu_probe(uint32_t* seen, uint32_t blocks, hipStream_t stream)
 {
     const int lds = 60 * 1024;
     hipLaunchKernelGGL(cu_probe_kernel, dim3(blocks), dim3(kBlockThreads), lds, stream, seen);
+    return hipGetLastError();
+}
+
+hipError_t launch_alpha_records(const AlphaRecArgs& a, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(alpha_records_kernel, dim3((a.n + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, stream, a);
     return hipGetLastError();
 }
 
