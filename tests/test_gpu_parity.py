@@ -536,8 +536,9 @@ def test_device_refit_matches_host_refit(va, engine, O):
     brute = O.trace_brute(otris, rays)
     assert (brute["t"].view(np.uint32) == got["t"].view(np.uint32)).all()
     # the single-ray path walks the host copy: stale until it is synchronised with the device
-    stale = scene.host_scene.trace_closest_host(rays)
-    assert not (stale.view(np.uint8) == ref.view(np.uint8)).all()
+    with pytest.raises(va._lib.VisTraceError) as stale:
+        scene.host_scene.trace_closest_host(rays)
+    assert "vt_host_scene_sync" in str(stale.value)
     scene.sync_host_scene()
     assert (scene.host_scene.tris().view(np.uint8) == dtris.view(np.uint8)).all()
     assert_hits_equal(scene.host_scene.trace_closest_host(rays), ref)

@@ -488,6 +488,9 @@ void refine_nodes(std::vector<vt_bvh_node>& N, int nthreads, int passes, float f
             std::pop_heap(heap.begin(), heap.end());
             const Entry e = heap.back(); heap.pop_back();
             if (!(e.cost + xa < best_cost)) break;                      // nothing below can beat the best position
+            // subtrees of non-finite triangles carry the empty box (area +inf): never a position, never searched -- an
+            // induced cost of -inf would otherwise draw every re-insertion into them and give them a real box
+            if (!(area[size_t(e.node)] <= FLT_MAX)) continue;
             const float direct = half_area(box_union(box[size_t(e.node)], xb));
             const float total = e.cost + direct;
             if (e.node != root && total < best_cost) { best_cost = total; best = e.node; }

@@ -447,6 +447,7 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
 
     vt_scene* s = new vt_scene();
     s->engine = e;
+    s->host_stale = hsw->stale;
     s->has_alpha = has_alpha;
     if (!hs.pairs.empty()) s->coherent_radius2 = packet_radius2(hs.pairs[0]);
     s->npairs = uint32_t(hs.pairs.size());
@@ -924,6 +925,7 @@ int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32
     RefitTrisArgs ta{static_cast<const float*>(e->d_rays), flags ? static_cast<const uint8_t*>(e->d_out) : nullptr,
                      s->d_prim_to_slot, s->d_tris, n, s->d_bad};
     VT_HIP(launch_refit_tris(ta, e->stream));
+    if (s->host_stale) s->host_stale->store(1, std::memory_order_release);   // the host copy (single-ray path) is now out of date
     rc = refit_levels(s);
     if (rc == VT_OK && flags && s->has_alpha && !s->alpha_ready) rc = build_alpha_records(s);   // the flags switched the test on
     return rc != VT_OK ? rc : end_finite_check(s, "vt_scene_refit");
@@ -987,6 +989,7 @@ int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uin
     if (rc != VT_OK) return rc;
     SkinTrisArgs ta{s->d_bind_verts, s->d_skin, s->d_matrix_base, d_prod, s->d_prim_to_slot, s->d_tris, s->ntris, nmat, s->d_bad};
     VT_HIP(launch_skin_tris(ta, e->stream));
+    if (s->host_stale) s->host_stale->store(1, std::memory_order_release);
     rc = refit_levels(s);
     return rc != VT_OK ? rc : end_finite_check(s, "vt_scene_skin_refit");
 }
@@ -1016,6 +1019,7 @@ int vt_host_scene_sync(vt_host_scene* hsw, vt_scene* s)
     bool alpha = false;                                   // a refit may change the flags
     for (const vt_tri64& t : hs.tris) alpha |= (t.flags & VT_TRI_ALPHATEST) != 0;
     hs.has_alpha = alpha;
+    hsw->stale->store(0, std::memory_order_release);
     return VT_OK;
 }
 

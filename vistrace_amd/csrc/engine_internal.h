@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -150,6 +152,7 @@ struct vt_scene {
     hipGraphExec_t  refit_graph = nullptr;   // the level-by-level refit launches, captured once (launch-bound: ~30 tiny kernels)
     uint32_t      npairs = 0, ntris = 0, max_depth = 0, root_leaf_count = 0;
     uint64_t      bytes = 0;
+    std::shared_ptr<std::atomic<int>> host_stale;   // the vt_host_scene this scene was uploaded from: set by a device-side refit
     // multi-GPU group: the same scene on every peer device (replicas[g-1] lives on engine->peers[g-1]); owned by this scene
     std::vector<vt_scene*> replicas;
 };

@@ -92,10 +92,10 @@ void AccelStruct::PopulateAccel(ILuaBase* LUA, const World* pWorld)
     LUA->PushNil();
     while (LUA->Next(-2) != 0) {
         if (!LUA->IsType(-1, Type::Entity)) LUA->ThrowError("Build list must only contain entities");   // :575
-        if (g_meshSource) {
-            if (mEntities.size() >= 65535) LUA->ThrowError("Too many entities in build list");           // uint16_t entIdx
-            AppendEntity(LUA->GetUserdataRaw(-1, Type::Entity));
-        }
+        // entIdx is a uint16_t: the limit counts the entities the mesh source actually delivers, not the ones it skips;
+        // the raise happens here, after AppendEntity's locals are gone (ThrowError does not unwind C++ frames)
+        if (g_meshSource && !AppendEntity(LUA->GetUserdataRaw(-1, Type::Entity)))
+            LUA->ThrowError("Too many entities in build list");
         LUA->Pop();                                                     // pop value, keep key
     }
     LUA->Pop();                                                         // pop entity table (:760)
@@ -110,18 +110,20 @@ void AccelStruct::PopulateAccel(ILuaBase* LUA, const World* pWorld)
     mAccelBuilt = true;
 }
 
-void AccelStruct::AppendEntity(void* entityUserData)
+bool AccelStruct::AppendEntity(void* entityUserData)
 {
     Entity ent;
     std::vector<Triangle> tris;
     std::vector<Material> mats;
-    if (!g_meshSource->AppendEntity(entityUserData, ent, tris, mats)) return;
+    if (!g_meshSource->AppendEntity(entityUserData, ent, tris, mats)) return true;     // skipped by the source: not counted
+    if (mEntities.size() >= 65535) return false;
     const size_t matBase = mMaterials.size();
     const uint16_t entIdx = uint16_t(mEntities.size());
     for (Triangle& t : tris) { t.material += matBase; t.entIdx = entIdx; }
     mMaterials.insert(mMaterials.end(), mats.begin(), mats.end());
     mTriangles.insert(mTriangles.end(), tris.begin(), tris.end());
     mEntities.push_back(ent);
+    return true;
 }
 
 int AccelStruct::BuildAndUpload(vt_engine* eng)

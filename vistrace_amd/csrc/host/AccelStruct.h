@@ -59,7 +59,7 @@ private:
     std::vector<Material> mMaterials;
 
     void ReleaseDevice();
-    void AppendEntity(void* entityUserData);
+    bool AppendEntity(void* entityUserData);   // false: the entity table is full (65535)
     int  BuildAndUpload(vt_engine* eng);
     int  UploadAlphaTestData(const std::vector<uint8_t>& flags);
     TraceResult* MakeResult(const vt_ray& ray, const vt_hit& hit, float coneWidth, float coneAngle) const;

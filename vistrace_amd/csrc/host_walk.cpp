@@ -13,6 +13,8 @@
 // Built with -ffp-contract=off: no FMA contraction, IEEE divide.
 #include "vt_internal.h"
 
+#include <string>
+
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -191,13 +193,21 @@ using namespace vt;
 
 extern "C" {
 
+static int stale_error(const char* who)
+{
+    return fail(VT_ERR_INVALID_ARG, std::string(who) + ": the device scene uploaded from this host scene has been refitted since; "
+                                    "call vt_host_scene_sync first (the host copy would answer for the old geometry)");
+}
+
 int vt_host_scene_trace_closest(const vt_host_scene* hs, const vt_ray* rays, uint64_t n, vt_hit* hits)
 {
+    if (hs && hs->stale->load(std::memory_order_acquire) != 0) return stale_error("vt_host_scene_trace_closest");
     return trace<false>(hs, rays, n, hits, nullptr);
 }
 
 int vt_host_scene_trace_any(const vt_host_scene* hs, const vt_ray* rays, uint64_t n, uint8_t* occluded)
 {
+    if (hs && hs->stale->load(std::memory_order_acquire) != 0) return stale_error("vt_host_scene_trace_any");
     return trace<true>(hs, rays, n, nullptr, occluded);
 }
 

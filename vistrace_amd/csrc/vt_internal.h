@@ -3,7 +3,9 @@
 
 #include "vistrace_hip.h"
 
+#include <atomic>
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -59,4 +61,9 @@ int  fail(int code, const std::string& msg);
 } // namespace vt
 
 struct vt_bvh        { vt::Bvh bvh; };
-struct vt_host_scene { vt::HostScene hs; };
+// `stale` is shared with every vt_scene uploaded from this host scene: a device-side refit / skin refit sets it, the host walk
+// refuses to answer from records the device no longer holds until vt_host_scene_sync has fetched the new ones
+struct vt_host_scene {
+    vt::HostScene hs;
+    std::shared_ptr<std::atomic<int>> stale = std::make_shared<std::atomic<int>>(0);
+};
