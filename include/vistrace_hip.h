@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 2   /* 2: launch-slot ring, host walk, multi-GPU entries (additive over 1) */
+#define VT_ABI_VERSION 3   /* 2: launch-slot ring, host walk, multi-GPU entries; 3: vt_batch, any-hit counters, gather timing (all additive) */
 
 enum vt_status {
     VT_OK              = 0,
@@ -245,6 +245,23 @@ int vt_trace_any_stats_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_
 /* TraceResult batch materialisation from hits (d_attrs: n x vt_hit_attrs). */
 int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64_t n,
                      void* d_attrs, void* stream);
+
+/* ---- one traced batch, kept on the device (what a GLua `accel:TraverseBatch(buffer)` returns a handle to) -----------
+ * The reference builds one TraceResult per ray on the host (source/objects/AccelStruct.cpp:825-831,
+ * source/objects/TraceResult.cpp:45-86); for a batch that is N constructor calls and N allocations.  vt_batch keeps the
+ * batch where it was traced: vt_batch_trace_closest uploads the rays, traces them and materialises vt_hit_attrs (and
+ * vt_hit_shade when vt_scene_set_tri_attribs has been called) with the device kernels, all enqueued on the engine's
+ * stream; nothing comes back until it is asked for.  vt_batch_hits / _attrs / _shade download their array ONCE (first
+ * call; the pointer stays valid until vt_batch_free) -- a consumer that only reads distances never pays for the rest.
+ * The batch owns its device memory; free it before closing the engine (vt_engine_close releases what is left and the
+ * arrays not yet downloaded are then lost: the getters fail).  Single device (a group's root). */
+typedef struct vt_batch vt_batch;
+int      vt_batch_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_batch** out);
+uint64_t vt_batch_count(const vt_batch* b);
+int      vt_batch_hits(vt_batch* b, const vt_hit** hits);
+int      vt_batch_attrs(vt_batch* b, const vt_hit_attrs** attrs);
+int      vt_batch_shade(vt_batch* b, const vt_hit_shade** shade);     /* VT_ERR_INVALID_ARG without vt_scene_set_tri_attribs */
+void     vt_batch_free(vt_batch* b);
 
 /* Launch configuration (also readable from VT_* environment variables at vt_engine_open).  Keys:
  *   "persistent"         0 = one ray per lane, 1 = persistent waves, 2 = auto by batch size (default)

@@ -204,6 +204,13 @@ public:
     double GetNumber(int pos = -1) override { Value* v = at(pos); return v && v->type == Type::Number ? v->num : 0.0; }
     double CheckNumber(int pos = -1) override { CheckType(pos, Type::Number); return at(pos)->num; }
     bool GetBool(int pos = -1) override { Value* v = at(pos); return v && v->type == Type::Bool && v->b; }
+    const char* GetString(int pos = -1, unsigned int* outLen = nullptr) override
+    {
+        Value* v = at(pos);
+        if (!v || v->type != Type::String) { if (outLen) *outLen = 0; return nullptr; }
+        if (outLen) *outLen = unsigned(v->str.size());
+        return v->str.data();
+    }
     const ::Vector& GetVector(int pos = -1) override
     {
         static const ::Vector zero{0, 0, 0};

@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <functional>
@@ -14,6 +15,7 @@
 #include "Binding.h"
 #include "FakeLua.h"
 #include "TraceResult.h"
+#include "TraceResultBatch.h"
 
 using namespace vistrace;
 using fakelua::LuaError;
@@ -351,6 +353,87 @@ static void test_gpu_side()
         }
         CHECK(nhit > 10 && nhit < 400);
         L.Pop(L.Top());
+
+        // The same 400 rays as ONE packed buffer -> ONE TraceResultBatch userdata: every getter with the ray's index
+        // equals the per-ray TraceResult's getter (Pos: computed on the device, within 1e-5 relative)
+        std::string packed(400 * sizeof(vt_ray), '\0');
+        for (int i = 0; i < 400; ++i) {
+            const vt_ray r{{od[i].first.x, od[i].first.y, od[i].first.z}, {od[i].second.x, od[i].second.y, od[i].second.z}, 0.f, FLT_MAX};
+            std::memcpy(&packed[size_t(i) * sizeof(vt_ray)], &r, sizeof(r));
+        }
+        fakelua::Value bufv;
+        bufv.type = LT::String; bufv.str = packed;
+        CHECK(call_method(L, accelValue, "TraverseBatch", {bufv}) == 1);
+        CHECK(L.Top() == 1 && L.GetType(1) == TraceResultBatch::id);
+        const fakelua::Value rb = L.stack.back();
+        CHECK(call_method(L, rb, "Count") == 1 && L.GetNumber(-1) == 400.0);
+        CHECK(call_method(L, rb, "__tostring") == 1 && L.stack.back().str == "VisTraceResultBatch");
+        CHECK(call_method(L, rb, "Hits") == 1 && L.stack.back().type == LT::String && L.stack.back().str.size() == 400 * sizeof(vt_hit));
+        int bhit = 0;
+        auto close = [](float a, float b) { return std::fabs(a - b) <= 1e-5f * std::max(1.0f, std::fabs(b)); };
+        for (int i = 0; i < 400; ++i) {
+            const int got = call_traverse(L, accel, {State::Vec(od[i].first.x, od[i].first.y, od[i].first.z),
+                                                     State::Vec(od[i].second.x, od[i].second.y, od[i].second.z)});
+            const fakelua::Value one = got ? L.stack[0] : fakelua::Value();
+            const fakelua::Value idx = State::Num(double(i + 1));
+            CHECK(call_method(L, rb, "Hit", {idx}) == 1 && L.GetBool(-1) == (got == 1));
+            if (got != 1) {
+                CHECK(call_method(L, rb, "Pos", {idx}) == 0 && call_method(L, rb, "Distance", {idx}) == 0 && call_method(L, rb, "Get", {idx}) == 0);
+                continue;
+            }
+            ++bhit;
+            TraceResult* a = static_cast<TraceResult*>(*one.ud);
+            CHECK(call_method(L, rb, "Distance", {idx}) == 1 && float(L.GetNumber(-1)) == a->distance);
+            CHECK(call_method(L, rb, "Pos", {idx}) == 1);
+            const ::Vector bp = L.GetVector(-1);
+            const Vec3& ap = a->GetPos();
+            CHECK(close(bp.x, ap.x) && close(bp.y, ap.y) && close(bp.z, ap.z));
+            CHECK(call_method(L, rb, "Barycentric", {idx}) == 1 && L.GetVector(-1).x == a->uvw.x && L.GetVector(-1).y == a->uvw.y);
+            CHECK(call_method(L, rb, "GeometricNormal", {idx}) == 1 && close(L.GetVector(-1).z, a->geometricNormal.z));
+            CHECK(call_method(L, rb, "Incident", {idx}) == 1 && close(L.GetVector(-1).z, a->wo.z) && close(L.GetVector(-1).x, a->wo.x));
+            CHECK(call_method(L, rb, "FrontFacing", {idx}) == 1 && L.GetBool(-1) == a->frontFacing);
+            CHECK(call_method(L, rb, "SubMaterialIndex", {idx}) == 1 && L.GetNumber(-1) == double(a->submatIdx + 1));
+            CHECK(call_method(L, rb, "MaterialFlags", {idx}) == 1 && L.GetNumber(-1) == double(a->GetMaterialFlags()));
+            CHECK(call_method(L, rb, "SurfaceFlags", {idx}) == 1 && L.GetNumber(-1) == double(a->GetSurfFlags()));
+            CHECK(call_method(L, rb, "HitSky", {idx}) == 1 && L.GetBool(-1) == a->hitSky);
+            CHECK(call_method(L, rb, "HitWater", {idx}) == 1 && L.GetBool(-1) == a->HitWater());
+            CHECK(call_method(L, rb, "TextureUV", {idx}) == 1 && L.GetType(-1) == LT::Table);
+            {
+                const auto& uvkv = L.stack.back().tab->kv;
+                CHECK(uvkv.size() == 2 && close(float(uvkv[0].second.num), a->texUV.x) && close(float(uvkv[1].second.num), a->texUV.y));
+            }
+            CHECK(call_method(L, rb, "Entity", {idx}) == 1 && L.GetType(-1) == LT::Entity);
+            void* be_ent = L.GetUserdataRaw(-1, LT::Entity);
+            CHECK(call_method(L, one, "Entity") == 1 && L.GetUserdataRaw(-1, LT::Entity) == be_ent);
+            CHECK(call_method(L, rb, "Get", {idx}) == 1 && L.GetType(-1) == TraceResult::id);
+            TraceResult* g = static_cast<TraceResult*>(*L.stack.back().ud);
+            CHECK(g->primitiveIndex == a->primitiveIndex && g->distance == a->distance && g->uvw.x == a->uvw.x && g->wo.z == a->wo.z);
+            delete g;
+            delete a;
+            L.Pop(L.Top());
+        }
+        CHECK(bhit == nhit);
+        // validation: whole records, the range checks of Traverse on every ray, index range
+        std::string bad = packed.substr(0, 100);
+        fakelua::Value badv; badv.type = LT::String; badv.str = bad;
+        int barg = 0;
+        std::string bmsg = error_of([&] { call_method(L, accelValue, "TraverseBatch", {badv}); }, &barg);
+        CHECK(contains(bmsg, "whole 32-byte records") && barg == 2);
+        vt_ray neg{{0, 0, 1}, {0, 0, -1}, -1.f, 5.f};
+        std::memcpy(&packed[7 * sizeof(vt_ray)], &neg, sizeof(neg));
+        bufv.str = packed;
+        CHECK(error_of([&] { call_method(L, accelValue, "TraverseBatch", {bufv}); }) == "tMin cannot be less than 0");
+        bmsg = error_of([&] { call_method(L, rb, "Pos", {State::Num(401)}); }, &barg);
+        CHECK(contains(bmsg, "index out of range") && barg == 2);
+        bmsg = error_of([&] { call_method(L, rb, "Pos", {State::Num(0)}); }, &barg);
+        CHECK(contains(bmsg, "index out of range"));
+        // the batch outlives a Rebuild of its accel (it shares the tables it was traced against) and its own __gc is final
+        CHECK(call_method(L, accelValue, "Rebuild", {State::Nil(), State::Bool(false)}) == 0);
+        CHECK(call_method(L, rb, "SubMaterialIndex", {State::Num(1)}) <= 1);
+        CHECK(call_method(L, rb, "__gc") == 0);
+        CHECK(contains(error_of([&] { call_method(L, rb, "Count"); }), "released"));
+        CHECK(call_method(L, accelValue, "Rebuild", {State::Array({State::User(&dummyEntity, LT::Entity)})}) == 0);
+        L.Pop(L.Top());
     }
 
     // Rebuild(nil, false): no world, no entities -> empty but valid accel, every trace misses
@@ -360,7 +443,7 @@ static void test_gpu_side()
         CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1)}) == 0);
         // Rebuild({ent}) with the world again
         CHECK(call_method(L, accelValue, "Rebuild", {State::Array({State::User(&dummyEntity, LT::Entity), State::User(&dummyEntity, LT::Entity)})}) == 0);
-        CHECK(accel->TriangleCount() == 4 && src.calls == 3);
+        CHECK(accel->TriangleCount() == 4 && src.calls == 4);
         CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1)}) == 1);
         delete L.GetUserType<TraceResult>(1, TraceResult::id);
     }
@@ -464,10 +547,107 @@ static void bench_single_calls()
     SetWorld(nullptr);
 }
 
+// The batch boundary end to end, through the fake Lua state: accel:TraverseBatch(table of ray tables) -> table of
+// TraceResults (the per-ray cost of the reference's interface: N table parses, N constructors) against
+// accel:TraverseBatch(packed buffer) -> one TraceResultBatch, then one getter over every ray.
+static void bench_batch_forms()
+{
+    State L;
+    RegisterTracingApi(&L);
+    World world;
+    world.materials.push_back(Material{"brush/floor", MATFLAG_NONE});
+    world.entities.push_back(Entity{nullptr, 0});
+    const int k = 224;                                          // 224 x 224 x 2 = 100 352 triangles
+    auto height = [](int i, int j) { return 6.0f * float((i * 7 + j * 13) % 11) / 11.0f; };
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) {
+            const float x0 = float(i) * 4 - 448, x1 = x0 + 4, y0 = float(j) * 4 - 448, y1 = y0 + 4;
+            world.triangles.push_back(make_tri({x0, y0, height(i, j)}, {x1, y0, height(i + 1, j)}, {x0, y1, height(i, j + 1)}, false, 0));
+            world.triangles.push_back(make_tri({x1, y0, height(i + 1, j)}, {x1, y1, height(i + 1, j + 1)}, {x0, y1, height(i, j + 1)}, false, 0));
+        }
+    SetWorld(&world);
+    L.PushValue(State::Array({}));
+    L.PushBool(true);
+    CHECK(vistrace_CreateAccel(&L) == 1);
+    const fakelua::Value accelValue = L.stack.back();
+    uint64_t rng = 0xBA7C4ull;
+    auto next = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return float(rng >> 40) / 16777216.0f; };
+    const size_t nbuf = size_t(1) << 20, ntab = size_t(1) << 17;
+    std::vector<vt_ray> rays(nbuf);
+    for (vt_ray& r : rays) r = vt_ray{{next() * 800 - 400, next() * 800 - 400, 40.f}, {next() - 0.5f, next() - 0.5f, -1.f}, 0.f, FLT_MAX};
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+
+    // buffer form: 1 Mi rays
+    fakelua::Value bufv; bufv.type = LT::String; bufv.str.assign(reinterpret_cast<const char*>(rays.data()), nbuf * sizeof(vt_ray));
+    call_method(L, accelValue, "TraverseBatch", {bufv});       // warm-up (first launch, allocations)
+    { const fakelua::Value w = L.stack.back(); call_method(L, w, "__gc"); }
+    double best_trace = 1e9, best_dist = 1e9, best_pos = 1e9;
+    double sum = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        const auto t0 = clk::now();
+        CHECK(call_method(L, accelValue, "TraverseBatch", {bufv}) == 1);
+        const fakelua::Value rb = L.stack.back();
+        // what a consumer does first: one scalar per ray (forces the hit records to arrive)
+        const fakelua::Value* dist = L.find_method(rb.type, "Distance");
+        for (size_t i = 0; i < nbuf; ++i) {
+            L.stack.clear(); L.stack.push_back(rb); L.stack.push_back(State::Num(double(i + 1)));
+            if (dist->fn(&L) == 1) sum += L.stack.back().num;
+        }
+        const auto t1 = clk::now();
+        const fakelua::Value* pos = L.find_method(rb.type, "Pos");
+        for (size_t i = 0; i < nbuf; ++i) {
+            L.stack.clear(); L.stack.push_back(rb); L.stack.push_back(State::Num(double(i + 1)));
+            if (pos->fn(&L) == 1) sum += L.stack.back().vec.z;
+        }
+        const auto t2 = clk::now();
+        call_method(L, rb, "__gc");
+        best_dist = std::min(best_dist, secs(t0, t1));
+        best_pos = std::min(best_pos, secs(t1, t2));
+    }
+    {   // the call alone (upload + enqueue; nothing downloaded)
+        for (int rep = 0; rep < 3; ++rep) {
+            const auto t0 = clk::now();
+            call_method(L, accelValue, "TraverseBatch", {bufv});
+            const auto t1 = clk::now();
+            const fakelua::Value rb = L.stack.back();
+            call_method(L, rb, "__gc");
+            best_trace = std::min(best_trace, secs(t0, t1));
+        }
+    }
+    std::printf("batch boundary, buffer form, %zu rays: TraverseBatch call %.2f ms; call + Distance(i) for every ray %.2f ms = %.1f Mrays/s end to end; "
+                "+ Pos(i) for every ray %.2f ms\n", nbuf, best_trace * 1e3, best_dist * 1e3, double(nbuf) / best_dist / 1e6, best_pos * 1e3);
+
+    // table form: 128 Ki rays (a Lua table per ray in, a TraceResult per hit out)
+    std::vector<fakelua::Value> many;
+    many.reserve(ntab);
+    for (size_t i = 0; i < ntab; ++i)
+        many.push_back(State::Array({State::Vec(rays[i].org[0], rays[i].org[1], rays[i].org[2]), State::Vec(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2])}));
+    const fakelua::Value tabv = State::Array(many);
+    double best_tab = 1e9;
+    for (int rep = 0; rep < 2; ++rep) {
+        const auto t0 = clk::now();
+        CHECK(call_method(L, accelValue, "TraverseBatch", {tabv}) == 1);
+        const fakelua::Value res = L.stack.back();
+        for (auto& kv : res.tab->kv)
+            if (kv.second.type == TraceResult::id) { TraceResult* r = static_cast<TraceResult*>(*kv.second.ud); sum += r->distance; }
+        const auto t1 = clk::now();
+        for (auto& kv : res.tab->kv)
+            if (kv.second.type == TraceResult::id) delete static_cast<TraceResult*>(*kv.second.ud);
+        best_tab = std::min(best_tab, secs(t0, t1));
+        L.Pop(L.Top());
+    }
+    std::printf("batch boundary, table form, %zu rays: TraverseBatch + distance of every result %.2f ms = %.2f Mrays/s end to end (checksum %.3g)\n",
+                ntab, best_tab * 1e3, double(ntab) / best_tab / 1e6, sum);
+    CHECK(call_method(L, accelValue, "__gc") == 0);
+    SetWorld(nullptr);
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1 && std::strcmp(argv[1], "--bench") == 0) {
         bench_single_calls();
+        bench_batch_forms();
         std::printf("binding (bench): %d checks, %d failed\n", g_run, g_fail);
         return g_fail ? 1 : 0;
     }

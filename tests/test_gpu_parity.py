@@ -328,6 +328,46 @@ def test_full_size_properties_s1m(va, engine, make_bundle):
     assert np.percentile(err, 99.9) < 0.05 and err.max() < 2.0    # Source units; fp32 t at ~1e3 scale
 
 
+def test_batch_object_matches_the_separate_calls(va, engine, make_bundle):
+    """vt_batch (what accel:TraverseBatch(buffer) holds): hits, attrs and shade fetched lazily equal the separate
+    vt_trace_closest / vt_hit_attrs_dev / vt_hit_shade_dev calls byte for byte."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    scene = upload(va, engine, b)
+    n = len(b.tris)
+    attribs = np.zeros(n, va.TRI_ATTRIBS)
+    rng = np.random.default_rng(5)
+    attribs["uv"] = rng.random((n, 3, 2), dtype=np.float32)
+    attribs["alpha"] = rng.random((n, 3), dtype=np.float32)
+    attribs["ent_id"] = rng.integers(0, 100, n)
+    attribs["material"] = rng.integers(0, 7, n)
+    rays = np.concatenate([W.primary_rays(64, 64), W.sphere_rays(5000, 12, origin=(3000.0, 0.0, 0.0))])   # hits and misses
+    batch = scene.trace_batch(rays)
+    assert len(batch) == len(rays)
+    with pytest.raises(va._lib.VisTraceError):
+        batch.shade()                                           # no side table yet when the batch was traced
+    hits = batch.hits()
+    assert_hits_equal(hits, b.oracle(rays))
+    dev = torch.device("cuda", 0)
+    d_rays = tp.to_device(rays, dev)
+    d_hits = tp.trace_closest(scene, d_rays, len(rays))
+    ref_attrs = tp.to_host(tp.hit_attrs(scene, d_rays, d_hits, len(rays)), va.HIT_ATTRS)
+    assert (batch.attrs().view(np.uint8) == ref_attrs.view(np.uint8)).all()
+    batch.free()
+    scene.set_tri_attribs(attribs)
+    batch2 = scene.trace_batch(rays)
+    d_shade = tp.empty_records(len(rays), va.HIT_SHADE, dev)
+    scene.hit_shade_dev(d_hits.data_ptr(), len(rays), d_shade.data_ptr(), tp.current_stream_handle(dev))
+    torch.cuda.synchronize()
+    assert (batch2.shade().view(np.uint8) == tp.to_host(d_shade, va.HIT_SHADE).view(np.uint8)).all()
+    assert (batch2.hits().view(np.uint8) == hits.view(np.uint8)).all()
+    empty = scene.trace_batch(rays[:0])
+    assert len(empty) == 0 and len(empty.hits()) == 0
+    scene.free()
+
+
 def test_hit_shade_vs_oracle(va, engine, make_bundle, O):
     """texUV / blendFactor / entIdx / submatIdx (TraceResult.cpp:70,73-78) from the per-triangle
     side table: floats bit-identical to the oracle, ids exact, misses flagged."""

@@ -96,6 +96,12 @@ SYMBOLS = {
     "vt_trace_any_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
     "vt_trace_stats_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "vt_trace_any_stats_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
+    "vt_batch_trace_closest": (C.c_int, [_vp, _vp, _u64, C.POINTER(C.c_void_p)]),
+    "vt_batch_count": (_u64, [_vp]),
+    "vt_batch_hits": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
+    "vt_batch_attrs": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
+    "vt_batch_shade": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
+    "vt_batch_free": (None, [_vp]),
     "vt_hit_attrs_dev": (C.c_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     "vt_scene_refit": (C.c_int, [_vp, _vp, _vp, _u32]),
     "vt_scene_set_alpha": (C.c_int, [_vp, _vp, _u32, _vp, _u64]),

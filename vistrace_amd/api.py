@@ -167,6 +167,41 @@ def shard_bounds(n: int, ndev: int, g: int):
     return int(lo.value), int(hi.value)
 
 
+class Batch:
+    """One traced batch resident on the device (vt_batch): arrays are downloaded once, on first use."""
+
+    def __init__(self, handle, scene):
+        self._h, self._scene = handle, scene      # the scene (and its engine) must outlive the device arrays
+
+    def __len__(self) -> int:
+        return int(lib.vt_batch_count(self._h))
+
+    def _fetch(self, fn, dtype) -> np.ndarray:
+        p = C.c_void_p()
+        check(fn(self._h, C.byref(p)))
+        return _copy_from(p.value, len(self), dtype)
+
+    def hits(self) -> np.ndarray:
+        return self._fetch(lib.vt_batch_hits, HIT)
+
+    def attrs(self) -> np.ndarray:
+        return self._fetch(lib.vt_batch_attrs, HIT_ATTRS)
+
+    def shade(self) -> np.ndarray:
+        return self._fetch(lib.vt_batch_shade, HIT_SHADE)
+
+    def free(self) -> None:
+        if self._h:
+            lib.vt_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def comm_unique_id() -> bytes:
     """128-byte RCCL id for vt_engine_comm_init_rank (rank 0 creates it, the launcher distributes it)."""
     buf = (C.c_char * 128)()
@@ -321,6 +356,13 @@ class Scene:
 
     def trace_stats_dev(self, d_rays: int, n: int, d_hits: int, d_stats: int, stream: int = 0) -> None:
         check(lib.vt_trace_stats_dev(self._h, d_rays, n, d_hits, d_stats, stream or None))
+
+    def trace_batch(self, rays: np.ndarray) -> "Batch":
+        """vt_batch_trace_closest: the batch stays on the device; hits / attrs / shade come back when first asked for."""
+        rays = np.ascontiguousarray(rays, RAY)
+        h = C.c_void_p()
+        check(lib.vt_batch_trace_closest(self._h, ptr(rays) if len(rays) else None, len(rays), C.byref(h)))
+        return Batch(h, self)
 
     def trace_any_stats_dev(self, d_rays: int, n: int, d_occ: int, d_stats: int, stream: int = 0) -> None:
         check(lib.vt_trace_any_stats_dev(self._h, d_rays, n, d_occ, d_stats, stream or None))

@@ -353,6 +353,12 @@ void vt_engine_close(vt_engine* e)
         sc->engine = nullptr;
     }
     e->scenes.clear();
+    for (vt_batch* b : e->batches) {            // batches that outlive their engine keep what they have downloaded
+        if (b->d_mem) (void)hipFree(b->d_mem);
+        if (b->done) (void)hipEventDestroy(b->done);
+        b->d_mem = nullptr; b->done = nullptr; b->engine = nullptr;
+    }
+    e->batches.clear();
     for (vt_engine::LaunchSlot& sl : e->slots) {
         if (sl.d_overflow) (void)hipFree(sl.d_overflow);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -830,6 +836,114 @@ int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t dep
     VT_HIP(hipEventRecord(e->ev_loop, stream));
     e->loop_used = true;
     return VT_OK;
+}
+
+// ---- vt_batch: a traced batch that stays on the device (see the header) ------------------------------------------------
+int vt_batch_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_batch** out)
+{
+    if (!out) return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest: out is NULL");
+    *out = nullptr;
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest: the scene\'s engine has been closed");
+    if (n != 0 && !rays) return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest: rays is NULL");
+    vt_engine* e = s->engine;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_batch_trace_closest: hipSetDevice failed");
+    vt_batch* b = new vt_batch();
+    b->engine = e;
+    b->n = n;
+    if (n != 0) {
+        auto al = [](uint64_t x) { return (x + 255) & ~uint64_t(255); };
+        const uint64_t ray_b = al(n * sizeof(vt_ray)), hit_b = al(n * sizeof(vt_hit)), att_b = al(n * sizeof(vt_hit_attrs));
+        const uint64_t sha_b = s->d_attribs ? al(n * sizeof(vt_hit_shade)) : 0;
+        hipError_t err = hipMalloc(reinterpret_cast<void**>(&b->d_mem), ray_b + hit_b + att_b + sha_b);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&b->done, hipEventDisableTiming);
+        if (err != hipSuccess) { if (b->d_mem) (void)hipFree(b->d_mem); delete b; return fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err)); }
+        b->d_hits = b->d_mem + ray_b;
+        b->d_attrs = b->d_mem + ray_b + hit_b;
+        b->d_shade = sha_b ? b->d_mem + ray_b + hit_b + att_b : nullptr;
+        int rc = VT_OK;
+        {
+            std::lock_guard<std::mutex> host_lock(e->host_mu);
+            err = hipMemcpyAsync(b->d_mem, rays, n * sizeof(vt_ray), hipMemcpyHostToDevice, e->stream);
+            if (err != hipSuccess) rc = fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err));
+            if (rc == VT_OK) rc = launch(s, b->d_mem, n, b->d_hits, nullptr, nullptr, false, false, e->stream);
+            if (rc == VT_OK) {
+                HitAttrsArgs a{s->d_tris, s->d_prim_to_slot, reinterpret_cast<const vt_ray*>(b->d_mem), static_cast<const vt_hit*>(b->d_hits),
+                               static_cast<vt_hit_attrs*>(b->d_attrs), n};
+                err = launch_hit_attrs(a, e->stream);
+                if (err == hipSuccess && b->d_shade) {
+                    HitShadeArgs sa{s->d_attribs, static_cast<const vt_hit*>(b->d_hits), static_cast<vt_hit_shade*>(b->d_shade), n};
+                    err = launch_hit_shade(sa, e->stream);
+                }
+                if (err == hipSuccess) err = hipEventRecord(b->done, e->stream);
+                if (err != hipSuccess) rc = fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err));
+            }
+        }
+        if (rc != VT_OK) { (void)hipStreamSynchronize(e->stream); (void)hipFree(b->d_mem); (void)hipEventDestroy(b->done); delete b; return rc; }
+    }
+    {
+        std::lock_guard<std::mutex> lock(e->launch_mu);
+        e->batches.push_back(b);
+    }
+    *out = b;
+    return VT_OK;
+}
+
+uint64_t vt_batch_count(const vt_batch* b) { return b ? b->n : 0; }
+
+extern "C++" {
+template <class T>
+static int batch_fetch(vt_batch* b, const void* d_src, std::vector<T>& dst, bool& have, const T** out, const char* who)
+{
+    *out = nullptr;
+    if (!have) {
+        if (b->n != 0) {
+            if (!b->engine || !d_src) return fail(VT_ERR_INVALID_ARG, std::string(who) + (b->engine ? ": not materialised for this batch" : ": the engine has been closed"));
+            DeviceGuard guard(b->engine->device);
+            if (!guard.ok) return fail(VT_ERR_HIP, std::string(who) + ": hipSetDevice failed");
+            dst.resize(b->n);
+            VT_HIP(hipEventSynchronize(b->done));
+            VT_HIP(hipMemcpy(dst.data(), d_src, b->n * sizeof(T), hipMemcpyDeviceToHost));
+        }
+        have = true;
+    }
+    *out = dst.empty() ? nullptr : dst.data();
+    return VT_OK;
+}
+} // extern "C++"
+
+int vt_batch_hits(vt_batch* b, const vt_hit** hits)
+{
+    if (!b || !hits) return fail(VT_ERR_INVALID_ARG, "vt_batch_hits: NULL");
+    return batch_fetch(b, b->d_hits, b->hits, b->have_hits, hits, "vt_batch_hits");
+}
+
+int vt_batch_attrs(vt_batch* b, const vt_hit_attrs** attrs)
+{
+    if (!b || !attrs) return fail(VT_ERR_INVALID_ARG, "vt_batch_attrs: NULL");
+    return batch_fetch(b, b->d_attrs, b->attrs, b->have_attrs, attrs, "vt_batch_attrs");
+}
+
+int vt_batch_shade(vt_batch* b, const vt_hit_shade** shade)
+{
+    if (!b || !shade) return fail(VT_ERR_INVALID_ARG, "vt_batch_shade: NULL");
+    if (b->n != 0 && !b->have_shade && b->engine && !b->d_shade)
+        return fail(VT_ERR_INVALID_ARG, "vt_batch_shade: the scene had no triangle attributes (vt_scene_set_tri_attribs) when the batch was traced");
+    return batch_fetch(b, b->d_shade, b->shade, b->have_shade, shade, "vt_batch_shade");
+}
+
+void vt_batch_free(vt_batch* b)
+{
+    if (!b) return;
+    if (vt_engine* e = b->engine) {
+        DeviceGuard guard(e->device);
+        if (b->done) { (void)hipEventSynchronize(b->done); (void)hipEventDestroy(b->done); }
+        if (b->d_mem) (void)hipFree(b->d_mem);
+        std::lock_guard<std::mutex> lock(e->launch_mu);
+        e->batches.erase(std::remove(e->batches.begin(), e->batches.end(), b), e->batches.end());
+    }
+    delete b;
 }
 
 void* vt_engine_stream(vt_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }

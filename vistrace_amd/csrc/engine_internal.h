@@ -93,6 +93,7 @@ struct vt_engine {
 
     // scenes uploaded through this engine: closing the engine releases their device memory and detaches them
     std::vector<vt_scene*> scenes;
+    std::vector<vt_batch*> batches;          // live vt_batch objects (their device arrays go with the engine)
 
     // last launch geometry
     uint32_t last_blocks = 0, last_threads = 0, last_lds = 0;
@@ -155,6 +156,19 @@ struct vt_scene {
     std::shared_ptr<std::atomic<int>> host_stale;   // the vt_host_scene this scene was uploaded from: set by a device-side refit
     // multi-GPU group: the same scene on every peer device (replicas[g-1] lives on engine->peers[g-1]); owned by this scene
     std::vector<vt_scene*> replicas;
+};
+
+// one traced batch, resident on the device until its arrays are asked for (include/vistrace_hip.h)
+struct vt_batch {
+    vt_engine* engine = nullptr;             // NULL once the engine was closed
+    uint64_t   n = 0;
+    char*      d_mem = nullptr;              // rays | hits | attrs | shade
+    void *d_hits = nullptr, *d_attrs = nullptr, *d_shade = nullptr;
+    hipEvent_t done = nullptr;               // behind the last kernel of the batch
+    std::vector<vt_hit>       hits;
+    std::vector<vt_hit_attrs> attrs;
+    std::vector<vt_hit_shade> shade;
+    bool have_hits = false, have_attrs = false, have_shade = false;
 };
 
 struct DeviceGuard {

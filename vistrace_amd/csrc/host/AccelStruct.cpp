@@ -10,6 +10,7 @@
 #include <string>
 
 #include "TraceResult.h"
+#include "TraceResultBatch.h"
 
 using namespace GarrysMod::Lua;
 
@@ -57,7 +58,7 @@ vt_engine* Engine(ILuaBase* LUA)
 
 void AccelStruct::SetEntityMeshSource(IEntityMeshSource* src) { g_meshSource = src; }
 
-AccelStruct::AccelStruct() : mAccelBuilt(false), mpScene(nullptr), mpHostScene(nullptr) {}
+AccelStruct::AccelStruct() : mAccelBuilt(false), mpScene(nullptr), mpHostScene(nullptr), mT(std::make_shared<SceneTables>()) {}
 
 AccelStruct::~AccelStruct() { ReleaseDevice(); }                       // AccelStruct.cpp:525-531
 
@@ -78,14 +79,12 @@ void AccelStruct::PopulateAccel(ILuaBase* LUA, const World* pWorld)
     // tear down the previous build (AccelStruct.cpp:537-550)
     mAccelBuilt = false;
     ReleaseDevice();
-    mTriangles.clear();
-    mEntities.clear();
-    mMaterials.clear();
+    mT = std::make_shared<SceneTables>();      // batches traced from the previous build keep their tables
 
     if (pWorld) {                                                       // :552-555
-        mTriangles = pWorld->triangles;
-        mEntities = pWorld->entities;
-        mMaterials = pWorld->materials;
+        mT->triangles = pWorld->triangles;
+        mT->entities = pWorld->entities;
+        mT->materials = pWorld->materials;
     }
 
     // iterate the entity table on top of the stack (:567-758)
@@ -116,26 +115,26 @@ bool AccelStruct::AppendEntity(void* entityUserData)
     std::vector<Triangle> tris;
     std::vector<Material> mats;
     if (!g_meshSource->AppendEntity(entityUserData, ent, tris, mats)) return true;     // skipped by the source: not counted
-    if (mEntities.size() >= 65535) return false;
-    const size_t matBase = mMaterials.size();
-    const uint16_t entIdx = uint16_t(mEntities.size());
+    if (mT->entities.size() >= 65535) return false;
+    const size_t matBase = mT->materials.size();
+    const uint16_t entIdx = uint16_t(mT->entities.size());
     for (Triangle& t : tris) { t.material += matBase; t.entIdx = entIdx; }
-    mMaterials.insert(mMaterials.end(), mats.begin(), mats.end());
-    mTriangles.insert(mTriangles.end(), tris.begin(), tris.end());
-    mEntities.push_back(ent);
+    mT->materials.insert(mT->materials.end(), mats.begin(), mats.end());
+    mT->triangles.insert(mT->triangles.end(), tris.begin(), tris.end());
+    mT->entities.push_back(ent);
     return true;
 }
 
 int AccelStruct::BuildAndUpload(vt_engine* eng)
 {
-    const uint32_t n = uint32_t(mTriangles.size());
+    const uint32_t n = uint32_t(mT->triangles.size());
     std::vector<float> verts(size_t(n) * 9);
     std::vector<uint8_t> flags(n);
     for (uint32_t i = 0; i < n; ++i) {
-        const Triangle& t = mTriangles[i];
+        const Triangle& t = mT->triangles[i];
         const float v[9] = {t.p0.x, t.p0.y, t.p0.z, t.p1.x, t.p1.y, t.p1.z, t.p2.x, t.p2.y, t.p2.z};
         std::memcpy(&verts[size_t(i) * 9], v, sizeof(v));
-        const uint32_t mflags = t.material < mMaterials.size() ? mMaterials[t.material].flags : 0u;
+        const uint32_t mflags = t.material < mT->materials.size() ? mT->materials[t.material].flags : 0u;
         uint8_t f = 0;
         if (t.oneSided && !(mflags & MATFLAG_NOCULL)) f |= VT_TRI_CULL_BACKFACE;   // Primitives.h:174
         if (mflags & MATFLAG_ALPHATEST) f |= VT_TRI_ALPHATEST;                     // Primitives.h:196
@@ -148,31 +147,33 @@ int AccelStruct::BuildAndUpload(vt_engine* eng)
     if (rc == VT_OK) rc = vt_scene_linearise(bvh, recs.data(), &mpHostScene);   // kept: single rays are walked on the host
     if (bvh) vt_bvh_free(bvh);
     if (rc == VT_OK) rc = vt_scene_upload(eng, mpHostScene, &mpScene);           // replicated to every device of the engine
-    if (rc == VT_OK) rc = UploadAlphaTestData(flags);
+    if (rc == VT_OK) rc = UploadSideTables(flags);
     if (rc != VT_OK) ReleaseDevice();
     return rc;
 }
 
-// Side data of the in-kernel alpha test (Primitives.h:196-208), only when a material carries the flag: per-triangle
-// uvs + material index, per-material transform / reference / alpha plane.
-int AccelStruct::UploadAlphaTestData(const std::vector<uint8_t>& flags)
+// Per-triangle side table (uvs, vertex alphas, entity id, material index): what the device needs for the shading part of
+// a batch's results (TraceResult.cpp:73-78, vt_hit_shade) -- always.  The side data of the in-kernel alpha test
+// (Primitives.h:196-208: per-material transform / reference / alpha plane) only when a material carries the flag.
+int AccelStruct::UploadSideTables(const std::vector<uint8_t>& flags)
 {
     bool any = false;
     for (uint8_t f : flags) any = any || (f & VT_TRI_ALPHATEST);
-    if (!any) return VT_OK;
-    std::vector<vt_tri_attribs> attribs(mTriangles.size());
-    for (size_t i = 0; i < mTriangles.size(); ++i) {
-        const Triangle& t = mTriangles[i];
+    std::vector<vt_tri_attribs> attribs(mT->triangles.size());
+    for (size_t i = 0; i < mT->triangles.size(); ++i) {
+        const Triangle& t = mT->triangles[i];
         vt_tri_attribs& a = attribs[i];
         for (int k = 0; k < 3; ++k) { a.uv[k][0] = t.uvs[k].x; a.uv[k][1] = t.uvs[k].y; a.alpha[k] = t.alphas[k]; }
-        a.ent_id = t.entIdx < mEntities.size() ? mEntities[t.entIdx].id : 0u;
+        a.ent_id = t.entIdx < mT->entities.size() ? mT->entities[t.entIdx].id : 0u;
         a.material = uint32_t(t.material);
         a.pad = 0;
     }
-    std::vector<vt_alpha_material> mats(mMaterials.size());
+    int rc = vt_scene_set_tri_attribs(mpScene, attribs.data(), uint32_t(attribs.size()));
+    if (rc != VT_OK || !any) return rc;
+    std::vector<vt_alpha_material> mats(mT->materials.size());
     std::vector<uint8_t> texels;
-    for (size_t i = 0; i < mMaterials.size(); ++i) {
-        const Material& m = mMaterials[i];
+    for (size_t i = 0; i < mT->materials.size(); ++i) {
+        const Material& m = mT->materials[i];
         vt_alpha_material& o = mats[i];
         std::memcpy(o.tex_mat, m.baseTexMat, sizeof(o.tex_mat));
         o.tex_scale = m.texScale;
@@ -186,8 +187,7 @@ int AccelStruct::UploadAlphaTestData(const std::vector<uint8_t>& flags)
         o.offset = texels.size();
         if (has_plane) texels.insert(texels.end(), m.baseAlpha.begin(), m.baseAlpha.begin() + size_t(m.alphaWidth) * m.alphaHeight);
     }
-    int rc = vt_scene_set_tri_attribs(mpScene, attribs.data(), uint32_t(attribs.size()));
-    if (rc == VT_OK) rc = vt_scene_set_alpha(mpScene, mats.data(), uint32_t(mats.size()), texels.data(), texels.size());
+    rc = vt_scene_set_alpha(mpScene, mats.data(), uint32_t(mats.size()), texels.data(), texels.size());
     if (rc == VT_OK)                                        // the same tables for the host walk
         rc = vt_host_scene_set_alpha(mpHostScene, attribs.data(), uint32_t(attribs.size()), mats.data(), uint32_t(mats.size()),
                                      texels.data(), texels.size());
@@ -196,11 +196,11 @@ int AccelStruct::UploadAlphaTestData(const std::vector<uint8_t>& flags)
 
 TraceResult* AccelStruct::MakeResult(const vt_ray& ray, const vt_hit& hit, float coneWidth, float coneAngle) const
 {
-    const Triangle& tri = mTriangles[hit.prim];                          // :821
+    const Triangle& tri = mT->triangles[hit.prim];                          // :821
     static const Entity kNoEntity{};
-    const Entity& ent = tri.entIdx < mEntities.size() ? mEntities[tri.entIdx] : kNoEntity;   // :822
+    const Entity& ent = tri.entIdx < mT->entities.size() ? mT->entities[tri.entIdx] : kNoEntity;   // :822
     static const Material kNoMaterial{};
-    const Material& mat = tri.material < mMaterials.size() ? mMaterials[tri.material] : kNoMaterial;   // :823
+    const Material& mat = tri.material < mT->materials.size() ? mT->materials[tri.material] : kNoMaterial;   // :823
     return new TraceResult(Vec3{ray.dir[0], ray.dir[1], ray.dir[2]}, hit.t, coneWidth, coneAngle, tri, hit.prim,
                            Vec2{hit.u, hit.v}, ent, mat);                // :825-831
 }
@@ -270,6 +270,7 @@ int AccelStruct::TraverseBatch(ILuaBase* LUA)
 {
     if (!mAccelBuilt)
         LUA->ThrowError("Unable to perform traversal, acceleration structure invalid (use AccelStruct:Rebuild to rebuild it)");
+    if (LUA->IsType(2, Type::String)) return TraverseBatchBuffer(LUA);
     LUA->CheckType(2, Type::Table);
     // rays[i] = { origin, direction, tMin?, tMax? } with the defaults and checks of Traverse.  Fields are read BY INDEX
     // (rays[i][k]): lua_next skips nil values and promises no order, so {o, d, nil, tMax} must not shift tMax to field 3.
@@ -326,6 +327,32 @@ int AccelStruct::TraverseBatch(ILuaBase* LUA)
     return 1;
 }
 
-const Material& AccelStruct::GetMaterial(size_t i) const { return mMaterials[i]; }     // :840-843
+// accel:TraverseBatch(buffer): N packed vt_ray records in, ONE TraceResultBatch out (TraceResultBatch.h).  Same range
+// checks as Traverse (AccelStruct.cpp:805-806) on every ray, in one pass over the bytes; no per-ray Lua traffic.
+int AccelStruct::TraverseBatchBuffer(ILuaBase* LUA)
+{
+    unsigned int len = 0;
+    const char* bytes = LUA->GetString(2, &len);
+    if (!bytes || len % sizeof(vt_ray) != 0) LUA->ArgError(2, "ray buffer must hold whole 32-byte records {origin, direction, tMin, tMax}");
+    const size_t n = len / sizeof(vt_ray);
+    mBatchRays.resize(n);
+    if (n) std::memcpy(mBatchRays.data(), bytes, len);           // Lua strings carry no alignment promise
+    for (size_t i = 0; i < n; ++i) {
+        if (mBatchRays[i].tmin < 0.f) LUA->ThrowError("tMin cannot be less than 0");
+        if (mBatchRays[i].tmax <= mBatchRays[i].tmin) LUA->ThrowError("tMax must be greater than tMin");
+    }
+    LUA->Pop(LUA->Top());
+    vt_batch* batch = nullptr;
+    if (vt_batch_trace_closest(mpScene, mBatchRays.data(), n, &batch) != VT_OK) {
+        static thread_local char msg[512];
+        std::snprintf(msg, sizeof(msg), "VisTrace: traversal failed: %s", vt_last_error());
+        LUA->ThrowError(msg);
+    }
+    LUA->PushUserType_Value(new TraceResultBatch(batch, mT, std::move(mBatchRays)), TraceResultBatch::id);
+    mBatchRays = std::vector<vt_ray>();
+    return 1;
+}
+
+const Material& AccelStruct::GetMaterial(size_t i) const { return mT->materials[i]; }     // :840-843
 
 } // namespace vistrace

@@ -27,8 +27,11 @@ public:
     void PopulateAccel(GarrysMod::Lua::ILuaBase* LUA, const World* pWorld = nullptr);
     // accel:Traverse(origin, direction, tMin=0, tMax=FLT_MAX, coneWidth=-1, coneAngle=-1)
     int Traverse(GarrysMod::Lua::ILuaBase* LUA);
-    // accel:TraverseBatch(rays) -- rays: array of {origin, direction[, tMin[, tMax]]} tables;
-    // returns an array with a TraceResult or false per ray.  New, does not alter Traverse.
+    // accel:TraverseBatch(rays) -- additive, does not alter Traverse.  Two forms:
+    //   rays = array of {origin, direction[, tMin[, tMax]]} tables -> array with a TraceResult or false per ray;
+    //   rays = string of N packed 32-byte records {origin xyz, direction xyz, tMin, tMax} (fp32, the layout of vt_ray)
+    //          -> ONE TraceResultBatch userdata: the batch stays on the device, getters take a ray index and fetch the
+    //          array they need once (TraceResultBatch.h).  No per-ray table parsing, no per-hit allocation.
     int TraverseBatch(GarrysMod::Lua::ILuaBase* LUA);
 
     const Material& GetMaterial(size_t i) const;
@@ -45,7 +48,7 @@ public:
     int TraceClosestDevice(const vt_ray* rays, uint64_t n, vt_hit* hits) const;
 
     static void SetEntityMeshSource(IEntityMeshSource* src);   // module-wide hook (see Scene.h)
-    size_t TriangleCount() const { return mTriangles.size(); }
+    size_t TriangleCount() const { return mT->triangles.size(); }
     bool   IsBuilt() const { return mAccelBuilt; }
 
 private:
@@ -54,14 +57,13 @@ private:
     vt_host_scene* mpHostScene;             // the same records on the host: single rays are walked here (config 1)
     std::vector<vt_ray> mBatchRays;         // TraverseBatch scratch (members: a Lua error must not skip a destructor)
     std::vector<vt_hit> mBatchHits;
-    std::vector<Triangle> mTriangles;
-    std::vector<Entity>   mEntities;
-    std::vector<Material> mMaterials;
+    std::shared_ptr<SceneTables> mT;        // mTriangles / mEntities / mMaterials of the reference (AccelStruct.h:64-66); replaced per build
 
     void ReleaseDevice();
     bool AppendEntity(void* entityUserData);   // false: the entity table is full (65535)
     int  BuildAndUpload(vt_engine* eng);
-    int  UploadAlphaTestData(const std::vector<uint8_t>& flags);
+    int  UploadSideTables(const std::vector<uint8_t>& flags);
+    int  TraverseBatchBuffer(GarrysMod::Lua::ILuaBase* LUA);
     TraceResult* MakeResult(const vt_ray& ray, const vt_hit& hit, float coneWidth, float coneAngle) const;
 };
 

@@ -7,7 +7,10 @@
 #include <cstdint>
 #include <cstring>
 
+#include <cstdio>
+
 #include "TraceResult.h"
+#include "TraceResultBatch.h"
 
 using namespace GarrysMod::Lua;
 
@@ -218,6 +221,219 @@ LUA_FUNCTION(TraceResult_tostring)                                     // VisTra
     return 1;
 }
 
+// ---- TraceResultBatch: the getters of TraceResult with the ray's 1-based index as argument (TraceResultBatch.h) -------
+// A miss yields no value (as Traverse returns nothing for a miss); batch:Hit(i) tells hits from misses.
+static TraceResultBatch* BatchSelf(ILuaBase* LUA)
+{
+    LUA->CheckType(1, TraceResultBatch::id);
+    TraceResultBatch* b = LUA->GetUserType<TraceResultBatch>(1, TraceResultBatch::id);
+    if (!b) LUA->ThrowError("VisTraceResultBatch has been released");
+    return b;
+}
+
+static uint64_t BatchIndex(ILuaBase* LUA, TraceResultBatch* b)
+{
+    const double d = LUA->CheckNumber(2);
+    if (!(d >= 1.0 && d <= double(b->Count())) || d != std::floor(d)) LUA->ArgError(2, "ray index out of range");
+    return uint64_t(d) - 1;
+}
+
+static void BatchFetchError(ILuaBase* LUA)
+{
+    static thread_local char msg[512];
+    std::snprintf(msg, sizeof(msg), "VisTrace: batch results unavailable: %s", vt_last_error());
+    LUA->ThrowError(msg);
+}
+
+static const vt_hit& BatchHit(ILuaBase* LUA, TraceResultBatch* b, uint64_t i)
+{
+    const vt_hit* h = b->Hits();
+    if (!h) BatchFetchError(LUA);
+    return h[i];
+}
+
+static const vt_hit_attrs* BatchAttrs(ILuaBase* LUA, TraceResultBatch* b, uint64_t i)   // NULL for a miss
+{
+    const vt_hit_attrs* a = b->Attrs();
+    if (!a) BatchFetchError(LUA);
+    return a[i].hit ? &a[i] : nullptr;
+}
+
+LUA_FUNCTION(TraceResultBatch_gc)
+{
+    LUA->CheckType(1, TraceResultBatch::id);
+    TraceResultBatch* p = LUA->GetUserType<TraceResultBatch>(1, TraceResultBatch::id);
+    LUA->SetUserType(1, nullptr);
+    delete p;
+    return 0;
+}
+
+LUA_FUNCTION(TraceResultBatch_tostring) { LUA->PushString("VisTraceResultBatch"); return 1; }
+
+LUA_FUNCTION(TraceResultBatch_Count) { LUA->PushNumber(double(BatchSelf(LUA)->Count())); return 1; }
+
+LUA_FUNCTION(TraceResultBatch_Hit)
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    LUA->PushBool(BatchHit(LUA, b, BatchIndex(LUA, b)).prim != VT_MISS);
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_Hits)                                    // the packed vt_hit records, for bulk consumers
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const vt_hit* h = b->Hits();
+    if (!h && b->Count()) BatchFetchError(LUA);
+    LUA->PushString(reinterpret_cast<const char*>(h), unsigned(b->Count() * sizeof(vt_hit)));
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_Get)                                     // the reference's per-ray object, or nothing
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const uint64_t i = BatchIndex(LUA, b);
+    if (!b->Hits()) BatchFetchError(LUA);
+    TraceResult* r = b->MakeResult(i);
+    if (!r) return 0;
+    LUA->PushUserType_Value(r, TraceResult::id);
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_Pos)                                     // TraceResult.cpp:255-262 on the device
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const vt_hit_attrs* a = BatchAttrs(LUA, b, BatchIndex(LUA, b));
+    if (!a) return 0;
+    LUA->PushVector(MakeVector(a->pos[0], a->pos[1], a->pos[2]));
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_Incident)
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const vt_hit_attrs* a = BatchAttrs(LUA, b, BatchIndex(LUA, b));
+    if (!a) return 0;
+    LUA->PushVector(MakeVector(a->wo[0], a->wo[1], a->wo[2]));
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_Distance)                                // needs the hit records only
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const vt_hit& h = BatchHit(LUA, b, BatchIndex(LUA, b));
+    if (h.prim == VT_MISS) return 0;
+    LUA->PushNumber(h.t);
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_GeometricNormal)
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const vt_hit_attrs* a = BatchAttrs(LUA, b, BatchIndex(LUA, b));
+    if (!a) return 0;
+    LUA->PushVector(MakeVector(a->ngeo[0], a->ngeo[1], a->ngeo[2]));
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_Barycentric)
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const vt_hit& h = BatchHit(LUA, b, BatchIndex(LUA, b));
+    if (h.prim == VT_MISS) return 0;
+    LUA->PushVector(MakeVector(h.u, h.v, 1.f - h.u - h.v));            // TraceResult.cpp:70
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_FrontFacing)
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const vt_hit_attrs* a = BatchAttrs(LUA, b, BatchIndex(LUA, b));
+    if (!a) return 0;
+    LUA->PushBool(a->front != 0);
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_TextureUV)
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const uint64_t i = BatchIndex(LUA, b);
+    if (BatchHit(LUA, b, i).prim == VT_MISS) return 0;
+    const vt_hit_shade* s = b->Shade();
+    if (!s) BatchFetchError(LUA);
+    LUA->CreateTable();
+    LUA->PushNumber(s[i].tex_uv[0]);
+    LUA->SetField(-2, "u");
+    LUA->PushNumber(s[i].tex_uv[1]);
+    LUA->SetField(-2, "v");
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_SubMaterialIndex)
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const vt_hit& h = BatchHit(LUA, b, BatchIndex(LUA, b));
+    if (h.prim == VT_MISS) return 0;
+    LUA->PushNumber(double(b->TriangleOf(h).material) + 1);
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_MaterialFlags)
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const vt_hit& h = BatchHit(LUA, b, BatchIndex(LUA, b));
+    if (h.prim == VT_MISS) return 0;
+    LUA->PushNumber(double(b->MaterialOf(h).flags));
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_SurfaceFlags)
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const vt_hit& h = BatchHit(LUA, b, BatchIndex(LUA, b));
+    if (h.prim == VT_MISS) return 0;
+    LUA->PushNumber(double(b->MaterialOf(h).surfFlags));
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_HitSky)
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const vt_hit& h = BatchHit(LUA, b, BatchIndex(LUA, b));
+    if (h.prim == VT_MISS) return 0;
+    LUA->PushBool((b->MaterialOf(h).surfFlags & SURF_SKY) != SURF_NONE);
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_HitWater)
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const vt_hit& h = BatchHit(LUA, b, BatchIndex(LUA, b));
+    if (h.prim == VT_MISS) return 0;
+    LUA->PushBool(b->MaterialOf(h).water);
+    return 1;
+}
+
+LUA_FUNCTION(TraceResultBatch_Entity)                                  // as TraceResult:Entity, VisTrace.cpp:495-513
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const vt_hit& h = BatchHit(LUA, b, BatchIndex(LUA, b));
+    if (h.prim == VT_MISS) return 0;
+    const Entity& ent = b->EntityOf(h);
+
+    LUA->PushSpecial(SPECIAL_GLOB);
+    LUA->GetField(-1, "Entity");
+    LUA->PushNumber(ent.id);
+    LUA->Call(1, 1);
+
+    void* pEnt = LUA->GetUserdataRaw(-1, Type::Entity);
+    if (pEnt == nullptr || pEnt != ent.rawEntity) {
+        LUA->GetField(-2, "Entity");
+        LUA->PushNumber(-1);
+        LUA->Call(1, 1);
+    }
+    return 1;
+}
+
 // ---- helpers ------------------------------------------------------------------------------------
 LUA_FUNCTION(vistrace_CalcRayOrigin)                                   // VisTrace.cpp:1478-1519
 {
@@ -273,6 +489,30 @@ void RegisterTracingApi(ILuaBase* LUA)
     Method(LUA, "HitSky", TraceResult_HitSky);
     Method(LUA, "HitWater", TraceResult_HitWater);
     Method(LUA, "FrontFacing", TraceResult_FrontFacing);
+    LUA->Pop();
+
+    TraceResultBatch::id = LUA->CreateMetaTable("VisTraceResultBatch");   // additive: what TraverseBatch(buffer) returns
+    LUA->Push(-1);
+    LUA->SetField(-2, "__index");
+    Method(LUA, "__tostring", TraceResultBatch_tostring);
+    Method(LUA, "__gc", TraceResultBatch_gc);
+    Method(LUA, "Count", TraceResultBatch_Count);
+    Method(LUA, "Hit", TraceResultBatch_Hit);
+    Method(LUA, "Hits", TraceResultBatch_Hits);
+    Method(LUA, "Get", TraceResultBatch_Get);
+    Method(LUA, "Pos", TraceResultBatch_Pos);
+    Method(LUA, "Incident", TraceResultBatch_Incident);
+    Method(LUA, "Distance", TraceResultBatch_Distance);
+    Method(LUA, "Entity", TraceResultBatch_Entity);
+    Method(LUA, "GeometricNormal", TraceResultBatch_GeometricNormal);
+    Method(LUA, "Barycentric", TraceResultBatch_Barycentric);
+    Method(LUA, "TextureUV", TraceResultBatch_TextureUV);
+    Method(LUA, "SubMaterialIndex", TraceResultBatch_SubMaterialIndex);
+    Method(LUA, "MaterialFlags", TraceResultBatch_MaterialFlags);
+    Method(LUA, "SurfaceFlags", TraceResultBatch_SurfaceFlags);
+    Method(LUA, "HitSky", TraceResultBatch_HitSky);
+    Method(LUA, "HitWater", TraceResultBatch_HitWater);
+    Method(LUA, "FrontFacing", TraceResultBatch_FrontFacing);
     LUA->Pop();
 
     AccelStruct_id = LUA->CreateMetaTable("AccelStruct");              // :1742-1752

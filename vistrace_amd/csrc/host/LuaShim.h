@@ -46,6 +46,7 @@ public:
     virtual double       GetNumber(int stackPos = -1) = 0;
     virtual double       CheckNumber(int stackPos = -1) = 0;
     virtual bool         GetBool(int stackPos = -1) = 0;
+    virtual const char*  GetString(int stackPos = -1, unsigned int* outLen = nullptr) = 0;   // binary safe: length in *outLen
     virtual const Vector& GetVector(int stackPos = -1) = 0;
     virtual void         PushNil() = 0;
     virtual void         PushNumber(double v) = 0;

@@ -57,6 +57,14 @@ struct Entity {
     uint32_t id = 0;
 };
 
+// What an AccelStruct keeps per build; shared (read-only after the build) with the TraceResultBatch objects traced from
+// it, which may outlive a Rebuild or the accel itself.
+struct SceneTables {
+    std::vector<Triangle> triangles;
+    std::vector<Entity>   entities;
+    std::vector<Material> materials;
+};
+
 struct World {
     std::vector<Triangle> triangles;
     std::vector<Entity>   entities;
