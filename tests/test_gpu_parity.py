@@ -111,7 +111,7 @@ def test_ragged_batch_sizes(va, engine, make_bundle, n):
 
 
 # ---- seeded scenes -------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["S1k", "S10k"])
+@pytest.mark.parametrize("name", ["S1k", "S10k", "HALL100k"])     # HALL100k: a brush hall -- huge faces across small props
 def test_scene_parity_with_counters(va, engine, make_bundle, name):
     from vistrace_amd import workloads as W
     b = make_bundle(name)

@@ -64,3 +64,24 @@ def test_bounce_and_shadow_rays(O, make_bundle, va):
     assert (bh["prim"] == hits["prim"]).mean() < 0.01          # origin offset avoids self-hits
     sr = W.shadow_rays(attrs, W.light_positions("S1k"), 4, per_hit=2)
     assert len(sr) == 2 * len(attrs) and (sr["tmax"] > 0).all()
+
+
+def test_brush_hall_scene(O, va):
+    from vistrace_amd import workloads as W
+    """HALL100k (workloads.make_hall): the Source-map-like scene -- a handful of huge one-quad brush faces crossing many
+    small prop triangles: size, determinism, extents, and the host walk against the oracle and brute force on it."""
+    verts = W.make_scene("HALL100k")
+    assert verts.shape == (98340, 3, 3) and np.isfinite(verts).all()
+    assert (W.make_scene("HALL100k") == verts).all()
+    area = 0.5 * np.linalg.norm(np.cross(verts[:, 1] - verts[:, 0], verts[:, 2] - verts[:, 0]), axis=1)
+    assert area[:12].min() > 1e5 and np.median(area) < 50.0            # the shell's triangles dwarf the props'
+    tris = va.tris_setup(verts)
+    bvh = va.HostBvh(tris)
+    hs = va.HostScene(bvh)
+    rays = np.concatenate([W.primary_rays(48, 48), W.sphere_rays(3000, 7, origin=(-300.0, 250.0, 40.0))])
+    ref = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris), rays)[0]
+    got = hs.trace_closest_host(rays)
+    assert (got["prim"] == ref["prim"]).all() and (got["t"].view(np.uint32) == ref["t"].view(np.uint32)).all()
+    assert (ref["prim"] != 0xFFFFFFFF).all()                             # a closed hall: every ray ends on something
+    brute = O.trace_brute(O.tris_from_tri64(tris), rays[:600])
+    assert (brute["t"].view(np.uint32) == ref["t"][:600].view(np.uint32)).all()

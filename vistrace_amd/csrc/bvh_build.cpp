@@ -367,6 +367,89 @@ void sah_build_subtree(const SahCtx& c, uint32_t begin, uint32_t end, std::vecto
     refine_nodes(out, 1, kLocalRefinePasses, kLocalRefineFraction);
 }
 
+// Second level of the task tree: a REGION of at most kRegionPrims triangles is split on the thread that runs its task
+// down to subtree tasks (above), and once those have finished, the stitched region is refined again as a whole --
+// re-insertion across the borders of its subtrees, where the subtree tasks could not look.  Measured on S1M (262 144 bounce
+// rays, oracle counters): 56.95 -> 55.40 steps per ray, 16 Mi bounce rays 4.30 -> 4.20 ms, camera rays 44.1 -> 41.8 steps, at an unchanged build time on 8 threads (profiles/r3/notes.md); the global pass of
+// VT_BUILDER_BINNED_SAH_REFINED still adds a little on top (55.1).
+#ifndef VT_REGION_PRIMS            // measurement overrides (make variant DEFS=-DVT_REGION_...): profiles/r3/notes.md
+#define VT_REGION_PRIMS 65536
+#endif
+#ifndef VT_REGION_REFINE_PASSES
+#define VT_REGION_REFINE_PASSES 3
+#endif
+#ifndef VT_REGION_REFINE_FRACTION
+#define VT_REGION_REFINE_FRACTION 0.02f
+#endif
+constexpr uint32_t kRegionPrims = VT_REGION_PRIMS;
+constexpr int      kRegionRefinePasses = VT_REGION_REFINE_PASSES;
+constexpr float    kRegionRefineFraction = VT_REGION_REFINE_FRACTION;
+
+// Splits [begin, end) on the calling thread until every piece holds at most piece_prims triangles, has every piece built by
+// build_piece(begin, end, nodes) -- as OpenMP tasks when `tasks` (the caller is inside a parallel region), else by a
+// parallel loop --, and stitches the result into `out` (v1 layout: out[0] = root, siblings adjacent, children behind their
+// parents; pieces appended in creation order, so the tree does not depend on scheduling or on the number of threads).
+template <class BuildPiece>
+void sah_build_split(const SahCtx& c, uint32_t begin, uint32_t end, uint32_t piece_prims, bool par_bins, bool tasks,
+                     const BuildPiece& build_piece, std::vector<vt_bvh_node>& out)
+{
+    struct Piece { uint32_t slot, begin, end; std::vector<vt_bvh_node> nodes; };
+    std::vector<vt_bvh_node> top;
+    top.emplace_back();
+    std::vector<Piece> pieces;
+    {
+        struct Task { uint32_t node, begin, end; };
+        std::vector<Task> stack{{0u, begin, end}};
+        while (!stack.empty()) {
+            const Task t = stack.back();
+            stack.pop_back();
+            if (t.end - t.begin <= piece_prims) { pieces.push_back(Piece{t.node, t.begin, t.end, {}}); continue; }
+            vt_bvh_node self{};
+            const uint32_t mid = sah_split_node(c, self, t.begin, t.end, par_bins);
+            if (mid != 0) {
+                self.first = uint32_t(top.size());
+                top.emplace_back();
+                top.emplace_back();
+                stack.push_back({self.first + 1, mid, t.end});
+                stack.push_back({self.first, t.begin, mid});
+            }
+            top[t.node] = self;
+        }
+    }
+    if (tasks) {
+        for (size_t k = 0; k < pieces.size(); ++k) {
+            Piece* p = &pieces[k];
+#pragma omp task firstprivate(p) shared(c, build_piece)
+            build_piece(p->begin, p->end, p->nodes);
+        }
+#pragma omp taskwait
+    } else {
+#pragma omp parallel num_threads(c.nthreads)
+#pragma omp single
+        {
+            for (size_t k = 0; k < pieces.size(); ++k) {
+                Piece* p = &pieces[k];
+#pragma omp task firstprivate(p) shared(c, build_piece)
+                build_piece(p->begin, p->end, p->nodes);
+            }
+#pragma omp taskwait
+        }
+    }
+    // stitch: a piece's root goes into its slot of the top, the rest behind everything emitted so far
+    size_t total = top.size();
+    for (const Piece& pc : pieces) total += pc.nodes.size() - 1;
+    top.reserve(total);
+    for (Piece& pc : pieces) {
+        const uint32_t base = uint32_t(top.size()) - 1u;         // local index i >= 1 -> base + i
+        for (vt_bvh_node& nd : pc.nodes)
+            if (nd.prim_count == 0) nd.first += base;
+        top[pc.slot] = pc.nodes[0];
+        top.insert(top.end(), pc.nodes.begin() + 1, pc.nodes.end());
+        std::vector<vt_bvh_node>().swap(pc.nodes);
+    }
+    out.swap(top);
+}
+
 int build_binned_sah(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out)
 {
     std::vector<Box> boxes(n);
@@ -389,46 +472,15 @@ int build_binned_sah(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out)
     }
     const SahCtx ctx{boxes.data(), centers.data(), idx.data(), nthreads};
 
-    // top of the tree on this thread; subtrees of <= kTaskPrims triangles as tasks, in creation order
-    struct Sub { uint32_t slot, begin, end; std::vector<vt_bvh_node> nodes; };
-    std::vector<vt_bvh_node> top;
-    top.emplace_back();
-    std::vector<Sub> subs;
-    {
-        struct Task { uint32_t node, begin, end; };
-        std::vector<Task> stack{{0u, 0u, n}};
-        while (!stack.empty()) {
-            const Task t = stack.back();
-            stack.pop_back();
-            if (t.end - t.begin <= kTaskPrims) { subs.push_back(Sub{t.node, t.begin, t.end, {}}); continue; }
-            vt_bvh_node self{};
-            const uint32_t mid = sah_split_node(ctx, self, t.begin, t.end, true);
-            if (mid != 0) {
-                self.first = uint32_t(top.size());
-                top.emplace_back();
-                top.emplace_back();
-                stack.push_back({self.first + 1, mid, t.end});
-                stack.push_back({self.first, t.begin, mid});
-            }
-            top[t.node] = self;
-        }
-    }
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
-    for (int64_t k = 0; k < int64_t(subs.size()); ++k) sah_build_subtree(ctx, subs[size_t(k)].begin, subs[size_t(k)].end, subs[size_t(k)].nodes);
-
-    // stitch: a subtree's root goes into its slot of the top, the rest behind everything emitted so far
-    size_t total = top.size();
-    for (const Sub& sb : subs) total += sb.nodes.size() - 1;
-    top.reserve(total);
-    for (Sub& sb : subs) {
-        const uint32_t base = uint32_t(top.size()) - 1u;         // local index i >= 1 -> base + i
-        for (vt_bvh_node& nd : sb.nodes)
-            if (nd.prim_count == 0) nd.first += base;
-        top[sb.slot] = sb.nodes[0];
-        top.insert(top.end(), sb.nodes.begin() + 1, sb.nodes.end());
-        std::vector<vt_bvh_node>().swap(sb.nodes);
-    }
-    out.nodes.swap(top);
+    // top of the tree on this thread (bins filled by all threads); regions of <= kRegionPrims triangles as tasks, each of
+    // which splits itself into subtree tasks of <= kTaskPrims triangles and refines the stitched region afterwards
+    const auto build_subtree = [&ctx](uint32_t b, uint32_t e, std::vector<vt_bvh_node>& nodes) { sah_build_subtree(ctx, b, e, nodes); };
+    const auto build_region = [&ctx, &build_subtree](uint32_t b, uint32_t e, std::vector<vt_bvh_node>& nodes) {
+        if (e - b <= kTaskPrims) { sah_build_subtree(ctx, b, e, nodes); return; }
+        sah_build_split(ctx, b, e, kTaskPrims, false, true, build_subtree, nodes);
+        refine_nodes(nodes, 1, kRegionRefinePasses, kRegionRefineFraction);
+    };
+    sah_build_split(ctx, 0u, n, kRegionPrims, true, false, build_region, out.nodes);
     out.prim_indices.swap(idx);
     return VT_OK;
 }

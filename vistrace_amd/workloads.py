@@ -25,7 +25,14 @@ SCENES = {
     "S1M": (770, 3, 35),       # 985 600 + 14 700 = 1 000 300
     "S10M": (1950, 4, 52),     # 9 984 000 + 32 448 = 10 016 448
 }
-SCENE_IDS = {"S1k": 0, "S10k": 1, "S100k": 2, "S1M": 3, "S10M": 5}
+SCENE_IDS = {"S1k": 0, "S10k": 1, "S100k": 2, "S1M": 3, "S10M": 5, "HALL100k": 7, "HALL1M": 8}
+# "brush hall" scenes (make_hall): Source-map-like geometry -- few huge one-piece brush faces (hall shell, partition walls,
+# pillars: 2 triangles per face, source/objects/AccelStruct.cpp:408-410) crossing thousands of small prop triangles
+#            props, subdivisions of a prop, partitions, pillars
+HALLS = {
+    "HALL100k": (306, 2, 10, 24),    # 306*320 + 12 + 10*12 + 24*12   =  98 340
+    "HALL1M": (780, 3, 14, 40),      # 780*1280 + 12 + 14*12 + 40*12  = 999 060
+}
 
 
 # ---- RNG ------------------------------------------------------------------------------------
@@ -111,8 +118,70 @@ def light_positions(name: str, count: int = 16) -> np.ndarray:
     return (u * 1600.0 - 800.0).astype(np.float32)
 
 
+def box_tris(lo, hi) -> np.ndarray:
+    """The 12 triangles of the axis-aligned box [lo, hi]: (12,3,3)."""
+    lo, hi = np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+    out = []
+    for axis in range(3):
+        u, v = (axis + 1) % 3, (axis + 2) % 3
+        for side in (lo[axis], hi[axis]):
+            def P(a, b):
+                p = np.empty(3); p[axis] = side; p[u] = a; p[v] = b
+                return p
+            q00, q10, q11, q01 = P(lo[u], lo[v]), P(hi[u], lo[v]), P(hi[u], hi[v]), P(lo[u], hi[v])
+            out += [np.stack([q00, q10, q11]), np.stack([q00, q11, q01])]
+    return np.stack(out)
+
+
+def make_hall(name: str) -> np.ndarray:
+    """A brush hall: the shell of the room [-1000,1000]^2 x [-300,300] as 12 huge triangles, thin partition walls
+    (boxes spanning most of the hall) and square pillars from floor to ceiling -- all of them one quad per face, as a map
+    compiler leaves brush faces -- and `props` icospheres of radius 6-30 resting on the floor or stacked in clusters
+    around seeded spots.  Large triangles whose boxes cover thousands of small ones are what a real Source map gives
+    the builder (the seeded S* scenes are uniform small triangles); nothing is enclosed around camera 0 (0,0,0)."""
+    props, subdiv, nparts, npillars = HALLS[name]
+    seed = SEED + SCENE_IDS[name]
+    zlo, zhi = -300.0, 300.0
+    parts = [box_tris((-ROOM, -ROOM, zlo), (ROOM, ROOM, zhi))]
+    u = uniform01(seed, 0, 8 * (nparts + npillars + props) + 64).astype(np.float64)
+    q = 0
+    for i in range(nparts):                                   # thin walls along x or y with a doorway-sized gap at one end
+        a, b, c, d = u[q:q + 4]; q += 4
+        pos = (a * 2.0 - 1.0) * 850.0
+        if abs(pos) < 120.0:
+            pos = 120.0 if pos >= 0 else -120.0                # keep the camera spot clear
+        span_lo, span_hi = -ROOM + 150.0 * b, ROOM - 400.0 * c - 100.0
+        height = zlo + 250.0 + 350.0 * d
+        if i % 2 == 0:
+            parts.append(box_tris((pos - 4.0, span_lo, zlo), (pos + 4.0, span_hi, height)))
+        else:
+            parts.append(box_tris((span_lo, pos - 4.0, zlo), (span_hi, pos + 4.0, height)))
+    for i in range(npillars):
+        a, b, c = u[q:q + 3]; q += 3
+        x, y, w = (a * 2.0 - 1.0) * 900.0, (b * 2.0 - 1.0) * 900.0, 12.0 + 20.0 * c
+        if x * x + y * y < 150.0 ** 2:
+            x += 300.0
+        parts.append(box_tris((x - w, y - w, zlo), (x + w, y + w, zhi)))
+    unit = icosphere(subdiv)
+    nspots = max(8, props // 12)                               # props cluster around spots (furniture, debris piles)
+    spots = (u[q:q + 2 * nspots].reshape(nspots, 2) * 2.0 - 1.0) * 880.0; q += 2 * nspots
+    pu = uniform01(seed + 77, 0, 5 * props).reshape(props, 5).astype(np.float64)
+    spot = (pu[:, 0] * nspots).astype(np.int64) % nspots
+    radii = 6.0 + 24.0 * pu[:, 1]
+    cx = spots[spot, 0] + (pu[:, 2] - 0.5) * 160.0
+    cy = spots[spot, 1] + (pu[:, 3] - 0.5) * 160.0
+    cz = zlo + radii + 120.0 * pu[:, 4] ** 3                   # most rest on the floor, a few are stacked
+    near = cx * cx + cy * cy < 150.0 ** 2
+    cx = np.where(near, cx + 320.0, cx)
+    centres = np.stack([np.clip(cx, -ROOM + 40, ROOM - 40), np.clip(cy, -ROOM + 40, ROOM - 40), cz], 1)
+    spheres = (unit[None] * radii[:, None, None, None] + centres[:, None, None, :]).reshape(-1, 3, 3)
+    return np.concatenate(parts + [spheres], 0).astype(np.float32)
+
+
 def make_scene(name: str) -> np.ndarray:
     """(n,3,3) float32 triangles of scene `name` (all two-sided, one material, flags 0)."""
+    if name in HALLS:
+        return make_hall(name)
     m, subdiv, k = SCENES[name]
     seed = SEED + SCENE_IDS[name]
     keep_out = np.concatenate([camera_positions(name), light_positions(name)], 0).astype(np.float64)
