@@ -254,10 +254,13 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
  * stream; nothing comes back until it is asked for.  vt_batch_hits / _attrs / _shade download their array ONCE (first
  * call; the pointer stays valid until vt_batch_free) -- a consumer that only reads distances never pays for the rest.
  * The batch owns its device memory; free it before closing the engine (vt_engine_close releases what is left and the
- * arrays not yet downloaded are then lost: the getters fail).  Single device (a group's root). */
+ * arrays not yet downloaded are then lost: the getters fail).  Single device (a group's root).  `rays` may be any byte
+ * address (it is only copied from; a Lua string carries no alignment promise).  A freed batch's device block is kept by
+ * the engine and handed to the next batch that fits (no hipMalloc per batch in a steady stream of equal batches). */
 typedef struct vt_batch vt_batch;
 int      vt_batch_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_batch** out);
 uint64_t vt_batch_count(const vt_batch* b);
+int      vt_batch_rays(vt_batch* b, const vt_ray** rays);     /* the rays as uploaded (so a caller need not keep its copy) */
 int      vt_batch_hits(vt_batch* b, const vt_hit** hits);
 int      vt_batch_attrs(vt_batch* b, const vt_hit_attrs** attrs);
 int      vt_batch_shade(vt_batch* b, const vt_hit_shade** shade);     /* VT_ERR_INVALID_ARG without vt_scene_set_tri_attribs */

@@ -181,6 +181,9 @@ class Batch:
         check(fn(self._h, C.byref(p)))
         return _copy_from(p.value, len(self), dtype)
 
+    def rays(self) -> np.ndarray:
+        return self._fetch(lib.vt_batch_rays, RAY)
+
     def hits(self) -> np.ndarray:
         return self._fetch(lib.vt_batch_hits, HIT)
 

@@ -359,6 +359,10 @@ void vt_engine_close(vt_engine* e)
         b->d_mem = nullptr; b->done = nullptr; b->engine = nullptr;
     }
     e->batches.clear();
+    if (e->d_batch_spare) (void)hipFree(e->d_batch_spare);
+    e->d_batch_spare = nullptr;
+    for (auto& ps : e->pinned_spare) (void)hipHostFree(ps.first);
+    e->pinned_spare.clear();
     for (vt_engine::LaunchSlot& sl : e->slots) {
         if (sl.d_overflow) (void)hipFree(sl.d_overflow);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -856,17 +860,33 @@ int vt_batch_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_batch
         auto al = [](uint64_t x) { return (x + 255) & ~uint64_t(255); };
         const uint64_t ray_b = al(n * sizeof(vt_ray)), hit_b = al(n * sizeof(vt_hit)), att_b = al(n * sizeof(vt_hit_attrs));
         const uint64_t sha_b = s->d_attribs ? al(n * sizeof(vt_hit_shade)) : 0;
-        hipError_t err = hipMalloc(reinterpret_cast<void**>(&b->d_mem), ray_b + hit_b + att_b + sha_b);
+        const size_t need = ray_b + hit_b + att_b + sha_b;
+        hipError_t err = hipSuccess;
+        {
+            std::lock_guard<std::mutex> lock(e->launch_mu);
+            if (e->d_batch_spare && e->d_batch_spare_bytes >= need && e->d_batch_spare_bytes <= 2 * need) {
+                b->d_mem = e->d_batch_spare; b->d_mem_bytes = e->d_batch_spare_bytes;
+                e->d_batch_spare = nullptr; e->d_batch_spare_bytes = 0;
+            }
+        }
+        if (!b->d_mem) { err = hipMalloc(reinterpret_cast<void**>(&b->d_mem), need); b->d_mem_bytes = need; }
         if (err == hipSuccess) err = hipEventCreateWithFlags(&b->done, hipEventDisableTiming);
         if (err != hipSuccess) { if (b->d_mem) (void)hipFree(b->d_mem); delete b; return fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err)); }
         b->d_hits = b->d_mem + ray_b;
         b->d_attrs = b->d_mem + ray_b + hit_b;
         b->d_shade = sha_b ? b->d_mem + ray_b + hit_b + att_b : nullptr;
         int rc = VT_OK;
+        bool copied = false;
+        hipEvent_t ev_copied = nullptr;
+        if (hipEventCreateWithFlags(&ev_copied, hipEventDisableTiming) != hipSuccess) ev_copied = nullptr;
         {
             std::lock_guard<std::mutex> host_lock(e->host_mu);
+            // from caller memory that may go away when this call returns (a Lua string): the copy is waited for below, the
+            // kernels behind it are not
             err = hipMemcpyAsync(b->d_mem, rays, n * sizeof(vt_ray), hipMemcpyHostToDevice, e->stream);
+            if (err == hipSuccess && ev_copied) err = hipEventRecord(ev_copied, e->stream);
             if (err != hipSuccess) rc = fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err));
+            copied = rc == VT_OK;
             if (rc == VT_OK) rc = launch(s, b->d_mem, n, b->d_hits, nullptr, nullptr, false, false, e->stream);
             if (rc == VT_OK) {
                 HitAttrsArgs a{s->d_tris, s->d_prim_to_slot, reinterpret_cast<const vt_ray*>(b->d_mem), static_cast<const vt_hit*>(b->d_hits),
@@ -880,6 +900,8 @@ int vt_batch_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_batch
                 if (err != hipSuccess) rc = fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err));
             }
         }
+        if (copied) { if (ev_copied) (void)hipEventSynchronize(ev_copied); else (void)hipStreamSynchronize(e->stream); }
+        if (ev_copied) (void)hipEventDestroy(ev_copied);
         if (rc != VT_OK) { (void)hipStreamSynchronize(e->stream); (void)hipFree(b->d_mem); (void)hipEventDestroy(b->done); delete b; return rc; }
     }
     {
@@ -892,45 +914,60 @@ int vt_batch_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_batch
 
 uint64_t vt_batch_count(const vt_batch* b) { return b ? b->n : 0; }
 
-extern "C++" {
-template <class T>
-static int batch_fetch(vt_batch* b, const void* d_src, std::vector<T>& dst, bool& have, const T** out, const char* who)
+// one array of a batch, device -> pinned host memory, once
+static int batch_fetch(vt_batch* b, const void* d_src, size_t elem, vt_batch::HostArray& h, const void** out, const char* who)
 {
     *out = nullptr;
-    if (!have) {
+    if (!h.have) {
         if (b->n != 0) {
-            if (!b->engine || !d_src) return fail(VT_ERR_INVALID_ARG, std::string(who) + (b->engine ? ": not materialised for this batch" : ": the engine has been closed"));
-            DeviceGuard guard(b->engine->device);
+            vt_engine* e = b->engine;
+            if (!e || !d_src) return fail(VT_ERR_INVALID_ARG, std::string(who) + (e ? ": not materialised for this batch" : ": the engine has been closed"));
+            DeviceGuard guard(e->device);
             if (!guard.ok) return fail(VT_ERR_HIP, std::string(who) + ": hipSetDevice failed");
-            dst.resize(b->n);
+            const size_t need = b->n * elem;
+            {
+                std::lock_guard<std::mutex> lock(e->launch_mu);
+                for (size_t k = 0; k < e->pinned_spare.size(); ++k)
+                    if (e->pinned_spare[k].second >= need && e->pinned_spare[k].second <= 2 * need) {
+                        h.p = e->pinned_spare[k].first; h.bytes = e->pinned_spare[k].second;
+                        e->pinned_spare.erase(e->pinned_spare.begin() + long(k));
+                        break;
+                    }
+            }
+            if (!h.p) { VT_HIP(hipHostMalloc(&h.p, need)); h.bytes = need; }
             VT_HIP(hipEventSynchronize(b->done));
-            VT_HIP(hipMemcpy(dst.data(), d_src, b->n * sizeof(T), hipMemcpyDeviceToHost));
+            VT_HIP(hipMemcpy(h.p, d_src, need, hipMemcpyDeviceToHost));
         }
-        have = true;
+        h.have = true;
     }
-    *out = dst.empty() ? nullptr : dst.data();
+    *out = h.p;
     return VT_OK;
 }
-} // extern "C++"
+
+int vt_batch_rays(vt_batch* b, const vt_ray** rays)
+{
+    if (!b || !rays) return fail(VT_ERR_INVALID_ARG, "vt_batch_rays: NULL");
+    return batch_fetch(b, b->d_mem, sizeof(vt_ray), b->h_rays, reinterpret_cast<const void**>(rays), "vt_batch_rays");
+}
 
 int vt_batch_hits(vt_batch* b, const vt_hit** hits)
 {
     if (!b || !hits) return fail(VT_ERR_INVALID_ARG, "vt_batch_hits: NULL");
-    return batch_fetch(b, b->d_hits, b->hits, b->have_hits, hits, "vt_batch_hits");
+    return batch_fetch(b, b->d_hits, sizeof(vt_hit), b->h_hits, reinterpret_cast<const void**>(hits), "vt_batch_hits");
 }
 
 int vt_batch_attrs(vt_batch* b, const vt_hit_attrs** attrs)
 {
     if (!b || !attrs) return fail(VT_ERR_INVALID_ARG, "vt_batch_attrs: NULL");
-    return batch_fetch(b, b->d_attrs, b->attrs, b->have_attrs, attrs, "vt_batch_attrs");
+    return batch_fetch(b, b->d_attrs, sizeof(vt_hit_attrs), b->h_attrs, reinterpret_cast<const void**>(attrs), "vt_batch_attrs");
 }
 
 int vt_batch_shade(vt_batch* b, const vt_hit_shade** shade)
 {
     if (!b || !shade) return fail(VT_ERR_INVALID_ARG, "vt_batch_shade: NULL");
-    if (b->n != 0 && !b->have_shade && b->engine && !b->d_shade)
+    if (b->n != 0 && !b->h_shade.have && b->engine && !b->d_shade)
         return fail(VT_ERR_INVALID_ARG, "vt_batch_shade: the scene had no triangle attributes (vt_scene_set_tri_attribs) when the batch was traced");
-    return batch_fetch(b, b->d_shade, b->shade, b->have_shade, shade, "vt_batch_shade");
+    return batch_fetch(b, b->d_shade, sizeof(vt_hit_shade), b->h_shade, reinterpret_cast<const void**>(shade), "vt_batch_shade");
 }
 
 void vt_batch_free(vt_batch* b)
@@ -939,10 +976,21 @@ void vt_batch_free(vt_batch* b)
     if (vt_engine* e = b->engine) {
         DeviceGuard guard(e->device);
         if (b->done) { (void)hipEventSynchronize(b->done); (void)hipEventDestroy(b->done); }
-        if (b->d_mem) (void)hipFree(b->d_mem);
         std::lock_guard<std::mutex> lock(e->launch_mu);
+        if (b->d_mem) {                                  // kept for the next batch; the previous spare goes
+            if (e->d_batch_spare) (void)hipFree(e->d_batch_spare);
+            e->d_batch_spare = b->d_mem; e->d_batch_spare_bytes = b->d_mem_bytes;
+        }
+        for (vt_batch::HostArray* h : {&b->h_rays, &b->h_hits, &b->h_attrs, &b->h_shade}) {
+            if (!h->p) continue;
+            if (e->pinned_spare.size() < 8) e->pinned_spare.push_back({h->p, h->bytes});
+            else (void)hipHostFree(h->p);
+            h->p = nullptr;
+        }
         e->batches.erase(std::remove(e->batches.begin(), e->batches.end(), b), e->batches.end());
     }
+    for (vt_batch::HostArray* h : {&b->h_rays, &b->h_hits, &b->h_attrs, &b->h_shade})
+        if (h->p) (void)hipHostFree(h->p);              // the engine is gone: nothing to hand the blocks back to
     delete b;
 }
 

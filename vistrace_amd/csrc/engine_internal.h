@@ -94,6 +94,9 @@ struct vt_engine {
     // scenes uploaded through this engine: closing the engine releases their device memory and detaches them
     std::vector<vt_scene*> scenes;
     std::vector<vt_batch*> batches;          // live vt_batch objects (their device arrays go with the engine)
+    char*  d_batch_spare = nullptr;          // the device block of the batch freed last, for the next one that fits
+    size_t d_batch_spare_bytes = 0;
+    std::vector<std::pair<void*, size_t>> pinned_spare;   // pinned host blocks of freed batches (their downloaded arrays)
 
     // last launch geometry
     uint32_t last_blocks = 0, last_threads = 0, last_lds = 0;
@@ -163,12 +166,12 @@ struct vt_batch {
     vt_engine* engine = nullptr;             // NULL once the engine was closed
     uint64_t   n = 0;
     char*      d_mem = nullptr;              // rays | hits | attrs | shade
+    size_t     d_mem_bytes = 0;
+    // host copies, each fetched on first use into pinned memory (taken from / returned to the engine's spare list)
+    struct HostArray { void* p = nullptr; size_t bytes = 0; bool have = false; };
+    HostArray h_rays, h_hits, h_attrs, h_shade;
     void *d_hits = nullptr, *d_attrs = nullptr, *d_shade = nullptr;
     hipEvent_t done = nullptr;               // behind the last kernel of the batch
-    std::vector<vt_hit>       hits;
-    std::vector<vt_hit_attrs> attrs;
-    std::vector<vt_hit_shade> shade;
-    bool have_hits = false, have_attrs = false, have_shade = false;
 };
 
 struct DeviceGuard {

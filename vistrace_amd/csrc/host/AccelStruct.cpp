@@ -335,21 +335,21 @@ int AccelStruct::TraverseBatchBuffer(ILuaBase* LUA)
     const char* bytes = LUA->GetString(2, &len);
     if (!bytes || len % sizeof(vt_ray) != 0) LUA->ArgError(2, "ray buffer must hold whole 32-byte records {origin, direction, tMin, tMax}");
     const size_t n = len / sizeof(vt_ray);
-    mBatchRays.resize(n);
-    if (n) std::memcpy(mBatchRays.data(), bytes, len);           // Lua strings carry no alignment promise
-    for (size_t i = 0; i < n; ++i) {
-        if (mBatchRays[i].tmin < 0.f) LUA->ThrowError("tMin cannot be less than 0");
-        if (mBatchRays[i].tmax <= mBatchRays[i].tmin) LUA->ThrowError("tMax must be greater than tMin");
+    for (size_t i = 0; i < n; ++i) {                             // Lua strings carry no alignment promise: copy the two fields out
+        float range[2];
+        std::memcpy(range, bytes + i * sizeof(vt_ray) + 24, sizeof(range));
+        if (range[0] < 0.f) LUA->ThrowError("tMin cannot be less than 0");
+        if (range[1] <= range[0]) LUA->ThrowError("tMax must be greater than tMin");
     }
-    LUA->Pop(LUA->Top());
+    // the rays go to the device straight from the string (still on the Lua stack); nothing is kept on the host
     vt_batch* batch = nullptr;
-    if (vt_batch_trace_closest(mpScene, mBatchRays.data(), n, &batch) != VT_OK) {
+    if (vt_batch_trace_closest(mpScene, reinterpret_cast<const vt_ray*>(bytes), n, &batch) != VT_OK) {
         static thread_local char msg[512];
         std::snprintf(msg, sizeof(msg), "VisTrace: traversal failed: %s", vt_last_error());
         LUA->ThrowError(msg);
     }
-    LUA->PushUserType_Value(new TraceResultBatch(batch, mT, std::move(mBatchRays)), TraceResultBatch::id);
-    mBatchRays = std::vector<vt_ray>();
+    LUA->Pop(LUA->Top());
+    LUA->PushUserType_Value(new TraceResultBatch(batch, mT), TraceResultBatch::id);
     return 1;
 }
 

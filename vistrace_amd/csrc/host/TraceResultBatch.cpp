@@ -7,8 +7,8 @@ namespace vistrace {
 
 int TraceResultBatch::id = -1;
 
-TraceResultBatch::TraceResultBatch(vt_batch* batch, std::shared_ptr<const SceneTables> tables, std::vector<vt_ray>&& rays)
-    : mBatch(batch), mTables(std::move(tables)), mRays(std::move(rays)) {}
+TraceResultBatch::TraceResultBatch(vt_batch* batch, std::shared_ptr<const SceneTables> tables)
+    : mBatch(batch), mTables(std::move(tables)) {}
 
 TraceResultBatch::~TraceResultBatch() { vt_batch_free(mBatch); }
 
@@ -48,8 +48,10 @@ TraceResult* TraceResultBatch::MakeResult(uint64_t i)
 {
     const vt_hit* hits = Hits();
     if (!hits || hits[i].prim == VT_MISS) return nullptr;
+    const vt_ray* rays = nullptr;                       // the ray's direction comes back from the device (fetched once)
+    if (vt_batch_rays(mBatch, &rays) != VT_OK || !rays) return nullptr;
     const vt_hit& h = hits[i];
-    const vt_ray& r = mRays[i];
+    const vt_ray& r = rays[i];
     return new TraceResult(Vec3{r.dir[0], r.dir[1], r.dir[2]}, h.t, -1.f, -1.f, TriangleOf(h), h.prim, Vec2{h.u, h.v},
                            EntityOf(h), MaterialOf(h));                                             // :825-831
 }

@@ -23,19 +23,18 @@ class TraceResultBatch {
 public:
     static int id;                                      // Lua user-type id
 
-    // takes ownership of `batch`; `rays` are kept for Get(i) (a full TraceResult needs the ray's direction)
-    TraceResultBatch(vt_batch* batch, std::shared_ptr<const SceneTables> tables, std::vector<vt_ray>&& rays);
+    // takes ownership of `batch`
+    TraceResultBatch(vt_batch* batch, std::shared_ptr<const SceneTables> tables);
     ~TraceResultBatch();
     TraceResultBatch(const TraceResultBatch&) = delete;
     TraceResultBatch& operator=(const TraceResultBatch&) = delete;
 
-    uint64_t Count() const { return mRays.size(); }
+    uint64_t Count() const { return vt_batch_count(mBatch); }
     // arrays of Count() records, fetched from the device on first use; NULL (and vt_last_error) on failure
     const vt_hit*       Hits();
     const vt_hit_attrs* Attrs();
     const vt_hit_shade* Shade();
     const SceneTables&  Tables() const { return *mTables; }
-    const vt_ray&       Ray(uint64_t i) const { return mRays[i]; }
     // the triangle / entity / material behind hit i (i must be a hit)
     const Triangle& TriangleOf(const vt_hit& h) const { return mTables->triangles[h.prim]; }
     const Entity&   EntityOf(const vt_hit& h) const;
@@ -46,7 +45,6 @@ public:
 private:
     vt_batch* mBatch;
     std::shared_ptr<const SceneTables> mTables;
-    std::vector<vt_ray> mRays;
 };
 
 } // namespace vistrace
