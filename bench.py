@@ -820,9 +820,11 @@ def main() -> None:
         # one host thread: the closest analogue of what a GLua script gets today (one ray per call, serial).
         # Timed like the multi-thread leg: a slice of the same sample, walked once to warm the caches, then timed.
         one_n = min(sample, 1 << 17)
-        ctx.traverse(rays_host[:one_n], any_hit=any_hit, nthreads=1)
+        one_rays = np.ascontiguousarray(rays_host[:sample][::max(1, sample // one_n)][:one_n])   # spread over the sample: same mix of rays
+        one_n = len(one_rays)
+        ctx.traverse(one_rays, any_hit=any_hit, nthreads=1)
         t10 = time.perf_counter()
-        ctx.traverse(rays_host[:one_n], any_hit=any_hit, nthreads=1)
+        ctx.traverse(one_rays, any_hit=any_hit, nthreads=1)
         one_thread = one_n / (time.perf_counter() - t10) / 1e6
         if any_hit:
             occ = d_hits[:sample].cpu().numpy()
@@ -856,7 +858,7 @@ def main() -> None:
             "numa_replicas": ctx.replicas,
             "one_thread_value": round(one_thread, 4),
             "scaling_vs_one_thread": round(sample / cpu_s / 1e6 / one_thread, 2) if one_thread > 0 else None,
-            "one_thread_how": f"{one_n} rays of the same sample on one pinned thread, second of two consecutive walks",
+            "one_thread_how": f"{one_n} rays spread evenly over the same sample, one pinned thread, second of two consecutive walks",
         }
         result["parity_sample"] = {"rays": sample, ("occluded_equal" if any_hit else "prim_bit_exact"): same_prim, "tuv_bit_exact": same_tuv,
                                    "counters_equal": same_stats}
