@@ -142,8 +142,15 @@ struct Lane {
     uint32_t astate;           // 0 none, 1 = wants its triangle's AlphaRec, 2 = texels requested
     uint32_t cprim;  float cu, cv, ct;
     float ax, ay, aref;        // state 2: bilinear weights (ax < 0: nearest, one texel) and the material's reference
-    uint32_t tx0, tx1, tx2, tx3;   // state 2: destinations of the texel loads in flight
 };
+
+// ALPHA: the texel loads of state 1 land one round later in v76..v79 -- registers the compiler does not allocate (the kernel
+// asks for at most kCompilerVgprs through amdgpu_num_vgpr; 76 + these 4 = 80 = six waves per SIMD).
+// Nothing the register allocator does (copies, re-use, spills) can then touch a load in flight; state 2 moves the values
+// out behind its own wait.  tests/test_kernel_asm.py reads the generated code of every ALPHA variant and fails if the
+// compiler ever mentions one of the four (the attribute is a request: a variant that needs more registers gets them).
+#define VT_TEXEL_REGS "v76", "v77", "v78", "v79"
+constexpr int kCompilerVgprs = 76;
 
 typedef __attribute__((address_space(1))) const void* global_cptr;
 typedef __attribute__((address_space(3))) void*       lds_ptr;
@@ -168,6 +175,16 @@ __device__ __forceinline__ uint32_t wrap_index(float f, uint32_t n)
     const int i = int(f);                        // f is integral and |f| < 1e9: fits; n <= 65535
     const int m = i % int(n);
     return uint32_t(m < 0 ? m + int(n) : m);
+}
+
+// alpha of the material's plane from the texel(s) read (a / 255; bilinear with texel centres at (i + 0.5) / W): ax < 0 = nearest
+__device__ __forceinline__ float alpha_from_texels(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, float ax, float ay)
+{
+    if (ax < 0.0f) return float(t0) / 255.0f;
+    const float a00 = float(t0), a10 = float(t1), a01 = float(t2), a11 = float(t3);
+    const float top = a00 * (1.0f - ax) + a10 * ax;
+    const float bot = a01 * (1.0f - ax) + a11 * ax;
+    return (top * (1.0f - ay) + bot * ay) / 255.0f;
 }
 
 // one thread per triangle slot: the AlphaRec of the triangle in that slot from the caller's side tables
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(kBlockThreads) void alpha_records_kernel(AlphaRecAr
 }
 
 template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA>
-__global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_vgpr(kCompilerVgprs))) void trace_kernel(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
     const uint32_t lane = lane_id();
@@ -235,7 +252,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
     }
 
     Lane L;
-    if constexpr (ALPHA) { L.astate = 0; L.tx0 = L.tx1 = L.tx2 = L.tx3 = 0; L.ax = L.ay = L.aref = 0.f; L.cprim = 0; L.cu = L.cv = L.ct = 0.f; }
+    if constexpr (ALPHA) { L.astate = 0; L.ax = L.ay = L.aref = 0.f; L.cprim = 0; L.cu = L.cv = L.ct = 0.f; }
     uint64_t ray_idx = 0;
     bool has_ray = false;
     [[maybe_unused]] uint32_t pf = 0;   // VT_EXP_PREFETCH: destination of the far-child prefetch, never read
@@ -555,20 +572,14 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
         } else if (ALPHA && (alpha1 || alpha2)) {
             if constexpr (ALPHA) {
                 bool decided = false, pass = false;
-                if (alpha2) {
+                if (!STATS && alpha2) {
                     // ---- ALPHA 2: the texels requested one round ago: alpha, then :205.  (In program order BEFORE the block
                     // that issues new texel loads, so the wait below never waits for loads of this round; with the DMA fetch
                     // it is already satisfied -- the record wait of this round covered the older texel loads.)
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(L.tx0), "+v"(L.tx1), "+v"(L.tx2), "+v"(L.tx3) : : "memory");
-                    float alpha;
-                    if (L.ax < 0.0f) {
-                        alpha = float(L.tx0) / 255.0f;
-                    } else {
-                        const float a00 = float(L.tx0), a10 = float(L.tx1), a01 = float(L.tx2), a11 = float(L.tx3);
-                        const float top = a00 * (1.0f - L.ax) + a10 * L.ax;
-                        const float bot = a01 * (1.0f - L.ax) + a11 * L.ax;
-                        alpha = (top * (1.0f - L.ay) + bot * L.ay) / 255.0f;
-                    }
+                    uint32_t t0, t1, t2, t3;
+                    asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v76\n\tv_mov_b32 %1, v77\n\tv_mov_b32 %2, v78\n\tv_mov_b32 %3, v79"
+                                 : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3) : : "memory");
+                    const float alpha = alpha_from_texels(t0, t1, t2, t3, L.ax, L.ay);
                     decided = true; pass = !(alpha < L.aref);
                 }
                 if (alpha1) {
@@ -584,15 +595,18 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                     else if (dims == 0u) { decided = true; pass = !(1.0f < L.aref); }         // no texture: alpha 1
                     else {
                         const uint32_t W = dims & 0xFFFFu, H = dims >> 16;
-                        const uint8_t* img = a.alpha_texels + (of & 0x7FFFFFFFu);
+                        const uint32_t plane = of & 0x7FFFFFFFu;          // texel offsets fit 32 bits (vt_scene_set_alpha: < 2 GiB)
                         float x = ss * float(W), y = tt * float(H);
                         if (!(fabsf(x) < 1.0e9f)) x = 0.0f;
                         if (!(fabsf(y) < 1.0e9f)) y = 0.0f;
-                        // the loads are issued behind the compiler's back (a load it knows of is waited for at the end of the
-                        // block): their destinations stay reserved until ALPHA 2 reads them one round later
+                        // STATS (diagnostic) variants read the texels in place -- the wave waits, only results and counters
+                        // matter there, and they may need more registers than the cap leaves.  The others issue the loads
+                        // behind the compiler's back (a load it knows of is waited for at the end of the block) into the
+                        // reserved registers; ALPHA 2 reads them one round later.
+                        uint32_t p0, p1 = plane, p2 = plane, p3 = plane;
                         if ((of >> 31) == 0u) {
                             const uint32_t xi = wrap_index(floorf(x), W), yi = wrap_index(floorf(y), H);
-                            asm volatile("global_load_ubyte %0, %1, off" : "=v"(L.tx0) : "v"(img + (size_t(yi) * W + xi)));
+                            p0 = plane + yi * W + xi;
                             L.ax = -1.0f; L.ay = 0.0f;
                         } else {
                             const float fx = x - 0.5f, fy = y - 0.5f;
@@ -600,13 +614,22 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
                             L.ax = fx - x0; L.ay = fy - y0;
                             const uint32_t i0 = wrap_index(x0, W), i1 = wrap_index(x0 + 1.0f, W);
                             const uint32_t j0 = wrap_index(y0, H), j1 = wrap_index(y0 + 1.0f, H);
-                            asm volatile("global_load_ubyte %0, %4, off\n\tglobal_load_ubyte %1, %5, off\n\t"
-                                         "global_load_ubyte %2, %6, off\n\tglobal_load_ubyte %3, %7, off"
-                                         : "=&v"(L.tx0), "=&v"(L.tx1), "=&v"(L.tx2), "=&v"(L.tx3)
-                                         : "v"(img + (size_t(j0) * W + i0)), "v"(img + (size_t(j0) * W + i1)),
-                                           "v"(img + (size_t(j1) * W + i0)), "v"(img + (size_t(j1) * W + i1)));
+                            p0 = plane + j0 * W + i0; p1 = plane + j0 * W + i1;
+                            p2 = plane + j1 * W + i0; p3 = plane + j1 * W + i1;
                         }
-                        L.astate = 2;
+                        if constexpr (STATS) {
+                            decided = true;
+                            const uint8_t* img = a.alpha_texels;
+                            pass = !(alpha_from_texels(img[p0], img[p1], img[p2], img[p3], L.ax, L.ay) < L.aref);
+                        } else {
+                            if (L.ax < 0.0f)
+                                asm volatile("global_load_ubyte v76, %0, %1" : : "v"(p0), "s"(a.alpha_texels) : VT_TEXEL_REGS);
+                            else
+                                asm volatile("global_load_ubyte v76, %0, %4\n\tglobal_load_ubyte v77, %1, %4\n\t"
+                                             "global_load_ubyte v78, %2, %4\n\tglobal_load_ubyte v79, %3, %4"
+                                             : : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(a.alpha_texels) : VT_TEXEL_REGS);
+                            L.astate = 2;
+                        }
                     }
                 }
                 if (decided) {
