@@ -205,7 +205,7 @@ def child_workload_args(args) -> list:
 
 def kernel_row_prefix(args) -> str:
     """How the dominant kernel's rows start in rocprofv3's CSVs (spaces removed): trace_kernel<ANY_HIT,STATS,..."""
-    return "trace_kernel<%s,false," % ("true" if args.kind == "shadow" else "false")
+    return "%s<%s,false," % ("trace_kernel_alpha" if args.alpha_frac > 0 else "trace_kernel", "true" if args.kind == "shadow" else "false")
 
 
 def collect_pmc_live(args, passes) -> dict:
@@ -724,8 +724,8 @@ def main() -> None:
             "alg_note": "algorithmic bytes (SURVEY 8(d)) / launch duration; > peak because records are served by L1/L2/Infinity Cache",
             "traffic_over_alg": round(traffic / alg_bytes, 4) if traffic else None,
             "compulsory_bytes": int(n * (32 + out_bytes) + scene.device_bytes),
-            "kernel": "vt::trace_kernel<%s,false,%s,%s,%s>" % ("true" if any_hit else "false", "true" if persistent else "false", "true" if dma else "false",
-                                                                "true" if args.alpha_frac > 0 else "false"),   # <ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>
+            "kernel": ("vt::trace_kernel_alpha<%s,false,%s,%s>" if args.alpha_frac > 0 else "vt::trace_kernel<%s,false,%s,%s,false>") % (
+                "true" if any_hit else "false", "true" if persistent else "false", "true" if dma else "false"),   # <ANY_HIT, STATS, PERSISTENT, FETCH_DMA[, ALPHA]>
             "kernel_ms": round(k_ms, 4),
             "kernel_ms_how": "HIP events on the launch stream around the K timed steps / K (cursor memset + kernel); single launches: %s ms" % (
                 ", ".join(f"{x:.3f}" for x in single_ms)),

@@ -8,7 +8,7 @@ TMP=$(mktemp -d)
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-gpu-flush-denormals-to-zero \
   -fno-slp-vectorize -I$ROOT/include -I$ROOT/vistrace_amd/csrc "$@" --cuda-device-only -S -o $TMP/all.s \
   $ROOT/vistrace_amd/csrc/trace_kernels.hip -Rpass-analysis=kernel-resource-usage 2> $TMP/res.txt
-SYM="_ZN2vt12trace_kernelILb${A}ELb${S}ELb${P}ELb${D}ELb${AL}EEEvNS_9TraceArgsE"
+if [ "$AL" = 1 ]; then SYM="_ZN2vt18trace_kernel_alphaILb${A}ELb${S}ELb${P}ELb${D}EEEvNS_9TraceArgsE"; else SYM="_ZN2vt12trace_kernelILb${A}ELb${S}ELb${P}ELb${D}ELb0EEEvNS_9TraceArgsE"; fi
 grep -A8 "Function Name: $SYM" $TMP/res.txt | grep -E "SGPRs:|VGPRs:|Spill|Occupancy" | sed 's/.*remark: *//'
 awk "/^$SYM:/,/s_endpgm/" $TMP/all.s > $OUT
 echo "$(grep -c '^\s*v_' $OUT) VALU, $(grep -c '^\s*s_' $OUT) SALU static instructions -> $OUT"

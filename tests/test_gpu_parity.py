@@ -368,6 +368,26 @@ def test_batch_object_matches_the_separate_calls(va, engine, make_bundle):
     scene.free()
 
 
+def test_batch_outliving_its_engine(va, make_bundle):
+    """vt_engine_close releases the device arrays of live batches: what a batch has downloaded stays readable, what it has
+    not is lost (the getter fails, nothing touches freed memory), and freeing the batch afterwards is safe."""
+    from vistrace_amd import workloads as W
+    b = make_bundle("S1k")
+    eng = va.Engine(0)
+    scene = va.Scene(eng, b.host_scene)
+    rays = W.sphere_rays(5000, 21)
+    batch = scene.trace_batch(rays)
+    hits = batch.hits()                                        # downloaded before the engine goes away
+    assert_hits_equal(hits, b.oracle(rays))
+    scene.free()
+    eng.close()
+    assert (batch.hits().view(np.uint8) == hits.view(np.uint8)).all()
+    with pytest.raises(va._lib.VisTraceError) as err:
+        batch.attrs()
+    assert "engine has been closed" in str(err.value)
+    batch.free()
+
+
 def test_hit_shade_vs_oracle(va, engine, make_bundle, O):
     """texUV / blendFactor / entIdx / submatIdx (TraceResult.cpp:70,73-78) from the per-triangle
     side table: floats bit-identical to the oracle, ids exact, misses flagged."""

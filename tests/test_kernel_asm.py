@@ -41,11 +41,14 @@ def kernel_asm(tmp_path_factory):
 
 
 def variants(usage):
-    """(mangled name, ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA) of every trace_kernel instantiation."""
+    """(mangled name, ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA) of every trace_kernel / trace_kernel_alpha instantiation."""
     for name in usage:
-        m = re.match(r"_ZN2vt12trace_kernelILb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)EEEvNS_9TraceArgsE$", name)
+        m = re.match(r"_ZN2vt12trace_kernelILb(\d)ELb(\d)ELb(\d)ELb(\d)ELb0EEEvNS_9TraceArgsE$", name)
         if m:
-            yield (name, *[int(x) for x in m.groups()])
+            yield (name, *[int(x) for x in m.groups()], 0)
+        m = re.match(r"_ZN2vt18trace_kernel_alphaILb(\d)ELb(\d)ELb(\d)ELb(\d)EEEvNS_9TraceArgsE$", name)
+        if m:
+            yield (name, *[int(x) for x in m.groups()], 1)
 
 
 def test_register_budgets(kernel_asm):

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kBlockThreads) void alpha_records_kernel(AlphaRecAr
 }
 
 template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_vgpr(kCompilerVgprs))) void trace_kernel(TraceArgs a)
+__device__ __forceinline__ void trace_body(const TraceArgs& a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
     const uint32_t lane = lane_id();
@@ -717,6 +717,22 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_vgpr(kComp
     }
 }
 
+// The two kernels around the body.  The variants without the alpha test are compiled as before; the ALPHA variants ask the
+// compiler to stay within kCompilerVgprs registers (see VT_TEXEL_REGS) -- an attribute cannot depend on a template argument,
+// hence two templates (`ALPHA` stays a parameter of the first so that its name reads as in rounds 1 and 2).
+template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA>
+__global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceArgs a)
+{
+    static_assert(!ALPHA, "the alpha-test variants are trace_kernel_alpha");
+    trace_body<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, false>(a);
+}
+
+template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_vgpr(kCompilerVgprs))) void trace_kernel_alpha(TraceArgs a)
+{
+    trace_body<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, true>(a);
+}
+
 // ---- TraceResult batch core: TraceResult.cpp:45-86, 255-262 -----------------------------
 __device__ __forceinline__ vt_hit_attrs make_hit_attrs(const vt_tri64& T, const vt_ray& r, const vt_hit& h)
 {
@@ -1044,8 +1060,10 @@ __global__ __launch_bounds__(kBlockThreads) void refit_level_kernel(RefitLevelAr
 template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA>
 static hipError_t launch_one(const TraceArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>), grid, dim3(kBlockThreads), lds_bytes,
-                       stream, a);
+    if constexpr (ALPHA)
+        hipLaunchKernelGGL((trace_kernel_alpha<ANY_HIT, STATS, PERSISTENT, FETCH_DMA>), grid, dim3(kBlockThreads), lds_bytes, stream, a);
+    else
+        hipLaunchKernelGGL((trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, false>), grid, dim3(kBlockThreads), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
@@ -1067,9 +1085,14 @@ namespace {
 template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA>
 hipError_t variant_op(const TraceArgs* a, dim3 grid, size_t lds_bytes, hipStream_t stream, int* blocks_per_cu)
 {
-    if (blocks_per_cu)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            blocks_per_cu, trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>, int(kBlockThreads), lds_bytes);
+    if (blocks_per_cu) {
+        if constexpr (ALPHA)
+            return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel_alpha<ANY_HIT, STATS, PERSISTENT, FETCH_DMA>,
+                                                                int(kBlockThreads), lds_bytes);
+        else
+            return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, false>,
+                                                                int(kBlockThreads), lds_bytes);
+    }
     return launch_one<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, ALPHA>(*a, grid, lds_bytes, stream);
 }
 
