@@ -819,8 +819,12 @@ def main() -> None:
         cpu_s = time.perf_counter() - tc0
         # one host thread: the closest analogue of what a GLua script gets today (one ray per call, serial).
         # Timed like the multi-thread leg: a slice of the same sample, walked once to warm the caches, then timed.
+        # ... on 32 runs of consecutive rays spread evenly over the sample: the same mix of rays AND the same locality between
+        # neighbours as the multi-thread leg sees (a strided pick would lose the locality, a prefix the mix)
         one_n = min(sample, 1 << 17)
-        one_rays = np.ascontiguousarray(rays_host[:sample][::max(1, sample // one_n)][:one_n])   # spread over the sample: same mix of rays
+        run = max(1, one_n // 32)
+        starts = np.linspace(0, max(0, sample - run), num=min(32, max(1, sample // run)), dtype=np.int64)
+        one_rays = np.ascontiguousarray(np.concatenate([rays_host[int(s0): int(s0) + run] for s0 in starts]))
         one_n = len(one_rays)
         ctx.traverse(one_rays, any_hit=any_hit, nthreads=1)
         t10 = time.perf_counter()
@@ -858,7 +862,7 @@ def main() -> None:
             "numa_replicas": ctx.replicas,
             "one_thread_value": round(one_thread, 4),
             "scaling_vs_one_thread": round(sample / cpu_s / 1e6 / one_thread, 2) if one_thread > 0 else None,
-            "one_thread_how": f"{one_n} rays spread evenly over the same sample, one pinned thread, second of two consecutive walks",
+            "one_thread_how": f"{one_n} rays (32 runs of consecutive rays spread evenly over the same sample), one pinned thread, second of two consecutive walks",
         }
         result["parity_sample"] = {"rays": sample, ("occluded_equal" if any_hit else "prim_bit_exact"): same_prim, "tuv_bit_exact": same_tuv,
                                    "counters_equal": same_stats}
