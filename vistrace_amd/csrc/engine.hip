@@ -158,6 +158,12 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     a.reserved_cus = p.persistent && e->reserved_cus ? e->d_reserved : nullptr;
     a.cu_slots = d_cu_slots;
     a.reserved_limit = e->reserved_limit;
+    {   // measurement builds only (VT_EXP_DIST_STACK): what a 32-bit stack entry has left beside the pair index
+        uint32_t idx_bits = 1;
+        while ((uint64_t(1) << idx_bits) < uint64_t(s->npairs) + 1) ++idx_bits;
+        const uint32_t spare = 32u - idx_bits;
+        a.dist_bits = spare >= 6 ? std::min(spare, 16u) : 0u;
+    }
 
     // the first block of every wave is static (block w -> wave w); the cursor hands out the rest
     if (a.reserved_cus) VT_HIP(hipMemsetAsync(a.cu_slots, 0, 4096, stream));

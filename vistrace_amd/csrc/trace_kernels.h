@@ -39,6 +39,7 @@ struct TraceArgs {
     const uint32_t*     reserved_cus;     // persistent mode: 1024-bit set of __smid() values of the reserved CUs, or NULL
     uint32_t*           cu_slots;         // 1024 counters (zeroed per launch): blocks that asked to stay on a reserved CU
     uint32_t            reserved_limit;   // blocks a reserved CU keeps (0 = none)
+    uint32_t            dist_bits;        // VT_EXP_DIST_STACK builds: bits of a stack entry that hold the entry distance (0 = off)
 };
 
 // One per triangle slot of a scene with alpha-tested triangles, in the scene's record array behind the triangles (so

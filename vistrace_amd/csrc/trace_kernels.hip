@@ -58,6 +58,9 @@
 #ifndef VT_EXP_DMA_MASK
 #define VT_EXP_DMA_MASK 0   // 1: lanes that need no record this round take no part in the DMA (no dummy fetch of record 0)
 #endif
+#ifndef VT_EXP_DIST_STACK
+#define VT_EXP_DIST_STACK 0 // 1: a stack entry also keeps its node's entry distance (in the bits the pair index leaves free, rounded
+#endif                      //    down); a popped pair that lies behind the current hit is skipped (exact for hits, not for step counts)
 #ifndef VT_EXP_DMA_AUX
 #define VT_EXP_DMA_AUX 0    // cache-policy bits of the record DMA: 1 = sc0, 2 = nt, 16 = sc1
 #endif
@@ -684,7 +687,15 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                 // near child first (ties keep left first); push the far child's pair
                 const bool swap = fl > fr;
                 next = swap ? rfirst : lfirst;
-                const uint32_t far = swap ? lfirst : rfirst;
+                uint32_t far = swap ? lfirst : rfirst;
+#if VT_EXP_DIST_STACK
+                if constexpr (!STATS) {
+                    // entry distance of the far child, truncated to the top dist_bits bits of its (non-negative) fp32 pattern
+                    const float fd = swap ? fl : fr;
+                    const uint32_t qd = fd > 0.0f ? __float_as_uint(fd) >> (31u - a.dist_bits) : 0u;
+                    far |= qd << (32u - a.dist_bits);
+                }
+#endif
                 if (L.sp < a.lds_entries) st_lds[L.sp * 64] = far;
                 else st_ovf[size_t(L.sp - a.lds_entries) * gstride] = far;
                 ++L.sp;
@@ -697,6 +708,20 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                 next = lfirst;
             } else if (go_r) {
                 next = rfirst;
+#if VT_EXP_DIST_STACK
+            } else if (!STATS && a.dist_bits != 0) {
+                next = kDone;
+                while (L.sp != 0) {
+                    --L.sp;
+                    uint32_t e;
+                    if (L.sp < a.lds_entries) e = st_lds[L.sp * 64];
+                    else e = st_ovf[size_t(L.sp - a.lds_entries) * gstride];
+                    const float lb = __uint_as_float((e >> (32u - a.dist_bits)) << (31u - a.dist_bits));   // <= the entry distance
+                    if (lb > L.tmax) continue;                  // everything below lies behind the hit found since the push
+                    next = e & (0xFFFFFFFFu >> a.dist_bits);
+                    break;
+                }
+#endif
             } else if (L.sp != 0) {
                 --L.sp;
                 // two separate loads on purpose: a pointer select would turn this into a flat_load
