@@ -711,6 +711,31 @@ def test_reserved_cus_do_not_change_results(va, make_bundle):
         eng.set_option("reserved_cus", 100000)
 
 
+def test_persistent_launches_leave_their_cursors_clean(va, make_bundle):
+    """A persistent launch starts from zeroed ray-block cursors and its last wave puts them back (no fill between launches):
+    three times round the ring of launch slots, with batch sizes, kernel kinds and cursor modes changing from launch to
+    launch, every result must stay exact."""
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    eng = va.Engine(0)
+    eng.set_option("persistent", 1)
+    scene = va.Scene(eng, b.host_scene)
+    rays = np.concatenate([W.primary_rays(128, 128), W.sphere_rays(50000, 21, origin=(-30.0, 15.0, 40.0))])
+    ref = b.oracle(rays)
+    occ = ref["prim"] != O_MISS
+    sizes = [len(rays), 1, 64, 65, 4097, 30000, 257, len(rays) - 1]
+    for k in range(52):
+        n = sizes[k % len(sizes)]
+        eng.set_option("xcd_cursors", 1 if k % 5 == 3 else 0)
+        eng.set_option("reserved_cus", 32 if k % 7 == 4 else 0)
+        if k % 3 == 2:
+            assert (scene.trace_any(rays[:n]) == occ[:n]).all(), f"launch {k}"
+        else:
+            assert_hits_equal(scene.trace_closest(rays[:n]), ref[:n])
+    hits, st = stats_on_device(va, scene, rays)
+    assert_hits_equal(hits, ref)
+
+
 def test_host_buffer_pipeline_ragged(va, engine, make_bundle):
     """vt_trace_closest / vt_trace_any with caller (pageable) buffers above the pipelining threshold and a ragged
     last chunk: identical to the device-resident path, and to the oracle on a sample."""

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -95,6 +96,10 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool 
     return VT_OK;
 }
 
+#ifndef VT_EXP_TIMELINE
+#define VT_EXP_TIMELINE 0   // measurement builds: see trace_kernels.hip
+#endif
+
 int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_occ, void* d_stats, bool any_hit,
            bool stats, hipStream_t stream)
 {
@@ -171,16 +176,27 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     a.nblocks = uint32_t((n + a.block_rays - 1) / a.block_rays);
     // 0 = by scene size: cheap rays (small trees) finish fast enough for the single cursor word to become the limit
     a.max_claim = e->max_claim ? e->max_claim : (s->npairs <= 200000u ? 4u : 1u);
-    if (p.persistent && a.xcd_cursors)
-        VT_HIP(hipMemsetAsync(d_cursor, 0, 512, stream));                    // eight cursors, 64 B apart
-    else if (p.persistent)
-        VT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_cursor),
-                                 a.reserved_cus ? 0 : int(p.grid_blocks * (kBlockThreads / 64)), 1, stream));
+    // the cursors are zero: engine open cleared them and every persistent launch leaves them so (leave_grid)
+    a.cursor_base = (a.reserved_cus || a.xcd_cursors) ? 0u : p.grid_blocks * (kBlockThreads / 64);
+#if VT_EXP_TIMELINE
+    static uint64_t* d_timeline = nullptr;          // measurement build: one process, one device
+    const size_t tl_words = size_t(p.grid_blocks) * (kBlockThreads / 64) * 8;
+    if (!d_timeline) VT_HIP(hipMalloc(reinterpret_cast<void**>(&d_timeline), 65536 * 8 * sizeof(uint64_t)));
+    a.timeline = p.persistent && tl_words <= 65536 * 8 ? d_timeline : nullptr;
+#endif
     if (e->timing) VT_HIP(hipEventRecord(e->ev_start, stream));
     VT_HIP(launch_trace(a, any_hit, stats, p.persistent, p.fetch_dma, s->has_alpha, p.grid_blocks, p.lds_bytes, stream));
     if (e->timing) { VT_HIP(hipEventRecord(e->ev_stop, stream)); e->ev_valid = true; }
     VT_HIP(hipEventRecord(slot.done, stream));
     slot.used = true;
+#if VT_EXP_TIMELINE
+    if (const char* path = std::getenv("VT_TIMELINE_FILE"); path && a.timeline && !stats) {     // the last plain launch's timeline
+        VT_HIP(hipStreamSynchronize(stream));
+        std::vector<uint64_t> h(tl_words);
+        VT_HIP(hipMemcpy(h.data(), d_timeline, tl_words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), sizeof(uint64_t), tl_words, f); std::fclose(f); }
+    }
+#endif
     e->last_blocks = p.grid_blocks; e->last_threads = kBlockThreads; e->last_lds = uint32_t(p.lds_bytes);
     e->last_persistent = p.persistent; e->last_dma = p.fetch_dma;
     return VT_OK;
@@ -325,6 +341,7 @@ int vt_engine_open(int device, vt_engine** out)
     e->fetch_dma = int(env_long("VT_FETCH_DMA", e->fetch_dma));
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->d_slot_ctl), vt_engine::kLaunchSlots * vt_engine::kSlotCtlBytes);
+    if (err == hipSuccess) err = hipMemset(e->d_slot_ctl, 0, vt_engine::kLaunchSlots * vt_engine::kSlotCtlBytes);
     for (uint32_t k = 0; k < vt_engine::kLaunchSlots && err == hipSuccess; ++k) {
         e->slots[k].d_ctl = reinterpret_cast<uint32_t*>(e->d_slot_ctl + k * vt_engine::kSlotCtlBytes);
         err = hipEventCreateWithFlags(&e->slots[k].done, hipEventDisableTiming);

@@ -11,6 +11,8 @@ namespace vt {
 
 constexpr uint32_t kBlockThreads = 256; // 4 waves of 64
 
+constexpr uint32_t kExitWord = 120;   // of the 128 cursor words of a launch slot: waves that have left the persistent grid
+
 struct TraceArgs {
     const void*         records;     // 64-B records: pairs [0, npairs), triangles from tri_base on
     const vt_ray*       rays;
@@ -18,7 +20,9 @@ struct TraceArgs {
     uint8_t*            occluded;    // any-hit output
     vt_ray_stats*       ray_stats;   // STATS kernels only
     uint32_t*           overflow;    // per-lane stack overflow area: entry k of thread g at [k*gstride + g]
-    uint32_t*           block_cursor;// persistent mode: next block of rays to hand out
+    uint32_t*           block_cursor;// persistent mode: next block of rays to hand out, counted from cursor_base.  Zero when a launch
+                                     // starts; the last wave to leave puts it back to zero (word kExitWord counts the leavers)
+    uint32_t            cursor_base; // the first ray block the cursor hands out (the blocks before it are assigned statically)
     uint64_t            nrays;
     uint32_t            npairs;
     uint32_t            tri_base;    // record index of triangle 0
@@ -39,6 +43,7 @@ struct TraceArgs {
     const uint32_t*     reserved_cus;     // persistent mode: 1024-bit set of __smid() values of the reserved CUs, or NULL
     uint32_t*           cu_slots;         // 1024 counters (zeroed per launch): blocks that asked to stay on a reserved CU
     uint32_t            reserved_limit;   // blocks a reserved CU keeps (0 = none)
+    uint64_t*           timeline;         // VT_EXP_TIMELINE builds: per wave {start, cursor exhausted, exit, iterations, ...} (else unused)
     uint32_t            dist_bits;        // VT_EXP_DIST_STACK builds: bits of a stack entry that hold the entry distance (0 = off)
 };
 

@@ -58,6 +58,9 @@
 #ifndef VT_EXP_DMA_MASK
 #define VT_EXP_DMA_MASK 0   // 1: lanes that need no record this round take no part in the DMA (no dummy fetch of record 0)
 #endif
+#ifndef VT_EXP_TIMELINE
+#define VT_EXP_TIMELINE 0   // 1: every wave of the persistent kernel reports when it started, found the ray cursor exhausted and left
+#endif                      //    (scripts/timeline.py: the drain at the end of a launch)
 #ifndef VT_EXP_DIST_STACK
 #define VT_EXP_DIST_STACK 0 // 1: a stack entry also keeps its node's entry distance (in the bits the pair index leaves free, rounded
 #endif                      //    down); a popped pair that lies behind the current hit is skipped (exact for hits, not for step counts)
@@ -215,6 +218,18 @@ __global__ __launch_bounds__(kBlockThreads) void alpha_records_kernel(AlphaRecAr
     a.out[slot] = r;
 }
 
+// The ray-block cursors of a launch slot are zero when a launch starts: the last wave of the persistent grid to leave puts them
+// back (all others have made their last claim by then), so that no fill kernel has to run between two launches -- on one stream
+// that was fill, wait, launch: 20 us between two traces instead of 8 (scripts/launch_gaps.py).
+__device__ __forceinline__ void leave_grid(const TraceArgs& a, uint32_t waves_leaving)
+{
+    const uint32_t waves = gridDim.x * (kBlockThreads / 64);
+    if (atomicAdd(a.block_cursor + kExitWord, waves_leaving) + waves_leaving == waves) {
+        for (uint32_t x = 0; x < 8u; ++x) __hip_atomic_store(a.block_cursor + 16u * x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.block_cursor + kExitWord, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA>
 __device__ __forceinline__ void trace_body(const TraceArgs& a)
 {
@@ -249,7 +264,10 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                                        (FETCH_DMA ? size_t(kBlockThreads / 64) * kStageBytes / 4 - 1 : 0);
                 if (threadIdx.x == 0) *flag = atomicAdd(&a.cu_slots[id], 1u) >= a.reserved_limit ? 1u : 0u;
                 __syncthreads();
-                if (*flag != 0) return;
+                if (*flag != 0) {
+                    if (threadIdx.x == 0) leave_grid(a, kBlockThreads / 64);
+                    return;
+                }
             }
         }
     }
@@ -338,7 +356,15 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
         if (has_ray && L.node == kDone && L.tri_cur >= L.tri_end) finish_ray();
     }
 
+#if VT_EXP_TIMELINE
+    const uint64_t tl_start = __builtin_amdgcn_s_memrealtime();
+    uint64_t tl_exhausted = 0, tl_iters = 0, tl_tail_iters = 0, tl_tail_lanes = 0;
+#endif
     for (;;) {
+#if VT_EXP_TIMELINE
+        ++tl_iters;
+        if (exhausted) { if (tl_exhausted == 0) tl_exhausted = __builtin_amdgcn_s_memrealtime(); ++tl_tail_iters; tl_tail_lanes += __popcll(__ballot(has_ray)); }
+#endif
         // Wave priority: high from here until this iteration's record fetch has been issued, low while the wave waits for
         // the records and computes on them.  Waves that are about to put loads in flight are then picked ahead of waves
         // that are computing, so the fetches of a SIMD's waves overlap better: 16 Mi bounce rays 4.52 -> 4.33 ms, camera
@@ -377,7 +403,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                                 k = k < 1u ? 1u : (k > a.max_claim ? a.max_claim : k);
                                 uint32_t c = 0;
                                 if (lane == 0) c = atomicAdd(a.block_cursor, k);
-                                claim_cur = __builtin_amdgcn_readfirstlane(c);
+                                claim_cur = a.cursor_base + __builtin_amdgcn_readfirstlane(c);
                                 claim_end = claim_cur + k;
                             }
                             b = claim_cur++;
@@ -740,6 +766,18 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
         }
         if (has_ray && L.node == kDone && L.tri_cur >= L.tri_end && (!ALPHA || L.astate == 0)) finish_ray();
     }
+    if constexpr (PERSISTENT) {
+        if (lane == 0) leave_grid(a, 1);
+    }
+#if VT_EXP_TIMELINE
+    if constexpr (PERSISTENT) {
+        if (a.timeline && lane == 0) {
+            uint64_t* t = a.timeline + (uint64_t(blockIdx.x) * (kBlockThreads / 64) + wave) * 8;
+            t[0] = tl_start; t[1] = tl_exhausted; t[2] = __builtin_amdgcn_s_memrealtime(); t[3] = tl_iters;
+            t[4] = tl_tail_iters; t[5] = tl_tail_lanes; t[6] = my_xcd; t[7] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);   // HW_ID
+        }
+    }
+#endif
 }
 
 // The two kernels around the body.  The variants without the alpha test are compiled as before; the ALPHA variants ask the
