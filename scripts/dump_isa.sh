@@ -10,6 +10,6 @@ TMP=$(mktemp -d)
   $ROOT/vistrace_amd/csrc/trace_kernels.hip -Rpass-analysis=kernel-resource-usage 2> $TMP/res.txt
 if [ "$AL" = 1 ]; then SYM="_ZN2vt18trace_kernel_alphaILb${A}ELb${S}ELb${P}ELb${D}EEEvNS_9TraceArgsE"; else SYM="_ZN2vt12trace_kernelILb${A}ELb${S}ELb${P}ELb${D}ELb0EEEvNS_9TraceArgsE"; fi
 grep -A8 "Function Name: $SYM" $TMP/res.txt | grep -E "SGPRs:|VGPRs:|Spill|Occupancy" | sed 's/.*remark: *//'
-awk "/^$SYM:/,/s_endpgm/" $TMP/all.s > $OUT
+awk "/^$SYM:/,/^.Lfunc_end/" $TMP/all.s > $OUT
 echo "$(grep -c '^\s*v_' $OUT) VALU, $(grep -c '^\s*s_' $OUT) SALU static instructions -> $OUT"
 rm -rf $TMP

@@ -69,7 +69,7 @@ def test_texel_registers_belong_to_the_hand_written_asm(kernel_asm):
     checked = 0
     for name, any_hit, stats, persistent, dma, alpha in variants(usage):
         body = text[text.index(f"\n{name}:"):]
-        body = body[: body.index("s_endpgm")]
+        body = body[: body.index("\n.Lfunc_end")]      # the whole function: a kernel may hold more than one s_endpgm
         in_asm = False
         loads = reads = 0
         for line in body.splitlines():
