@@ -61,6 +61,9 @@
 #ifndef VT_EXP_TIMELINE
 #define VT_EXP_TIMELINE 0   // 1: every wave of the persistent kernel reports when it started, found the ray cursor exhausted and left
 #endif                      //    (scripts/timeline.py: the drain at the end of a launch)
+#ifndef VT_EXP_ANY_ORDER
+#define VT_EXP_ANY_ORDER 0  // any-hit walks only: 1 = left child first whatever the distances, 2 = far child first (same occlusion flags)
+#endif
 #ifndef VT_EXP_DIST_STACK
 #define VT_EXP_DIST_STACK 0 // 1: a stack entry also keeps its node's entry distance (in the bits the pair index leaves free, rounded
 #endif                      //    down); a popped pair that lies behind the current hit is skipped (exact for hits, not for step counts)
@@ -711,7 +714,12 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             uint32_t next;
             if (go_l && go_r) {
                 // near child first (ties keep left first); push the far child's pair
+#if VT_EXP_ANY_ORDER
+                // any-hit: whether a ray is occluded does not depend on the order of the walk (its interval never shrinks)
+                const bool swap = (ANY_HIT && !STATS) ? (VT_EXP_ANY_ORDER == 2 ? fl < fr : false) : fl > fr;
+#else
                 const bool swap = fl > fr;
+#endif
                 next = swap ? rfirst : lfirst;
                 uint32_t far = swap ? lfirst : rfirst;
 #if VT_EXP_DIST_STACK
