@@ -645,7 +645,7 @@ def main() -> None:
     engine.set_timing(False)
 
     value = n_total * args.steps / elapsed / 1e6
-    k_ms = region_ms / args.steps                      # mean launch duration over the timed region (memset + kernel)
+    k_ms = region_ms / args.steps                      # mean launch duration over the timed region (launch to launch on the stream)
     alg_achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
     # ---- fabric-side traffic + SQ counters of that launch (rank 0, N = 1) -------------------------------------------
