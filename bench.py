@@ -770,6 +770,39 @@ def main() -> None:
         except Exception as exc:   # a secondary figure must never cost the headline line
             log(f"[bench] alt_builder leg failed: {exc}")
 
+    # ---- independent batches on two streams (rank 0, N = 1): an extra figure, never `value` ---------------------------------
+    # A launch ends with ~0.3 ms of drain (profiles/r3/notes.md section 6); a caller whose batches are independent can hide it by
+    # alternating between two streams -- the next grid's blocks move in as this one's leave.  Reported beside the serial figure.
+    if rank == 0 and world == 1 and not dist_on and n > 0 and not under_profiler():
+        try:
+            two = [torch.cuda.Stream(device=device) for _ in range(2)]
+            buf2 = [d_hits, torch.empty_like(d_hits)]
+
+            def launch_on(k):
+                if any_hit:
+                    scene.trace_any_dev(d_rays.data_ptr(), n, buf2[k % 2].data_ptr(), two[k % 2].cuda_stream)
+                else:
+                    scene.trace_closest_dev(d_rays.data_ptr(), n, buf2[k % 2].data_ptr(), two[k % 2].cuda_stream)
+            k2 = max(10, min(args.steps, 200))
+            for k in range(4):
+                launch_on(k)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for k in range(k2):
+                launch_on(k)
+            torch.cuda.synchronize(device)
+            ms2 = (time.perf_counter() - t0) / k2 * 1e3
+            same = bool((buf2[0].view(torch.uint8) == buf2[1].view(torch.uint8)).all())
+            result["two_streams"] = {
+                "value": round(n / ms2 / 1e3, 2), "unit": result["unit"], "ms_per_step": round(ms2, 4), "steps": k2,
+                "results_equal": same,
+                "note": "the same step alternating between two HIP streams (two result buffers): the start of one launch hides the drain of "
+                        "the other.  Only for callers whose consecutive batches are independent; `value` above is the one-stream figure",
+            }
+            del buf2
+        except Exception as exc:   # a secondary figure must never cost the headline line
+            log(f"[bench] two-stream leg failed: {exc}")
+
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) -------------------
     if rank == 0 and world == 1 and not args.no_cpu and n > 0:
         from oracle import binding as O
