@@ -383,7 +383,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                     if (blk_cur == blk_end) { // acquire the next block of consecutive rays
                         uint32_t b = 0;
                         if (first_block) {            // block w goes to wave w without touching the cursor,
-                            b = blockIdx.x * (kBlockThreads / 64) + wave;   // which the host starts at #waves
+                            b = blockIdx.x * (kBlockThreads / 64) + wave;   // which hands out the blocks from cursor_base = #waves on
                             first_block = false;
                         } else if (a.xcd_cursors != 0) {
                             b = 0xFFFFFFFFu;
