@@ -189,6 +189,16 @@ PMC_PASSES = {
 }
 
 
+def apply_image_hint(args, engine) -> int:
+    """Camera-ray workloads are images in row-major order: tell the engine their row length (engine option "ray_image_width":
+    a wave takes a 4 x 16 pixel tile instead of 64 neighbours of one row; scheduling only, arrays and results unchanged)."""
+    width = 0
+    if args.image_hint == "on" and (args.kind == "primary" or args.scaling == "strong"):
+        width = 1024 if args.scaling == "strong" else args.side
+    engine.set_option("ray_image_width", width)
+    return width
+
+
 def under_profiler() -> bool:
     return any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")) or \
         "ROCPROFILER_LIBRARY_CTOR" in os.environ
@@ -419,6 +429,9 @@ def main() -> None:
                          "0 = off (the gather then only starts when the resident grid drains)")
     ap.add_argument("--chunks", type=int, default=1, help="torch gather: launches per batch in the trace/gather pipeline")
     ap.add_argument("--mode", default=None, choices=[None, "persistent", "static"])
+    ap.add_argument("--image-hint", default="on", choices=["on", "off"],
+                    help="camera-ray workloads (--kind primary, --scaling strong): pass the image's row length to the engine "
+                         "(option ray_image_width); off = lanes take consecutive rays as for any other batch")
     args = ap.parse_args()
 
     import torch
@@ -446,6 +459,7 @@ def main() -> None:
     if args.pmc_child:
         tris, bvh, host_scene, engine, scene, _ = build_scene(args, va, W, dev_index, 1)
         d_rays, n, _, _, _ = make_rays(args, 0, 1, va, W, tp, engine, scene, device)
+        apply_image_hint(args, engine)
         if args.kind == "shadow":
             d_occ = torch.empty(n, dtype=torch.uint8, device=device)
             for _ in range(3):
@@ -482,6 +496,7 @@ def main() -> None:
     tris, bvh, host_scene, engine, scene, host_threads = build_scene(args, va, W, dev_index, world)
     d_rays, n, n_total, workload, rays_host = make_rays(args, rank, world, va, W, tp, engine, scene, device)
     d_hits = tp.empty_records(max(n, 1), HIT, device) if not any_hit else torch.empty(max(n, 1), dtype=torch.uint8, device=device)
+    image_width = apply_image_hint(args, engine)       # after the rays exist: bounce / shadow rays are made from an un-hinted camera pass
     t4 = time.time()
     log(f"[bench] scene + ray set-up {t4 - t3:.2f}s; workload {workload}, {n} rays on this rank, {n_total} in the job")
 
@@ -707,7 +722,7 @@ def main() -> None:
             "gather_verified": gather_verified,
             "dist_breakdown": dist_breakdown,
             "kernel_mode": ("persistent" + ("+lds-dma-fetch" if dma else "")) if persistent else "static",
-            "launch_options": {k: engine.get_option(k) for k in ("lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold", "reserved_cus", "reserved_limit")},
+            "launch_options": {k: engine.get_option(k) for k in ("lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold", "reserved_cus", "reserved_limit", "ray_image_width")},
             "launch": engine.launch_info(),
         },
         "roofline": {
@@ -745,6 +760,7 @@ def main() -> None:
             alt_args.builder = args.alt_builder
             a_tris, a_bvh, a_hs, a_engine, a_scene, _ = build_scene(alt_args, va, W, dev_index, world)
             a_rays, a_n, _, _, _ = make_rays(alt_args, rank, world, va, W, tp, a_engine, a_scene, device)
+            apply_image_hint(alt_args, a_engine)
             a_hits = tp.empty_records(a_n, HIT, device)
             _, a_stats = tp.trace_stats(a_scene, a_rays, a_n)
             a_st = a_stats.view(torch.int32).view(a_n, 2).sum(dim=0, dtype=torch.int64).cpu().numpy() / a_n

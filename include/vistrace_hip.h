@@ -288,6 +288,13 @@ void     vt_batch_free(vt_batch* b);
  *                        stealing (default 0).  Keeps neighbouring rays in one L2: S1M primary rays 3.34 -> 3.20 ms,
  *                        but eight distant ray ranges in flight enlarge the Infinity-Cache working set: S10M bounce
  *                        rays 8.28 -> 8.62 ms; no effect on S1M bounce / S10M primary.
+ *   "ray_image_width"    rays per image row of the batches to come (0 = unknown, the default).  For batches in image order
+ *                        (camera rays, row-major) a wave then takes its 64 rays as a 4-wide, 16-high pixel tile instead of 64
+ *                        neighbours of one row, so its lanes walk the same nodes for longer: 16 Mi camera rays into 1 M
+ *                        triangles 2.00 -> 1.87 ms, into 10 M 4.24 -> 3.76 ms, 1 Mi into 100 k 0.113 -> 0.095 ms.  Scheduling
+ *                        only: the ray and hit arrays keep their order and every result is unchanged.  Needs a multiple of 4;
+ *                        whole bands of 16 rows are tiled, the rest of a batch is taken in order.  No gain for bounce or
+ *                        shadow rays (their directions differ from pixel to pixel anyway); not used by the alpha-test kernels.
  *   "spin_wait"          host batches of <= 256 rays: watch the pinned result slots change instead of waiting on
  *                        the stream (default 1; saves ~5 us of the ~24 us single-ray call)
  *   "reserved_cus"       CUs on which the persistent grid leaves room (0 = off): set it when another stream runs

@@ -736,6 +736,35 @@ def test_persistent_launches_leave_their_cursors_clean(va, make_bundle):
     assert_hits_equal(hits, ref)
 
 
+@pytest.mark.parametrize("persistent", [0, 1])
+def test_ray_image_width_changes_no_result(va, make_bundle, persistent):
+    """Engine option ray_image_width: lanes take 4 x 16 pixel tiles of an image-order batch instead of consecutive rays.  Scheduling
+    only -- hits, any-hit flags and the per-ray counters must stay exact for row lengths that are multiples of 8, of 4 only, of
+    neither (hint ignored), for images whose height is no multiple of 16 (the rest is taken in order) and for batches that are no
+    image at all."""
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    eng = va.Engine(0)
+    eng.set_option("persistent", persistent)
+    scene = va.Scene(eng, b.host_scene)
+    for width, height in ((256, 256), (100, 37), (36, 50), (255, 64), (8, 16), (4, 15)):
+        rays = W.primary_rays(width, height)
+        ref = b.oracle(rays)
+        eng.set_option("ray_image_width", width)
+        assert eng.get_option("ray_image_width") == width
+        assert_hits_equal(scene.trace_closest(rays), ref)
+        assert (scene.trace_any(rays) == (ref["prim"] != O_MISS)).all()
+        hits, st = stats_on_device(va, scene, rays)
+        assert_hits_equal(hits, ref)
+        eng.set_option("ray_image_width", 0)
+        _, st0 = stats_on_device(va, scene, rays)
+        assert (st["steps"] == st0["steps"]).all() and (st["tests"] == st0["tests"]).all()
+    rays = W.sphere_rays(70001, 77, origin=(5.0, -20.0, 30.0))         # not an image: any multiple of 4 is still harmless
+    eng.set_option("ray_image_width", 128)
+    assert_hits_equal(scene.trace_closest(rays), b.oracle(rays))
+    eng.set_option("ray_image_width", 0)
+
+
 def test_host_buffer_pipeline_ragged(va, engine, make_bundle):
     """vt_trace_closest / vt_trace_any with caller (pageable) buffers above the pipelining threshold and a ragged
     last chunk: identical to the device-resident path, and to the oracle on a sample."""

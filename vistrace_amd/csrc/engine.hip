@@ -174,6 +174,17 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     if (a.reserved_cus) VT_HIP(hipMemsetAsync(a.cu_slots, 0, 4096, stream));
     a.xcd_cursors = e->xcd_cursors != 0;
     a.nblocks = uint32_t((n + a.block_rays - 1) / a.block_rays);
+    // image-order batches: whole bands of 16 rows are taken tile-wise; a block of the persistent kernel is one tile (64 rays) or two
+    // side by side (128), so the row length must be a multiple of 4 resp. 8
+    if (e->ray_image_width >= 4 && e->ray_image_width % 4 == 0 && n < (uint64_t(1) << 32)) {
+        const uint64_t band = uint64_t(e->ray_image_width) * 16;
+        a.tile_w = e->ray_image_width;
+        a.tiled_rays = n / band * band;
+        if (a.block_rays > 128 || (a.block_rays == 128 && e->ray_image_width % 8 != 0)) a.block_rays = e->ray_image_width % 8 == 0 ? 128 : 64;
+        if (a.block_rays != 64 && a.block_rays != 128) a.block_rays = 64;
+        a.nblocks = uint32_t((n + a.block_rays - 1) / a.block_rays);
+        if (a.tiled_rays == 0) a.tile_w = 0;
+    }
     // 0 = by scene size: cheap rays (small trees) finish fast enough for the single cursor word to become the limit
     a.max_claim = e->max_claim ? e->max_claim : (s->npairs <= 200000u ? 4u : 1u);
     // the cursors are zero: engine open cleared them and every persistent launch leaves them so (leave_grid)
@@ -432,6 +443,7 @@ int vt_engine_set_option(vt_engine* e, const char* key, int64_t value)
     else if (k == "spin_wait") e->spin_wait = value != 0;
     else if (k == "xcd_cursors") e->xcd_cursors = value != 0;
     else if (k == "max_claim" && value >= 0 && value <= 1024) e->max_claim = uint32_t(value);
+    else if (k == "ray_image_width" && value >= 0) e->ray_image_width = uint32_t(value);
     else if (k == "reserved_cus" && value >= 0 && value <= e->cu_count / 2) return reserve_cus(e, uint32_t(value));
     else if (k == "reserved_limit" && value >= 0 && value <= 64) e->reserved_limit = uint32_t(value);
     else if (k == "gather_overlap") e->sched.overlap = value != 0;
@@ -456,6 +468,7 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
     else if (k == "spin_wait") *value = e->spin_wait;
     else if (k == "xcd_cursors") *value = e->xcd_cursors;
     else if (k == "max_claim") *value = e->max_claim;
+    else if (k == "ray_image_width") *value = int(e->ray_image_width);
     else if (k == "reserved_cus") *value = e->reserved_cus;
     else if (k == "reserved_limit") *value = e->reserved_limit;
     else if (k == "gather_overlap") *value = e->sched.overlap;

@@ -39,6 +39,7 @@ struct vt_engine {
     uint32_t refill_threshold = 8;    // idle lanes that trigger a re-fill
     uint32_t tri_threshold    = 4;    // lanes with pending triangles that trigger the TRI branch
     int      fetch_dma        = 1;    // quad-cooperative global->LDS record fetch (persistent mode)
+    uint32_t ray_image_width  = 0;    // rays per image row of the batches to come (0 = unknown): lanes take 4 x 16 pixel tiles
     uint32_t max_claim        = 0;    // persistent mode: ray blocks one cursor atomic may claim while plenty are left (0 = auto)
     int      xcd_cursors      = 0;    // persistent mode: one ray-block cursor per XCD over its own eighth of the batch (opt-in)
     int      spin_wait        = 1;    // tiny host batches: watch the pinned result slots instead of a stream sync

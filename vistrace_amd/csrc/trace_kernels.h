@@ -24,6 +24,11 @@ struct TraceArgs {
                                      // starts; the last wave to leave puts it back to zero (word kExitWord counts the leavers)
     uint32_t            cursor_base; // the first ray block the cursor hands out (the blocks before it are assigned statically)
     uint64_t            nrays;
+    // Image-order batches (engine option "ray_image_width"): the rays are rows of tile_w rays.  A wave then takes its 64 rays as a
+    // 4-wide, 16-high pixel tile instead of 64 consecutive rays of one row -- neighbours in both directions walk the same nodes for
+    // longer (camera rays: -8..-18 % kernel time).  The ray and hit arrays keep their order: only the lane <-> ray mapping changes.
+    uint32_t            tile_w;      // 0 = off; a multiple of 4
+    uint64_t            tiled_rays;  // the first tiled_rays rays (whole 16-row bands, < 2^32) are taken tile-wise, the rest in order
     uint32_t            npairs;
     uint32_t            tri_base;    // record index of triangle 0
     uint32_t            root_leaf_count;

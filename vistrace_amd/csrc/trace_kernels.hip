@@ -283,6 +283,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
 
     // wave-uniform block cursor (PERSISTENT)
     uint64_t blk_cur = 0, blk_end = 0;
+    bool blk_tiled = false;             // wave-uniform: the current block is taken tile-wise
+    uint32_t blk_first = 0;             // its first (tile-order) index
+    uint64_t blk_base = 0;              // ray index of its top left pixel
     bool exhausted = false;
     bool coherent = false;   // wave-uniform: this wave's rays share a direction octant
     // wave-uniform: the first block of rays is assigned statically (not with reserved CUs: a block that
@@ -354,7 +357,12 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
     };
 
     if constexpr (!PERSISTENT) {
-        const uint64_t idx = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
+        uint64_t idx = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
+        if (!ALPHA && a.tile_w != 0 && idx < a.tiled_rays) { // this wave's 64 rays are one 4 x 16 pixel tile (see TraceArgs::tile_w)
+            const uint32_t j = uint32_t(idx), t = j >> 6, k = j & 63u, tpr = a.tile_w >> 2;
+            const uint32_t ty = t / tpr, tx = t - ty * tpr;
+            idx = uint64_t(ty * 16u + (k >> 2)) * a.tile_w + tx * 4u + (k & 3u);
+        }
         if (idx < a.nrays) start_ray(idx);
         if (has_ray && L.node == kDone && L.tri_cur >= L.tri_end) finish_ray();
     }
@@ -414,13 +422,27 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                         b = __builtin_amdgcn_readfirstlane(b);
                         blk_cur = uint64_t(b) * a.block_rays;
                         blk_end = blk_cur + a.block_rays < a.nrays ? blk_cur + a.block_rays : a.nrays;
+                        // image-order batch: the block is one or two 4 x 16 pixel tiles side by side (see TraceArgs::tile_w)
+                        // (not in the ALPHA variants: their register budget has no room for the extra wave state)
+                        blk_tiled = !ALPHA && a.tile_w != 0 && blk_cur + a.block_rays <= a.tiled_rays;
+                        if (blk_tiled) {
+                            const uint32_t t = uint32_t(blk_cur >> 6), tpr = a.tile_w >> 2;
+                            const uint32_t ty = t / tpr, tx = t - ty * tpr;
+                            blk_first = uint32_t(blk_cur);
+                            blk_base = uint64_t(ty) * 16u * a.tile_w + tx * 4u;
+                        }
                         if (blk_cur >= a.nrays) { exhausted = true; blk_cur = blk_end = 0; }
                     }
                     if (!exhausted) {
                         const uint64_t avail = blk_end - blk_cur;
                         const uint32_t mine = prefix_count(idle);
                         if (!has_ray && mine < avail) {
-                            start_ray(blk_cur + mine);
+                            uint64_t idx = blk_cur + mine;
+                            if (blk_tiled) {
+                                const uint32_t k = uint32_t(idx) - blk_first;
+                                idx = blk_base + ((k >> 6) << 2) + (k & 3u) + uint64_t((k >> 2) & 15u) * a.tile_w;
+                            }
+                            start_ray(idx);
                             if (L.node == kDone && L.tri_cur >= L.tri_end) finish_ray(); // empty scene / NaN range
                         }
                         blk_cur += nidle < avail ? nidle : avail;
