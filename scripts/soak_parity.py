@@ -80,6 +80,8 @@ for seed in range(first, first + count):
         print(f"HOST WALK MISMATCH seed {seed} n {n}", flush=True)
     for mode in (1, 0, 2):
         eng.set_option("persistent", mode)
+        # every third scene: the batch is declared an image of some row length (lanes then take 4 x 16 tiles; results must not move)
+        eng.set_option("ray_image_width", int(rng.integers(1, 64)) * int(rng.choice([1, 4, 4, 8])) if seed % 3 == 0 else 0)
         d_rays = tp.to_device(rays, dev)
         d_hits, d_stats = tp.trace_stats(scene, d_rays, m)
         torch.cuda.synchronize()
