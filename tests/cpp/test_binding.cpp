@@ -369,6 +369,18 @@ static void test_gpu_side()
         CHECK(call_method(L, rb, "Count") == 1 && L.GetNumber(-1) == 400.0);
         CHECK(call_method(L, rb, "__tostring") == 1 && L.stack.back().str == "VisTraceResultBatch");
         CHECK(call_method(L, rb, "Hits") == 1 && L.stack.back().type == LT::String && L.stack.back().str.size() == 400 * sizeof(vt_hit));
+        {   // the optional image-width hint (rays per row; scheduling only): same records, bad values are argument errors
+            const std::string plain = L.stack.back().str;
+            for (double w : {20.0, 16.0, 8.0, 7.0, 0.0}) {
+                CHECK(call_method(L, accelValue, "TraverseBatch", {bufv, State::Num(w)}) == 1);
+                const fakelua::Value hinted = L.stack.back();
+                CHECK(call_method(L, hinted, "Hits") == 1 && L.stack.back().str == plain);
+            }
+            const std::string we = error_of([&] { call_method(L, accelValue, "TraverseBatch", {bufv, State::Num(2.5)}); });
+            CHECK(we.find("imageWidth") != std::string::npos);
+            const std::string wn = error_of([&] { call_method(L, accelValue, "TraverseBatch", {bufv, State::Num(-4)}); });
+            CHECK(wn.find("imageWidth") != std::string::npos);
+        }
         int bhit = 0;
         auto close = [](float a, float b) { return std::fabs(a - b) <= 1e-5f * std::max(1.0f, std::fabs(b)); };
         for (int i = 0; i < 400; ++i) {

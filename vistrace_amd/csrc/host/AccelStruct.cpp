@@ -4,6 +4,7 @@
 #include "AccelStruct.h"
 
 #include <cfloat>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -341,9 +342,21 @@ int AccelStruct::TraverseBatchBuffer(ILuaBase* LUA)
         if (range[0] < 0.f) LUA->ThrowError("tMin cannot be less than 0");
         if (range[1] <= range[0]) LUA->ThrowError("tMax must be greater than tMin");
     }
+    // optional: the rays are an image in row-major order with this many rays per row (camera rays): the engine then walks them
+    // as pixel tiles (engine option "ray_image_width"; scheduling only)
+    int width = 0;
+    if (LUA->Top() >= 3 && !LUA->IsType(3, Type::Nil)) {
+        const double w = LUA->CheckNumber(3);
+        if (!(w >= 0.0 && w <= 1048576.0) || w != std::floor(w)) LUA->ArgError(3, "imageWidth must be a whole number of rays per row");
+        width = int(w);
+    }
     // the rays go to the device straight from the string (still on the Lua stack); nothing is kept on the host
     vt_batch* batch = nullptr;
-    if (vt_batch_trace_closest(mpScene, reinterpret_cast<const vt_ray*>(bytes), n, &batch) != VT_OK) {
+    vt_engine* eng = Engine(LUA);
+    if (width != 0) (void)vt_engine_set_option(eng, "ray_image_width", width);
+    const int rc = vt_batch_trace_closest(mpScene, reinterpret_cast<const vt_ray*>(bytes), n, &batch);
+    if (width != 0) (void)vt_engine_set_option(eng, "ray_image_width", 0);
+    if (rc != VT_OK) {
         static thread_local char msg[512];
         std::snprintf(msg, sizeof(msg), "VisTrace: traversal failed: %s", vt_last_error());
         LUA->ThrowError(msg);

@@ -32,6 +32,8 @@ public:
     //   rays = string of N packed 32-byte records {origin xyz, direction xyz, tMin, tMax} (fp32, the layout of vt_ray)
     //          -> ONE TraceResultBatch userdata: the batch stays on the device, getters take a ray index and fetch the
     //          array they need once (TraceResultBatch.h).  No per-ray table parsing, no per-hit allocation.
+    //          accel:TraverseBatch(buffer, imageWidth): the rays are an image of imageWidth rays per row (camera rays) --
+    //          a hint for the device's scheduling, results are the same with and without it.
     int TraverseBatch(GarrysMod::Lua::ILuaBase* LUA);
 
     const Material& GetMaterial(size_t i) const;
