@@ -337,8 +337,10 @@ def test_config5_full_size_128_tiles_one_call(va, make_bundle):
     cap = va.shard_capacity(n, 1)
     assert cap == n
     d_hits = torch.empty(cap * 16, dtype=torch.uint8, device=dev)
+    eng.set_option("ray_image_width", 1024)                                             # what bench.py passes for this workload: lanes take pixel tiles
     scene.trace_closest_gather_dev([d_rays.data_ptr()], n, d_hits.data_ptr())          # ONE call
     eng.synchronize()
+    eng.set_option("ray_image_width", 0)
     H = d_hits.view(torch.int32).view(n, 4)
     R = d_rays.view(torch.float32).view(n, 8)
     hit = H[:, 0] != -1
