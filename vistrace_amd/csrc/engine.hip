@@ -96,10 +96,6 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool 
     return VT_OK;
 }
 
-#ifndef VT_EXP_TIMELINE
-#define VT_EXP_TIMELINE 0   // measurement builds: see trace_kernels.hip
-#endif
-
 int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_occ, void* d_stats, bool any_hit,
            bool stats, hipStream_t stream)
 {
@@ -110,6 +106,12 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     if (s->has_alpha && (!s->d_attribs || !s->d_alpha_mats || !s->alpha_ready))
         return fail(VT_ERR_UNSUPPORTED, "the scene holds alpha-tested triangles (Primitives.h:196-208): call "
                                         "vt_scene_set_tri_attribs and vt_scene_set_alpha before tracing");
+    if (s->has_alpha && !e->alpha_regs_checked) {
+        bool ok = true;
+        VT_HIP(alpha_kernels_within_budget(&ok));
+        if (!ok) return fail(VT_ERR_UNSUPPORTED, "the alpha-test kernels of this build exceed their register reservation (see check_isa.py); rebuild the library");
+        e->alpha_regs_checked = true;
+    }
     LaunchPlan p;
     int rc = plan_launch(e, s, n, any_hit, stats, p);
     if (rc != VT_OK) return rc;
@@ -163,12 +165,6 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     a.reserved_cus = p.persistent && e->reserved_cus ? e->d_reserved : nullptr;
     a.cu_slots = d_cu_slots;
     a.reserved_limit = e->reserved_limit;
-    {   // measurement builds only (VT_EXP_DIST_STACK): what a 32-bit stack entry has left beside the pair index
-        uint32_t idx_bits = 1;
-        while ((uint64_t(1) << idx_bits) < uint64_t(s->npairs) + 1) ++idx_bits;
-        const uint32_t spare = 32u - idx_bits;
-        a.dist_bits = spare >= 6 ? std::min(spare, 16u) : 0u;
-    }
 
     // the first block of every wave is static (block w -> wave w); the cursor hands out the rest
     if (a.reserved_cus) VT_HIP(hipMemsetAsync(a.cu_slots, 0, 4096, stream));
@@ -189,25 +185,11 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     a.max_claim = e->max_claim ? e->max_claim : (s->npairs <= 200000u ? 4u : 1u);
     // the cursors are zero: engine open cleared them and every persistent launch leaves them so (leave_grid)
     a.cursor_base = (a.reserved_cus || a.xcd_cursors) ? 0u : p.grid_blocks * (kBlockThreads / 64);
-#if VT_EXP_TIMELINE
-    static uint64_t* d_timeline = nullptr;          // measurement build: one process, one device
-    const size_t tl_words = size_t(p.grid_blocks) * (kBlockThreads / 64) * 8;
-    if (!d_timeline) VT_HIP(hipMalloc(reinterpret_cast<void**>(&d_timeline), 65536 * 8 * sizeof(uint64_t)));
-    a.timeline = p.persistent && tl_words <= 65536 * 8 ? d_timeline : nullptr;
-#endif
     if (e->timing) VT_HIP(hipEventRecord(e->ev_start, stream));
     VT_HIP(launch_trace(a, any_hit, stats, p.persistent, p.fetch_dma, s->has_alpha, p.grid_blocks, p.lds_bytes, stream));
     if (e->timing) { VT_HIP(hipEventRecord(e->ev_stop, stream)); e->ev_valid = true; }
     VT_HIP(hipEventRecord(slot.done, stream));
     slot.used = true;
-#if VT_EXP_TIMELINE
-    if (const char* path = std::getenv("VT_TIMELINE_FILE"); path && a.timeline && !stats) {     // the last plain launch's timeline
-        VT_HIP(hipStreamSynchronize(stream));
-        std::vector<uint64_t> h(tl_words);
-        VT_HIP(hipMemcpy(h.data(), d_timeline, tl_words * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), sizeof(uint64_t), tl_words, f); std::fclose(f); }
-    }
-#endif
     e->last_blocks = p.grid_blocks; e->last_threads = kBlockThreads; e->last_lds = uint32_t(p.lds_bytes);
     e->last_persistent = p.persistent; e->last_dma = p.fetch_dma;
     return VT_OK;
@@ -280,7 +262,6 @@ int build_alpha_records(vt_scene* s)
 {
     s->alpha_ready = false;
     if (!s->has_alpha || !s->d_attribs || !s->d_alpha_mats || s->ntris == 0) return VT_OK;
-    if (s->interleaved) return fail(VT_ERR_UNSUPPORTED, "alpha-tested triangles are not available with VT_LAYOUT_INTERLEAVE");
     vt_engine* e = s->engine;
     if (s->alpha_base == 0) {
         const uint32_t base = (s->tri_base + s->ntris + 1u) & ~1u;
@@ -507,48 +488,10 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
         prim_to_slot[hs.tris[i].prim] = uint32_t(i);
     }
 
-    // Record layout.  Default: pairs first, triangles behind them on a 128-B boundary.  interleaved (measurement knob
-    // VT_LAYOUT_INTERLEAVE=1, profiles/r3/notes.md): the triangles of a pair's leaf children lie directly behind the
-    // pair's record -- [pair][left leaf][right leaf] --, so the first triangle a NODE step finds shares its 128-B line
-    // or the next one; child indices, prim_to_slot and the level lists then hold absolute record indices, tri_base = 0.
-    s->interleaved = env_long("VT_LAYOUT_INTERLEAVE", 0) != 0 && !hs.pairs.empty();
-    std::vector<uint32_t> pair_at;                       // interleaved: record index of pair i
+    // Record layout: pairs first, triangles behind them on a 128-B boundary.
     hipError_t err = hipSuccess;
     if (uint64_t(s->npairs) + 2 * uint64_t(s->ntris) + 4 >= 0xFFFFFFFFull) { delete s; return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: scene too large"); }
-    if (s->interleaved) {
-        std::vector<uint32_t> tri_at(hs.tris.size());
-        pair_at.resize(hs.pairs.size());
-        uint32_t cur = 0;
-        for (size_t i = 0; i < hs.pairs.size(); ++i) {
-            pair_at[i] = cur++;
-            for (int side = 0; side < 2; ++side) {
-                const vt_bvh_node& c = hs.pairs[i].child[side];
-                for (uint32_t q = 0; q < c.prim_count; ++q) tri_at[c.first + q] = cur++;
-            }
-        }
-        std::vector<vt_node_pair> recs(cur);
-        static_assert(sizeof(vt_node_pair) == sizeof(vt_tri64), "one record size");
-        for (size_t i = 0; i < hs.pairs.size(); ++i) {
-            vt_node_pair P = hs.pairs[i];
-            for (int side = 0; side < 2; ++side) {
-                vt_bvh_node& c = P.child[side];
-                c.first = c.prim_count != 0 ? tri_at[c.first] : pair_at[c.first];
-            }
-            recs[pair_at[i]] = P;
-        }
-        for (size_t j = 0; j < hs.tris.size(); ++j) {
-            std::memcpy(&recs[tri_at[j]], &hs.tris[j], sizeof(vt_tri64));
-            prim_to_slot[hs.tris[j].prim] = tri_at[j];
-        }
-        s->tri_base = 0;
-        s->record_capacity = std::max<size_t>(recs.size(), 2);
-        const size_t rec_bytes = std::max<size_t>(recs.size() * 64, 128);
-        err = hipMalloc(reinterpret_cast<void**>(&s->d_records), rec_bytes);
-        if (err == hipSuccess) err = hipMemset(s->d_records, 0, rec_bytes);
-        if (err == hipSuccess) err = hipMemcpy(s->d_records, recs.data(), recs.size() * 64, hipMemcpyHostToDevice);
-        s->d_tris = reinterpret_cast<vt_tri64*>(s->d_records);
-        s->bytes += rec_bytes;
-    } else {
+    {
         s->tri_base = (s->npairs + 1u) & ~1u;
         const size_t pair_bytes = hs.pairs.size() * sizeof(vt_node_pair);
         const size_t tri_off = size_t(s->tri_base) * 64, tri_bytes = hs.tris.size() * sizeof(vt_tri64);
@@ -580,7 +523,7 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
         uint32_t acc = 0;
         for (uint32_t d = hs.max_depth; d >= 1; --d) { start[d] = acc; acc += count[d]; s->level_begin.push_back(acc); }
         std::vector<uint32_t> order(hs.pairs.size());
-        for (uint32_t p = 0; p < hs.pairs.size(); ++p) order[start[hs.pair_depth[p]]++] = s->interleaved ? pair_at[p] : p;
+        for (uint32_t p = 0; p < hs.pairs.size(); ++p) order[start[hs.pair_depth[p]]++] = p;
         err = hipMalloc(reinterpret_cast<void**>(&s->d_level_pairs), order.size() * sizeof(uint32_t));
         if (err == hipSuccess) err = hipMemcpy(s->d_level_pairs, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         s->bytes += order.size() * sizeof(uint32_t);
@@ -1199,7 +1142,6 @@ int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_o
     DeviceGuard guard(s->engine->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_read_records: hipSetDevice failed");
     VT_HIP(hipStreamSynchronize(s->engine->stream));
-    if (s->interleaved) return fail(VT_ERR_UNSUPPORTED, "vt_scene_read_records: not available with VT_LAYOUT_INTERLEAVE");
     if (pairs_out && s->npairs) VT_HIP(hipMemcpy(pairs_out, s->d_records, size_t(s->npairs) * sizeof(vt_node_pair), hipMemcpyDeviceToHost));
     if (tris_out && s->ntris) VT_HIP(hipMemcpy(tris_out, s->d_tris, size_t(s->ntris) * sizeof(vt_tri64), hipMemcpyDeviceToHost));
     return VT_OK;

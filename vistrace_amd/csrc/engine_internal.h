@@ -99,6 +99,8 @@ struct vt_engine {
     size_t d_batch_spare_bytes = 0;
     std::vector<std::pair<void*, size_t>> pinned_spare;   // pinned host blocks of freed batches (their downloaded arrays)
 
+    bool alpha_regs_checked = false;         // ALPHA kernels: hipFuncGetAttributes agreed with the build-time ISA check
+
     // last launch geometry
     uint32_t last_blocks = 0, last_threads = 0, last_lds = 0;
     int      last_persistent = 0, last_dma = 0;
@@ -127,7 +129,6 @@ struct vt_scene {
     char*         d_records = nullptr; // pairs, then (128-B aligned) the leaf-ordered triangles
     vt_tri64*     d_tris = nullptr;    // = d_records + tri_base * 64
     uint32_t      tri_base = 0;
-    bool          interleaved = false; // measurement layout (VT_LAYOUT_INTERLEAVE): leaf triangles behind their pair, tri_base = 0
     uint32_t*     d_prim_to_slot = nullptr;
     vt_tri_attribs* d_attribs = nullptr;   // optional side table, original triangle order
     // refit: pair indices sorted by depth (deepest level first) and where each level starts

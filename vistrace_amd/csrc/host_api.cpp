@@ -36,14 +36,6 @@ void parallel_copy(void* dst, const void* src, size_t bytes)
     }
 }
 
-Layout layout_from_env()
-{
-    Layout l;
-    if (const char* e = std::getenv("VT_LAYOUT_BIG_FIRST")) l.big_first = std::atoi(e) != 0;
-    if (const char* e = std::getenv("VT_LAYOUT_BFS_LEVELS")) l.bfs_levels = uint32_t(std::max(0, std::min(40, std::atoi(e))));
-    return l;
-}
-
 } // namespace vt
 
 using namespace vt;
@@ -133,7 +125,7 @@ int vt_scene_linearise(const vt_bvh* bvh, const vt_tri64* tris, vt_host_scene** 
     *out = nullptr;
     try {
         vt_host_scene* hs = new vt_host_scene();
-        int rc = scene_linearise(bvh->bvh, tris, hs->hs, layout_from_env());
+        int rc = scene_linearise(bvh->bvh, tris, hs->hs);
         if (rc != VT_OK) { delete hs; return rc; }
         *out = hs;
         return VT_OK;

@@ -34,7 +34,7 @@ void tri_setup(const float p0[3], const float p1[3], const float p2[3], uint32_t
     out.pad[0] = out.pad[1] = 0;
 }
 
-int scene_linearise(const Bvh& bvh, const vt_tri64* tris, HostScene& out, const Layout& layout)
+int scene_linearise(const Bvh& bvh, const vt_tri64* tris, HostScene& out)
 {
     out = HostScene();
     const auto& nodes = bvh.nodes;
@@ -63,22 +63,14 @@ int scene_linearise(const Bvh& bvh, const vt_tri64* tris, HostScene& out, const 
     const size_t npairs = (nodes.size() - 1) / 2;
     out.pairs.resize(npairs);
     out.pair_depth.resize(npairs);
-    // Numbering = the order in which pairs are visited below.  A pair's children keep their sides (left = child[0]:
-    // the walk's tie rule depends on it); only WHERE a pair's record lies changes with the layout, so every layout
-    // yields the same hits and the same step / test counts.  The two leaves of a pair are emitted when the pair is
-    // numbered (left before right), which keeps sibling leaves contiguous in the triangle array.
-    //   default            depth-first, left subtree first: a ray that descends to the left reads the next record
-    //   layout.big_first   depth-first, the child with the larger half-area first (the likelier descent)
-    //   layout.bfs_levels  the top K levels breadth-first (the part of the tree every ray walks sits in one
-    //                      contiguous block), the subtrees below depth-first
+    // Numbering = the order in which pairs are visited below: depth-first, left subtree first, so a ray that descends to
+    // the left reads the next record.  A pair's children keep their sides (left = child[0]: the walk's tie rule depends on
+    // it).  The two leaves of a pair are emitted when the pair is numbered (left before right), which keeps sibling leaves
+    // contiguous in the triangle array.  (Round 3 measured larger-child-first, a breadth-first top and triangles interleaved
+    // with their pairs: fabric traffic -5 %, kernel time unchanged on S1M and -2.4 % on S10M -- profiles/r3/notes.md; not kept.)
     struct Item { uint32_t fc, depth, parent, side; }; // fc = v1 index of the pair's left node
     uint32_t next_pair = 0;
     bool malformed = false;
-    auto half_area = [](const vt_bvh_node& n) {
-        const float dx = n.bounds[1] - n.bounds[0], dy = n.bounds[3] - n.bounds[2], dz = n.bounds[5] - n.bounds[4];
-        const float a = (dx + dy) * dz + dx * dy;
-        return a == a ? a : 0.0f;
-    };
     // numbers one pair, copies its two children, emits their leaves; returns the inner children in visiting order
     auto visit = [&](const Item& it, Item kids[2]) -> int {
         const uint32_t me = next_pair++;
@@ -93,34 +85,19 @@ int scene_linearise(const Bvh& bvh, const vt_tri64* tris, HostScene& out, const 
             if (c.prim_count != 0) P.child[side].first = emit_leaf(c);
         }
         int nk = 0;
-        const bool swap = layout.big_first && half_area(nodes[it.fc + 1]) > half_area(nodes[it.fc]);
-        for (int q = 0; q < 2; ++q) {
-            const int side = swap ? 1 - q : q;
+        for (int side = 0; side < 2; ++side) {
             const vt_bvh_node& c = nodes[it.fc + side];
             if (c.prim_count == 0) kids[nk++] = {c.first, it.depth + 1, me, uint32_t(side)};
         }
         return nk;
     };
-    std::vector<Item> level{{nodes[0].first, 1, 0xFFFFFFFFu, 0}}, below;
-    for (uint32_t d = 0; d < layout.bfs_levels && !level.empty() && !malformed; ++d) {
-        below.clear();
-        for (const Item& it : level) {
-            Item kids[2];
-            const int nk = visit(it, kids);
-            for (int q = 0; q < nk; ++q) below.push_back(kids[q]);
-        }
-        level.swap(below);
-    }
-    std::vector<Item> stack;
-    for (const Item& root : level) {           // what is left: depth-first below every open item, in level order
-        stack.push_back(root);
-        while (!stack.empty() && !malformed) {
-            const Item it = stack.back();
-            stack.pop_back();
-            Item kids[2];
-            const int nk = visit(it, kids);
-            for (int q = nk - 1; q >= 0; --q) stack.push_back(kids[q]);   // first child popped first
-        }
+    std::vector<Item> stack{{nodes[0].first, 1, 0xFFFFFFFFu, 0}};
+    while (!stack.empty() && !malformed) {
+        const Item it = stack.back();
+        stack.pop_back();
+        Item kids[2];
+        const int nk = visit(it, kids);
+        for (int q = nk - 1; q >= 0; --q) stack.push_back(kids[q]);   // left child popped first
     }
     if (malformed) return fail(VT_ERR_INVALID_ARG, "vt_scene_linearise: malformed tree");
     if (next_pair != npairs) return fail(VT_ERR_INVALID_ARG, "vt_scene_linearise: malformed tree");

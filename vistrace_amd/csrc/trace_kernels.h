@@ -13,6 +13,18 @@ constexpr uint32_t kBlockThreads = 256; // 4 waves of 64
 
 constexpr uint32_t kExitWord = 120;   // of the 128 cursor words of a launch slot: waves that have left the persistent grid
 
+// One batch of a merged launch (vt_trace_closest_multi_dev): the launch numbers the ray blocks of all its batches through, a
+// wave that acquires block b finds the batch with first_block <= b in this table (device memory, nseg entries in block order).
+struct TraceSeg {
+    const vt_ray* rays;         // ray 0 of the batch
+    int64_t       out_off;      // result record of its ray 0, counted from TraceArgs::hits (16-B records) / occluded (bytes)
+    uint64_t      n;            // rays
+    uint64_t      tiled_rays;   // as TraceArgs::tiled_rays, for this batch
+    uint32_t      first_block;  // its first ray block in the launch's numbering (persistent: block_rays rays, else 256)
+    uint32_t      tile_w;       // as TraceArgs::tile_w
+};
+static_assert(sizeof(TraceSeg) == 40, "TraceSeg layout");
+
 struct TraceArgs {
     const void*         records;     // 64-B records: pairs [0, npairs), triangles from tri_base on
     const vt_ray*       rays;
@@ -23,7 +35,9 @@ struct TraceArgs {
     uint32_t*           block_cursor;// persistent mode: next block of rays to hand out, counted from cursor_base.  Zero when a launch
                                      // starts; the last wave to leave puts it back to zero (word kExitWord counts the leavers)
     uint32_t            cursor_base; // the first ray block the cursor hands out (the blocks before it are assigned statically)
-    uint64_t            nrays;
+    uint64_t            nrays;       // plain launch: rays in the batch; merged launch: of all batches together (informational)
+    const TraceSeg*     segs;        // merged launch: its batches; NULL for a plain launch
+    uint32_t            nseg;        // 0 = plain launch: ONE batch described by rays / nrays / tile_w / tiled_rays
     // Image-order batches (engine option "ray_image_width"): the rays are rows of tile_w rays.  A wave then takes its 64 rays as a
     // 4-wide, 16-high pixel tile instead of 64 consecutive rays of one row -- neighbours in both directions walk the same nodes for
     // longer (camera rays: -8..-18 % kernel time).  The ray and hit arrays keep their order: only the lane <-> ray mapping changes.
@@ -48,8 +62,6 @@ struct TraceArgs {
     const uint32_t*     reserved_cus;     // persistent mode: 1024-bit set of __smid() values of the reserved CUs, or NULL
     uint32_t*           cu_slots;         // 1024 counters (zeroed per launch): blocks that asked to stay on a reserved CU
     uint32_t            reserved_limit;   // blocks a reserved CU keeps (0 = none)
-    uint64_t*           timeline;         // VT_EXP_TIMELINE builds: per wave {start, cursor exhausted, exit, iterations, ...} (else unused)
-    uint32_t            dist_bits;        // VT_EXP_DIST_STACK builds: bits of a stack entry that hold the entry distance (0 = off)
 };
 
 // One per triangle slot of a scene with alpha-tested triangles, in the scene's record array behind the triangles (so
@@ -118,6 +130,8 @@ size_t     trace_lds_bytes(uint32_t lds_entries, bool fetch_dma);
 hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, bool fetch_dma, bool alpha,
                         uint32_t grid_blocks, size_t lds_bytes, hipStream_t stream);
 hipError_t trace_blocks_per_cu(bool any_hit, bool stats, bool persistent, bool fetch_dma, bool alpha, size_t lds_bytes, int* out);
+// ALPHA variants: false when the loaded code object gives one of them more VGPRs than the texel-register reservation allows
+hipError_t alpha_kernels_within_budget(bool* ok);
 hipError_t launch_hit_attrs(const HitAttrsArgs& a, hipStream_t stream);
 // every CU that receives a block sets bit __smid() of the 1024-bit set `seen` (32 words, zeroed by the caller)
 hipError_t launch_cu_probe(uint32_t* seen, uint32_t blocks, hipStream_t stream);

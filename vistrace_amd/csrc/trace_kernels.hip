@@ -45,32 +45,6 @@
 
 #pragma clang fp contract(off)
 
-// measurement switches of profiles/r3/notes.md (make variant NAME=.. DEFS=-DVT_EXP_..=1); the product is built without
-#ifndef VT_EXP_PREFETCH
-#define VT_EXP_PREFETCH 0   // 1: a lane that pushes its far child loads one word of that record (pulls the line into L2)
-#endif
-#ifndef VT_EXP_PREFETCH_ROOT
-#define VT_EXP_PREFETCH_ROOT 0   // with VT_EXP_PREFETCH: load record 0 instead (always an L1 hit): the instruction without the L2 request
-#endif
-#ifndef VT_EXP_DMA_DUP
-#define VT_EXP_DMA_DUP 0    // 1: every record DMA issued twice (the second one hits L1): front-end requests without L2 requests
-#endif
-#ifndef VT_EXP_DMA_MASK
-#define VT_EXP_DMA_MASK 0   // 1: lanes that need no record this round take no part in the DMA (no dummy fetch of record 0)
-#endif
-#ifndef VT_EXP_TIMELINE
-#define VT_EXP_TIMELINE 0   // 1: every wave of the persistent kernel reports when it started, found the ray cursor exhausted and left
-#endif                      //    (scripts/timeline.py: the drain at the end of a launch)
-#ifndef VT_EXP_ANY_ORDER
-#define VT_EXP_ANY_ORDER 0  // any-hit walks only: 1 = left child first whatever the distances, 2 = far child first (same occlusion flags)
-#endif
-#ifndef VT_EXP_DIST_STACK
-#define VT_EXP_DIST_STACK 0 // 1: a stack entry also keeps its node's entry distance (in the bits the pair index leaves free, rounded
-#endif                      //    down); a popped pair that lies behind the current hit is skipped (exact for hits, not for step counts)
-#ifndef VT_EXP_DMA_AUX
-#define VT_EXP_DMA_AUX 0    // cache-policy bits of the record DMA: 1 = sc0, 2 = nt, 16 = sc1
-#endif
-
 namespace vt {
 
 namespace {
@@ -279,7 +253,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
     if constexpr (ALPHA) { L.astate = 0; L.ax = L.ay = L.aref = 0.f; L.cprim = 0; L.cu = L.cv = L.ct = 0.f; }
     uint64_t ray_idx = 0;
     bool has_ray = false;
-    [[maybe_unused]] uint32_t pf = 0;   // VT_EXP_PREFETCH: destination of the far-child prefetch, never read
 
     // wave-uniform block cursor (PERSISTENT)
     uint64_t blk_cur = 0, blk_end = 0;
@@ -367,15 +340,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
         if (has_ray && L.node == kDone && L.tri_cur >= L.tri_end) finish_ray();
     }
 
-#if VT_EXP_TIMELINE
-    const uint64_t tl_start = __builtin_amdgcn_s_memrealtime();
-    uint64_t tl_exhausted = 0, tl_iters = 0, tl_tail_iters = 0, tl_tail_lanes = 0;
-#endif
     for (;;) {
-#if VT_EXP_TIMELINE
-        ++tl_iters;
-        if (exhausted) { if (tl_exhausted == 0) tl_exhausted = __builtin_amdgcn_s_memrealtime(); ++tl_tail_iters; tl_tail_lanes += __popcll(__ballot(has_ray)); }
-#endif
         // Wave priority: high from here until this iteration's record fetch has been issued, low while the wave waits for
         // the records and computes on them.  Waves that are about to put loads in flight are then picked ahead of waves
         // that are computing, so the fetches of a SIMD's waves overlap better: 16 Mi bounce rays 4.52 -> 4.33 ms, camera
@@ -520,46 +485,14 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             const uint32_t piece = (lane & 3u) * 16u;
             const uint32_t r0 = quad_broadcast<0>(rec), r1 = quad_broadcast<1>(rec),
                            r2 = quad_broadcast<2>(rec), r3 = quad_broadcast<3>(rec);
-#if VT_EXP_DMA_MASK == 2
-            // EXEC of DMA k = the quads whose lane k needs a record, formed on the scalar unit: no dummy accesses
-            const uint64_t needm = __ballot(do_tri || want_node);
-            const uint64_t nib = 0x1111111111111111ull;
-            uint64_t e0 = needm & nib, e1 = (needm >> 1) & nib, e2 = (needm >> 2) & nib, e3 = (needm >> 3) & nib;
-            e0 = (e0 << 4) - e0; e1 = (e1 << 4) - e1; e2 = (e2 << 4) - e2; e3 = (e3 << 4) - e3;
-            uint64_t save;
-            asm volatile("s_mov_b64 %[sv], exec\n\t"
-                         "s_mov_b32 m0, %[l0]\n\ts_mov_b64 exec, %[e0]\n\tglobal_load_lds_dwordx4 %[a0], %[base]\n\t"
-                         "s_mov_b32 m0, %[l1]\n\ts_mov_b64 exec, %[e1]\n\tglobal_load_lds_dwordx4 %[a1], %[base]\n\t"
-                         "s_mov_b32 m0, %[l2]\n\ts_mov_b64 exec, %[e2]\n\tglobal_load_lds_dwordx4 %[a2], %[base]\n\t"
-                         "s_mov_b32 m0, %[l3]\n\ts_mov_b64 exec, %[e3]\n\tglobal_load_lds_dwordx4 %[a3], %[base]\n\t"
-                         "s_mov_b64 exec, %[sv]"
-                         : [sv] "=&s"(save)
-                         : [a0] "v"((r0 << 6) | piece), [a1] "v"((r1 << 6) | piece), [a2] "v"((r2 << 6) | piece), [a3] "v"((r3 << 6) | piece),
-                           [base] "s"(records), [l0] "s"(stage_lds), [l1] "s"(stage_lds + kStageRow), [l2] "s"(stage_lds + 2u * kStageRow),
-                           [l3] "s"(stage_lds + 3u * kStageRow), [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [e3] "s"(e3)
-                         : "memory", "m0");
-#elif VT_EXP_DMA_MASK
-            const uint32_t need = (do_tri || want_node) ? 1u : 0u;
-            if (quad_broadcast<0>(need))
-                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r0 << 6) | piece)), (lds_ptr)(uintptr_t)(stage_lds + 0u * kStageRow), 16, 0, 0);
-            if (quad_broadcast<1>(need))
-                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r1 << 6) | piece)), (lds_ptr)(uintptr_t)(stage_lds + 1u * kStageRow), 16, 0, 0);
-            if (quad_broadcast<2>(need))
-                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r2 << 6) | piece)), (lds_ptr)(uintptr_t)(stage_lds + 2u * kStageRow), 16, 0, 0);
-            if (quad_broadcast<3>(need))
-                __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r3 << 6) | piece)), (lds_ptr)(uintptr_t)(stage_lds + 3u * kStageRow), 16, 0, 0);
-#else
-            for (int rep = 0; rep < 1 + VT_EXP_DMA_DUP; ++rep) {
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r0 << 6) | piece)),
-                                             (lds_ptr)(uintptr_t)(stage_lds + 0u * kStageRow), 16, 0, VT_EXP_DMA_AUX);
+                                             (lds_ptr)(uintptr_t)(stage_lds + 0u * kStageRow), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r1 << 6) | piece)),
-                                             (lds_ptr)(uintptr_t)(stage_lds + 1u * kStageRow), 16, 0, VT_EXP_DMA_AUX);
+                                             (lds_ptr)(uintptr_t)(stage_lds + 1u * kStageRow), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r2 << 6) | piece)),
-                                             (lds_ptr)(uintptr_t)(stage_lds + 2u * kStageRow), 16, 0, VT_EXP_DMA_AUX);
+                                             (lds_ptr)(uintptr_t)(stage_lds + 2u * kStageRow), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r3 << 6) | piece)),
-                                             (lds_ptr)(uintptr_t)(stage_lds + 3u * kStageRow), 16, 0, VT_EXP_DMA_AUX);
-            }
-#endif
+                                             (lds_ptr)(uintptr_t)(stage_lds + 3u * kStageRow), 16, 0, 0);
             // Wait for the DMA rows, then read this lane's 64-B record back with four ds_read_b128
             // (conflict-free with the padded rows).  One asm statement holds the reads and their
             // waits, so hipcc can neither split the reads nor consume a destination early
@@ -577,9 +510,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                          : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
                          : "v"(my_rec)
                          : "memory");
-#if VT_EXP_PREFETCH
-            asm volatile("" :: "v"(pf));     // keeps the prefetch destination reserved until the wait above has covered it
-#endif
             q0 = make_float4(v0.x, v0.y, v0.z, v0.w); q1 = make_float4(v1.x, v1.y, v1.z, v1.w);
             q2 = make_float4(v2.x, v2.y, v2.z, v2.w); q3 = make_float4(v3.x, v3.y, v3.z, v3.w);
         } else if (!fetched) {
@@ -736,59 +666,21 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             uint32_t next;
             if (go_l && go_r) {
                 // near child first (ties keep left first); push the far child's pair
-#if VT_EXP_ANY_ORDER
-                // any-hit: whether a ray is occluded does not depend on the order of the walk (its interval never shrinks)
-                const bool swap = (ANY_HIT && !STATS) ? (VT_EXP_ANY_ORDER == 2 ? fl < fr : false) : fl > fr;
-#else
                 const bool swap = fl > fr;
-#endif
                 next = swap ? rfirst : lfirst;
                 uint32_t far = swap ? lfirst : rfirst;
-#if VT_EXP_DIST_STACK
-                if constexpr (!STATS) {
-                    // entry distance of the far child, truncated to the top dist_bits bits of its (non-negative) fp32 pattern
-                    const float fd = swap ? fl : fr;
-                    const uint32_t qd = fd > 0.0f ? __float_as_uint(fd) >> (31u - a.dist_bits) : 0u;
-                    far |= qd << (32u - a.dist_bits);
-                }
-#endif
                 if (L.sp < a.lds_entries) st_lds[L.sp * 64] = far;
                 else st_ovf[size_t(L.sp - a.lds_entries) * gstride] = far;
                 ++L.sp;
-#if VT_EXP_PREFETCH
-                // issued behind the compiler's back: a load it knows of is waited for at the end of the block
-                if constexpr (FETCH_DMA && PERSISTENT && !STATS)
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf) : "v"(records + (VT_EXP_PREFETCH_ROOT ? size_t(0) : size_t(far) << 6)));
-#endif
             } else if (go_l) {
                 next = lfirst;
             } else if (go_r) {
                 next = rfirst;
-#if VT_EXP_DIST_STACK
-            } else if (!STATS && a.dist_bits != 0) {
-                next = kDone;
-                while (L.sp != 0) {
-                    --L.sp;
-                    uint32_t e;
-                    if (L.sp < a.lds_entries) e = st_lds[L.sp * 64];
-                    else e = st_ovf[size_t(L.sp - a.lds_entries) * gstride];
-                    const float lb = __uint_as_float((e >> (32u - a.dist_bits)) << (31u - a.dist_bits));   // <= the entry distance
-                    if (lb > L.tmax) continue;                  // everything below lies behind the hit found since the push
-                    next = e & (0xFFFFFFFFu >> a.dist_bits);
-                    break;
-                }
-#endif
             } else if (L.sp != 0) {
                 --L.sp;
                 // two separate loads on purpose: a pointer select would turn this into a flat_load
                 if (L.sp < a.lds_entries) next = st_lds[L.sp * 64];
-#if VT_EXP_PREFETCH
-                // waits inside the (rare) branch, so that the end of the iteration does not wait for the prefetch
-                else asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)"
-                                  : "=v"(next) : "v"(st_ovf + size_t(L.sp - a.lds_entries) * gstride) : "memory");
-#else
                 else next = st_ovf[size_t(L.sp - a.lds_entries) * gstride];
-#endif
             } else {
                 next = kDone;
             }
@@ -799,15 +691,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
     if constexpr (PERSISTENT) {
         if (lane == 0) leave_grid(a, 1);
     }
-#if VT_EXP_TIMELINE
-    if constexpr (PERSISTENT) {
-        if (a.timeline && lane == 0) {
-            uint64_t* t = a.timeline + (uint64_t(blockIdx.x) * (kBlockThreads / 64) + wave) * 8;
-            t[0] = tl_start; t[1] = tl_exhausted; t[2] = __builtin_amdgcn_s_memrealtime(); t[3] = tl_iters;
-            t[4] = tl_tail_iters; t[5] = tl_tail_lanes; t[6] = my_xcd; t[7] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);   // HW_ID
-        }
-    }
-#endif
 }
 
 // The two kernels around the body.  The variants without the alpha test are compiled as before; the ALPHA variants ask the
@@ -1217,6 +1100,26 @@ hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persi
 {
     return alpha ? dispatch<true>(&a, any_hit, stats, persistent, fetch_dma, dim3(grid_blocks), lds_bytes, stream, nullptr)
                  : dispatch<false>(&a, any_hit, stats, persistent, fetch_dma, dim3(grid_blocks), lds_bytes, stream, nullptr);
+}
+
+// Run-time half of the ALPHA build contract (check_isa.py is the build-time half): the variants that keep texel loads in
+// flight in v76..v79 must not have been given more registers than 76 + those four.
+hipError_t alpha_kernels_within_budget(bool* ok)
+{
+    *ok = true;
+    auto probe = [&](const void* fn) -> hipError_t {
+        hipFuncAttributes at;
+        const hipError_t err = hipFuncGetAttributes(&at, fn);
+        if (err == hipSuccess && at.numRegs > kCompilerVgprs + 4) *ok = false;
+        return err;
+    };
+    hipError_t err = probe(reinterpret_cast<const void*>(&trace_kernel_alpha<false, false, true, true>));
+    if (err == hipSuccess) err = probe(reinterpret_cast<const void*>(&trace_kernel_alpha<true, false, true, true>));
+    if (err == hipSuccess) err = probe(reinterpret_cast<const void*>(&trace_kernel_alpha<false, false, true, false>));
+    if (err == hipSuccess) err = probe(reinterpret_cast<const void*>(&trace_kernel_alpha<true, false, true, false>));
+    if (err == hipSuccess) err = probe(reinterpret_cast<const void*>(&trace_kernel_alpha<false, false, false, false>));
+    if (err == hipSuccess) err = probe(reinterpret_cast<const void*>(&trace_kernel_alpha<true, false, false, false>));
+    return err;
 }
 
 hipError_t trace_blocks_per_cu(bool any_hit, bool stats, bool persistent, bool fetch_dma, bool alpha, size_t lds_bytes, int* out)

@@ -41,13 +41,7 @@ struct HostScene {
 };
 
 int  bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, int builder, Bvh& out);
-// where the pair records lie in the device array (linearise.cpp); results do not depend on it
-struct Layout {
-    bool     big_first  = false;  // depth-first with the child of larger half-area first instead of the left one
-    uint32_t bfs_levels = 0;      // top levels numbered breadth-first
-};
-Layout layout_from_env();         // VT_LAYOUT_BIG_FIRST, VT_LAYOUT_BFS_LEVELS (measurement knobs, profiles/r3/notes.md)
-int  scene_linearise(const Bvh& bvh, const vt_tri64* tris, HostScene& out, const Layout& layout = Layout());
+int  scene_linearise(const Bvh& bvh, const vt_tri64* tris, HostScene& out);
 int  bvh_refit(Bvh& bvh, const vt_tri64* tris);
 void tri_setup(const float p0[3], const float p1[3], const float p2[3], uint32_t prim,
                uint32_t flags, vt_tri64& out);
