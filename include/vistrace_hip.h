@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 3   /* 2: launch-slot ring, host walk, multi-GPU entries; 3: vt_batch, any-hit counters, gather timing (all additive) */
+#define VT_ABI_VERSION 4   /* 2: launch-slot ring, host walk, multi-GPU entries; 3: vt_batch, any-hit counters, gather timing; 4: merged launches, chunked gather, batch sets (all additive) */
 
 enum vt_status {
     VT_OK              = 0,
@@ -235,6 +235,24 @@ int vt_trace_any(vt_scene* s, const vt_ray* rays, uint64_t n, uint8_t* occluded)
  * vt_engine_stream() returns the engine's private non-blocking stream. */
 int vt_trace_closest_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* stream);
 int vt_trace_any_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_occluded, void* stream);
+/* Several batches in ONE launch.  A launch costs ~0.3 ms beyond its rays (grid start, and the drain in which every wave walks
+ * its last, longest rays with most lanes idle): 7 % of a 16 Mi-ray batch, 40 % of a 1 Mi-ray one, nearly all of a 64 Ki-ray
+ * one -- what a per-frame caller with many small ray sets (one per light, per tile, per entity; the reference's call shape is
+ * one ray per call, source/VisTrace.cpp:831-836) pays again for every set.  Here the ray blocks of all batches are numbered
+ * through and handed out by one cursor, so the batches share one start and one drain; every batch keeps its own ray and result
+ * arrays (any device addresses, 16-B aligned; result ranges must not overlap) and its own ray_image_width (0 = not in image
+ * order; see the engine option of that name, which the single-batch calls use instead).  Results are exactly those of nbatches
+ * separate calls.  Batches may be empty; in a launch of several, each holds fewer than 2^32 rays.  Asynchronous like the other
+ * _dev calls; `batches` is read before the call returns.  d_out: n x vt_hit (closest) or n bytes (any). */
+typedef struct vt_batch_desc {
+    const void* d_rays;
+    void*       d_out;
+    uint64_t    n;
+    uint32_t    ray_image_width;
+    uint32_t    reserved;          /* 0 */
+} vt_batch_desc;
+int vt_trace_closest_multi_dev(vt_scene* s, const vt_batch_desc* batches, uint32_t nbatches, void* stream);
+int vt_trace_any_multi_dev(vt_scene* s, const vt_batch_desc* batches, uint32_t nbatches, void* stream);
 /* Closest hit + per-ray counters (diagnostic kernel; same visitation order). */
 int vt_trace_stats_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits,
                        void* d_ray_stats, void* stream);

@@ -1,0 +1,179 @@
+"""Merged launches (vt_trace_closest_multi_dev / vt_trace_any_multi_dev): several batches, one grid start, one drain.
+
+Bar: the results of a merged launch are BYTE-EQUAL to those of one call per batch (which the other GPU tests pin to the
+oracle), and equal to the oracle directly -- for ragged batch sizes including 0 and 1, batches in image order beside
+batches that are not, result arrays scattered over one allocation or over several, both kernels (persistent waves and
+one ray per lane) and the alpha-test variants.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+O_MISS = 0xFFFFFFFF
+
+
+def assert_hits_equal(got, ref):
+    assert (got["prim"] == ref["prim"]).all(), f"{int((got['prim'] != ref['prim']).sum())} primitive indices differ"
+    for k in ("t", "u", "v"):
+        assert (got[k].view(np.uint32) == ref[k].view(np.uint32)).all(), f"{k} not bit-identical"
+
+
+def ray_sets(W, sizes, seed=3):
+    """one ray set per size: camera images where the size is a whole image, scattered rays otherwise"""
+    out = []
+    for k, n in enumerate(sizes):
+        side = int(round(n ** 0.5))
+        if n >= 256 and side * side == n:
+            out.append((W.primary_rays(side, side, pos=(float(3 * k), -2.0 * k, 1.0 * k)), side))
+        else:
+            out.append((W.sphere_rays(n, seed + k, origin=(10.0 * (k % 3), -5.0 * k, 7.0)), 0))
+    return out
+
+
+@pytest.mark.parametrize("sizes", [
+    (4096, 0, 1, 65, 1024, 30000, 63, 16384, 0),          # ragged, with empty batches in front of, between and behind others
+    (64,) * 40,                                            # many tiny batches: more batches than some grids have waves
+    (1,),                                                  # a "merged" launch of one batch of one ray
+    (0, 0, 0),                                             # nothing at all
+    (65536,) * 16,                                         # configs[1] cut into 16 segments of 64 Ki rays
+])
+def test_merged_launch_equals_separate_calls(va, engine, make_bundle, sizes):
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    dev = torch.device("cuda", 0)
+    b = make_bundle("S10k")
+    scene = va.Scene(engine, b.host_scene)
+    sets = ray_sets(W, sizes)
+    d_rays = [tp.to_device(r, dev) if len(r) else None for r, _ in sets]
+    # separate calls (engine option for the image hint), each into its own array
+    sep = []
+    for (r, width), d in zip(sets, d_rays):
+        if len(r) == 0:
+            sep.append(np.zeros(0, va.HIT))
+            continue
+        engine.set_option("ray_image_width", width)
+        sep.append(tp.to_host(tp.trace_closest(scene, d, len(r)), va.HIT))
+    engine.set_option("ray_image_width", 0)
+    torch.cuda.synchronize()
+    # merged: results scattered over ONE allocation in reverse batch order (offsets relative to batch 0 may be negative)
+    total = sum(len(r) for r, _ in sets)
+    d_all = torch.full(((total + 16) * 16,), 0xAB, dtype=torch.uint8, device=dev)
+    offs, cur = [], total
+    for r, _ in sets:
+        cur -= len(r)
+        offs.append(cur)
+    stream = tp.current_stream_handle(dev)
+    batches = [(d.data_ptr() if d is not None else 0, d_all.data_ptr() + 16 * o if len(r) else 0, len(r), width)
+               for (r, width), d, o in zip(sets, d_rays, offs)]
+    scene.trace_multi_dev(batches, stream)
+    torch.cuda.synchronize()
+    got_all = tp.to_host(d_all, va.HIT)
+    for k, ((r, _), o) in enumerate(zip(sets, offs)):
+        got = got_all[o:o + len(r)]
+        assert got.tobytes() == sep[k].tobytes(), f"batch {k} of {len(sets)} differs from its separate call"
+        if len(r) and k < 6:
+            assert_hits_equal(got, b.oracle(r))
+    assert (tp.to_host(d_all, np.uint8)[total * 16:] == 0xAB).all(), "a merged launch wrote outside its batches"
+    # any-hit, results in separate allocations
+    d_occ = [torch.full((max(len(r), 1),), 7, dtype=torch.uint8, device=dev) for r, _ in sets]
+    scene.trace_multi_dev([(d.data_ptr() if d is not None else 0, o.data_ptr(), len(r), width)
+                           for (r, width), d, o in zip(sets, d_rays, d_occ)], stream, any_hit=True)
+    torch.cuda.synchronize()
+    for k, ((r, _), o) in enumerate(zip(sets, d_occ)):
+        if len(r):
+            assert (o.cpu().numpy()[:len(r)] == (sep[k]["prim"] != O_MISS)).all(), f"any-hit batch {k}"
+
+
+def test_merged_launch_validates_its_arguments(va, engine, make_bundle):
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    dev = torch.device("cuda", 0)
+    scene = va.Scene(engine, make_bundle("S1k").host_scene)
+    rays = W.sphere_rays(1000, 5)
+    d_rays = tp.to_device(rays, dev)
+    d_hits = tp.empty_records(2000, va.HIT, dev)
+    p, h = d_rays.data_ptr(), d_hits.data_ptr()
+    E = va._lib.VisTraceError
+    with pytest.raises(E, match="overlap"):
+        scene.trace_multi_dev([(p, h, 1000), (p, h + 16 * 500, 1000)])
+    with pytest.raises(E, match="aligned"):
+        scene.trace_multi_dev([(p, h, 500), (p, h + 16 * 500 + 8, 500)])
+    with pytest.raises(E, match="NULL"):
+        scene.trace_multi_dev([(p, h, 500), (0, h + 16 * 500, 500)])
+    desc = np.zeros(1, va._lib.BATCH_DESC)
+    desc["d_rays"], desc["d_out"], desc["n"], desc["reserved"] = p, h, 10, 1
+    assert va._lib.lib.vt_trace_closest_multi_dev(scene._h, va._lib.ptr(desc), 1, None) == va._lib.VT_ERR_INVALID_ARG
+    scene.trace_multi_dev([])                                   # no batches: nothing to do
+    scene.trace_multi_dev([(p, h, 1000), (p, h + 16 * 1000, 1000)], tp.current_stream_handle(dev))   # the same rays twice is fine
+    torch.cuda.synchronize()
+    got = tp.to_host(d_hits, va.HIT)
+    assert got[:1000].tobytes() == got[1000:].tobytes()
+
+
+def test_merged_launch_round_the_slot_ring(va, make_bundle):
+    """40 merged launches with changing batch tables (the table travels through the slot's pinned block, which must not be
+    rewritten while an earlier launch on that slot may still read it), alternating with plain launches."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    dev = torch.device("cuda", 0)
+    b = make_bundle("S10k")
+    eng = va.Engine(0)
+    eng.set_option("persistent", 1)
+    scene = va.Scene(eng, b.host_scene)
+    rays = W.sphere_rays(60000, 11, origin=(-30.0, 15.0, 40.0))
+    ref = b.oracle(rays)
+    d_rays = tp.to_device(rays, dev)
+    stream = tp.current_stream_handle(dev)
+    rng = np.random.default_rng(5)
+    outs = []
+    for it in range(40):
+        cuts = np.sort(rng.choice(np.arange(1, len(rays)), size=int(rng.integers(1, 90)), replace=False))
+        bounds = np.concatenate([[0], cuts, [len(rays)]])
+        d_hits = torch.zeros(len(rays) * 16, dtype=torch.uint8, device=dev)
+        batches = [(d_rays.data_ptr() + 32 * int(lo), d_hits.data_ptr() + 16 * int(lo), int(hi - lo)) for lo, hi in zip(bounds[:-1], bounds[1:])]
+        scene.trace_multi_dev(batches, stream)
+        outs.append(d_hits)
+        if it % 4 == 1:
+            outs.append(tp.trace_closest(scene, d_rays, len(rays)))
+    torch.cuda.synchronize()
+    for k, o in enumerate(outs):
+        assert_hits_equal(tp.to_host(o, va.HIT), ref), f"launch {k}"
+
+
+def test_merged_launch_with_alpha_tested_triangles(va, engine, O):
+    """the ALPHA kernel variants read their batches through the same table"""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    dev = torch.device("cuda", 0)
+    verts = W.make_scene("S1k")
+    n = len(verts)
+    rng = np.random.default_rng(12)
+    flags = np.where(rng.random(n) < 0.4, va._lib.VT_TRI_ALPHATEST, 0).astype(np.uint8)
+    tris = va.tris_setup(verts, flags)
+    scene = va.Scene(engine, va.HostScene(va.HostBvh(tris)))
+    attribs = np.zeros(n, va.TRI_ATTRIBS)
+    attribs["uv"] = rng.random((n, 3, 2)).astype(np.float32) * 4
+    attribs["material"] = rng.integers(0, 2, n)
+    mats = np.zeros(2, va.ALPHA_MATERIAL)
+    mats["tex_mat"][:, 0, 0] = 1
+    mats["tex_mat"][:, 1, 1] = 1
+    mats["tex_scale"], mats["alpha_ref"] = 1.0, 0.5
+    mats["width"], mats["height"], mats["filter"] = (8, 16), (8, 4), (0, 1)
+    mats["offset"] = (0, 64)
+    texels = rng.integers(0, 256, 128).astype(np.uint8)
+    scene.set_tri_attribs(attribs)
+    scene.set_alpha(mats, texels)
+    rays = np.concatenate([W.primary_rays(64, 64), W.sphere_rays(9000, 2)])
+    d_rays = tp.to_device(rays, dev)
+    whole = tp.to_host(tp.trace_closest(scene, d_rays, len(rays)), va.HIT)
+    d_hits = tp.empty_records(len(rays), va.HIT, dev)
+    cuts = [0, 1, 700, 4096, 4097, 9000, len(rays)]
+    scene.trace_multi_dev([(d_rays.data_ptr() + 32 * lo, d_hits.data_ptr() + 16 * lo, hi - lo) for lo, hi in zip(cuts[:-1], cuts[1:])],
+                          tp.current_stream_handle(dev))
+    torch.cuda.synchronize()
+    assert tp.to_host(d_hits, va.HIT).tobytes() == whole.tobytes()

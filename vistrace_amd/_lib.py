@@ -40,6 +40,8 @@ CAMERA = np.dtype([("pos", "<f4", 3), ("forward", "<f4", 3), ("up", "<f4", 3), (
 ALPHA_MATERIAL = np.dtype([("tex_mat", "<f4", (2, 4)), ("tex_scale", "<f4"), ("alpha_ref", "<f4"), ("width", "<u4"),
                            ("height", "<u4"), ("filter", "<u4"), ("pad", "<u4"), ("offset", "<u8")])
 SKIN_VERTEX = np.dtype([("weight", "<f4", 3), ("bone", "i1", 3), ("num_bones", "u1")])
+BATCH_DESC = np.dtype([("d_rays", "<u8"), ("d_out", "<u8"), ("n", "<u8"), ("ray_image_width", "<u4"), ("reserved", "<u4")])
+assert BATCH_DESC.itemsize == 32
 assert TRI_ATTRIBS.itemsize == 48 and HIT_SHADE.itemsize == 32 and SKIN_VERTEX.itemsize == 16 and ALPHA_MATERIAL.itemsize == 64
 assert RAY.itemsize == 32 and HIT.itemsize == 16 and BVH_NODE.itemsize == 32
 assert NODE_PAIR.itemsize == 64 and TRI64.itemsize == 64 and HIT_ATTRS.itemsize == 64
@@ -94,6 +96,8 @@ SYMBOLS = {
     "vt_trace_any": (C.c_int, [_vp, _vp, _u64, _vp]),
     "vt_trace_closest_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
     "vt_trace_any_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
+    "vt_trace_closest_multi_dev": (C.c_int, [_vp, _vp, _u32, _vp]),
+    "vt_trace_any_multi_dev": (C.c_int, [_vp, _vp, _u32, _vp]),
     "vt_trace_stats_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "vt_trace_any_stats_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "vt_batch_trace_closest": (C.c_int, [_vp, _vp, _u64, C.POINTER(C.c_void_p)]),
@@ -161,7 +165,10 @@ def _load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C vistrace_amd/csrc). vistrace_amd has no pure-Python or CPU tracing path.")
     lib = C.CDLL(LIB_PATH)
+    older = bool(os.environ.get("VISTRACE_HIP_LIB")) and os.environ.get("VT_ALLOW_OLDER_ABI") == "1"   # dev: A/B against an earlier build
     for name, (res, args) in SYMBOLS.items():
+        if older and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args

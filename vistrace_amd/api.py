@@ -340,6 +340,16 @@ class Scene:
     def trace_closest_dev(self, d_rays: int, n: int, d_hits: int, stream: int = 0) -> None:
         check(lib.vt_trace_closest_dev(self._h, d_rays, n, d_hits, stream or None))
 
+    def trace_multi_dev(self, batches, stream: int = 0, any_hit: bool = False) -> None:
+        """ONE launch over several batches (vt_trace_closest_multi_dev / vt_trace_any_multi_dev): batches = sequence of
+        (d_rays, d_out, n[, ray_image_width]) with device addresses; results equal those of separate calls."""
+        desc = np.zeros(len(batches), dtype=_lib.BATCH_DESC)
+        for k, b in enumerate(batches):
+            desc[k]["d_rays"], desc[k]["d_out"], desc[k]["n"] = b[0] or 0, b[1] or 0, b[2]
+            desc[k]["ray_image_width"] = b[3] if len(b) > 3 else 0
+        fn = lib.vt_trace_any_multi_dev if any_hit else lib.vt_trace_closest_multi_dev
+        check(fn(self._h, ptr(desc) if len(desc) else None, len(desc), stream or None))
+
     def trace_closest_gather_dev(self, d_rays_per_device, n: int, d_hits_root: int) -> None:
         """Multi-GPU group: d_rays_per_device[g] = address (on device g) of shard g's rays; the hit records of all
         shards are gathered to d_hits_root on the root device (ndev * shard_capacity records, ray i at record i).

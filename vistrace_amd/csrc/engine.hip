@@ -47,7 +47,8 @@ struct LaunchPlan {
     uint32_t ovf_entries;
 };
 
-int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool stats, LaunchPlan& p)
+// n = rays of all batches of the launch; static_blocks = 256-ray blocks the one-ray-per-lane kernel would need for them
+int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, uint64_t static_blocks, bool any_hit, bool stats, LaunchPlan& p)
 {
     // stack entries a ray can need = inner levels below the root pair
     const uint32_t need = s->max_depth;
@@ -62,7 +63,7 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool 
     // the DMA-fetch kernel addresses records as base + 32-bit byte offset: scenes below 4 GiB
     const uint64_t rec_bytes = uint64_t(s->record_capacity) * 64;
     p.fetch_dma = p.persistent && e->fetch_dma != 0 && rec_bytes < (uint64_t(1) << 32);
-    const uint64_t blocks_for_rays = (n + kBlockThreads - 1) / kBlockThreads;
+    const uint64_t blocks_for_rays = static_blocks;
     if (p.persistent) {
         p.lds_entries = std::min(std::max(e->lds_entries, 1u), std::max(need, 1u));
         p.ovf_entries = need > p.lds_entries ? need - p.lds_entries : 0;
@@ -96,11 +97,29 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, bool any_hit, bool 
     return VT_OK;
 }
 
-int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_occ, void* d_stats, bool any_hit,
-           bool stats, hipStream_t stream)
+// One launch over one or several batches (vt_trace_*_multi_dev): the ray blocks of all batches are numbered through, so the
+// batches share one grid start and one drain.  d_out of a batch = its vt_hit array (closest hit) or its byte array (any hit).
+struct BatchReq { const void* d_rays; void* d_out; uint64_t n; uint32_t image_width; };
+
+int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_stats, bool any_hit, bool stats, hipStream_t stream)
 {
     vt_engine* e = s->engine;
+    uint64_t n = 0, static_blocks = 0;
+    const BatchReq* first = nullptr;                       // the first batch that holds rays: results are addressed from its array
+    const size_t out_elem = any_hit ? 1 : sizeof(vt_hit);
+    for (uint32_t k = 0; k < nreq; ++k) {
+        const BatchReq& r = reqs[k];
+        if (r.n == 0) continue;
+        if (!r.d_rays || !r.d_out) return fail(VT_ERR_INVALID_ARG, "vt_trace_dev: NULL device buffer");
+        if (reinterpret_cast<uintptr_t>(r.d_rays) % 16 != 0 || (!any_hit && reinterpret_cast<uintptr_t>(r.d_out) % 16 != 0))
+            return fail(VT_ERR_INVALID_ARG, "vt_trace_dev: ray and hit arrays must be 16-byte aligned");
+        if (nreq > 1 && r.n >= (uint64_t(1) << 32)) return fail(VT_ERR_INVALID_ARG, "vt_trace_multi_dev: a batch of a merged launch holds at most 2^32 - 1 rays");
+        if (!first) first = &r;
+        n += r.n;
+        static_blocks += (r.n + kBlockThreads - 1) / kBlockThreads;
+    }
     if (n == 0) return VT_OK;
+    if (stats && nreq != 1) return fail(VT_ERR_INVALID_ARG, "the counters kernels take one batch per launch");
     if (s->poisoned)
         return fail(VT_ERR_INVALID_ARG, "the scene was last refitted with non-finite vertex positions; refit it with finite data");
     if (s->has_alpha && (!s->d_attribs || !s->d_alpha_mats || !s->alpha_ready))
@@ -113,7 +132,7 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
         e->alpha_regs_checked = true;
     }
     LaunchPlan p;
-    int rc = plan_launch(e, s, n, any_hit, stats, p);
+    int rc = plan_launch(e, s, n, static_blocks, any_hit, stats, p);
     if (rc != VT_OK) return rc;
 
     // this launch's private scratch: the next slot of the ring (see vt_engine::LaunchSlot)
@@ -134,17 +153,21 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     }
     uint32_t* const d_cursor = slot.d_ctl;                   // 8 cursors, 64 B apart
     uint32_t* const d_cu_slots = slot.d_ctl + 128;           // 1024 counters
+    if (slot.dirty) {
+        // the slot's previous launch did not end normally (enqueue error): its cursors may not have been put back to zero by
+        // the last wave out, so they are cleared here -- once, in stream order behind the wait above
+        VT_HIP(hipMemsetAsync(d_cursor, 0, 512, stream));
+        slot.dirty = false;
+    }
 
     TraceArgs a{};
     a.records = s->d_records;
     a.tri_base = s->tri_base;
-    a.rays = static_cast<const vt_ray*>(d_rays);
-    a.hits = static_cast<vt_hit*>(d_hits);
-    a.occluded = static_cast<uint8_t*>(d_occ);
+    a.hits = any_hit ? nullptr : static_cast<vt_hit*>(first->d_out);
+    a.occluded = any_hit ? static_cast<uint8_t*>(first->d_out) : nullptr;
     a.ray_stats = static_cast<vt_ray_stats*>(d_stats);
     a.overflow = slot.d_overflow;
     a.block_cursor = d_cursor;
-    a.nrays = n;
     a.npairs = s->npairs;
     a.root_leaf_count = s->root_leaf_count;
     a.lds_entries = p.lds_entries;
@@ -169,30 +192,99 @@ int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_oc
     // the first block of every wave is static (block w -> wave w); the cursor hands out the rest
     if (a.reserved_cus) VT_HIP(hipMemsetAsync(a.cu_slots, 0, 4096, stream));
     a.xcd_cursors = e->xcd_cursors != 0;
-    a.nblocks = uint32_t((n + a.block_rays - 1) / a.block_rays);
     // image-order batches: whole bands of 16 rows are taken tile-wise; a block of the persistent kernel is one tile (64 rays) or two
     // side by side (128), so the row length must be a multiple of 4 resp. 8
-    if (e->ray_image_width >= 4 && e->ray_image_width % 4 == 0 && n < (uint64_t(1) << 32)) {
-        const uint64_t band = uint64_t(e->ray_image_width) * 16;
-        a.tile_w = e->ray_image_width;
-        a.tiled_rays = n / band * band;
-        if (a.block_rays > 128 || (a.block_rays == 128 && e->ray_image_width % 8 != 0)) a.block_rays = e->ray_image_width % 8 == 0 ? 128 : 64;
+    auto tile_width = [](const BatchReq& r) -> uint32_t {
+        if (r.image_width < 4 || r.image_width % 4 != 0 || r.n >= (uint64_t(1) << 32)) return 0;
+        return r.n / (uint64_t(r.image_width) * 16) != 0 ? r.image_width : 0;
+    };
+    bool any_tiled = false, all_mult8 = true;
+    for (uint32_t k = 0; k < nreq; ++k)
+        if (reqs[k].n != 0 && tile_width(reqs[k]) != 0) { any_tiled = true; all_mult8 = all_mult8 && reqs[k].image_width % 8 == 0; }
+    if (any_tiled) {
+        if (a.block_rays > 128 || (a.block_rays == 128 && !all_mult8)) a.block_rays = all_mult8 ? 128 : 64;
         if (a.block_rays != 64 && a.block_rays != 128) a.block_rays = 64;
-        a.nblocks = uint32_t((n + a.block_rays - 1) / a.block_rays);
-        if (a.tiled_rays == 0) a.tile_w = 0;
     }
+    const uint32_t unit = p.persistent ? a.block_rays : kBlockThreads;      // rays per ray block of this launch
+    auto describe = [&](const BatchReq& r, uint32_t first_block, TraceSeg& sg) -> uint64_t {    // returns the batch's block count
+        sg = TraceSeg{};
+        sg.rays = static_cast<const vt_ray*>(r.d_rays);
+        sg.n = r.n;
+        sg.first_block = sg.end_block = first_block;
+        if (r.n == 0) return 0;
+        sg.out_off = (static_cast<const char*>(r.d_out) - static_cast<const char*>(first->d_out)) / ptrdiff_t(out_elem);
+        sg.tile_w = tile_width(r);
+        if (sg.tile_w) { const uint64_t band = uint64_t(sg.tile_w) * 16; sg.tiled_rays = r.n / band * band; }
+        const uint64_t blocks = (r.n + unit - 1) / unit;
+        sg.end_block = first_block + uint32_t(blocks);
+        return blocks;
+    };
+    uint64_t nblocks = 0;
+    if (nreq == 1) {
+        nblocks = describe(reqs[0], 0, a.seg0);
+        if (nblocks > 0xFFFFFFFEull) return fail(VT_ERR_INVALID_ARG, "too many rays for one launch");
+    } else {
+        // the batch table travels in the slot's pinned block -> its device block, in stream order ahead of the kernel; the
+        // pinned block is only rewritten once the launch that last read it is over
+        if (nreq > slot.segs_cap) {
+            if (slot.used) VT_HIP(hipEventSynchronize(slot.done));
+            if (slot.d_segs) { VT_HIP(hipFree(slot.d_segs)); slot.d_segs = nullptr; }
+            if (slot.h_segs) { VT_HIP(hipHostFree(slot.h_segs)); slot.h_segs = nullptr; }
+            slot.segs_cap = 0;
+            const size_t cap = std::max<size_t>(64, size_t(nreq) * 2);
+            VT_HIP(hipMalloc(reinterpret_cast<void**>(&slot.d_segs), cap * sizeof(TraceSeg)));
+            VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&slot.h_segs), cap * sizeof(TraceSeg)));
+            slot.segs_cap = cap;
+        } else if (slot.segs_in_flight) {
+            VT_HIP(hipEventSynchronize(slot.done));
+        }
+        {   // result ranges of one launch must not overlap (they are written in no particular order)
+            std::vector<std::pair<const char*, const char*>> ranges;
+            for (uint32_t k = 0; k < nreq; ++k)
+                if (reqs[k].n != 0) ranges.push_back({static_cast<const char*>(reqs[k].d_out), static_cast<const char*>(reqs[k].d_out) + reqs[k].n * out_elem});
+            std::sort(ranges.begin(), ranges.end());
+            for (size_t k = 1; k < ranges.size(); ++k)
+                if (ranges[k].first < ranges[k - 1].second)
+                    return fail(VT_ERR_INVALID_ARG, "vt_trace_multi_dev: the result arrays of two batches overlap");
+        }
+        for (uint32_t k = 0; k < nreq; ++k) {
+            if (reqs[k].n != 0 && (static_cast<const char*>(reqs[k].d_out) - static_cast<const char*>(first->d_out)) % ptrdiff_t(out_elem) != 0)
+                return fail(VT_ERR_INVALID_ARG, "vt_trace_multi_dev: hit arrays must be 16-byte aligned");
+            nblocks += describe(reqs[k], uint32_t(nblocks), slot.h_segs[k]);
+            if (nblocks > 0xFFFFFFFEull) return fail(VT_ERR_INVALID_ARG, "too many rays for one launch");
+        }
+        a.seg0 = slot.h_segs[0];
+        a.segs = slot.d_segs;
+        a.nseg = nreq;
+        VT_HIP(hipMemcpyAsync(slot.d_segs, slot.h_segs, size_t(nreq) * sizeof(TraceSeg), hipMemcpyHostToDevice, stream));
+    }
+    slot.segs_in_flight = nreq > 1;
+    a.nblocks = uint32_t(nblocks);
+    if (!p.persistent) p.grid_blocks = uint32_t(nblocks);
     // 0 = by scene size: cheap rays (small trees) finish fast enough for the single cursor word to become the limit
     a.max_claim = e->max_claim ? e->max_claim : (s->npairs <= 200000u ? 4u : 1u);
     // the cursors are zero: engine open cleared them and every persistent launch leaves them so (leave_grid)
     a.cursor_base = (a.reserved_cus || a.xcd_cursors) ? 0u : p.grid_blocks * (kBlockThreads / 64);
     if (e->timing) VT_HIP(hipEventRecord(e->ev_start, stream));
-    VT_HIP(launch_trace(a, any_hit, stats, p.persistent, p.fetch_dma, s->has_alpha, p.grid_blocks, p.lds_bytes, stream));
+    const hipError_t lerr = launch_trace(a, any_hit, stats, p.persistent, p.fetch_dma, s->has_alpha, p.grid_blocks, p.lds_bytes, stream);
+    if (lerr != hipSuccess) {
+        slot.dirty = true;                                   // whatever did run may have left cursors behind
+        return fail(VT_ERR_HIP, std::string("trace launch: ") + hipGetErrorString(lerr));
+    }
     if (e->timing) { VT_HIP(hipEventRecord(e->ev_stop, stream)); e->ev_valid = true; }
     VT_HIP(hipEventRecord(slot.done, stream));
     slot.used = true;
     e->last_blocks = p.grid_blocks; e->last_threads = kBlockThreads; e->last_lds = uint32_t(p.lds_bytes);
     e->last_persistent = p.persistent; e->last_dma = p.fetch_dma;
     return VT_OK;
+}
+
+int launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_occ, void* d_stats, bool any_hit,
+           bool stats, hipStream_t stream)
+{
+    if (n == 0) return VT_OK;
+    const BatchReq one{d_rays, any_hit ? d_occ : d_hits, n, s->engine->ray_image_width};
+    return launch_batches(s, &one, 1, d_stats, any_hit, stats, stream);
 }
 
 // Pick `want` CUs, spread over the XCDs, that the persistent grid will leave empty.  The CUs are named by
@@ -380,6 +472,8 @@ void vt_engine_close(vt_engine* e)
     e->pinned_spare.clear();
     for (vt_engine::LaunchSlot& sl : e->slots) {
         if (sl.d_overflow) (void)hipFree(sl.d_overflow);
+        if (sl.d_segs) (void)hipFree(sl.d_segs);
+        if (sl.h_segs) (void)hipHostFree(sl.h_segs);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (e->d_slot_ctl) (void)hipFree(e->d_slot_ctl);
@@ -724,6 +818,33 @@ int vt_trace_closest_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hi
 int vt_trace_any_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_occluded, void* stream)
 {
     return trace_dev(s, d_rays, n, nullptr, d_occluded, nullptr, true, false, stream);
+}
+
+static int trace_multi_dev(vt_scene* s, const vt_batch_desc* batches, uint32_t nbatches, bool any_hit, void* stream, const char* who)
+{
+    if (!s) return fail(VT_ERR_INVALID_ARG, std::string(who) + ": scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, std::string(who) + ": the scene's engine has been closed");
+    if (nbatches == 0) return VT_OK;
+    if (!batches) return fail(VT_ERR_INVALID_ARG, std::string(who) + ": batches is NULL");
+    vt_engine* e = s->engine;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, std::string(who) + ": hipSetDevice failed");
+    std::vector<BatchReq> reqs(nbatches);
+    for (uint32_t k = 0; k < nbatches; ++k) {
+        if (batches[k].reserved != 0) return fail(VT_ERR_INVALID_ARG, std::string(who) + ": vt_batch_desc::reserved must be 0");
+        reqs[k] = BatchReq{batches[k].d_rays, batches[k].d_out, batches[k].n, batches[k].ray_image_width};
+    }
+    return launch_batches(s, reqs.data(), nbatches, nullptr, any_hit, false, static_cast<hipStream_t>(stream));
+}
+
+int vt_trace_closest_multi_dev(vt_scene* s, const vt_batch_desc* batches, uint32_t nbatches, void* stream)
+{
+    return trace_multi_dev(s, batches, nbatches, false, stream, "vt_trace_closest_multi_dev");
+}
+
+int vt_trace_any_multi_dev(vt_scene* s, const vt_batch_desc* batches, uint32_t nbatches, void* stream)
+{
+    return trace_multi_dev(s, batches, nbatches, true, stream, "vt_trace_any_multi_dev");
 }
 
 int vt_trace_stats_dev(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_ray_stats, void* stream)

@@ -59,6 +59,12 @@ struct vt_engine {
         size_t     overflow_words = 0;
         hipEvent_t done = nullptr;
         bool       used = false;
+        bool       dirty = false;            // a launch on this slot failed: the cursors are cleared before the next one
+        // merged launches (vt_trace_*_multi_dev): the batch table, pinned on the host and on the device
+        vt::TraceSeg* h_segs = nullptr;
+        vt::TraceSeg* d_segs = nullptr;
+        size_t        segs_cap = 0;
+        bool          segs_in_flight = false; // the slot's latest launch read h_segs (it must be over before h_segs changes)
     };
     LaunchSlot slots[kLaunchSlots];
     char*      d_slot_ctl = nullptr;

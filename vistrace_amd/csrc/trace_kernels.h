@@ -13,21 +13,31 @@ constexpr uint32_t kBlockThreads = 256; // 4 waves of 64
 
 constexpr uint32_t kExitWord = 120;   // of the 128 cursor words of a launch slot: waves that have left the persistent grid
 
-// One batch of a merged launch (vt_trace_closest_multi_dev): the launch numbers the ray blocks of all its batches through, a
-// wave that acquires block b finds the batch with first_block <= b in this table (device memory, nseg entries in block order).
+// One batch of a launch.  A plain launch has one (TraceArgs::seg0, in the kernel arguments); a merged launch
+// (vt_trace_closest_multi_dev) numbers the ray blocks of all its batches through, and a wave that acquires block b finds the
+// batch with first_block <= b < end_block in TraceArgs::segs (device memory, nseg entries in block order) -- many small
+// batches then share ONE grid start and ONE drain.
 struct TraceSeg {
     const vt_ray* rays;         // ray 0 of the batch
     int64_t       out_off;      // result record of its ray 0, counted from TraceArgs::hits (16-B records) / occluded (bytes)
     uint64_t      n;            // rays
-    uint64_t      tiled_rays;   // as TraceArgs::tiled_rays, for this batch
-    uint32_t      first_block;  // its first ray block in the launch's numbering (persistent: block_rays rays, else 256)
-    uint32_t      tile_w;       // as TraceArgs::tile_w
+    // Image-order batches (engine option "ray_image_width", vt_batch_desc::ray_image_width): the rays are rows of tile_w rays.  A
+    // wave then takes its 64 rays as a 4-wide, 16-high pixel tile instead of 64 consecutive rays of one row -- neighbours in both
+    // directions walk the same nodes for longer (camera rays: -8..-18 % kernel time).  The ray and hit arrays keep their order: only
+    // the lane <-> ray mapping changes.
+    uint64_t      tiled_rays;   // the first tiled_rays rays (whole 16-row bands, < 2^32) are taken tile-wise, the rest in order
+    uint32_t      first_block;  // its ray blocks [first_block, end_block) in the launch's numbering (persistent: block_rays rays
+    uint32_t      end_block;    //   each, else 256); an empty batch has none
+    uint32_t      tile_w;       // 0 = off; a multiple of 4
+    uint32_t      pad;
 };
-static_assert(sizeof(TraceSeg) == 40, "TraceSeg layout");
+static_assert(sizeof(TraceSeg) == 48, "TraceSeg layout");
 
 struct TraceArgs {
     const void*         records;     // 64-B records: pairs [0, npairs), triangles from tri_base on
-    const vt_ray*       rays;
+    TraceSeg            seg0;        // the batch of a plain launch (a merged launch starts from it: its batch 0)
+    const TraceSeg*     segs;        // merged launch: its batches; NULL for a plain launch
+    uint32_t            nseg;        // 0 = plain launch
     vt_hit*             hits;        // closest-hit output (or nullptr for any-hit)
     uint8_t*            occluded;    // any-hit output
     vt_ray_stats*       ray_stats;   // STATS kernels only
@@ -35,14 +45,6 @@ struct TraceArgs {
     uint32_t*           block_cursor;// persistent mode: next block of rays to hand out, counted from cursor_base.  Zero when a launch
                                      // starts; the last wave to leave puts it back to zero (word kExitWord counts the leavers)
     uint32_t            cursor_base; // the first ray block the cursor hands out (the blocks before it are assigned statically)
-    uint64_t            nrays;       // plain launch: rays in the batch; merged launch: of all batches together (informational)
-    const TraceSeg*     segs;        // merged launch: its batches; NULL for a plain launch
-    uint32_t            nseg;        // 0 = plain launch: ONE batch described by rays / nrays / tile_w / tiled_rays
-    // Image-order batches (engine option "ray_image_width"): the rays are rows of tile_w rays.  A wave then takes its 64 rays as a
-    // 4-wide, 16-high pixel tile instead of 64 consecutive rays of one row -- neighbours in both directions walk the same nodes for
-    // longer (camera rays: -8..-18 % kernel time).  The ray and hit arrays keep their order: only the lane <-> ray mapping changes.
-    uint32_t            tile_w;      // 0 = off; a multiple of 4
-    uint64_t            tiled_rays;  // the first tiled_rays rays (whole 16-row bands, < 2^32) are taken tile-wise, the rest in order
     uint32_t            npairs;
     uint32_t            tri_base;    // record index of triangle 0
     uint32_t            root_leaf_count;

@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cstddef>
 #include <cstdint>
 
 #include "trace_kernels.h"
@@ -136,6 +137,9 @@ struct Lane {
 constexpr int kCompilerVgprs = 76;
 
 typedef __attribute__((address_space(1))) const void* global_cptr;
+// batch descriptors are read through the constant address space: wave-uniform scalar loads, nothing of a batch occupies
+// registers while the wave walks (the kernels sit at the SGPR limit)
+typedef __attribute__((address_space(4))) const TraceSeg* seg_cptr;
 typedef __attribute__((address_space(3))) void*       lds_ptr;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -257,10 +261,14 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
     // wave-uniform block cursor (PERSISTENT)
     uint64_t blk_cur = 0, blk_end = 0;
     bool blk_tiled = false;             // wave-uniform: the current block is taken tile-wise
+    uint32_t blk_tile_w = 0;            // ... in rows of this many rays
     uint32_t blk_first = 0;             // its first (tile-order) index
     uint64_t blk_base = 0;              // ray index of its top left pixel
     bool exhausted = false;
     bool coherent = false;   // wave-uniform: this wave's rays share a direction octant
+    // wave-uniform: the batch the current ray block belongs to (see TraceSeg).  Only the pointer lives in registers; rays,
+    // result offset, size and tiling are scalar loads when a block is acquired / a lane is re-filled.
+    seg_cptr cur = (seg_cptr)((__attribute__((address_space(4))) const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TraceArgs, seg0));
     // wave-uniform: the first block of rays is assigned statically (not with reserved CUs: a block that
     // leaves must not take rays with it, so the cursor hands out everything)
     bool first_block = a.reserved_cus == nullptr && a.xcd_cursors == 0;
@@ -273,10 +281,27 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
     // ~90 M claims per second (11 ns each, measured), i.e. 5.8 Grays/s with 64-ray claims.
     uint32_t claim_cur = 0, claim_end = 0;   // wave-uniform: ray blocks claimed but not yet started
 
+    // the batch that holds ray block b (wave-uniform) becomes the current one; returns b's index within it.  Batches are
+    // listed in block order; an empty batch shares its first block with its successor, which the search then prefers.
+    auto enter_batch = [&](uint32_t b) -> uint32_t {
+        uint32_t first = cur->first_block;
+        if (b < first || b >= cur->end_block) {        // never on a plain launch: its one batch holds every block
+            const seg_cptr table = (seg_cptr)(uintptr_t)a.segs;
+            uint32_t lo = 0, hi = a.nseg;              // table[lo].first_block <= b < table[hi].first_block
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (table[mid].first_block <= b) lo = mid; else hi = mid;
+            }
+            cur = table + lo;
+            first = cur->first_block;
+        }
+        return b - first;
+    };
+
     auto start_ray = [&](uint64_t idx) {
         // rays are read once and hits written once: non-temporal, so that 48 B per ray of streaming data do not push
         // records out of L2 / Infinity Cache (S10M, whose records do not fit there: 5.97 -> 5.86 ms; S1M unchanged)
-        const f32x4* r4 = reinterpret_cast<const f32x4*>(a.rays + idx);
+        const f32x4* r4 = reinterpret_cast<const f32x4*>(cur->rays + idx);
         const f32x4 r0 = __builtin_nontemporal_load(r4), r1 = __builtin_nontemporal_load(r4 + 1);
         L.ox = r0.x; L.oy = r0.y; L.oz = r0.z; L.dx = r0.w;
         L.dy = r1.x; L.dz = r1.y; L.tmin = r1.z; L.tmax = r1.w;
@@ -309,7 +334,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             L.tests = a.root_leaf_count;
             L.node = kDone; L.tri_cur = 0; L.tri_end = 0;
         }
-        ray_idx = idx;
+        ray_idx = uint64_t(cur->out_off) + idx;    // where the result goes: all that a lane keeps of its batch
         has_ray = true;
     };
 
@@ -330,13 +355,14 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
     };
 
     if constexpr (!PERSISTENT) {
-        uint64_t idx = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
-        if (!ALPHA && a.tile_w != 0 && idx < a.tiled_rays) { // this wave's 64 rays are one 4 x 16 pixel tile (see TraceArgs::tile_w)
-            const uint32_t j = uint32_t(idx), t = j >> 6, k = j & 63u, tpr = a.tile_w >> 2;
+        uint64_t idx = uint64_t(enter_batch(blockIdx.x)) * kBlockThreads + threadIdx.x;
+        const uint32_t tile_w = cur->tile_w;
+        if (!ALPHA && tile_w != 0 && idx < cur->tiled_rays) { // this wave's 64 rays are one 4 x 16 pixel tile (see TraceSeg::tile_w)
+            const uint32_t j = uint32_t(idx), t = j >> 6, k = j & 63u, tpr = tile_w >> 2;
             const uint32_t ty = t / tpr, tx = t - ty * tpr;
-            idx = uint64_t(ty * 16u + (k >> 2)) * a.tile_w + tx * 4u + (k & 3u);
+            idx = uint64_t(ty * 16u + (k >> 2)) * tile_w + tx * 4u + (k & 3u);
         }
-        if (idx < a.nrays) start_ray(idx);
+        if (idx < cur->n) start_ray(idx);
         if (has_ray && L.node == kDone && L.tri_cur >= L.tri_end) finish_ray();
     }
 
@@ -385,18 +411,24 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                             b = claim_cur++;
                         }
                         b = __builtin_amdgcn_readfirstlane(b);
-                        blk_cur = uint64_t(b) * a.block_rays;
-                        blk_end = blk_cur + a.block_rays < a.nrays ? blk_cur + a.block_rays : a.nrays;
-                        // image-order batch: the block is one or two 4 x 16 pixel tiles side by side (see TraceArgs::tile_w)
-                        // (not in the ALPHA variants: their register budget has no room for the extra wave state)
-                        blk_tiled = !ALPHA && a.tile_w != 0 && blk_cur + a.block_rays <= a.tiled_rays;
-                        if (blk_tiled) {
-                            const uint32_t t = uint32_t(blk_cur >> 6), tpr = a.tile_w >> 2;
-                            const uint32_t ty = t / tpr, tx = t - ty * tpr;
-                            blk_first = uint32_t(blk_cur);
-                            blk_base = uint64_t(ty) * 16u * a.tile_w + tx * 4u;
+                        if (b >= a.nblocks) {
+                            exhausted = true; blk_cur = blk_end = 0;
+                        } else {
+                            b = enter_batch(b);                  // now the block's index within its batch
+                            const uint64_t n = cur->n;
+                            blk_cur = uint64_t(b) * a.block_rays;
+                            blk_end = blk_cur + a.block_rays < n ? blk_cur + a.block_rays : n;
+                            // image-order batch: the block is one or two 4 x 16 pixel tiles side by side (see TraceSeg::tile_w)
+                            // (not in the ALPHA variants: their register budget has no room for the extra wave state)
+                            blk_tile_w = cur->tile_w;
+                            blk_tiled = !ALPHA && blk_tile_w != 0 && blk_cur + a.block_rays <= cur->tiled_rays;
+                            if (blk_tiled) {
+                                const uint32_t t = uint32_t(blk_cur >> 6), tpr = blk_tile_w >> 2;
+                                const uint32_t ty = t / tpr, tx = t - ty * tpr;
+                                blk_first = uint32_t(blk_cur);
+                                blk_base = uint64_t(ty) * 16u * blk_tile_w + tx * 4u;
+                            }
                         }
-                        if (blk_cur >= a.nrays) { exhausted = true; blk_cur = blk_end = 0; }
                     }
                     if (!exhausted) {
                         const uint64_t avail = blk_end - blk_cur;
@@ -405,7 +437,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                             uint64_t idx = blk_cur + mine;
                             if (blk_tiled) {
                                 const uint32_t k = uint32_t(idx) - blk_first;
-                                idx = blk_base + ((k >> 6) << 2) + (k & 3u) + uint64_t((k >> 2) & 15u) * a.tile_w;
+                                idx = blk_base + ((k >> 6) << 2) + (k & 3u) + uint64_t((k >> 2) & 15u) * blk_tile_w;
                             }
                             start_ray(idx);
                             if (L.node == kDone && L.tri_cur >= L.tri_end) finish_ray(); // empty scene / NaN range
