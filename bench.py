@@ -355,12 +355,38 @@ class NativeGather:
         # the root traces straight into its slice of the result (ncclGather in place: sendbuff == recvbuff + rank * count)
         self.hits = [self.recv[b][: n * 16] if rank == 0 else torch.empty(n * 16, dtype=torch.uint8, device=device) for b in range(2)]
         self.batch = 0
+        self.device, self.alt, self.two_streams = device, None, True
+        self.ev_main, self.ev_alt = torch.cuda.Event(), torch.cuda.Event()
 
-    def submit(self, trace, stream):
+    def submit(self, trace, stream, chunks=1):
+        """One batch.  chunks = K > 1: the shard is traced in K pieces and piece c is gathered (vt_gather_hits_part_dev) while piece
+        c + 1 is traced -- what a one-shot batch needs; K = 1: one trace, one ncclGather."""
+        import torch
+        import vistrace_amd as va
         b = self.batch % 2
         self.engine.gather_wait(1, stream)                      # the gather that read hits[b] two batches ago is over
-        trace(self.hits[b])
-        self.engine.gather_hits_dev(self.hits[b].data_ptr(), self.n, self.recv[b].data_ptr() if self.rank == 0 else 0, 0, stream)
+        recv = self.recv[b].data_ptr() if self.rank == 0 else 0
+        if chunks <= 1:
+            trace(self.hits[b])
+            self.engine.gather_hits_dev(self.hits[b].data_ptr(), self.n, recv, 0, stream)
+        else:
+            # the pieces alternate between two launch streams: the drain of piece c (its last, longest rays on a few lanes) then
+            # runs beside the start of piece c + 1 instead of in front of it
+            if self.alt is None:
+                self.alt = torch.cuda.Stream(self.device)
+            alt = int(self.alt.cuda_stream) if self.two_streams else stream
+            if alt != stream:
+                self.engine.gather_wait(1, alt)
+                self.ev_main.record()                           # everything the caller enqueued so far (ray generation, earlier steps)
+                self.alt.wait_event(self.ev_main)
+            for c in range(chunks):
+                lo, hi = va.gather_chunk_bounds(self.n, chunks, c)
+                s = alt if c & 1 else stream
+                trace(self.hits[b], lo, hi, s)
+                self.engine.gather_hits_part_dev(self.hits[b].data_ptr(), self.n, c, chunks, recv, 0, s)
+            if alt != stream:
+                self.ev_alt.record(self.alt)                    # later work on the caller's stream stays behind the odd pieces
+                torch.cuda.current_stream(self.device).wait_event(self.ev_alt)
         self.batch += 1
         return b
 
@@ -427,7 +453,10 @@ def main() -> None:
                     help="N > 1: CUs (one per shader engine of every XCD) on which the persistent trace grid leaves room "
                          "for the RCCL gather's kernels, so that the transfer of batch b overlaps the trace of batch b+1; "
                          "0 = off (the gather then only starts when the resident grid drains)")
-    ap.add_argument("--chunks", type=int, default=1, help="torch gather: launches per batch in the trace/gather pipeline")
+    ap.add_argument("--chunks", type=int, default=1,
+                    help="N > 1: pieces a rank's batch is traced and gathered in (piece c crosses the links while piece c + 1 is traced; "
+                         "native: vt_gather_hits_part_dev, 1 .. 16).  1 = one trace + one ncclGather per step: in a stream of steps the gather "
+                         "of step b already overlaps the trace of step b + 1; pieces pay for a one-shot batch (dist_breakdown.single_batch_ms)")
     ap.add_argument("--mode", default=None, choices=[None, "persistent", "static"])
     ap.add_argument("--image-hint", default="on", choices=["on", "off"],
                     help="camera-ray workloads (--kind primary, --scaling strong): pass the image's row length to the engine "
@@ -541,10 +570,10 @@ def main() -> None:
             pipe = HitGatherPipeline(n_send, device, nchunks=args.chunks, via_host=args.backend == "gloo")
             gather_kind = "torch.distributed.gather" + (" via host (gloo test mode)" if args.backend == "gloo" else " (RCCL)")
 
-    def trace_into(hits_buf, lo=0, hi=None):
+    def trace_into(hits_buf, lo=0, hi=None, on=None):
         hi = n if hi is None else min(hi, n)
         if hi > lo:
-            scene.trace_closest_dev(d_rays.data_ptr() + lo * RAY.itemsize, hi - lo, hits_buf.data_ptr() + lo * HIT.itemsize, stream)
+            scene.trace_closest_dev(d_rays.data_ptr() + lo * RAY.itemsize, hi - lo, hits_buf.data_ptr() + lo * HIT.itemsize, on or stream)
 
     def step():
         if any_hit:
@@ -552,7 +581,7 @@ def main() -> None:
         elif not dist_on:
             tp.trace_closest(scene, d_rays, n, d_hits)
         elif native is not None:
-            native.submit(trace_into, stream)
+            native.submit(trace_into, stream, args.chunks)
         else:
             # chunked and double-buffered: the gather of one chunk/batch overlaps the tracing of the next
             pipe.submit(trace_into)
@@ -637,6 +666,25 @@ def main() -> None:
                     ga.append(engine.last_gather_ms())
                 except Exception:
                     pass
+        # ONE batch from idle to "every record on rank 0", cut into K pieces: trace + gather for K = 1, about max(trace, gather) +
+        # one piece when the pieces overlap (each extra piece costs one more launch's drain)
+        single = {}
+        if native is not None:
+            for K, two in ((1, True), (2, True), (4, True), (8, True), (2, False), (4, False), (8, False)):
+                native.two_streams = two
+                ts = []
+                for _ in range(4):
+                    torch.cuda.synchronize(device)
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                    native.submit(trace_into, stream, K)
+                    native.drain()
+                    torch.cuda.synchronize(device)
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                tk = torch.tensor([float(np.mean(ts[1:]))], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+                dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+                single[str(K) if two else f"{K}_one_launch_stream"] = round(float(tk.item()), 4)
+            native.two_streams = True
         t_mean, g_mean = float(np.mean(tr)), (float(np.mean(ga)) if ga else 0.0)
         dev_t = device if args.backend == "nccl" else "cpu"
         hi = torch.tensor([t_mean, g_mean], dtype=torch.float64, device=dev_t)
@@ -651,6 +699,10 @@ def main() -> None:
             "gather_ms_how": "HIP events on the communication stream around one ncclGather with no trace beside it (vt_engine_last_gather_ms)" if ga
                              else "not measured (torch.distributed.gather path)",
             "step_ms": round(ms_per_step, 4),
+            "chunks": args.chunks,
+            "single_batch_ms": single or None,
+            "single_batch_how": "one isolated batch (device idle before, every record on rank 0 after; wall clock, max over ranks) traced and "
+                                "gathered in K pieces, K = the keys (pieces alternate between two launch streams; *_one_launch_stream: all on one)",
             "overlap": args.overlap,
             "overlap_frac": round(min(1.0, hidden / min(t_max, g_max)), 3) if ga and min(t_max, g_max) > 0 else None,
             "overlap_note": "(trace + gather - step) / min(trace, gather): 1 = the shorter of the two is fully hidden, 0 = they run back to back",

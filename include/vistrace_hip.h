@@ -214,6 +214,20 @@ int vt_comm_unique_id(void* id128);
 int vt_engine_comm_init_rank(vt_engine* e, int nranks, int rank, const void* id128);
 int vt_gather_hits_dev(vt_engine* e, const void* d_send, uint64_t count, void* d_recv_root, int root, void* stream);
 int vt_gather_wait(vt_engine* e, int batches_in_flight, void* stream);
+/* ONE batch in pieces (round 4): a one-shot batch costs trace + gather, because its gather can only start when its trace
+ * has ended.  Cut into K pieces -- piece c = records [lo, hi) of every shard, vt_gather_chunk_bounds(count, K, c) -- piece c
+ * crosses the links while piece c + 1 is traced, and the batch costs about max(trace, gather) + one piece.
+ *   single process: engine option "gather_chunks" = K (1 .. 16) makes vt_trace_closest_gather_dev trace and gather every
+ *     device's shard in K pieces (same arguments, same result array);
+ *   one process per GPU: after vt_gather_wait(e, 1, stream), for c = 0 .. K-1: trace the rays of piece c into d_send + lo
+ *     records on `stream`, then vt_gather_hits_part_dev(e, d_send, count, c, K, d_recv_root, root, stream).  Every rank
+ *     passes the same count and K; the pieces of a batch are handed over in order.  vt_gather_hits_dev = one piece.
+ * A piece of every shard cannot land at its final place through ncclGather (it puts rank r's data at r * piece size), so
+ * pieces move as the sends and receives ncclGather consists of, one group per piece; K = 1 is the single ncclGather.
+ * Each extra piece costs one more launch (~0.3 ms of drain): worth it for a one-shot batch whose gather is as long as its
+ * trace (configs[4]); in a stream of batches the gather of batch b already hides behind the trace of batch b + 1. */
+void vt_gather_chunk_bounds(uint64_t count, int nchunks, int chunk, uint64_t* lo, uint64_t* hi);
+int  vt_gather_hits_part_dev(vt_engine* e, const void* d_send, uint64_t count, int chunk, int nchunks, void* d_recv_root, int root, void* stream);
 int vt_engine_last_gather_ms(vt_engine* e, float* ms);
 
 /* Upload once per Rebuild (north star: "uploaded once per Rebuild"). */
@@ -311,8 +325,12 @@ void     vt_batch_free(vt_batch* b);
  *                        neighbours of one row, so its lanes walk the same nodes for longer: 16 Mi camera rays into 1 M
  *                        triangles 2.00 -> 1.87 ms, into 10 M 4.24 -> 3.76 ms, 1 Mi into 100 k 0.113 -> 0.095 ms.  Scheduling
  *                        only: the ray and hit arrays keep their order and every result is unchanged.  Needs a multiple of 4;
- *                        whole bands of 16 rows are tiled, the rest of a batch is taken in order.  No gain for bounce or
- *                        shadow rays (their directions differ from pixel to pixel anyway); not used by the alpha-test kernels.
+ *                        whole bands of 16 rows are tiled, the rest of a batch is taken in order.  The hint is also a PROMISE
+ *                        that the batch is coherent (camera rays): with "persistent" = 2 such batches run one ray per lane at
+ *                        every size while the scene's records fit the caches (<= 256 MiB: 1 M triangles 4 Mi rays 0.84 ->
+ *                        0.59 ms).  Do not set it for bounce or shadow rays, even when they are stored in image order: their
+ *                        directions differ from pixel to pixel, tiles gain nothing and the kernel choice would be the
+ *                        wrong one (16 Mi bounce rays: 7.9 instead of 4.2 ms).  Not used by the alpha-test kernels.
  *   "spin_wait"          host batches of <= 256 rays: watch the pinned result slots change instead of waiting on
  *                        the stream (default 1; saves ~5 us of the ~24 us single-ray call)
  *   "reserved_cus"       CUs on which the persistent grid leaves room (0 = off): set it when another stream runs
@@ -324,6 +342,9 @@ void     vt_batch_free(vt_batch* b);
  *   "reserved_limit"     blocks of the grid a reserved CU still keeps (2: measured to leave room for one
  *                        256-thread workgroup with the footprint of RCCL's kernel, 280 VGPRs + 20 KB LDS --
  *                        3 does not; 0 = keep the CU empty).  Later arrivals on a full reserved CU exit at once.
+ *   "gather_overlap"     multi-GPU: 0 = every trace waits for the previous batch's gather (diagnostic: step = trace + gather)
+ *   "gather_chunks"      multi-GPU, single-process form: pieces a shard is traced and gathered in (1 .. 16, default 1; see
+ *                        vt_gather_hits_part_dev)
  * Read-only: "cu_count", "device", "device_count", "last_persistent", "last_fetch_dma" (what the last launch used).
  * Results never depend on these, only speed does. */
 int vt_engine_set_option(vt_engine* e, const char* key, int64_t value);

@@ -1,16 +1,23 @@
 // test_gather_schedule.cpp -- the multi-GPU batch schedule (vistrace_amd/csrc/gather_schedule.h) on a simulated group.
 //
-// multi_gpu.hip executes the planner's steps with HIP streams, events and ncclGather; no multi-GPU node was available,
+// multi_gpu.hip executes the planner's steps with HIP streams, events and RCCL calls; no multi-GPU node was available,
 // so this program executes the SAME steps on a model of ndev devices x {trace stream, communication stream}:
 //   * a stream runs its operations in order; which runnable stream advances next is drawn at random (every legal
 //     interleaving of asynchronous streams is some such sequence);
 //   * hipStreamWaitEvent blocks the stream until the event's latest record (at enqueue time) has executed;
-//   * the collective completes on a device only once every device has reached its call (ncclGather);
+//   * the collective that moves piece c of batch b completes on a device only once every device has reached its call
+//     (the root receives from every peer; a send completes when it has been received);
 //   * the per-rank form (one process per GPU, bench.py) runs the same steps, each process enqueueing its own device's.
-// Checked while running: a Trace never starts while a Gather that reads its send buffer is unfinished (the double
-// buffer), a Gather never starts before the Trace that fills its send buffer has finished (the hand-over), and with
-// overlap on, some gather of batch b really runs beside a trace of batch b + 1.  A deliberately broken schedule (the
-// wait for sent[buf] dropped) must trip the first check -- the checker checks itself.
+// A batch is cut into K pieces (K = 1: one gather per batch; K > 1: piece c is gathered while piece c + 1 is traced).
+// Checked while running, for K in {1, 2, 4, 8} x ndev in {1, 2, 4, 8}:
+//   * a Trace never starts while a Gather that reads the piece of the send buffer it writes is unfinished (the double
+//     buffer across batches),
+//   * a Gather never starts before the Trace that fills ITS piece of the send buffer has finished (the hand-over),
+//   * with overlap on, some gather of batch b really runs beside a trace of batch b + 1, and for K > 1 some gather of
+//     piece c really runs beside the trace of piece c + 1 of the SAME batch,
+//   * with overlap off (diagnostic mode) neither ever happens.
+// A deliberately broken schedule (the wait for sent[buf] dropped, or the wait for traced[c] dropped) must trip the
+// checks -- the checker checks itself.  gather_chunk_bounds must tile a shard exactly.
 // Built by `make -C tests/cpp schedule`; exit code 0 = all checks passed.
 #include <cstdio>
 #include <cstdlib>
@@ -26,9 +33,11 @@ using vt::GatherStep;
 
 namespace {
 
+constexpr int kMaxK = vt::kMaxGatherChunks;
+
 struct Op {
     GatherOp op;
-    int dev, buf;
+    int dev, buf, chunk;
     uint64_t batch;
     long wait_gen = -1;     // WaitSent / WaitTraced: generation of the event that must have executed
 };
@@ -37,37 +46,37 @@ struct Sim {
     int ndev;
     // streams: [dev][0] = trace, [dev][1] = communication
     std::vector<std::deque<Op>> q;
-    // events: records enqueued / executed so far (generation counters), per device
-    std::vector<long> traced_enq, traced_done;
+    // events: records enqueued / executed so far (generation counters), per device (traced: per device and piece)
+    std::vector<long> traced_enq, traced_done;             // [dev * kMaxK + chunk]
     std::vector<long> sent_enq[2], sent_done[2];
-    // buffers: per device and buffer, the batch whose trace last wrote it / whose gather is reading it
-    std::vector<long> written_by[2];       // batch that last finished a trace into the buffer (-1 none)
-    std::vector<int>  readers[2];          // gathers in flight that read the buffer
-    // collective rendezvous: devices that have reached the gather of batch b
-    std::vector<int> arrived;              // indexed by batch
-    std::vector<int> gather_started;       // per device: batch whose gather has started but not completed (-1 none)
-    int hazards_rewrite = 0, hazards_early = 0, overlaps = 0;
-    std::vector<long> tracing;             // per device: batch being traced "now" (a Trace op occupies one tick)
+    // buffers: per device, buffer and piece, the batch whose trace last wrote it / gathers in flight that read it
+    std::vector<long> written_by[2];       // [dev * kMaxK + chunk]: batch that last finished a trace into the piece (-1 none)
+    std::vector<int>  readers[2];          // [dev * kMaxK + chunk]
+    // collective rendezvous: devices that have reached the gather of (batch, piece)
+    std::vector<int> arrived;              // [batch * kMaxK + chunk]
+    std::vector<long> gather_started;      // per device: batch * kMaxK + chunk whose gather has started but not completed (-1 none)
+    int hazards_rewrite = 0, hazards_early = 0, overlaps_batches = 0, overlaps_pieces = 0;
 
-    explicit Sim(int n) : ndev(n), q(size_t(n) * 2), traced_enq(n, 0), traced_done(n, 0), arrived(), gather_started(n, -1), tracing(n, -1)
+    explicit Sim(int n) : ndev(n), q(size_t(n) * 2), traced_enq(size_t(n) * kMaxK, 0), traced_done(size_t(n) * kMaxK, 0), gather_started(n, -1)
     {
         for (int b = 0; b < 2; ++b) {
             sent_enq[b].assign(n, 0); sent_done[b].assign(n, 0);
-            written_by[b].assign(n, -1); readers[b].assign(n, 0);
+            written_by[b].assign(size_t(n) * kMaxK, -1); readers[b].assign(size_t(n) * kMaxK, 0);
         }
     }
 
     // enqueue = what the host thread does when it walks the planner's steps (events capture their generation here)
     void enqueue(const std::vector<GatherStep>& steps, uint64_t batch)
     {
-        if (arrived.size() <= batch) arrived.resize(batch + 1, 0);
+        if (arrived.size() <= (batch + 1) * kMaxK) arrived.resize((batch + 1) * kMaxK, 0);
         for (const GatherStep& s : steps) {
-            Op o{s.op, s.dev, s.buf, batch, -1};
+            Op o{s.op, s.dev, s.buf, s.chunk, batch, -1};
+            const size_t pc = size_t(s.dev) * kMaxK + size_t(s.chunk);
             switch (s.op) {
             case GatherOp::WaitSent:     o.wait_gen = sent_enq[s.buf][s.dev]; q[size_t(s.dev) * 2 + 0].push_back(o); break;
             case GatherOp::Trace:        q[size_t(s.dev) * 2 + 0].push_back(o); break;
-            case GatherOp::RecordTraced: ++traced_enq[s.dev]; o.wait_gen = traced_enq[s.dev]; q[size_t(s.dev) * 2 + 0].push_back(o); break;
-            case GatherOp::WaitTraced:   o.wait_gen = traced_enq[s.dev]; q[size_t(s.dev) * 2 + 1].push_back(o); break;
+            case GatherOp::RecordTraced: ++traced_enq[pc]; o.wait_gen = traced_enq[pc]; q[size_t(s.dev) * 2 + 0].push_back(o); break;
+            case GatherOp::WaitTraced:   o.wait_gen = traced_enq[pc]; q[size_t(s.dev) * 2 + 1].push_back(o); break;
             case GatherOp::Gather:       q[size_t(s.dev) * 2 + 1].push_back(o); break;
             case GatherOp::RecordSent:   ++sent_enq[s.buf][s.dev]; o.wait_gen = sent_enq[s.buf][s.dev]; q[size_t(s.dev) * 2 + 1].push_back(o); break;
             }
@@ -80,32 +89,38 @@ struct Sim {
         if (q[si].empty()) return false;
         Op& o = q[si].front();
         const int d = o.dev;
+        const size_t pc = size_t(d) * kMaxK + size_t(o.chunk);
+        const long id = long(o.batch) * kMaxK + o.chunk;
         switch (o.op) {
         case GatherOp::WaitSent:
             if (sent_done[o.buf][d] < o.wait_gen) return false;
             break;
         case GatherOp::Trace: {
-            if (readers[o.buf][d] != 0) ++hazards_rewrite;                           // a gather still reads this send buffer
-            if (gather_started[d] >= 0 && uint64_t(gather_started[d]) + 1 == o.batch) ++overlaps;   // beside this device's previous gather
-            written_by[o.buf][d] = long(o.batch);
+            if (readers[o.buf][pc] != 0) ++hazards_rewrite;                           // a gather still reads this piece of the send buffer
+            if (gather_started[d] >= 0) {
+                const long gb = gather_started[d] / kMaxK, gc = gather_started[d] % kMaxK;
+                if (uint64_t(gb) + 1 == o.batch) ++overlaps_batches;                  // beside this device's previous batch's gather
+                if (uint64_t(gb) == o.batch && gc < o.chunk) ++overlaps_pieces;       // beside the gather of an earlier piece of this batch
+            }
+            written_by[o.buf][pc] = long(o.batch);
             break;
         }
         case GatherOp::RecordTraced:
-            traced_done[d] = o.wait_gen;
+            traced_done[pc] = o.wait_gen;
             break;
         case GatherOp::WaitTraced:
-            if (traced_done[d] < o.wait_gen) return false;
+            if (traced_done[pc] < o.wait_gen) return false;
             break;
         case GatherOp::Gather:
-            if (gather_started[d] != long(o.batch)) {                                 // first visit: the device reaches its call
-                if (written_by[o.buf][d] != long(o.batch)) ++hazards_early;           // its send buffer is not this batch's yet
-                gather_started[d] = long(o.batch);
-                ++readers[o.buf][d];
-                ++arrived[o.batch];
+            if (gather_started[d] != id) {                                            // first visit: the device reaches its call
+                if (written_by[o.buf][pc] != long(o.batch)) ++hazards_early;          // its piece is not this batch's yet
+                gather_started[d] = id;
+                ++readers[o.buf][pc];
+                ++arrived[size_t(id)];
                 return true;
             }
-            if (arrived[o.batch] < ndev) return false;                                // the collective waits for every device
-            --readers[o.buf][d];
+            if (arrived[size_t(id)] < ndev) return false;                             // the collective waits for every device
+            --readers[o.buf][pc];
             gather_started[d] = -1;
             break;
         case GatherOp::RecordSent:
@@ -126,11 +141,26 @@ struct Sim {
 int fails = 0;
 #define CHECK(c) do { if (!(c)) { ++fails; std::printf("FAIL line %d: %s\n", __LINE__, #c); } } while (0)
 
-struct Outcome { int rewrite, early, overlaps; bool deadlock; };
+struct Outcome { int rewrite, early, overlaps_batches, overlaps_pieces; bool deadlock; };
 
-// `batches` batches through a group of ndev devices; the host enqueues batch b + 1 at a random moment (it never waits
-// for the device: the ABI call is asynchronous).  break_wait drops the WaitSent steps (negative control).
-Outcome run(int ndev, int batches, unsigned seed, bool overlap, bool break_wait)
+enum Break { kNone, kDropWaitSent, kDropWaitTraced };
+
+std::vector<GatherStep> planned(GatherSchedule& sched, int ndev, int chunks, Break br)
+{
+    std::vector<GatherStep> steps = sched.plan(ndev, chunks);
+    if (br == kNone) return steps;
+    std::vector<GatherStep> kept;
+    for (const GatherStep& s : steps) {
+        if (br == kDropWaitSent && s.op == GatherOp::WaitSent) continue;
+        if (br == kDropWaitTraced && s.op == GatherOp::WaitTraced) continue;
+        kept.push_back(s);
+    }
+    return kept;
+}
+
+// `batches` batches of `chunks` pieces through a group of ndev devices; the host enqueues batch b + 1 at a random moment (it
+// never waits for the device: the ABI call is asynchronous).
+Outcome run(int ndev, int chunks, int batches, unsigned seed, bool overlap, Break br)
 {
     std::mt19937 rng(seed);
     GatherSchedule sched;
@@ -138,15 +168,10 @@ Outcome run(int ndev, int batches, unsigned seed, bool overlap, bool break_wait)
     Sim sim(ndev);
     int enq = 0;
     long guard = 0;
+    auto out = [&](bool dead) { return Outcome{sim.hazards_rewrite, sim.hazards_early, sim.overlaps_batches, sim.overlaps_pieces, dead}; };
     while (enq < batches || !sim.idle()) {
         if (enq < batches && (sim.idle() || rng() % 4 == 0)) {
-            std::vector<GatherStep> steps = sched.plan(ndev);
-            if (break_wait) {
-                std::vector<GatherStep> kept;
-                for (const GatherStep& s : steps) if (s.op != GatherOp::WaitSent) kept.push_back(s);
-                steps.swap(kept);
-            }
-            sim.enqueue(steps, uint64_t(enq));
+            sim.enqueue(planned(sched, ndev, chunks, br), uint64_t(enq));
             ++enq;
             continue;
         }
@@ -154,45 +179,77 @@ Outcome run(int ndev, int batches, unsigned seed, bool overlap, bool break_wait)
         const size_t nstreams = sim.q.size(), start = rng() % nstreams;
         bool moved = false;
         for (size_t k = 0; k < nstreams && !moved; ++k) moved = sim.advance((start + k) % nstreams);
-        if (!moved && enq >= batches) return {sim.hazards_rewrite, sim.hazards_early, sim.overlaps, true};
+        if (!moved && enq >= batches) return out(true);
         if (!moved && enq < batches) {                       // everything blocked on work not yet enqueued
-            sim.enqueue(sched.plan(ndev), uint64_t(enq));
+            sim.enqueue(planned(sched, ndev, chunks, br), uint64_t(enq));
             ++enq;
         }
-        if (++guard > 50000000) return {sim.hazards_rewrite, sim.hazards_early, sim.overlaps, true};
+        if (++guard > 50000000) return out(true);
     }
-    return {sim.hazards_rewrite, sim.hazards_early, sim.overlaps, false};
+    return out(false);
+}
+
+void chunk_bounds()
+{
+    for (uint64_t cap : {uint64_t(0), uint64_t(1), uint64_t(63), uint64_t(64), uint64_t(65), uint64_t(1000), uint64_t(1048576), uint64_t(16777216), uint64_t(16777217)}) {
+        for (int K = 1; K <= kMaxK; ++K) {
+            uint64_t expect = 0;
+            for (int c = 0; c < K; ++c) {
+                uint64_t lo = 1, hi = 0;
+                vt::gather_chunk_bounds(cap, K, c, &lo, &hi);
+                CHECK(lo == expect && hi >= lo && hi <= cap);                     // contiguous, in order, inside the shard
+                CHECK(lo % 64 == 0 || lo == cap);                                 // pieces start on a wave's worth of records
+                if (cap >= uint64_t(K) * uint64_t(K) * 64) CHECK(hi > lo);         // no empty piece when the shard is large enough (rounding to 64)
+                expect = hi;
+            }
+            CHECK(expect == cap);                                                 // the pieces tile the shard exactly
+        }
+    }
 }
 
 } // namespace
 
 int main()
 {
+    chunk_bounds();
     for (int ndev : {1, 2, 4, 8}) {
-        int overlaps = 0;
-        for (unsigned seed = 1; seed <= 200; ++seed) {
-            const Outcome o = run(ndev, 24, seed * 7919u + unsigned(ndev), true, false);
-            CHECK(!o.deadlock);
-            CHECK(o.rewrite == 0);
-            CHECK(o.early == 0);
-            overlaps += o.overlaps;
+        for (int K : {1, 2, 4, 8}) {
+            int ov_batches = 0, ov_pieces = 0;
+            for (unsigned seed = 1; seed <= 120; ++seed) {
+                const Outcome o = run(ndev, K, 16, seed * 7919u + unsigned(ndev * 31 + K), true, kNone);
+                CHECK(!o.deadlock);
+                CHECK(o.rewrite == 0);
+                CHECK(o.early == 0);
+                ov_batches += o.overlaps_batches;
+                ov_pieces += o.overlaps_pieces;
+            }
+            CHECK(ov_batches > 0);                                // the gather of batch b does run beside the trace of batch b + 1
+            if (K > 1) CHECK(ov_pieces > 0);                      // ... and inside a batch piece c is gathered while piece c + 1 is traced
+            else CHECK(ov_pieces == 0);
+            // diagnostic mode: no overlap at all, whatever number of pieces was asked for
+            int off_b = 0, off_p = 0;
+            for (unsigned seed = 1; seed <= 40; ++seed) {
+                const Outcome o = run(ndev, K, 10, seed * 31u + unsigned(K), false, kNone);
+                CHECK(!o.deadlock && o.rewrite == 0 && o.early == 0);
+                off_b += o.overlaps_batches; off_p += o.overlaps_pieces;
+            }
+            CHECK(off_b == 0 && off_p == 0);
+            // negative controls: without the wait for sent[buf] the simulator must see a send buffer re-written under a gather
+            // (needs a second device: a lone device's collective completes at once) ...
+            if (ndev > 1) {
+                int seen = 0;
+                for (unsigned seed = 1; seed <= 200; ++seed) seen += run(ndev, K, 16, seed * 13u, true, kDropWaitSent).rewrite;
+                CHECK(seen > 0);
+            }
+            // ... and without the wait for traced[c] a gather that starts before its piece has been traced
+            {
+                int seen = 0;
+                for (unsigned seed = 1; seed <= 200; ++seed) seen += run(ndev, K, 8, seed * 17u, true, kDropWaitTraced).early;
+                CHECK(seen > 0);
+            }
+            std::printf("ndev %d, %d piece(s) per batch: ok (trace beside the previous batch's gather: %d; beside an earlier piece's gather: %d)\n",
+                        ndev, K, ov_batches, ov_pieces);
         }
-        CHECK(overlaps > 0);                                  // the gather of batch b does run beside the trace of batch b + 1
-        // diagnostic mode: no overlap at all
-        int ov_off = 0;
-        for (unsigned seed = 1; seed <= 50; ++seed) {
-            const Outcome o = run(ndev, 12, seed * 31u, false, false);
-            CHECK(!o.deadlock && o.rewrite == 0 && o.early == 0);
-            ov_off += o.overlaps;
-        }
-        CHECK(ov_off == 0);
-        // negative control: without the wait for sent[buf] the simulator must see a send buffer re-written under a gather
-        if (ndev > 1) {
-            int seen = 0;
-            for (unsigned seed = 1; seed <= 200; ++seed) seen += run(ndev, 24, seed * 13u, true, true).rewrite;
-            CHECK(seen > 0);
-        }
-        std::printf("ndev %d: ok (overlapping trace/gather pairs observed: %d)\n", ndev, overlaps);
     }
     std::printf(fails ? "%d checks FAILED\n" : "gather schedule: all checks passed\n", fails);
     return fails ? 1 : 0;

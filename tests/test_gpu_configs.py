@@ -276,6 +276,25 @@ def test_multi_gpu_abi_with_one_device(va, make_bundle):
     eng.synchronize()
     for o in outs:
         assert_hits_equal(tp.to_host(o[: n * 16], va.HIT), ref)
+    # one batch in K pieces (engine option gather_chunks): piece c is gathered while piece c + 1 is traced -- same bytes
+    whole = outs[0][: n * 16].clone()
+    for K in (2, 4, 16, 3):
+        eng.set_option("gather_chunks", K)
+        assert eng.get_option("gather_chunks") == K
+        for o in outs:
+            o.zero_()
+            scene.trace_closest_gather_dev([d_rays.data_ptr()], n, o.data_ptr())
+        eng.synchronize()
+        for o in outs:
+            assert bool((o[: n * 16] == whole).all()), f"{K} pieces"
+    with pytest.raises(va._lib.VisTraceError):
+        eng.set_option("gather_chunks", 17)
+    # the diagnostic mode (no overlap) falls back to one piece per batch
+    eng.set_option("gather_overlap", 0)
+    outs[0].zero_()
+    scene.trace_closest_gather_dev([d_rays.data_ptr()], n, outs[0].data_ptr())
+    eng.synchronize()
+    assert bool((outs[0][: n * 16] == whole).all())
     scene.free()
     eng.close()
 
@@ -307,6 +326,35 @@ def test_native_gather_single_rank(va, make_bundle):
     torch.cuda.synchronize()
     for k in range(2):
         assert_hits_equal(tp.to_host(recv[k], va.HIT), ref)
+    # the same batches in K pieces (vt_gather_hits_part_dev): traced piece by piece, each piece handed to the communication stream
+    for K in (4, 1, 7):
+        for r in recv:
+            r.zero_()
+        for batch in range(4):
+            k = batch % 2
+            eng.gather_wait(1, stream)
+            covered = 0
+            for c in range(K):
+                lo, hi = va.gather_chunk_bounds(n, K, c)
+                assert lo == covered and hi >= lo
+                covered = hi
+                if hi > lo:
+                    scene.trace_closest_dev(d_rays.data_ptr() + 32 * lo, hi - lo, send[k].data_ptr() + 16 * lo, stream)
+                eng.gather_hits_part_dev(send[k].data_ptr(), n, c, K, recv[k].data_ptr(), 0, stream)
+            assert covered == n
+        eng.gather_wait(0)
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert_hits_equal(tp.to_host(recv[k], va.HIT), ref)
+    # pieces must come in order, all of them
+    eng.gather_hits_part_dev(send[0].data_ptr(), n, 0, 4, recv[0].data_ptr(), 0, stream)
+    with pytest.raises(va._lib.VisTraceError, match="in order"):
+        eng.gather_hits_part_dev(send[0].data_ptr(), n, 2, 4, recv[0].data_ptr(), 0, stream)
+    for c in (1, 2, 3):
+        eng.gather_hits_part_dev(send[0].data_ptr(), n, c, 4, recv[0].data_ptr(), 0, stream)
+    with pytest.raises(va._lib.VisTraceError):
+        eng.gather_hits_part_dev(send[0].data_ptr(), n, 0, 17, recv[0].data_ptr(), 0, stream)
+    eng.gather_wait(0)
     scene.free()
     eng.close()
 
@@ -368,6 +416,14 @@ def test_config5_full_size_128_tiles_one_call(va, make_bundle):
     assert bool((d_occ.bool() == hit).all())
     # and the plain single-device entry point gives the same bytes as the group call
     d_h2 = tp.trace_closest(scene, d_rays, n)
+    assert bool((d_h2.view(torch.int64) == d_hits.view(torch.int64)).all())
+    # ... and so does the group call that traces and gathers the batch in four pieces (gather_chunks = 4)
+    d_h2.zero_()
+    eng.set_option("gather_chunks", 4)
+    eng.set_option("ray_image_width", 1024)
+    scene.trace_closest_gather_dev([d_rays.data_ptr()], n, d_h2.data_ptr())
+    eng.synchronize()
+    eng.set_option("ray_image_width", 0)
     assert bool((d_h2.view(torch.int64) == d_hits.view(torch.int64)).all())
     scene.free()
     eng.close()

@@ -88,6 +88,8 @@ SYMBOLS = {
     "vt_engine_comm_init_rank": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "vt_gather_hits_dev": (C.c_int, [_vp, _vp, _u64, _vp, C.c_int, _vp]),
     "vt_gather_wait": (C.c_int, [_vp, C.c_int, _vp]),
+    "vt_gather_chunk_bounds": (None, [_u64, C.c_int, C.c_int, C.POINTER(_u64), C.POINTER(_u64)]),
+    "vt_gather_hits_part_dev": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "vt_engine_last_gather_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "vt_scene_upload": (C.c_int, [_vp, _vp, _pp]),
     "vt_scene_free": (None, [_vp]),

@@ -160,6 +160,13 @@ def shard_capacity(n: int, ndev: int) -> int:
     return int(lib.vt_shard_capacity(n, ndev))
 
 
+def gather_chunk_bounds(count: int, nchunks: int, chunk: int):
+    """Records [lo, hi) of a count-record shard that form piece `chunk` of `nchunks` (vt_gather_chunk_bounds)."""
+    lo, hi = C.c_uint64(0), C.c_uint64(0)
+    lib.vt_gather_chunk_bounds(count, nchunks, chunk, C.byref(lo), C.byref(hi))
+    return int(lo.value), int(hi.value)
+
+
 def shard_bounds(n: int, ndev: int, g: int):
     """Contiguous shard [lo, hi) of an n-ray batch for device g of ndev (vt_shard_bounds)."""
     lo, hi = C.c_uint64(0), C.c_uint64(0)
@@ -238,6 +245,10 @@ class Engine:
 
     def gather_hits_dev(self, d_send: int, count: int, d_recv_root: int, root: int = 0, stream: int = 0) -> None:
         check(lib.vt_gather_hits_dev(self._h, d_send, count, d_recv_root or None, root, stream or None))
+
+    def gather_hits_part_dev(self, d_send: int, count: int, chunk: int, nchunks: int, d_recv_root: int, root: int = 0, stream: int = 0) -> None:
+        """Piece `chunk` of `nchunks` of every rank's count-record shard to the root (vt_gather_hits_part_dev)."""
+        check(lib.vt_gather_hits_part_dev(self._h, d_send, count, chunk, nchunks, d_recv_root or None, root, stream or None))
 
     def gather_wait(self, batches_in_flight: int = 0, stream: int = 0) -> None:
         check(lib.vt_gather_wait(self._h, batches_in_flight, stream or None))
@@ -441,6 +452,6 @@ def build_scene(engine: Engine, verts: np.ndarray, flags: Optional[np.ndarray] =
 
 
 __all__ = ["Engine", "Scene", "HostBvh", "HostScene", "tris_setup", "build_scene", "make_rays", "device_count",
-           "shard_capacity", "shard_bounds", "comm_unique_id",
+           "shard_capacity", "shard_bounds", "gather_chunk_bounds", "comm_unique_id",
            "RAY", "HIT", "TRI64", "BVH_NODE", "NODE_PAIR", "RAY_STATS", "HIT_ATTRS", "TRI_ATTRIBS", "HIT_SHADE", "SKIN_VERTEX", "ALPHA_MATERIAL",
            "FLT_MAX", "_lib"]

@@ -48,7 +48,8 @@ struct LaunchPlan {
 };
 
 // n = rays of all batches of the launch; static_blocks = 256-ray blocks the one-ray-per-lane kernel would need for them
-int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, uint64_t static_blocks, bool any_hit, bool stats, LaunchPlan& p)
+// camera_rays = every batch came with a usable ray_image_width (camera rays in image order)
+int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, uint64_t static_blocks, bool camera_rays, bool any_hit, bool stats, LaunchPlan& p)
 {
     // stack entries a ray can need = inner levels below the root pair
     const uint32_t need = s->max_depth;
@@ -59,9 +60,15 @@ int plan_launch(vt_engine* e, const vt_scene* s, uint64_t n, uint64_t static_blo
     // up to half of it: scripts/sweep.py tables in profiles/r1/notes.md)
     const uint64_t factor = s->npairs <= 200000u ? uint64_t(e->auto_static_factor) * 2 : (uint64_t(e->auto_static_factor) + 1) / 2;
     p.persistent = e->persistent == 1 || (e->persistent == 2 && n > factor * e->cu_count * 8 * kBlockThreads);
+    const uint64_t rec_bytes = uint64_t(s->record_capacity) * 64;
+    // Camera rays in image order (the caller said so with ray_image_width) walk in lock step as 4 x 16 pixel tiles and finish
+    // together: nothing for the re-fill machinery to win, and one ray per lane is ahead at EVERY batch size while the scene's
+    // records stay in the caches (round 4, profiles/r4/auto_policy_sweep.txt: 100 k triangles 0.88 against 1.18 ms for 16 Mi
+    // rays, 1 M triangles 0.59 against 0.84 ms for 4 Mi and 6.4 against 6.8 ms for 64 Mi; 10 M triangles -- 1 GB of records,
+    // beyond the 256 MiB Infinity Cache -- the other way round: 4.5 against 3.8 ms for 16 Mi)
+    if (e->persistent == 2 && camera_rays && rec_bytes <= (uint64_t(256) << 20) && static_blocks <= 0x7FFFFFFFull) p.persistent = false;
     if (any_hit && stats) p.persistent = false;        // the any-hit counters kernel exists as the one-ray-per-lane variant only
     // the DMA-fetch kernel addresses records as base + 32-bit byte offset: scenes below 4 GiB
-    const uint64_t rec_bytes = uint64_t(s->record_capacity) * 64;
     p.fetch_dma = p.persistent && e->fetch_dma != 0 && rec_bytes < (uint64_t(1) << 32);
     const uint64_t blocks_for_rays = static_blocks;
     if (p.persistent) {
@@ -131,8 +138,20 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
         if (!ok) return fail(VT_ERR_UNSUPPORTED, "the alpha-test kernels of this build exceed their register reservation (see check_isa.py); rebuild the library");
         e->alpha_regs_checked = true;
     }
+    // image-order batches: whole bands of 16 rows are taken tile-wise; a block of the persistent kernel is one tile (64 rays) or two
+    // side by side (128), so the row length must be a multiple of 4 resp. 8
+    auto tile_width = [](const BatchReq& r) -> uint32_t {
+        if (r.image_width < 4 || r.image_width % 4 != 0 || r.n >= (uint64_t(1) << 32)) return 0;
+        return r.n / (uint64_t(r.image_width) * 16) != 0 ? r.image_width : 0;
+    };
+    bool any_tiled = false, all_tiled = true, all_mult8 = true;
+    for (uint32_t k = 0; k < nreq; ++k) {
+        if (reqs[k].n == 0) continue;
+        if (tile_width(reqs[k]) != 0) { any_tiled = true; all_mult8 = all_mult8 && reqs[k].image_width % 8 == 0; }
+        else all_tiled = false;
+    }
     LaunchPlan p;
-    int rc = plan_launch(e, s, n, static_blocks, any_hit, stats, p);
+    int rc = plan_launch(e, s, n, static_blocks, any_tiled && all_tiled && !s->has_alpha, any_hit, stats, p);
     if (rc != VT_OK) return rc;
 
     // this launch's private scratch: the next slot of the ring (see vt_engine::LaunchSlot)
@@ -192,15 +211,6 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
     // the first block of every wave is static (block w -> wave w); the cursor hands out the rest
     if (a.reserved_cus) VT_HIP(hipMemsetAsync(a.cu_slots, 0, 4096, stream));
     a.xcd_cursors = e->xcd_cursors != 0;
-    // image-order batches: whole bands of 16 rows are taken tile-wise; a block of the persistent kernel is one tile (64 rays) or two
-    // side by side (128), so the row length must be a multiple of 4 resp. 8
-    auto tile_width = [](const BatchReq& r) -> uint32_t {
-        if (r.image_width < 4 || r.image_width % 4 != 0 || r.n >= (uint64_t(1) << 32)) return 0;
-        return r.n / (uint64_t(r.image_width) * 16) != 0 ? r.image_width : 0;
-    };
-    bool any_tiled = false, all_mult8 = true;
-    for (uint32_t k = 0; k < nreq; ++k)
-        if (reqs[k].n != 0 && tile_width(reqs[k]) != 0) { any_tiled = true; all_mult8 = all_mult8 && reqs[k].image_width % 8 == 0; }
     if (any_tiled) {
         if (a.block_rays > 128 || (a.block_rays == 128 && !all_mult8)) a.block_rays = all_mult8 ? 128 : 64;
         if (a.block_rays != 64 && a.block_rays != 128) a.block_rays = 64;
@@ -522,6 +532,7 @@ int vt_engine_set_option(vt_engine* e, const char* key, int64_t value)
     else if (k == "reserved_cus" && value >= 0 && value <= e->cu_count / 2) return reserve_cus(e, uint32_t(value));
     else if (k == "reserved_limit" && value >= 0 && value <= 64) e->reserved_limit = uint32_t(value);
     else if (k == "gather_overlap") e->sched.overlap = value != 0;
+    else if (k == "gather_chunks" && value >= 1 && value <= vt::kMaxGatherChunks) e->gather_chunks = uint32_t(value);
     else return fail(VT_ERR_INVALID_ARG, "vt_engine_set_option: unknown key or value out of range: " + k);
     return VT_OK;
 }
@@ -547,6 +558,7 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
     else if (k == "reserved_cus") *value = e->reserved_cus;
     else if (k == "reserved_limit") *value = e->reserved_limit;
     else if (k == "gather_overlap") *value = e->sched.overlap;
+    else if (k == "gather_chunks") *value = e->gather_chunks;
     else if (k == "cu_count") *value = e->cu_count;
     else if (k == "last_persistent") *value = e->last_persistent;
     else if (k == "last_fetch_dma") *value = e->last_dma;

@@ -121,7 +121,10 @@ struct vt_engine {
     bool        comm_from_init_all = false;   // made by ncclCommInitAll for the single-process group (not by vt_engine_comm_init_rank)
     int         comm_rank = 0, comm_size = 1;
     hipStream_t s_comm = nullptr;             // the gather of batch b runs here, beside the trace of batch b+1
-    hipEvent_t  ev_traced = nullptr;          // trace stream -> comm stream
+    hipEvent_t  ev_traced[vt::kMaxGatherChunks] = {};   // trace stream -> comm stream, one per piece of a batch
+    uint32_t    gather_chunks = 1;            // option "gather_chunks": pieces a shard is traced and gathered in (vt_trace_closest_gather_dev)
+    std::vector<vt::GatherStep> part_steps;   // per-rank form: the steps of the batch whose pieces are being handed over
+    int         part_next = 0, part_chunks = 0;
     hipEvent_t  ev_sent[2] = {nullptr, nullptr};   // comm stream: the gather that read send buffer b has completed
     hipEvent_t  ev_g0 = nullptr, ev_g1 = nullptr;  // comm stream, around the latest gather when `timing` is on
     bool        gather_timed = false;

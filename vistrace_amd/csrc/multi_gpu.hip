@@ -11,6 +11,12 @@
 //     `ncclCommInitRank` with an id from vt_comm_unique_id that the launcher distributes.
 // The gather of batch b runs on a communication stream beside the trace of batch b+1 (send buffers are double-buffered;
 // engine option "reserved_cus" keeps room on the CUs for RCCL's kernels while a persistent trace grid is resident).
+// Inside ONE batch (engine option "gather_chunks" = K > 1) a device's shard is traced in K pieces and piece c crosses the
+// links while piece c + 1 is traced: a one-shot call then costs about max(trace, gather) + one piece instead of their sum.
+// ncclGather places rank r's data at recvbuff + r * count, so a piece of every shard cannot land at its final place (stride
+// = shard capacity) through it; the pieces therefore move as what ncclGather is made of -- one ncclSend per peer and the
+// matching ncclRecv's on the root, all in one group (rccl.h: "ncclGather ... implemented with ncclSend / ncclRecv").
+// K = 1 keeps the single ncclGather per batch.
 //
 // RCCL is loaded with dlopen on first use: a single-GPU user never needs the library, and a process that already
 // holds a copy (PyTorch bundles one) keeps using that one.
@@ -42,6 +48,8 @@ struct RcclApi {
     decltype(&ncclCommInitAll)    CommInitAll = nullptr;
     decltype(&ncclCommDestroy)    CommDestroy = nullptr;
     decltype(&ncclGather)         Gather = nullptr;
+    decltype(&ncclSend)           Send = nullptr;
+    decltype(&ncclRecv)           Recv = nullptr;
     decltype(&ncclGroupStart)     GroupStart = nullptr;
     decltype(&ncclGroupEnd)       GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -81,6 +89,8 @@ RcclApi* rccl()
         sym(api.CommInitAll, "ncclCommInitAll");
         sym(api.CommDestroy, "ncclCommDestroy");
         sym(api.Gather, "ncclGather");
+        sym(api.Send, "ncclSend");
+        sym(api.Recv, "ncclRecv");
         sym(api.GroupStart, "ncclGroupStart");
         sym(api.GroupEnd, "ncclGroupEnd");
         sym(api.GetErrorString, "ncclGetErrorString");
@@ -105,7 +115,8 @@ int rccl_fail(const char* what, ncclResult_t r)
 int ensure_comm_side(vt_engine* e)
 {
     if (!e->s_comm) VT_HIP(hipStreamCreateWithFlags(&e->s_comm, hipStreamNonBlocking));
-    if (!e->ev_traced) VT_HIP(hipEventCreateWithFlags(&e->ev_traced, hipEventDisableTiming));
+    for (int c = 0; c < kMaxGatherChunks; ++c)
+        if (!e->ev_traced[c]) VT_HIP(hipEventCreateWithFlags(&e->ev_traced[c], hipEventDisableTiming));
     for (int b = 0; b < 2; ++b)
         if (!e->ev_sent[b]) VT_HIP(hipEventCreateWithFlags(&e->ev_sent[b], hipEventDisableTiming));
     if (!e->ev_g0) VT_HIP(hipEventCreate(&e->ev_g0));
@@ -153,6 +164,30 @@ int ensure_group_comms(vt_engine* root)
     return VT_OK;
 }
 
+// This device's calls for moving records [lo, hi) of every rank's `cap`-record shard to `root` (inside the caller's group):
+// the whole shard through ncclGather, a piece through the sends / receives ncclGather is made of (see the file comment).
+// d_send = this rank's shard; d_recv = the root's ndev * cap records (root only).  The root's own piece is already in place
+// when it traced into its slice; otherwise it is copied on the communication stream.
+ncclResult_t move_part(RcclApi* R, vt_engine* e, const void* d_send, void* d_recv, uint64_t cap, uint64_t lo, uint64_t hi, bool whole, int root)
+{
+    const ncclComm_t comm = static_cast<ncclComm_t>(e->comm);
+    if (whole) return R->Gather(d_send, d_recv, cap * sizeof(vt_hit), ncclUint8, root, comm, e->s_comm);
+    if (hi <= lo) return ncclSuccess;
+    const size_t bytes = (hi - lo) * sizeof(vt_hit);
+    if (e->comm_rank != root) return R->Send(static_cast<const char*>(d_send) + lo * sizeof(vt_hit), bytes, ncclUint8, root, comm, e->s_comm);
+    for (int r = 0; r < e->comm_size; ++r) {
+        char* dst = static_cast<char*>(d_recv) + (uint64_t(r) * cap + lo) * sizeof(vt_hit);
+        if (r == root) {
+            const char* src = static_cast<const char*>(d_send) + lo * sizeof(vt_hit);
+            if (src != dst && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, e->s_comm) != hipSuccess) return ncclUnhandledCudaError;
+            continue;
+        }
+        const ncclResult_t rc = R->Recv(dst, bytes, ncclUint8, r, comm, e->s_comm);
+        if (rc != ncclSuccess) return rc;
+    }
+    return ncclSuccess;
+}
+
 } // namespace
 
 namespace vt {
@@ -169,8 +204,10 @@ void multi_release(vt_engine* e)
         if (e->ev_sent[b]) (void)hipEventDestroy(e->ev_sent[b]);
         e->ev_sent[b] = nullptr;
     }
-    if (e->ev_traced) (void)hipEventDestroy(e->ev_traced);
-    e->ev_traced = nullptr;
+    for (int c = 0; c < kMaxGatherChunks; ++c) {
+        if (e->ev_traced[c]) (void)hipEventDestroy(e->ev_traced[c]);
+        e->ev_traced[c] = nullptr;
+    }
     if (e->ev_g0) (void)hipEventDestroy(e->ev_g0);
     if (e->ev_g1) (void)hipEventDestroy(e->ev_g1);
     e->ev_g0 = e->ev_g1 = nullptr;
@@ -286,7 +323,8 @@ int vt_trace_closest_gather_dev(vt_scene* s, const void* const* d_rays, uint64_t
     // hand over to the communication stream; then ONE gather -- cap records from every device into the root's buffer,
     // shard g at record g * cap (ray order) --, all devices' calls in one group
     bool in_group = false;
-    for (const GatherStep& st : root->sched.plan(ndev)) {
+    const int K = root->sched.effective_chunks(int(root->gather_chunks));
+    for (const GatherStep& st : root->sched.plan(ndev, K)) {
         vt_engine* e = g[size_t(st.dev)];
         DeviceGuard guard(e->device);
         if (!guard.ok) { if (in_group) (void)R->GroupEnd(); return fail(VT_ERR_HIP, "vt_trace_closest_gather_dev: hipSetDevice failed"); }
@@ -296,24 +334,31 @@ int vt_trace_closest_gather_dev(vt_scene* s, const void* const* d_rays, uint64_t
             VT_HIP(hipStreamWaitEvent(e->stream, e->ev_sent[st.buf], 0));
             break;
         case GatherOp::Trace: {
-            uint64_t lo = 0, hi = 0;
+            // chunk st.chunk of this device's shard: records [clo, chi) of the shard, as far as the shard has rays
+            uint64_t lo = 0, hi = 0, clo = 0, chi = 0;
             vt_shard_bounds(n, ndev, st.dev, &lo, &hi);
-            if (hi > lo) {
-                rc = engine_launch(scenes[size_t(st.dev)], d_rays[st.dev], hi - lo, send[size_t(st.dev)], nullptr, nullptr, false, false, e->stream);
+            gather_chunk_bounds(cap, K, st.chunk, &clo, &chi);
+            const uint64_t have = hi - lo;
+            if (clo < have) {
+                const uint64_t m = std::min(chi, have) - clo;
+                rc = engine_launch(scenes[size_t(st.dev)], static_cast<const char*>(d_rays[st.dev]) + clo * sizeof(vt_ray), m,
+                                   static_cast<char*>(send[size_t(st.dev)]) + clo * sizeof(vt_hit), nullptr, nullptr, false, false, e->stream);
                 if (rc != VT_OK) return rc;
             }
             break;
         }
         case GatherOp::RecordTraced:
-            VT_HIP(hipEventRecord(e->ev_traced, e->stream));
+            VT_HIP(hipEventRecord(e->ev_traced[st.chunk], e->stream));
             break;
         case GatherOp::WaitTraced:
-            VT_HIP(hipStreamWaitEvent(e->s_comm, e->ev_traced, 0));
+            VT_HIP(hipStreamWaitEvent(e->s_comm, e->ev_traced[st.chunk], 0));
             break;
         case GatherOp::Gather: {
             if (!in_group) { VT_NCCL(R->GroupStart()); in_group = true; }
-            const ncclResult_t r = R->Gather(send[size_t(st.dev)], d_hits_root, cap * sizeof(vt_hit), ncclUint8, 0, static_cast<ncclComm_t>(e->comm), e->s_comm);
-            if (r != ncclSuccess) { (void)R->GroupEnd(); return rccl_fail("ncclGather", r); }
+            uint64_t clo = 0, chi = 0;
+            gather_chunk_bounds(cap, K, st.chunk, &clo, &chi);
+            const ncclResult_t r = move_part(R, e, send[size_t(st.dev)], d_hits_root, cap, clo, chi, K == 1, 0);
+            if (r != ncclSuccess) { (void)R->GroupEnd(); return rccl_fail("gather", r); }
             break;
         }
         case GatherOp::RecordSent:
@@ -359,34 +404,68 @@ int vt_engine_comm_init_rank(vt_engine* e, int nranks, int rank, const void* id1
     return ensure_comm_side(e);
 }
 
-int vt_gather_hits_dev(vt_engine* e, const void* d_send, uint64_t count, void* d_recv_root, int root, void* stream_)
+void vt_gather_chunk_bounds(uint64_t count, int nchunks, int chunk, uint64_t* lo, uint64_t* hi)
+{
+    uint64_t a = 0, b = 0;
+    if (chunk >= 0 && chunk < std::max(nchunks, 1)) gather_chunk_bounds(count, nchunks, chunk, &a, &b);
+    if (lo) *lo = a;
+    if (hi) *hi = b;
+}
+
+int vt_gather_hits_part_dev(vt_engine* e, const void* d_send, uint64_t count, int chunk, int nchunks, void* d_recv_root, int root, void* stream_)
 {
     if (!e || !d_send) return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_dev: NULL");
     if (!e->comm || !e->peers.empty() || e->root) return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_dev: call vt_engine_comm_init_rank first");
     if (root < 0 || root >= e->comm_size) return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_dev: bad root");
     if (e->comm_rank == root && !d_recv_root) return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_dev: the root needs a receive buffer");
+    if (nchunks < 1 || nchunks > kMaxGatherChunks || chunk < 0 || chunk >= nchunks)
+        return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_part_dev: chunk / nchunks out of range (1 .. 16 pieces)");
+    // the pieces of one batch come in order, every rank with the same nchunks: the batch's steps are planned at its first piece
+    if (chunk == 0 ? !e->part_steps.empty() : (e->part_steps.empty() || e->part_next != chunk || e->part_chunks != nchunks))
+        return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_part_dev: the pieces of a batch must be handed over in order, 0 .. nchunks - 1");
     if (count == 0) return VT_OK;
     RcclApi* R = rccl();
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_gather_hits_dev: hipSetDevice failed");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    // the records were produced on `stream`; the gather runs on the engine's comm stream so that the next trace on
-    // `stream` does not queue behind it.  Steps as gather_schedule.h plans them for one rank; the wait and the trace in
-    // front of them are the caller's (vt_gather_wait + its own launch).
-    for (const GatherStep& st : e->sched.plan(1)) {
+    if (chunk == 0) {
+        if (e->sched.effective_chunks(nchunks) != nchunks)
+            return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_part_dev: engine option gather_overlap = 0 allows one piece per batch only");
+        e->part_steps = e->sched.plan(1, nchunks);
+        e->part_chunks = nchunks;
+    }
+    e->part_next = chunk + 1;
+    uint64_t lo = 0, hi = 0;
+    gather_chunk_bounds(count, nchunks, chunk, &lo, &hi);
+    // The records were produced on `stream`; the transfer runs on the engine's comm stream so that the next trace on `stream`
+    // does not queue behind it.  Steps as gather_schedule.h plans them for one rank; the wait and the trace in front of them
+    // are the caller's (vt_gather_wait + its own launch).
+    int rc = VT_OK;
+    for (const GatherStep& st : e->part_steps) {
+        if (st.chunk != chunk || rc != VT_OK) continue;
         switch (st.op) {
         case GatherOp::WaitSent: case GatherOp::Trace: break;
-        case GatherOp::RecordTraced: VT_HIP(hipEventRecord(e->ev_traced, stream)); break;
-        case GatherOp::WaitTraced:   VT_HIP(hipStreamWaitEvent(e->s_comm, e->ev_traced, 0)); break;
-        case GatherOp::Gather:
-            if (e->timing) VT_HIP(hipEventRecord(e->ev_g0, e->s_comm));
-            VT_NCCL(R->Gather(d_send, d_recv_root, count * sizeof(vt_hit), ncclUint8, root, static_cast<ncclComm_t>(e->comm), e->s_comm));
-            if (e->timing) { VT_HIP(hipEventRecord(e->ev_g1, e->s_comm)); e->gather_timed = true; }
+        case GatherOp::RecordTraced: if (hipEventRecord(e->ev_traced[chunk], stream) != hipSuccess) rc = fail(VT_ERR_HIP, "vt_gather_hits_dev: hipEventRecord failed"); break;
+        case GatherOp::WaitTraced:   if (hipStreamWaitEvent(e->s_comm, e->ev_traced[chunk], 0) != hipSuccess) rc = fail(VT_ERR_HIP, "vt_gather_hits_dev: hipStreamWaitEvent failed"); break;
+        case GatherOp::Gather: {
+            if (e->timing) (void)hipEventRecord(e->ev_g0, e->s_comm);
+            ncclResult_t r = nchunks == 1 ? ncclSuccess : R->GroupStart();
+            if (r == ncclSuccess) r = move_part(R, e, d_send, d_recv_root, count, lo, hi, nchunks == 1, root);
+            if (nchunks != 1) { const ncclResult_t r2 = R->GroupEnd(); if (r == ncclSuccess) r = r2; }
+            if (r != ncclSuccess) rc = rccl_fail("gather", r);
+            if (e->timing) { (void)hipEventRecord(e->ev_g1, e->s_comm); e->gather_timed = true; }
             break;
-        case GatherOp::RecordSent:   VT_HIP(hipEventRecord(e->ev_sent[st.buf], e->s_comm)); break;
+        }
+        case GatherOp::RecordSent:   if (hipEventRecord(e->ev_sent[st.buf], e->s_comm) != hipSuccess) rc = fail(VT_ERR_HIP, "vt_gather_hits_dev: hipEventRecord failed"); break;
         }
     }
-    return VT_OK;
+    if (chunk + 1 == nchunks || rc != VT_OK) { e->part_steps.clear(); e->part_next = 0; e->part_chunks = 0; }
+    return rc;
+}
+
+int vt_gather_hits_dev(vt_engine* e, const void* d_send, uint64_t count, void* d_recv_root, int root, void* stream)
+{
+    return vt_gather_hits_part_dev(e, d_send, count, 0, 1, d_recv_root, root, stream);
 }
 
 int vt_engine_last_gather_ms(vt_engine* e, float* ms)
