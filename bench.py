@@ -355,13 +355,10 @@ class NativeGather:
         # the root traces straight into its slice of the result (ncclGather in place: sendbuff == recvbuff + rank * count)
         self.hits = [self.recv[b][: n * 16] if rank == 0 else torch.empty(n * 16, dtype=torch.uint8, device=device) for b in range(2)]
         self.batch = 0
-        self.device, self.alt, self.two_streams = device, None, True
-        self.ev_main, self.ev_alt = torch.cuda.Event(), torch.cuda.Event()
 
     def submit(self, trace, stream, chunks=1):
         """One batch.  chunks = K > 1: the shard is traced in K pieces and piece c is gathered (vt_gather_hits_part_dev) while piece
         c + 1 is traced -- what a one-shot batch needs; K = 1: one trace, one ncclGather."""
-        import torch
         import vistrace_amd as va
         b = self.batch % 2
         self.engine.gather_wait(1, stream)                      # the gather that read hits[b] two batches ago is over
@@ -370,23 +367,13 @@ class NativeGather:
             trace(self.hits[b])
             self.engine.gather_hits_dev(self.hits[b].data_ptr(), self.n, recv, 0, stream)
         else:
-            # the pieces alternate between two launch streams: the drain of piece c (its last, longest rays on a few lanes) then
-            # runs beside the start of piece c + 1 instead of in front of it
-            if self.alt is None:
-                self.alt = torch.cuda.Stream(self.device)
-            alt = int(self.alt.cuda_stream) if self.two_streams else stream
-            if alt != stream:
-                self.engine.gather_wait(1, alt)
-                self.ev_main.record()                           # everything the caller enqueued so far (ray generation, earlier steps)
-                self.alt.wait_event(self.ev_main)
+            # all pieces on the caller's stream.  (Alternating two launch streams would hide each piece's drain behind the next
+            # piece's start, but not with reserved CUs, which N > 1 needs for RCCL's kernels: the second grid's blocks are
+            # dispatched to the only free room -- the reserved CUs -- and leave at once; measured 40 ms instead of 5.)
             for c in range(chunks):
                 lo, hi = va.gather_chunk_bounds(self.n, chunks, c)
-                s = alt if c & 1 else stream
-                trace(self.hits[b], lo, hi, s)
-                self.engine.gather_hits_part_dev(self.hits[b].data_ptr(), self.n, c, chunks, recv, 0, s)
-            if alt != stream:
-                self.ev_alt.record(self.alt)                    # later work on the caller's stream stays behind the odd pieces
-                torch.cuda.current_stream(self.device).wait_event(self.ev_alt)
+                trace(self.hits[b], lo, hi)
+                self.engine.gather_hits_part_dev(self.hits[b].data_ptr(), self.n, c, chunks, recv, 0, stream)
         self.batch += 1
         return b
 
@@ -570,10 +557,10 @@ def main() -> None:
             pipe = HitGatherPipeline(n_send, device, nchunks=args.chunks, via_host=args.backend == "gloo")
             gather_kind = "torch.distributed.gather" + (" via host (gloo test mode)" if args.backend == "gloo" else " (RCCL)")
 
-    def trace_into(hits_buf, lo=0, hi=None, on=None):
+    def trace_into(hits_buf, lo=0, hi=None):
         hi = n if hi is None else min(hi, n)
         if hi > lo:
-            scene.trace_closest_dev(d_rays.data_ptr() + lo * RAY.itemsize, hi - lo, hits_buf.data_ptr() + lo * HIT.itemsize, on or stream)
+            scene.trace_closest_dev(d_rays.data_ptr() + lo * RAY.itemsize, hi - lo, hits_buf.data_ptr() + lo * HIT.itemsize, stream)
 
     def step():
         if any_hit:
@@ -670,8 +657,7 @@ def main() -> None:
         # one piece when the pieces overlap (each extra piece costs one more launch's drain)
         single = {}
         if native is not None:
-            for K, two in ((1, True), (2, True), (4, True), (8, True), (2, False), (4, False), (8, False)):
-                native.two_streams = two
+            for K in (1, 2, 4, 8):
                 ts = []
                 for _ in range(4):
                     torch.cuda.synchronize(device)
@@ -683,8 +669,7 @@ def main() -> None:
                     ts.append((time.perf_counter() - t0) * 1e3)
                 tk = torch.tensor([float(np.mean(ts[1:]))], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
                 dist.all_reduce(tk, op=dist.ReduceOp.MAX)
-                single[str(K) if two else f"{K}_one_launch_stream"] = round(float(tk.item()), 4)
-            native.two_streams = True
+                single[str(K)] = round(float(tk.item()), 4)
         t_mean, g_mean = float(np.mean(tr)), (float(np.mean(ga)) if ga else 0.0)
         dev_t = device if args.backend == "nccl" else "cpu"
         hi = torch.tensor([t_mean, g_mean], dtype=torch.float64, device=dev_t)
@@ -702,7 +687,7 @@ def main() -> None:
             "chunks": args.chunks,
             "single_batch_ms": single or None,
             "single_batch_how": "one isolated batch (device idle before, every record on rank 0 after; wall clock, max over ranks) traced and "
-                                "gathered in K pieces, K = the keys (pieces alternate between two launch streams; *_one_launch_stream: all on one)",
+                                "gathered in K pieces, K = the keys",
             "overlap": args.overlap,
             "overlap_frac": round(min(1.0, hidden / min(t_max, g_max)), 3) if ga and min(t_max, g_max) > 0 else None,
             "overlap_note": "(trace + gather - step) / min(trace, gather): 1 = the shorter of the two is fully hidden, 0 = they run back to back",

@@ -339,6 +339,9 @@ void     vt_batch_free(vt_batch* b);
  *                        ray, so such kernels would otherwise only start when the trace ends.  The CUs are
  *                        chosen one per shader engine of every XCD in turn (the dispatcher binds a workgroup to
  *                        an XCD/SE before it looks for a CU, so 32 = one per SE is the useful value on MI355X);
+ *                        Keep traces on ONE stream while it is set: a second persistent grid launched beside a resident one
+ *                        finds free room only on the reserved CUs, where its blocks leave at once (measured: two 8 Mi-ray
+ *                        launches on two streams 40 ms instead of 5);
  *   "reserved_limit"     blocks of the grid a reserved CU still keeps (2: measured to leave room for one
  *                        256-thread workgroup with the footprint of RCCL's kernel, 280 VGPRs + 20 KB LDS --
  *                        3 does not; 0 = keep the CU empty).  Later arrivals on a full reserved CU exit at once.
