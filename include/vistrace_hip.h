@@ -291,6 +291,19 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
  * the engine and handed to the next batch that fits (no hipMalloc per batch in a steady stream of equal batches). */
 typedef struct vt_batch vt_batch;
 int      vt_batch_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_batch** out);
+/* The same with what a scripting front end needs on the way in and out (round 4: accel:TraverseBatch(buffer) went from 106 to
+ * > 400 Mrays/s end to end at 1 Mi rays).  The batch flows in chunks of 256 Ki rays through pinned staging buffers: chunk c is
+ * copied out of the caller's memory by a few host threads and uploaded while chunk c - 1 is traced.
+ *   ray_image_width        as vt_batch_desc::ray_image_width (vt_batch_trace_closest takes the engine option instead);
+ *   VT_BATCH_CHECK_RANGES  the staging copy looks at every ray's range: tMin < 0 or tMax <= tMin (the checks of
+ *                          AccelStruct::Traverse, source/objects/AccelStruct.cpp:805-806) fails the call with
+ *                          VT_ERR_INVALID_ARG and *bad_ray = the first such ray (else *bad_ray = n); no batch is returned;
+ *   VT_BATCH_FETCH_HITS    the hit records of chunk c - 2 come back into pinned host memory while chunk c - 1 is traced:
+ *                          vt_batch_hits then only waits for the last chunk instead of downloading n records. */
+#define VT_BATCH_CHECK_RANGES 1u
+#define VT_BATCH_FETCH_HITS   2u
+int      vt_batch_trace_closest_ex(vt_scene* s, const vt_ray* rays, uint64_t n, uint32_t ray_image_width, uint32_t flags, uint64_t* bad_ray,
+                                   vt_batch** out);
 uint64_t vt_batch_count(const vt_batch* b);
 int      vt_batch_rays(vt_batch* b, const vt_ray** rays);     /* the rays as uploaded (so a caller need not keep its copy) */
 int      vt_batch_hits(vt_batch* b, const vt_hit** hits);

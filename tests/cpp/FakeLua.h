@@ -231,7 +231,12 @@ public:
     void PushNil() override { stack.push_back(Nil()); }
     void PushNumber(double v) override { stack.push_back(Num(v)); }
     void PushBool(bool v) override { stack.push_back(Bool(v)); }
-    void PushString(const char* s, unsigned len = 0) override { stack.push_back(Str(len ? std::string(s, len) : std::string(s))); }
+    void PushString(const char* s, unsigned len = 0) override
+    {   // ONE copy of the bytes, as lua_pushlstring makes
+        stack.emplace_back();
+        stack.back().type = Type::String;
+        if (len) stack.back().str.assign(s, len); else stack.back().str.assign(s);
+    }
     void PushVector(const ::Vector& v) override { stack.push_back(Vec(v.x, v.y, v.z)); }
     void PushCFunction(CFunc f) override { Value v; v.type = Type::Function; v.fn = f; stack.push_back(v); }
     int CreateMetaTable(const char* name) override

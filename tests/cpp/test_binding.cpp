@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <chrono>
+#include <malloc.h>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -564,6 +565,10 @@ static void bench_single_calls()
 // accel:TraverseBatch(packed buffer) -> one TraceResultBatch, then one getter over every ray.
 static void bench_batch_forms()
 {
+    // The fake VM frees a Lua string the moment it leaves the stack; with glibc's defaults a 32-MB block is then unmapped page by
+    // page (1-2 ms inside the timed call).  A Lua VM's allocator keeps such blocks: tell malloc to do the same.
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
     State L;
     RegisterTracingApi(&L);
     World world;

@@ -368,6 +368,51 @@ def test_batch_object_matches_the_separate_calls(va, engine, make_bundle):
     scene.free()
 
 
+def test_batch_pipeline_options(va, engine, make_bundle):
+    """vt_batch_trace_closest_ex: the batch streams to the device in 256 Ki-ray chunks; with VT_BATCH_FETCH_HITS the hit records
+    come back behind the trace, with VT_BATCH_CHECK_RANGES the staging copy applies the range checks of AccelStruct::Traverse
+    (AccelStruct.cpp:805-806) and names the FIRST offender; an image width tiles every chunk.  Every form = the plain batch."""
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    scene = upload(va, engine, b)
+    side = 640                                                              # 409 600 rays: two chunks, the second one ragged
+    rays = np.concatenate([W.primary_rays(side, side), W.sphere_rays(70001, 9, origin=(2.0, 1.0, 0.5))])
+    plain = scene.trace_batch(rays)
+    ref = plain.hits().copy()
+    assert_hits_equal(ref[:20000], b.oracle(rays[:20000]))
+    for kw in ({"fetch_hits": True}, {"check_ranges": True}, {"fetch_hits": True, "check_ranges": True, "image_width": side},
+               {"image_width": 100}, {"fetch_hits": True, "image_width": 4}):
+        bt = scene.trace_batch(rays, **kw)
+        assert bt.hits().tobytes() == ref.tobytes(), kw
+        assert bt.attrs().tobytes() == plain.attrs().tobytes(), kw
+        assert bt.rays().tobytes() == rays.tobytes(), kw
+        bt.free()
+    # the first bad ray is reported, wherever it sits (first chunk, chunk boundary, last ray), and no batch comes back
+    for bad_at in ([5], [262143, 262144, 300000], [len(rays) - 1], [400000, 7]):
+        r = rays.copy()
+        for k, i in enumerate(bad_at):
+            if k % 2 == 0:
+                r["tmin"][i] = -1.0
+            else:
+                r["tmax"][i] = r["tmin"][i]
+        with pytest.raises(ValueError, match=f"ray {min(bad_at)}:"):
+            scene.trace_batch(r, check_ranges=True, fetch_hits=True)
+        assert scene.trace_batch(r).hits() is not None                      # without the flag such rays are traced (and miss)
+    nan = rays[:1000].copy()
+    nan["tmax"][::7] = np.nan                                               # NaN ranges pass the reference's checks too (and miss)
+    bt = scene.trace_batch(nan, check_ranges=True, fetch_hits=True)
+    assert (bt.hits()["prim"][::7] == O_MISS).all()
+    for n in (0, 1, 63, 300):                                               # tiny batches through the same pipeline
+        bt = scene.trace_batch(rays[:n], check_ranges=True, fetch_hits=True)
+        assert bt.hits().tobytes() == ref[:n].tobytes()
+    # several batches alive at once, freed out of order (device and pinned blocks are recycled)
+    live = [scene.trace_batch(rays[k * 1000:(k + 40) * 1000], fetch_hits=True) for k in range(6)]
+    for k in (3, 0, 5, 1, 4, 2):
+        assert live[k].hits().tobytes() == ref[k * 1000:(k + 40) * 1000].tobytes()
+        live[k].free()
+    scene.free()
+
+
 def test_batch_outliving_its_engine(va, make_bundle):
     """vt_engine_close releases the device arrays of live batches: what a batch has downloaded stays readable, what it has
     not is lost (the getter fails, nothing touches freed memory), and freeing the batch afterwards is safe."""

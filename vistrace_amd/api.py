@@ -381,11 +381,22 @@ class Scene:
     def trace_stats_dev(self, d_rays: int, n: int, d_hits: int, d_stats: int, stream: int = 0) -> None:
         check(lib.vt_trace_stats_dev(self._h, d_rays, n, d_hits, d_stats, stream or None))
 
-    def trace_batch(self, rays: np.ndarray) -> "Batch":
-        """vt_batch_trace_closest: the batch stays on the device; hits / attrs / shade come back when first asked for."""
+    def trace_batch(self, rays: np.ndarray, image_width: Optional[int] = None, check_ranges: bool = False,
+                    fetch_hits: bool = False) -> "Batch":
+        """vt_batch_trace_closest[_ex]: the batch stays on the device; hits / attrs / shade come back when first asked for.
+        check_ranges: the range checks of AccelStruct::Traverse on every ray while it is staged (ValueError naming the first
+        offender); fetch_hits: the hit records come back behind the trace; image_width: camera rays, rays per image row."""
         rays = np.ascontiguousarray(rays, RAY)
         h = C.c_void_p()
-        check(lib.vt_batch_trace_closest(self._h, ptr(rays) if len(rays) else None, len(rays), C.byref(h)))
+        if image_width is None and not check_ranges and not fetch_hits:
+            check(lib.vt_batch_trace_closest(self._h, ptr(rays) if len(rays) else None, len(rays), C.byref(h)))
+            return Batch(h, self)
+        bad = C.c_uint64(len(rays))
+        rc = lib.vt_batch_trace_closest_ex(self._h, ptr(rays) if len(rays) else None, len(rays), image_width or 0,
+                                           (1 if check_ranges else 0) | (2 if fetch_hits else 0), C.byref(bad), C.byref(h))
+        if rc != _lib.VT_OK and bad.value < len(rays):
+            raise ValueError(f"ray {bad.value}: tMin < 0 or tMax <= tMin")
+        check(rc)
         return Batch(h, self)
 
     def trace_any_stats_dev(self, d_rays: int, n: int, d_occ: int, d_stats: int, stream: int = 0) -> None:

@@ -389,6 +389,95 @@ int build_alpha_records(vt_scene* s)
     return VT_OK;
 }
 
+// a pinned host block of at least `need` bytes from the engine's spare list, or a new one
+int take_pinned(vt_engine* e, size_t need, vt_batch::HostArray& h)
+{
+    {
+        std::lock_guard<std::mutex> lock(e->launch_mu);
+        for (size_t k = 0; k < e->pinned_spare.size(); ++k)
+            if (e->pinned_spare[k].second >= need && e->pinned_spare[k].second <= 2 * need) {
+                h.p = e->pinned_spare[k].first; h.bytes = e->pinned_spare[k].second;
+                e->pinned_spare.erase(e->pinned_spare.begin() + long(k));
+                return VT_OK;
+            }
+    }
+    VT_HIP(hipHostMalloc(&h.p, need));
+    h.bytes = need;
+    return VT_OK;
+}
+
+int ensure_host_pipeline(vt_engine* e)
+{
+    if (e->s_in) return VT_OK;
+    const uint64_t C = vt_engine::kHostChunk;
+    VT_HIP(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
+    VT_HIP(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage_in[k]), C * sizeof(vt_ray)));
+        VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage_out[k]), C * sizeof(vt_hit)));
+        VT_HIP(hipEventCreateWithFlags(&e->ev_in[k], hipEventDisableTiming));
+        VT_HIP(hipEventCreateWithFlags(&e->ev_k[k], hipEventDisableTiming));
+        VT_HIP(hipEventCreateWithFlags(&e->ev_out[k], hipEventDisableTiming));
+    }
+    return VT_OK;
+}
+
+// The batch's rays -> device, traced, hit records -> the batch's pinned host block, chunk by chunk: while chunk c is staged (a few
+// host threads copy it from the caller's bytes into a pinned buffer, looking at every ray's range on the way if asked to) and
+// uploaded, chunk c - 1 is traced and the hit records of chunk c - 2 come back.  The caller's memory is free when this returns;
+// the tail of the trace, the result kernels and the last download are not waited for (b->done, b->hits_down).
+// e->host_mu is held.  *bad_ray < n: a ray failed the range checks, nothing of the batch is valid.
+int batch_pipeline(vt_scene* s, vt_batch* b, const void* rays, uint64_t n, uint32_t image_width, uint32_t flags, uint64_t* bad_ray)
+{
+    vt_engine* e = s->engine;
+    int rc = ensure_host_pipeline(e);
+    if (rc != VT_OK) return rc;
+    // chunk = 256 Ki rays (8 MB of rays: long enough to stream at the link's rate, short enough for four stages to overlap within
+    // a 1 Mi-ray batch); whole bands of 16 image rows when the batch is an image, so that every chunk is tiled like the whole
+    uint64_t C = uint64_t(1) << 18;
+    if (image_width >= 4 && image_width % 4 == 0) {
+        const uint64_t band = uint64_t(image_width) * 16;
+        if (band <= vt_engine::kHostChunk) C = std::max<uint64_t>(C / band, 1) * band;
+    }
+    const bool check = (flags & VT_BATCH_CHECK_RANGES) != 0;
+    const bool fetch = (flags & VT_BATCH_FETCH_HITS) != 0;
+    if (fetch) {
+        rc = take_pinned(e, n * sizeof(vt_hit), b->h_hits);
+        if (rc != VT_OK) return rc;
+    }
+    // (the pinned staging buffers are free: every host-pointer call leaves them so, and e->host_mu is held; the kernels an earlier
+    // batch may still have in flight on the engine's stream work on that batch's own device block)
+    const uint64_t nchunks = (n + C - 1) / C;
+    for (uint64_t c = 0; c < nchunks; ++c) {
+        const int k = int(c & 1);
+        const uint64_t lo = c * C, m = std::min(C, n - lo);
+        if (c >= 2) VT_HIP(hipEventSynchronize(e->ev_in[k]));             // pinned input buffer k is free again
+        vt_ray* stage = reinterpret_cast<vt_ray*>(e->h_stage_in[k]);
+        if (check) {
+            const uint64_t bad = parallel_copy_checked(stage, static_cast<const char*>(rays) + lo * sizeof(vt_ray), m);
+            if (bad < m) { *bad_ray = lo + bad; return VT_OK; }
+        } else {
+            parallel_copy(stage, static_cast<const char*>(rays) + lo * sizeof(vt_ray), m * sizeof(vt_ray));
+        }
+        char* d_in = b->d_mem + lo * sizeof(vt_ray);
+        char* d_res = static_cast<char*>(b->d_hits) + lo * sizeof(vt_hit);
+        VT_HIP(hipMemcpyAsync(d_in, stage, m * sizeof(vt_ray), hipMemcpyHostToDevice, e->s_in));
+        VT_HIP(hipEventRecord(e->ev_in[k], e->s_in));
+        VT_HIP(hipStreamWaitEvent(e->stream, e->ev_in[k], 0));
+        const BatchReq one{d_in, d_res, m, image_width};
+        rc = launch_batches(s, &one, 1, nullptr, false, false, e->stream);
+        if (rc != VT_OK) return rc;
+        if (fetch) {
+            VT_HIP(hipEventRecord(e->ev_k[k], e->stream));
+            VT_HIP(hipStreamWaitEvent(e->s_out, e->ev_k[k], 0));
+            VT_HIP(hipMemcpyAsync(static_cast<char*>(b->h_hits.p) + lo * sizeof(vt_hit), d_res, m * sizeof(vt_hit), hipMemcpyDeviceToHost, e->s_out));
+        }
+    }
+    if (fetch) { VT_HIP(hipEventRecord(b->hits_down, e->s_out)); b->hits_in_flight = true; }
+    VT_HIP(hipStreamSynchronize(e->s_in));                   // every upload has left the staging buffers (and the caller's memory long before)
+    return VT_OK;
+}
+
 long env_long(const char* name, long dflt)
 {
     const char* v = std::getenv(name);
@@ -473,7 +562,9 @@ void vt_engine_close(vt_engine* e)
     for (vt_batch* b : e->batches) {            // batches that outlive their engine keep what they have downloaded
         if (b->d_mem) (void)hipFree(b->d_mem);
         if (b->done) (void)hipEventDestroy(b->done);
-        b->d_mem = nullptr; b->done = nullptr; b->engine = nullptr;
+        if (b->hits_down) (void)hipEventDestroy(b->hits_down);
+        if (b->hits_in_flight) { b->hits_in_flight = false; b->h_hits.have = true; }   // the device was synchronised above: they have arrived
+        b->d_mem = nullptr; b->done = nullptr; b->hits_down = nullptr; b->engine = nullptr;
     }
     e->batches.clear();
     if (e->d_batch_spare) (void)hipFree(e->d_batch_spare);
@@ -749,17 +840,7 @@ static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, si
 
     // Large batch: chunks of C rays flow through pinned double buffers -- while chunk c is traced, chunk c+1 is
     // staged and uploaded and chunk c-1 comes back and is copied out to the caller's (pageable) memory.
-    if (!e->s_in) {
-        VT_HIP(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
-        VT_HIP(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
-        for (int k = 0; k < 2; ++k) {
-            VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage_in[k]), C * sizeof(vt_ray)));
-            VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage_out[k]), C * sizeof(vt_hit)));
-            VT_HIP(hipEventCreateWithFlags(&e->ev_in[k], hipEventDisableTiming));
-            VT_HIP(hipEventCreateWithFlags(&e->ev_k[k], hipEventDisableTiming));
-            VT_HIP(hipEventCreateWithFlags(&e->ev_out[k], hipEventDisableTiming));
-        }
-    }
+    if (int prc = ensure_host_pipeline(e); prc != VT_OK) return prc;
     int rc = ensure_bytes(&e->d_rays, &e->d_rays_bytes, 2 * C * sizeof(vt_ray));
     if (rc == VT_OK) rc = ensure_bytes(&e->d_out, &e->d_out_bytes, 2 * C * sizeof(vt_hit));
     if (rc != VT_OK) return rc;
@@ -955,19 +1036,24 @@ int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t dep
 }
 
 // ---- vt_batch: a traced batch that stays on the device (see the header) ------------------------------------------------
-int vt_batch_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_batch** out)
+int vt_batch_trace_closest_ex(vt_scene* s, const vt_ray* rays, uint64_t n, uint32_t ray_image_width, uint32_t flags, uint64_t* bad_ray,
+                              vt_batch** out)
 {
     if (!out) return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest: out is NULL");
     *out = nullptr;
+    if (bad_ray) *bad_ray = n;
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest: scene is NULL");
     if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest: the scene\'s engine has been closed");
     if (n != 0 && !rays) return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest: rays is NULL");
+    if (flags & ~(VT_BATCH_CHECK_RANGES | VT_BATCH_FETCH_HITS)) return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest: unknown flag");
+    if ((flags & VT_BATCH_CHECK_RANGES) && !bad_ray) return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest: VT_BATCH_CHECK_RANGES needs bad_ray");
     vt_engine* e = s->engine;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_batch_trace_closest: hipSetDevice failed");
     vt_batch* b = new vt_batch();
     b->engine = e;
     b->n = n;
+    uint64_t bad = n;
     if (n != 0) {
         auto al = [](uint64_t x) { return (x + 255) & ~uint64_t(255); };
         const uint64_t ray_b = al(n * sizeof(vt_ray)), hit_b = al(n * sizeof(vt_hit)), att_b = al(n * sizeof(vt_hit_attrs));
@@ -983,24 +1069,23 @@ int vt_batch_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_batch
         }
         if (!b->d_mem) { err = hipMalloc(reinterpret_cast<void**>(&b->d_mem), need); b->d_mem_bytes = need; }
         if (err == hipSuccess) err = hipEventCreateWithFlags(&b->done, hipEventDisableTiming);
-        if (err != hipSuccess) { if (b->d_mem) (void)hipFree(b->d_mem); delete b; return fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err)); }
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&b->hits_down, hipEventDisableTiming);
+        if (err != hipSuccess) {
+            if (b->d_mem) (void)hipFree(b->d_mem);
+            if (b->done) (void)hipEventDestroy(b->done);
+            delete b;
+            return fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err));
+        }
         b->d_hits = b->d_mem + ray_b;
         b->d_attrs = b->d_mem + ray_b + hit_b;
         b->d_shade = sha_b ? b->d_mem + ray_b + hit_b + att_b : nullptr;
         int rc = VT_OK;
-        bool copied = false;
-        hipEvent_t ev_copied = nullptr;
-        if (hipEventCreateWithFlags(&ev_copied, hipEventDisableTiming) != hipSuccess) ev_copied = nullptr;
         {
             std::lock_guard<std::mutex> host_lock(e->host_mu);
-            // from caller memory that may go away when this call returns (a Lua string): the copy is waited for below, the
-            // kernels behind it are not
-            err = hipMemcpyAsync(b->d_mem, rays, n * sizeof(vt_ray), hipMemcpyHostToDevice, e->stream);
-            if (err == hipSuccess && ev_copied) err = hipEventRecord(ev_copied, e->stream);
-            if (err != hipSuccess) rc = fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err));
-            copied = rc == VT_OK;
-            if (rc == VT_OK) rc = launch(s, b->d_mem, n, b->d_hits, nullptr, nullptr, false, false, e->stream);
-            if (rc == VT_OK) {
+            // the rays come from caller memory that may go away when this call returns (a Lua string): every upload is waited
+            // for, the kernels behind them are not
+            rc = batch_pipeline(s, b, rays, n, ray_image_width, flags, &bad);
+            if (rc == VT_OK && bad == n) {
                 HitAttrsArgs a{s->d_tris, s->d_prim_to_slot, reinterpret_cast<const vt_ray*>(b->d_mem), static_cast<const vt_hit*>(b->d_hits),
                                static_cast<vt_hit_attrs*>(b->d_attrs), n};
                 err = launch_hit_attrs(a, e->stream);
@@ -1011,10 +1096,21 @@ int vt_batch_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_batch
                 if (err == hipSuccess) err = hipEventRecord(b->done, e->stream);
                 if (err != hipSuccess) rc = fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err));
             }
+            if (rc != VT_OK || bad != n) {                   // nothing of this batch survives: wait for what was enqueued, give the blocks back
+                (void)hipStreamSynchronize(e->s_in); (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->s_out);
+            }
         }
-        if (copied) { if (ev_copied) (void)hipEventSynchronize(ev_copied); else (void)hipStreamSynchronize(e->stream); }
-        if (ev_copied) (void)hipEventDestroy(ev_copied);
-        if (rc != VT_OK) { (void)hipStreamSynchronize(e->stream); (void)hipFree(b->d_mem); (void)hipEventDestroy(b->done); delete b; return rc; }
+        if (rc != VT_OK || bad != n) {
+            b->hits_in_flight = false;
+            {
+                std::lock_guard<std::mutex> lock(e->launch_mu);
+                e->batches.push_back(b);                     // vt_batch_free takes it off again and recycles its blocks
+            }
+            vt_batch_free(b);
+            if (rc != VT_OK) return rc;
+            *bad_ray = bad;
+            return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest: ray " + std::to_string(bad) + " fails the range checks (tMin < 0 or tMax <= tMin)");
+        }
     }
     {
         std::lock_guard<std::mutex> lock(e->launch_mu);
@@ -1022,6 +1118,11 @@ int vt_batch_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_batch
     }
     *out = b;
     return VT_OK;
+}
+
+int vt_batch_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_batch** out)
+{
+    return vt_batch_trace_closest_ex(s, rays, n, s && s->engine ? s->engine->ray_image_width : 0, 0, nullptr, out);
 }
 
 uint64_t vt_batch_count(const vt_batch* b) { return b ? b->n : 0; }
@@ -1036,19 +1137,15 @@ static int batch_fetch(vt_batch* b, const void* d_src, size_t elem, vt_batch::Ho
             if (!e || !d_src) return fail(VT_ERR_INVALID_ARG, std::string(who) + (e ? ": not materialised for this batch" : ": the engine has been closed"));
             DeviceGuard guard(e->device);
             if (!guard.ok) return fail(VT_ERR_HIP, std::string(who) + ": hipSetDevice failed");
-            const size_t need = b->n * elem;
-            {
-                std::lock_guard<std::mutex> lock(e->launch_mu);
-                for (size_t k = 0; k < e->pinned_spare.size(); ++k)
-                    if (e->pinned_spare[k].second >= need && e->pinned_spare[k].second <= 2 * need) {
-                        h.p = e->pinned_spare[k].first; h.bytes = e->pinned_spare[k].second;
-                        e->pinned_spare.erase(e->pinned_spare.begin() + long(k));
-                        break;
-                    }
+            if (&h == &b->h_hits && b->hits_in_flight) {     // VT_BATCH_FETCH_HITS: the records came back behind the trace
+                VT_HIP(hipEventSynchronize(b->hits_down));
+                b->hits_in_flight = false;
+            } else {
+                const size_t need = b->n * elem;
+                if (!h.p) { const int rc = take_pinned(e, need, h); if (rc != VT_OK) return rc; }
+                VT_HIP(hipEventSynchronize(b->done));
+                VT_HIP(hipMemcpy(h.p, d_src, need, hipMemcpyDeviceToHost));
             }
-            if (!h.p) { VT_HIP(hipHostMalloc(&h.p, need)); h.bytes = need; }
-            VT_HIP(hipEventSynchronize(b->done));
-            VT_HIP(hipMemcpy(h.p, d_src, need, hipMemcpyDeviceToHost));
         }
         h.have = true;
     }
@@ -1088,6 +1185,7 @@ void vt_batch_free(vt_batch* b)
     if (vt_engine* e = b->engine) {
         DeviceGuard guard(e->device);
         if (b->done) { (void)hipEventSynchronize(b->done); (void)hipEventDestroy(b->done); }
+        if (b->hits_down) { if (b->hits_in_flight) (void)hipEventSynchronize(b->hits_down); (void)hipEventDestroy(b->hits_down); }
         std::lock_guard<std::mutex> lock(e->launch_mu);
         if (b->d_mem) {                                  // kept for the next batch; the previous spare goes
             if (e->d_batch_spare) (void)hipFree(e->d_batch_spare);

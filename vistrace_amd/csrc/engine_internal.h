@@ -183,6 +183,8 @@ struct vt_batch {
     HostArray h_rays, h_hits, h_attrs, h_shade;
     void *d_hits = nullptr, *d_attrs = nullptr, *d_shade = nullptr;
     hipEvent_t done = nullptr;               // behind the last kernel of the batch
+    hipEvent_t hits_down = nullptr;          // VT_BATCH_FETCH_HITS: behind the last download of hit records into h_hits
+    bool       hits_in_flight = false;       // ... which vt_batch_hits still has to wait for
 };
 
 struct DeviceGuard {

@@ -329,33 +329,34 @@ int AccelStruct::TraverseBatch(ILuaBase* LUA)
 }
 
 // accel:TraverseBatch(buffer): N packed vt_ray records in, ONE TraceResultBatch out (TraceResultBatch.h).  Same range
-// checks as Traverse (AccelStruct.cpp:805-806) on every ray, in one pass over the bytes; no per-ray Lua traffic.
+// checks as Traverse (AccelStruct.cpp:805-806) on every ray -- made by the engine's staging copy while the batch streams to
+// the device (vt_batch_trace_closest_ex, VT_BATCH_CHECK_RANGES), not in a pass of their own; no per-ray Lua traffic.
 int AccelStruct::TraverseBatchBuffer(ILuaBase* LUA)
 {
     unsigned int len = 0;
     const char* bytes = LUA->GetString(2, &len);
     if (!bytes || len % sizeof(vt_ray) != 0) LUA->ArgError(2, "ray buffer must hold whole 32-byte records {origin, direction, tMin, tMax}");
     const size_t n = len / sizeof(vt_ray);
-    for (size_t i = 0; i < n; ++i) {                             // Lua strings carry no alignment promise: copy the two fields out
-        float range[2];
-        std::memcpy(range, bytes + i * sizeof(vt_ray) + 24, sizeof(range));
-        if (range[0] < 0.f) LUA->ThrowError("tMin cannot be less than 0");
-        if (range[1] <= range[0]) LUA->ThrowError("tMax must be greater than tMin");
-    }
     // optional: the rays are an image in row-major order with this many rays per row (camera rays): the engine then walks them
-    // as pixel tiles (engine option "ray_image_width"; scheduling only)
-    int width = 0;
+    // as pixel tiles (vt_batch_desc::ray_image_width; scheduling only)
+    uint32_t width = 0;
     if (LUA->Top() >= 3 && !LUA->IsType(3, Type::Nil)) {
         const double w = LUA->CheckNumber(3);
         if (!(w >= 0.0 && w <= 1048576.0) || w != std::floor(w)) LUA->ArgError(3, "imageWidth must be a whole number of rays per row");
-        width = int(w);
+        width = uint32_t(w);
     }
-    // the rays go to the device straight from the string (still on the Lua stack); nothing is kept on the host
+    // the rays go to the device straight from the string (still on the Lua stack); nothing is kept on the host.  The hit records
+    // come back behind the trace (VT_BATCH_FETCH_HITS): a script that asks for a batch reads at least those.
     vt_batch* batch = nullptr;
-    vt_engine* eng = Engine(LUA);
-    if (width != 0) (void)vt_engine_set_option(eng, "ray_image_width", width);
-    const int rc = vt_batch_trace_closest(mpScene, reinterpret_cast<const vt_ray*>(bytes), n, &batch);
-    if (width != 0) (void)vt_engine_set_option(eng, "ray_image_width", 0);
+    uint64_t bad = n;
+    const int rc = vt_batch_trace_closest_ex(mpScene, reinterpret_cast<const vt_ray*>(bytes), n, width,
+                                             VT_BATCH_CHECK_RANGES | VT_BATCH_FETCH_HITS, &bad, &batch);
+    if (rc != VT_OK && bad < n) {                                // Lua strings carry no alignment promise: copy the two fields out
+        float range[2];
+        std::memcpy(range, bytes + bad * sizeof(vt_ray) + 24, sizeof(range));
+        if (range[0] < 0.f) LUA->ThrowError("tMin cannot be less than 0");
+        LUA->ThrowError("tMax must be greater than tMin");
+    }
     if (rc != VT_OK) {
         static thread_local char msg[512];
         std::snprintf(msg, sizeof(msg), "VisTrace: traversal failed: %s", vt_last_error());

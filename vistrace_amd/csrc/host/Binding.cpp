@@ -284,6 +284,8 @@ LUA_FUNCTION(TraceResultBatch_Hits)                                    // the pa
     TraceResultBatch* b = BatchSelf(LUA);
     const vt_hit* h = b->Hits();
     if (!h && b->Count()) BatchFetchError(LUA);
+    if (b->Count() * sizeof(vt_hit) > 0xFFFFFFFFull)             // PushString takes an unsigned length
+        LUA->ThrowError("VisTraceResultBatch:Hits: more than 4 GiB of hit records do not fit one Lua string (read them through the getters)");
     LUA->PushString(reinterpret_cast<const char*>(h), unsigned(b->Count() * sizeof(vt_hit)));
     return 1;
 }

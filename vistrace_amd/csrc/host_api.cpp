@@ -36,6 +36,25 @@ void parallel_copy(void* dst, const void* src, size_t bytes)
     }
 }
 
+// parallel_copy of n rays that also looks at every ray's range on the way (the copy in `dst` is aligned, the source need not
+// be): returns the index of the first ray with tmin < 0 or tmax <= tmin (the checks of AccelStruct::Traverse,
+// source/objects/AccelStruct.cpp:805-806; NaN ranges pass, as they do there), or n if there is none.
+uint64_t parallel_copy_checked(vt_ray* dst, const void* src, uint64_t n)
+{
+    const long long piece = 1 << 15;                         // rays per piece = 1 MiB
+    const long long pieces = (static_cast<long long>(n) + piece - 1) / piece;
+    const int threads = int(std::max<long long>(1, std::min<long long>({8, pieces, omp_get_max_threads()})));
+    uint64_t bad = n;
+#pragma omp parallel for num_threads(threads) schedule(static) reduction(min : bad)
+    for (long long k = 0; k < pieces; ++k) {
+        const uint64_t lo = uint64_t(k) * uint64_t(piece), hi = std::min<uint64_t>(n, lo + uint64_t(piece));
+        std::memcpy(dst + lo, static_cast<const char*>(src) + lo * sizeof(vt_ray), (hi - lo) * sizeof(vt_ray));
+        for (uint64_t i = lo; i < hi; ++i)
+            if (dst[i].tmin < 0.f || dst[i].tmax <= dst[i].tmin) { bad = std::min(bad, i); break; }
+    }
+    return bad;
+}
+
 } // namespace vt
 
 using namespace vt;

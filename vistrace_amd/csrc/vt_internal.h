@@ -48,6 +48,8 @@ void tri_setup(const float p0[3], const float p1[3], const float p2[3], uint32_t
 
 // memcpy split over a few host threads (staging copies of the host-buffer entry points)
 void parallel_copy(void* dst, const void* src, size_t bytes);
+// ... of n rays, returning the first ray whose range fails the checks of AccelStruct::Traverse (n = none)
+uint64_t parallel_copy_checked(vt_ray* dst, const void* src, uint64_t n);
 
 void set_error(const std::string& msg);
 int  fail(int code, const std::string& msg);
