@@ -56,7 +56,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured streaming copy)
-ROUND = "r3"
+ROUND = "r4"
 KERNEL_SOURCES = ("vistrace_amd/csrc/trace_kernels.hip", "vistrace_amd/csrc/trace_kernels.h", "vistrace_amd/csrc/engine.hip",
                   "vistrace_amd/csrc/engine_internal.h", "vistrace_amd/csrc/Makefile")
 # issue cost per wave-instruction and SIMD in cycles, measured on this part (scripts/ubench_valu.hip, profiles/r1/notes.md)
@@ -419,6 +419,10 @@ def main() -> None:
     ap.add_argument("--pmc-passes", default="fetch,write,sq,mix,tcp,l2")
     ap.add_argument("--pmc-timeout", type=float, default=240.0)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--legs", default=None, choices=["all", "host", "off"],
+                    help="extra figures beside `value` at N = 1: host = host_inclusive (vt_trace_closest on host arrays: PCIe inside the call); "
+                         "all = + beyond_cache (the same ray kind into S10M).  Default: all for the default workload, host otherwise")
+    ap.add_argument("--beyond-cache-pmc", action="store_true", help="collect the beyond_cache leg's FETCH / WRITE counters live (two more child passes)")
     ap.add_argument("--builder", default="sah", choices=["ploc", "sah", "sah_refined"],
                     help="sah = binned SAH, the product's default builder (vt_bvh_build); ploc = the reference's algorithm "
                          "(PLOC r=14 + leaf collapse); sah_refined = binned SAH + insertion-based optimisation (opt-in)")
@@ -449,6 +453,8 @@ def main() -> None:
                     help="camera-ray workloads (--kind primary, --scaling strong): pass the image's row length to the engine "
                          "(option ray_image_width); off = lanes take consecutive rays as for any other batch")
     args = ap.parse_args()
+    if args.legs is None:   # the S10M leg only beside the default (headline) workload: the other configs are lines of their own
+        args.legs = "all" if (args.scene == "S1M" and args.kind == "bounce" and args.side == 4096 and args.scaling == "weak" and args.alpha_frac == 0) else "host"
 
     import torch
     import torch.distributed as dist
@@ -789,6 +795,18 @@ def main() -> None:
             "kernel_sources_sha": sha,
         },
     }
+    # the limits that actually bind, flat beside the HBM figures the contract asks for (details in bound_actual / gather_path):
+    # GB/s per CU through the vector L1 against the per-CU gather ceiling MI355X_MICROARCH.md measures, VALU issue, lane use
+    ba, gp = result["roofline"]["bound_actual"] or {}, result["roofline"]["gather_path"] or {}
+    result["roofline"].update({
+        "l1_gather_gbs_per_cu": gp.get("l1_gb_s_per_cu"),
+        "l1_gather_ceiling": [66, 73],
+        "l1_gather_frac": round(gp["l1_gb_s_per_cu"] / 73.0, 3) if gp.get("l1_gb_s_per_cu") else None,
+        "l1_gather_note": "64-B record accesses of every CU's vector L1 per second x 64 B / CUs, against 66-73 GB/s per CU (L2-resident random "
+                          "gather, MI355X_MICROARCH.md); frac is taken against 73",
+        "valu_busy_frac": ba.get("valu_busy_frac"),
+        "lane_utilisation": ba.get("lane_utilisation"),
+    })
 
     # ---- the same workload on the other builder's tree (N = 1): what the tree is worth ------------------------------------
     if rank == 0 and world == 1 and not dist_on and args.alt_builder not in ("none", args.builder) and n > 0 and not any_hit and args.alpha_frac == 0:
@@ -855,6 +873,88 @@ def main() -> None:
             del buf2
         except Exception as exc:   # a secondary figure must never cost the headline line
             log(f"[bench] two-stream leg failed: {exc}")
+
+    # ---- the transfer-inclusive figure of SURVEY 8(d) (rank 0, N = 1): never `value` ------------------------------------------
+    # vt_trace_closest on HOST buffers: the same rays from pageable caller memory, every copy inside the call (the engine's chunked
+    # pinned pipeline: upload of chunk c + 1, trace of chunk c and download of chunk c - 1 overlap)
+    if rank == 0 and world == 1 and not dist_on and n > 0 and not under_profiler() and args.legs != "off":
+        try:
+            h_rays = rays_host if rays_host is not None else tp.to_host(d_rays, RAY)
+            rays_host = h_rays
+            nh = len(h_rays)
+            h_out = np.empty(nh, dtype=np.uint8) if any_hit else np.empty(nh, dtype=HIT)
+            fn = (lambda: va._lib.check(va._lib.lib.vt_trace_any(scene._h, va._lib.ptr(h_rays), nh, va._lib.ptr(h_out)))) if any_hit else \
+                 (lambda: scene.trace_closest(h_rays, h_out))
+            engine.set_option("ray_image_width", 0)
+            fn()
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            apply_image_hint(args, engine)
+            ref_dev = d_hits[:nh].cpu().numpy() if any_hit else tp.to_host(d_hits[: nh * HIT.itemsize], HIT)
+            result["host_inclusive"] = {
+                "value": round(nh / min(ts) / 1e6, 2), "unit": result["unit"], "ms_per_call": round(min(ts) * 1e3, 3), "rays": nh,
+                "bytes_over_pcie_per_ray": 32 + out_bytes,
+                "results_equal_device_resident": bool((h_out.view(np.uint8) == ref_dev.view(np.uint8)).all()),
+                "note": "vt_trace_closest / vt_trace_any on pageable host arrays, best of 3 calls: staging copies, H2D, trace, D2H and copy-out "
+                        "all inside the call.  The transfer-inclusive second figure of SURVEY 8(d); `value` above has rays and hits resident in HBM",
+            }
+            del h_out
+        except Exception as exc:   # a secondary figure must never cost the headline line
+            log(f"[bench] host-inclusive leg failed: {exc}")
+
+    # ---- beyond every cache (rank 0, N = 1): the same ray kind into S10M, where HBM CAN bind ------------------------------------
+    # The headline scene (104 MB of records) lives in L2 / Infinity Cache, so its HBM fraction says little about the kernel.  S10M is
+    # 1.04 GB of records -- beyond the 256 MiB Infinity Cache: this leg reports its rate, its algorithmic bytes and, from the FETCH /
+    # WRITE counters (live with --beyond-cache-pmc, else the committed pass of exactly these kernel sources), its HBM fraction.
+    if rank == 0 and world == 1 and not dist_on and n > 0 and not under_profiler() and args.legs == "all" and args.scene != "S10M" \
+            and not any_hit and args.alpha_frac == 0 and args.scaling == "weak":
+        try:
+            b_args = argparse.Namespace(**vars(args))
+            b_args.scene, b_args.kind = "S10M", "bounce"
+            _, _, _, b_engine, b_scene, _ = build_scene(b_args, va, W, dev_index, world)
+            b_rays, b_n, _, b_workload, _ = make_rays(b_args, rank, world, va, W, tp, b_engine, b_scene, device)
+            b_engine.set_option("ray_image_width", 0)
+            b_hits = tp.empty_records(b_n, HIT, device)
+            _, b_stats = tp.trace_stats(b_scene, b_rays, b_n)
+            b_st = b_stats.view(torch.int32).view(b_n, 2).sum(dim=0, dtype=torch.int64).cpu().numpy()
+            del b_stats
+            for _ in range(3):
+                tp.trace_closest(b_scene, b_rays, b_n, b_hits)
+            torch.cuda.synchronize(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b_steps = 20
+            e0.record()
+            for _ in range(b_steps):
+                tp.trace_closest(b_scene, b_rays, b_n, b_hits)
+            e1.record()
+            torch.cuda.synchronize(device)
+            b_ms = e0.elapsed_time(e1) / b_steps
+            b_alg = float(b_n) * 48.0 + 64.0 * float(b_st[0] + b_st[1])
+            b_pmc, b_src = {}, None
+            if args.beyond_cache_pmc:
+                b_pmc = collect_pmc_live(b_args, ["FETCH_SIZE", "WRITE_SIZE"])
+                b_src = "live rocprofv3 --pmc passes of this launch (child processes of this run)" if "FETCH_SIZE" in b_pmc else None
+            if "FETCH_SIZE" not in b_pmc:
+                b_pmc = committed_pmc(b_workload, args.builder, sha)
+                b_src = b_pmc.pop("_source") + " (kernel sources unchanged since that pass)" if "FETCH_SIZE" in b_pmc else None
+            b_traffic = int(b_pmc["FETCH_SIZE"] * 1024 + b_pmc.get("WRITE_SIZE", 0.0) * 1024) if "FETCH_SIZE" in b_pmc else None
+            result["beyond_cache"] = {
+                "workload": b_workload, "scene_record_bytes": int(b_scene.device_bytes),
+                "value": round(b_n / (b_ms * 1e-3) / 1e6, 2), "unit": "Mrays/s", "kernel_ms": round(b_ms, 4), "steps": b_steps,
+                "steps_per_ray": round(float(b_st[0]) / b_n, 2), "tests_per_ray": round(float(b_st[1]) / b_n, 2),
+                "alg_achieved_gb_s": round(b_alg / (b_ms * 1e-3) / 1e9, 1), "alg_over_peak": round(b_alg / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "traffic": b_traffic, "traffic_source": b_src,
+                "achieved_gb_s": round(b_traffic / (b_ms * 1e-3) / 1e9, 1) if b_traffic else None,
+                "frac": round(b_traffic / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b_traffic else None,
+                "note": "16 Mi bounce rays into 10 M triangles (1.04 GB of records: beyond L2 and the Infinity Cache); frac = (FETCH_SIZE + "
+                        "WRITE_SIZE) x 1024 B / kernel time / 8 TB/s, as roofline.frac",
+            }
+            del b_rays, b_hits, b_scene, b_engine
+        except Exception as exc:   # a secondary figure must never cost the headline line
+            log(f"[bench] beyond-cache leg failed: {exc}")
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) -------------------
     if rank == 0 and world == 1 and not args.no_cpu and n > 0:
