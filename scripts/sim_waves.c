@@ -105,7 +105,8 @@ int main(int argc, char** argv)
 
     const uint64_t per_wave = 4096;                 /* rays a wave works through (re-filling as lanes retire) */
     uint64_t iters = 0, node_passes = 0, tri_passes = 0, node_lanes = 0, tri_lanes = 0, steps = 0, tests = 0, retests_failed = 0, stalled = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : iters, node_passes, tri_passes, node_lanes, tri_lanes, steps, tests, retests_failed, stalled)
+    uint64_t idle_lanes = 0, wait_lanes = 0;     /* lane-iterations without a ray / with a pending triangle while no TRI pass runs */
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : iters, node_passes, tri_passes, node_lanes, tri_lanes, steps, tests, retests_failed, stalled, idle_lanes, wait_lanes)
     for (int64_t w = 0; w < (int64_t)((nrays + per_wave - 1) / per_wave); ++w) {
         lane_t* L = calloc(LANES, sizeof(lane_t));
         uint64_t cur = (uint64_t)w * per_wave, end = cur + per_wave < nrays ? cur + per_wave : nrays;
@@ -117,6 +118,7 @@ int main(int argc, char** argv)
             for (int l = 0; l < LANES; ++l) active += L[l].has_ray;
             if (!active) break;
             ++iters;
+            idle_lanes += (uint64_t)(LANES - active);
             if (policy == 2) {
                 /* the kernel design: live head range [tri_cur, tri_end) as today + ONE queued, unchecked group */
                 int want_tri = 0, can_step = 0, blocked = 0;
@@ -191,6 +193,7 @@ int main(int argc, char** argv)
                 for (int l = 0; l < LANES; ++l) can_step += stepped[l];
                 const int fire = holders && (policy == 0 ? (holders >= p1 || can_step == 0)
                                                          : (holders >= p1 || blocked * 4 >= active || can_step == 0));
+                if (!fire) wait_lanes += (uint64_t)holders;
                 if (fire) {
                     int used = 0;
                     for (int l = 0; l < LANES; ++l) {
@@ -252,5 +255,11 @@ int main(int argc, char** argv)
            policy, p1, refill, qcap, (unsigned long long)nrays, (unsigned long long)iters, (unsigned long long)node_passes, (double)node_lanes / node_passes,
            (unsigned long long)tri_passes, tri_passes ? (double)tri_lanes / tri_passes : 0.0, (double)steps / nrays, (double)osteps / nrays, (double)tests / nrays,
            (double)otests / nrays, (double)retests_failed / nrays, (double)stalled / nrays, cost / nrays, (unsigned long long)bad);
+    /* where a wave's 64 lanes are in an average iteration (policy 0 = the shipped kernel) */
+    printf("  lanes per iteration: NODE step %.1f, TRI test %.1f, waiting for the TRI pass %.1f, no ray %.1f; TRI pass in %.0f %% of the iterations, "
+           "lanes per TRI pass %.1f; VALU lane use (78 x NODE + 61 x TRI + 30 per iteration, lanes active / 64) %.3f\n",
+           (double)node_lanes / iters, (double)tri_lanes / iters, (double)wait_lanes / iters, (double)idle_lanes / iters,
+           100.0 * tri_passes / iters, tri_passes ? (double)tri_lanes / tri_passes : 0.0,
+           (78.0 * node_lanes + 61.0 * tri_lanes + 30.0 * (double)(iters * LANES - idle_lanes)) / (64.0 * (78.0 * node_passes + 61.0 * tri_passes + 30.0 * iters)));
     return bad ? 1 : 0;
 }

@@ -373,12 +373,15 @@ int build_alpha_records(vt_scene* s)
         hipError_t err = hipMemset(grown, 0, cap * 64);
         if (err == hipSuccess) err = hipMemcpy(grown, s->d_records, s->record_capacity * 64, hipMemcpyDeviceToDevice);
         if (err != hipSuccess) { (void)hipFree(grown); return fail(VT_ERR_HIP, std::string("alpha records: ") + hipGetErrorString(err)); }
-        (void)hipFree(s->d_records);
-        s->bytes += (cap - s->record_capacity) * 64;
-        s->d_records = grown;
-        s->d_tris = reinterpret_cast<vt_tri64*>(grown + size_t(s->tri_base) * 64);
-        s->record_capacity = cap;
-        s->alpha_base = base;
+        {   // launches read these under launch_mu; the device is idle (the callers synchronised), so the old block can go
+            std::lock_guard<std::mutex> swap_lock(e->launch_mu);
+            (void)hipFree(s->d_records);
+            s->bytes += (cap - s->record_capacity) * 64;
+            s->d_records = grown;
+            s->d_tris = reinterpret_cast<vt_tri64*>(grown + size_t(s->tri_base) * 64);
+            s->record_capacity = cap;
+            s->alpha_base = base;
+        }
         if (s->refit_graph) { (void)hipGraphExecDestroy(s->refit_graph); s->refit_graph = nullptr; }   // it captured the old pointers
     }
     AlphaRecArgs a{s->d_tris, s->d_attribs, s->d_alpha_mats, s->n_alpha_mats,
@@ -1405,6 +1408,7 @@ int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_set_tri_attribs: hipSetDevice failed");
     if (n == 0) return VT_OK;
     const size_t bytes = size_t(n) * sizeof(vt_tri_attribs);
+    std::lock_guard<std::mutex> host_lock(s->engine->host_mu);   // as vt_scene_refit: one call that rewrites the scene at a time
     if (!s->d_attribs) {
         VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_attribs), bytes));
         s->bytes += bytes;
@@ -1426,13 +1430,15 @@ int vt_scene_set_alpha(vt_scene* s, const vt_alpha_material* mats, uint32_t nmat
         if ((m.width == 0) != (m.height == 0)) return fail(VT_ERR_INVALID_ARG, "vt_scene_set_alpha: width and height must both be 0 or both be set");
         if (m.width && (m.offset > ntexels || uint64_t(m.width) * m.height > ntexels - m.offset || !texels))
             return fail(VT_ERR_INVALID_ARG, "vt_scene_set_alpha: an alpha plane lies outside the texel array");
-        // what one 64-B AlphaRec can hold (trace_kernels.h): 16-bit plane sides, 31-bit texel offsets
-        if (m.width > 65535u || m.height > 65535u || (m.width && m.offset >= (uint64_t(1) << 31)))
-            return fail(VT_ERR_UNSUPPORTED, "vt_scene_set_alpha: alpha planes are limited to 65535 x 65535 texels and 2 GiB of texels in all");
+        // what one 64-B AlphaRec can hold (trace_kernels.h): 16-bit plane sides, and 31-bit texel indices -- the kernels form
+        // plane offset + y * width + x in 32 bits, so the plane's LAST texel must lie below 2^31 too
+        if (m.width > 65535u || m.height > 65535u || (m.width && m.offset + uint64_t(m.width) * m.height > (uint64_t(1) << 31)))
+            return fail(VT_ERR_UNSUPPORTED, "vt_scene_set_alpha: alpha planes are limited to 65535 x 65535 texels and must end within the first 2 GiB of the texel array");
     }
     vt_engine* e = s->engine;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_set_alpha: hipSetDevice failed");
+    std::lock_guard<std::mutex> host_lock(e->host_mu);           // as vt_scene_refit: one call that rewrites the scene at a time
     VT_HIP(hipDeviceSynchronize());                              // no launch may still read the old tables
     if (s->d_alpha_mats) { VT_HIP(hipFree(s->d_alpha_mats)); s->d_alpha_mats = nullptr; }
     if (s->d_alpha_texels) { VT_HIP(hipFree(s->d_alpha_texels)); s->d_alpha_texels = nullptr; }
