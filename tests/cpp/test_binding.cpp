@@ -382,6 +382,39 @@ static void test_gpu_side()
             const std::string wn = error_of([&] { call_method(L, accelValue, "TraverseBatch", {bufv, State::Num(-4)}); });
             CHECK(wn.find("imageWidth") != std::string::npos);
         }
+        {   // a TABLE of buffers = a set of batches traced by one merged launch: each equals its single-buffer batch
+            CHECK(call_method(L, rb, "Hits") == 1);
+            const std::string whole = L.stack.back().str;
+            std::vector<fakelua::Value> bufs;
+            const size_t cuts[] = {0, 1, 130, 130, 256, 400};                // ragged, one empty
+            for (size_t k = 0; k + 1 < sizeof(cuts) / sizeof(cuts[0]); ++k) {
+                fakelua::Value v; v.type = LT::String; v.str = packed.substr(cuts[k] * sizeof(vt_ray), (cuts[k + 1] - cuts[k]) * sizeof(vt_ray));
+                bufs.push_back(v);
+            }
+            CHECK(call_method(L, accelValue, "TraverseBatch", {State::Array(bufs), State::Array({State::Num(0), State::Num(8)})}) == 1);
+            CHECK(L.Top() == 1 && L.GetType(1) == LT::Table);
+            const fakelua::Value set = L.stack.back();
+            CHECK(set.tab->kv.size() == bufs.size());
+            std::string joined;
+            for (auto& kv : set.tab->kv) {
+                CHECK(kv.second.type == TraceResultBatch::id);
+                CHECK(call_method(L, kv.second, "Hits") == 1);
+                joined += L.stack.back().str;
+            }
+            CHECK(joined == whole);
+            CHECK(call_method(L, set.tab->kv[4].second, "Count") == 1 && L.GetNumber(-1) == 144.0);
+            CHECK(call_method(L, set.tab->kv[2].second, "Count") == 1 && L.GetNumber(-1) == 0.0);
+            for (auto& kv : set.tab->kv) call_method(L, kv.second, "__gc");
+            // a bad ray in the third buffer is reported with Traverse's message; a non-string member is an argument error
+            std::vector<fakelua::Value> badset = bufs;
+            vt_ray inv{{0, 0, 1}, {0, 0, -1}, 2.f, 2.f};
+            std::memcpy(&badset[4].str[9 * sizeof(vt_ray)], &inv, sizeof(inv));
+            CHECK(error_of([&] { call_method(L, accelValue, "TraverseBatch", {State::Array(badset)}); }) == "tMax must be greater than tMin");
+            badset[4] = State::Num(3);
+            int sarg = 0;
+            CHECK(contains(error_of([&] { call_method(L, accelValue, "TraverseBatch", {State::Array(badset)}); }, &sarg), "strings only") && sarg == 2);
+            L.Pop(L.Top());
+        }
         int bhit = 0;
         auto close = [](float a, float b) { return std::fabs(a - b) <= 1e-5f * std::max(1.0f, std::fabs(b)); };
         for (int i = 0; i < 400; ++i) {

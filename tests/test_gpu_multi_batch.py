@@ -177,3 +177,34 @@ def test_merged_launch_with_alpha_tested_triangles(va, engine, O):
                           tp.current_stream_handle(dev))
     torch.cuda.synchronize()
     assert tp.to_host(d_hits, va.HIT).tobytes() == whole.tobytes()
+
+
+def test_batch_set_equals_single_batches(va, engine, make_bundle):
+    """vt_batch_trace_closest_set: host ray arrays -> staged uploads -> ONE merged launch -> one vt_batch each, equal to the batches
+    traced one by one (hits, attrs, rays), with images beside scattered rays, empty and one-ray batches, the range checks naming
+    batch and ray, and blocks recycled across calls."""
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    scene = va.Scene(engine, b.host_scene)
+    sets = ray_sets(W, (4096, 0, 1, 300, 65536, 12345, 1024))
+    arrs, widths = [r for r, _ in sets], [w for _, w in sets]
+    singles = [scene.trace_batch(r) for r in arrs]
+    for rep in range(3):
+        got = scene.trace_batch_set(arrs, image_widths=widths, check_ranges=True, fetch_hits=rep != 1)
+        assert len(got) == len(arrs)
+        for k, (g, one) in enumerate(zip(got, singles)):
+            assert len(g) == len(arrs[k])
+            assert g.hits().tobytes() == one.hits().tobytes(), f"batch {k}"
+            assert g.attrs().tobytes() == one.attrs().tobytes(), f"batch {k}"
+            assert g.rays().tobytes() == arrs[k].tobytes(), f"batch {k}"
+        for g in reversed(got):
+            g.free()
+    assert_hits_equal(singles[4].hits(), b.oracle(arrs[4]))
+    bad = [a.copy() for a in arrs]
+    bad[5]["tmax"][77] = -3.0
+    bad[6]["tmin"][0] = -1.0
+    with pytest.raises(ValueError, match="batch 5, ray 77"):
+        scene.trace_batch_set(bad, check_ranges=True)
+    assert scene.trace_batch_set([]) == []
+    assert len(scene.trace_batch_set([arrs[0][:0]])[0]) == 0
+    scene.free()

@@ -104,6 +104,13 @@ SYMBOLS = {
     "vt_trace_any_stats_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "vt_batch_trace_closest": (C.c_int, [_vp, _vp, _u64, C.POINTER(C.c_void_p)]),
     "vt_batch_trace_closest_ex": (C.c_int, [_vp, _vp, _u64, _u32, _u32, C.POINTER(_u64), C.POINTER(C.c_void_p)]),
+    "vt_batch_trace_closest_set": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(_u64), C.POINTER(_u32), _u32, _u32, C.POINTER(_u32),
+                                             C.POINTER(_u64), C.POINTER(C.c_void_p)]),
+    "vt_batch_set_begin": (C.c_int, [_vp, _u32, C.POINTER(C.c_void_p)]),
+    "vt_batch_set_add": (C.c_int, [_vp, _vp, _u64, _u32, C.POINTER(_u64)]),
+    "vt_batch_set_count": (_u32, [_vp]),
+    "vt_batch_set_trace": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
+    "vt_batch_set_abort": (None, [_vp]),
     "vt_batch_count": (_u64, [_vp]),
     "vt_batch_rays": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
     "vt_batch_hits": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),

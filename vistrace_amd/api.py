@@ -399,6 +399,22 @@ class Scene:
         check(rc)
         return Batch(h, self)
 
+    def trace_batch_set(self, ray_sets, image_widths=None, check_ranges: bool = False, fetch_hits: bool = False) -> list:
+        """vt_batch_trace_closest_set: several host ray arrays -> one merged launch -> one Batch per array."""
+        arrs = [np.ascontiguousarray(r, RAY) for r in ray_sets]
+        nb = len(arrs)
+        ptrs = (C.c_void_p * max(nb, 1))(*[C.c_void_p(ptr(a) if len(a) else None) for a in arrs])
+        ns = (C.c_uint64 * max(nb, 1))(*[len(a) for a in arrs])
+        ws = (C.c_uint32 * max(nb, 1))(*[int(w) for w in image_widths]) if image_widths is not None else None
+        outs = (C.c_void_p * max(nb, 1))()
+        bad_b, bad_r = C.c_uint32(nb), C.c_uint64(0)
+        rc = lib.vt_batch_trace_closest_set(self._h, ptrs, ns, ws, nb, (1 if check_ranges else 0) | (2 if fetch_hits else 0),
+                                            C.byref(bad_b), C.byref(bad_r), outs)
+        if rc != _lib.VT_OK and bad_b.value < nb:
+            raise ValueError(f"batch {bad_b.value}, ray {bad_r.value}: tMin < 0 or tMax <= tMin")
+        check(rc)
+        return [Batch(C.c_void_p(outs[k]), self) for k in range(nb)]
+
     def trace_any_stats_dev(self, d_rays: int, n: int, d_occ: int, d_stats: int, stream: int = 0) -> None:
         check(lib.vt_trace_any_stats_dev(self._h, d_rays, n, d_occ, d_stats, stream or None))
 

@@ -430,7 +430,10 @@ int ensure_host_pipeline(vt_engine* e)
 // uploaded, chunk c - 1 is traced and the hit records of chunk c - 2 come back.  The caller's memory is free when this returns;
 // the tail of the trace, the result kernels and the last download are not waited for (b->done, b->hits_down).
 // e->host_mu is held.  *bad_ray < n: a ray failed the range checks, nothing of the batch is valid.
-int batch_pipeline(vt_scene* s, vt_batch* b, const void* rays, uint64_t n, uint32_t image_width, uint32_t flags, uint64_t* bad_ray)
+// trace_chunks = false: only staged and uploaded (a batch set is traced by ONE merged launch behind all its uploads).
+// *stage_turn: which of the two pinned staging buffers is next (carried across the batches of a set).
+int batch_pipeline(vt_scene* s, vt_batch* b, const void* rays, uint64_t n, uint32_t image_width, uint32_t flags, uint64_t* bad_ray,
+                   bool trace_chunks = true, uint64_t* stage_turn = nullptr)
 {
     vt_engine* e = s->engine;
     int rc = ensure_host_pipeline(e);
@@ -448,13 +451,15 @@ int batch_pipeline(vt_scene* s, vt_batch* b, const void* rays, uint64_t n, uint3
         rc = take_pinned(e, n * sizeof(vt_hit), b->h_hits);
         if (rc != VT_OK) return rc;
     }
+    uint64_t own_turn = 0;
+    uint64_t& turn = stage_turn ? *stage_turn : own_turn;
     // (the pinned staging buffers are free: every host-pointer call leaves them so, and e->host_mu is held; the kernels an earlier
     // batch may still have in flight on the engine's stream work on that batch's own device block)
     const uint64_t nchunks = (n + C - 1) / C;
-    for (uint64_t c = 0; c < nchunks; ++c) {
-        const int k = int(c & 1);
+    for (uint64_t c = 0; c < nchunks; ++c, ++turn) {
+        const int k = int(turn & 1);
         const uint64_t lo = c * C, m = std::min(C, n - lo);
-        if (c >= 2) VT_HIP(hipEventSynchronize(e->ev_in[k]));             // pinned input buffer k is free again
+        if (turn >= 2) VT_HIP(hipEventSynchronize(e->ev_in[k]));          // pinned input buffer k is free again
         vt_ray* stage = reinterpret_cast<vt_ray*>(e->h_stage_in[k]);
         if (check) {
             const uint64_t bad = parallel_copy_checked(stage, static_cast<const char*>(rays) + lo * sizeof(vt_ray), m);
@@ -467,6 +472,7 @@ int batch_pipeline(vt_scene* s, vt_batch* b, const void* rays, uint64_t n, uint3
         VT_HIP(hipMemcpyAsync(d_in, stage, m * sizeof(vt_ray), hipMemcpyHostToDevice, e->s_in));
         VT_HIP(hipEventRecord(e->ev_in[k], e->s_in));
         VT_HIP(hipStreamWaitEvent(e->stream, e->ev_in[k], 0));
+        if (!trace_chunks) continue;
         const BatchReq one{d_in, d_res, m, image_width};
         rc = launch_batches(s, &one, 1, nullptr, false, false, e->stream);
         if (rc != VT_OK) return rc;
@@ -476,9 +482,77 @@ int batch_pipeline(vt_scene* s, vt_batch* b, const void* rays, uint64_t n, uint3
             VT_HIP(hipMemcpyAsync(static_cast<char*>(b->h_hits.p) + lo * sizeof(vt_hit), d_res, m * sizeof(vt_hit), hipMemcpyDeviceToHost, e->s_out));
         }
     }
+    if (!trace_chunks) return VT_OK;                         // the set's caller traces, downloads and waits for the uploads
     if (fetch) { VT_HIP(hipEventRecord(b->hits_down, e->s_out)); b->hits_in_flight = true; }
     VT_HIP(hipStreamSynchronize(e->s_in));                   // every upload has left the staging buffers (and the caller's memory long before)
     return VT_OK;
+}
+
+// a batch object with its device block (rays | hits | attrs | shade) from the engine's spare blocks or a new allocation
+int batch_new(vt_scene* s, uint64_t n, vt_batch** out)
+{
+    vt_engine* e = s->engine;
+    vt_batch* b = new vt_batch();
+    b->engine = e;
+    b->n = n;
+    *out = b;
+    if (n == 0) return VT_OK;
+    auto al = [](uint64_t x) { return (x + 255) & ~uint64_t(255); };
+    const uint64_t ray_b = al(n * sizeof(vt_ray)), hit_b = al(n * sizeof(vt_hit)), att_b = al(n * sizeof(vt_hit_attrs));
+    const uint64_t sha_b = s->d_attribs ? al(n * sizeof(vt_hit_shade)) : 0;
+    const size_t need = ray_b + hit_b + att_b + sha_b;
+    hipError_t err = hipSuccess;
+    {
+        std::lock_guard<std::mutex> lock(e->launch_mu);
+        for (size_t k = 0; k < e->device_spare.size(); ++k)
+            if (e->device_spare[k].second >= need && e->device_spare[k].second <= 2 * need) {
+                b->d_mem = e->device_spare[k].first; b->d_mem_bytes = e->device_spare[k].second;
+                e->device_spare.erase(e->device_spare.begin() + long(k));
+                break;
+            }
+    }
+    if (!b->d_mem) { err = hipMalloc(reinterpret_cast<void**>(&b->d_mem), need); b->d_mem_bytes = need; }
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&b->done, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&b->hits_down, hipEventDisableTiming);
+    if (err != hipSuccess) {
+        if (b->d_mem) (void)hipFree(b->d_mem);
+        if (b->done) (void)hipEventDestroy(b->done);
+        delete b;
+        *out = nullptr;
+        return fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err));
+    }
+    b->d_hits = b->d_mem + ray_b;
+    b->d_attrs = b->d_mem + ray_b + hit_b;
+    b->d_shade = sha_b ? b->d_mem + ray_b + hit_b + att_b : nullptr;
+    return VT_OK;
+}
+
+// the result kernels behind a batch's trace (TraceResult core, shading part) and its `done` event, on the engine's stream
+int batch_finish(vt_scene* s, vt_batch* b)
+{
+    if (b->n == 0) return VT_OK;
+    vt_engine* e = s->engine;
+    HitAttrsArgs a{s->d_tris, s->d_prim_to_slot, reinterpret_cast<const vt_ray*>(b->d_mem), static_cast<const vt_hit*>(b->d_hits),
+                   static_cast<vt_hit_attrs*>(b->d_attrs), b->n};
+    hipError_t err = launch_hit_attrs(a, e->stream);
+    if (err == hipSuccess && b->d_shade) {
+        HitShadeArgs sa{s->d_attribs, static_cast<const vt_hit*>(b->d_hits), static_cast<vt_hit_shade*>(b->d_shade), b->n};
+        err = launch_hit_shade(sa, e->stream);
+    }
+    if (err == hipSuccess) err = hipEventRecord(b->done, e->stream);
+    if (err != hipSuccess) return fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err));
+    return VT_OK;
+}
+
+// a batch that will not be handed out: its blocks go back to the engine (everything enqueued for it has been waited for)
+void batch_discard(vt_engine* e, vt_batch* b)
+{
+    b->hits_in_flight = false;
+    {
+        std::lock_guard<std::mutex> lock(e->launch_mu);
+        e->batches.push_back(b);                             // vt_batch_free takes it off again and recycles its blocks
+    }
+    vt_batch_free(b);
 }
 
 long env_long(const char* name, long dflt)
@@ -570,8 +644,8 @@ void vt_engine_close(vt_engine* e)
         b->d_mem = nullptr; b->done = nullptr; b->hits_down = nullptr; b->engine = nullptr;
     }
     e->batches.clear();
-    if (e->d_batch_spare) (void)hipFree(e->d_batch_spare);
-    e->d_batch_spare = nullptr;
+    for (auto& ds : e->device_spare) (void)hipFree(ds.first);
+    e->device_spare.clear();
     for (auto& ps : e->pinned_spare) (void)hipHostFree(ps.first);
     e->pinned_spare.clear();
     for (vt_engine::LaunchSlot& sl : e->slots) {
@@ -1053,63 +1127,23 @@ int vt_batch_trace_closest_ex(vt_scene* s, const vt_ray* rays, uint64_t n, uint3
     vt_engine* e = s->engine;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_batch_trace_closest: hipSetDevice failed");
-    vt_batch* b = new vt_batch();
-    b->engine = e;
-    b->n = n;
+    vt_batch* b = nullptr;
+    int rc = batch_new(s, n, &b);
+    if (rc != VT_OK) return rc;
     uint64_t bad = n;
     if (n != 0) {
-        auto al = [](uint64_t x) { return (x + 255) & ~uint64_t(255); };
-        const uint64_t ray_b = al(n * sizeof(vt_ray)), hit_b = al(n * sizeof(vt_hit)), att_b = al(n * sizeof(vt_hit_attrs));
-        const uint64_t sha_b = s->d_attribs ? al(n * sizeof(vt_hit_shade)) : 0;
-        const size_t need = ray_b + hit_b + att_b + sha_b;
-        hipError_t err = hipSuccess;
-        {
-            std::lock_guard<std::mutex> lock(e->launch_mu);
-            if (e->d_batch_spare && e->d_batch_spare_bytes >= need && e->d_batch_spare_bytes <= 2 * need) {
-                b->d_mem = e->d_batch_spare; b->d_mem_bytes = e->d_batch_spare_bytes;
-                e->d_batch_spare = nullptr; e->d_batch_spare_bytes = 0;
-            }
-        }
-        if (!b->d_mem) { err = hipMalloc(reinterpret_cast<void**>(&b->d_mem), need); b->d_mem_bytes = need; }
-        if (err == hipSuccess) err = hipEventCreateWithFlags(&b->done, hipEventDisableTiming);
-        if (err == hipSuccess) err = hipEventCreateWithFlags(&b->hits_down, hipEventDisableTiming);
-        if (err != hipSuccess) {
-            if (b->d_mem) (void)hipFree(b->d_mem);
-            if (b->done) (void)hipEventDestroy(b->done);
-            delete b;
-            return fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err));
-        }
-        b->d_hits = b->d_mem + ray_b;
-        b->d_attrs = b->d_mem + ray_b + hit_b;
-        b->d_shade = sha_b ? b->d_mem + ray_b + hit_b + att_b : nullptr;
-        int rc = VT_OK;
         {
             std::lock_guard<std::mutex> host_lock(e->host_mu);
             // the rays come from caller memory that may go away when this call returns (a Lua string): every upload is waited
             // for, the kernels behind them are not
             rc = batch_pipeline(s, b, rays, n, ray_image_width, flags, &bad);
-            if (rc == VT_OK && bad == n) {
-                HitAttrsArgs a{s->d_tris, s->d_prim_to_slot, reinterpret_cast<const vt_ray*>(b->d_mem), static_cast<const vt_hit*>(b->d_hits),
-                               static_cast<vt_hit_attrs*>(b->d_attrs), n};
-                err = launch_hit_attrs(a, e->stream);
-                if (err == hipSuccess && b->d_shade) {
-                    HitShadeArgs sa{s->d_attribs, static_cast<const vt_hit*>(b->d_hits), static_cast<vt_hit_shade*>(b->d_shade), n};
-                    err = launch_hit_shade(sa, e->stream);
-                }
-                if (err == hipSuccess) err = hipEventRecord(b->done, e->stream);
-                if (err != hipSuccess) rc = fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err));
-            }
+            if (rc == VT_OK && bad == n) rc = batch_finish(s, b);
             if (rc != VT_OK || bad != n) {                   // nothing of this batch survives: wait for what was enqueued, give the blocks back
                 (void)hipStreamSynchronize(e->s_in); (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->s_out);
             }
         }
         if (rc != VT_OK || bad != n) {
-            b->hits_in_flight = false;
-            {
-                std::lock_guard<std::mutex> lock(e->launch_mu);
-                e->batches.push_back(b);                     // vt_batch_free takes it off again and recycles its blocks
-            }
-            vt_batch_free(b);
+            batch_discard(e, b);
             if (rc != VT_OK) return rc;
             *bad_ray = bad;
             return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest: ray " + std::to_string(bad) + " fails the range checks (tMin < 0 or tMax <= tMin)");
@@ -1121,6 +1155,142 @@ int vt_batch_trace_closest_ex(vt_scene* s, const vt_ray* rays, uint64_t n, uint3
     }
     *out = b;
     return VT_OK;
+}
+
+// ---- a SET of batches: buffers are added one by one (staged and uploaded at once), then traced by ONE merged launch ----------
+struct vt_batch_set {
+    vt_scene* scene = nullptr;
+    uint32_t flags = 0;
+    std::vector<vt_batch*> batches;
+    std::vector<uint32_t> widths;
+    uint64_t stage_turn = 0;
+};
+
+int vt_batch_set_begin(vt_scene* s, uint32_t flags, vt_batch_set** out)
+{
+    if (!out) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_begin: out is NULL");
+    *out = nullptr;
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_begin: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_begin: the scene\'s engine has been closed");
+    if (flags & ~(VT_BATCH_CHECK_RANGES | VT_BATCH_FETCH_HITS)) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_begin: unknown flag");
+    vt_batch_set* set = new vt_batch_set();
+    set->scene = s;
+    set->flags = flags;
+    *out = set;
+    return VT_OK;
+}
+
+void vt_batch_set_abort(vt_batch_set* set)
+{
+    if (!set) return;
+    if (vt_scene* s = set->scene; s && s->engine) {
+        vt_engine* e = s->engine;
+        DeviceGuard guard(e->device);
+        (void)hipStreamSynchronize(e->s_in); (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->s_out);
+        for (vt_batch* b : set->batches) batch_discard(e, b);
+    }
+    delete set;
+}
+
+int vt_batch_set_add(vt_batch_set* set, const vt_ray* rays, uint64_t n, uint32_t ray_image_width, uint64_t* bad_ray)
+{
+    if (!set) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_add: set is NULL");
+    if (bad_ray) *bad_ray = n;
+    vt_scene* s = set->scene;
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_add: the scene\'s engine has been closed");
+    if (n != 0 && !rays) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_add: rays is NULL");
+    if (n >= (uint64_t(1) << 32)) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_add: a batch of a set holds at most 2^32 - 1 rays");
+    if ((set->flags & VT_BATCH_CHECK_RANGES) && !bad_ray) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_add: VT_BATCH_CHECK_RANGES needs bad_ray");
+    vt_engine* e = s->engine;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_batch_set_add: hipSetDevice failed");
+    vt_batch* b = nullptr;
+    int rc = batch_new(s, n, &b);
+    if (rc != VT_OK) return rc;
+    uint64_t bad = n;
+    if (n != 0) {
+        std::lock_guard<std::mutex> host_lock(e->host_mu);
+        rc = batch_pipeline(s, b, rays, n, 0, set->flags, &bad, false, &set->stage_turn);
+        // the staging buffers are free again (and the caller's memory long before) when this returns: other host-pointer calls may
+        // run between two adds
+        if (hipStreamSynchronize(e->s_in) != hipSuccess && rc == VT_OK) rc = fail(VT_ERR_HIP, "vt_batch_set_add: hipStreamSynchronize failed");
+        set->stage_turn = 0;
+    }
+    if (rc != VT_OK || bad != n) {
+        batch_discard(e, b);
+        if (rc != VT_OK) return rc;
+        *bad_ray = bad;
+        return fail(VT_ERR_INVALID_ARG, "vt_batch_set_add: ray " + std::to_string(bad) + " fails the range checks (tMin < 0 or tMax <= tMin)");
+    }
+    set->batches.push_back(b);
+    set->widths.push_back(ray_image_width);
+    return VT_OK;
+}
+
+uint32_t vt_batch_set_count(const vt_batch_set* set) { return set ? uint32_t(set->batches.size()) : 0; }
+
+int vt_batch_set_trace(vt_batch_set* set, vt_batch** out)
+{
+    if (!set) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_trace: set is NULL");
+    const uint32_t nb = uint32_t(set->batches.size());
+    if (nb != 0 && !out) { vt_batch_set_abort(set); return fail(VT_ERR_INVALID_ARG, "vt_batch_set_trace: out is NULL"); }
+    vt_scene* s = set->scene;
+    if (!s->engine) { delete set; return fail(VT_ERR_INVALID_ARG, "vt_batch_set_trace: the scene\'s engine has been closed"); }
+    vt_engine* e = s->engine;
+    DeviceGuard guard(e->device);
+    int rc = guard.ok ? VT_OK : fail(VT_ERR_HIP, "vt_batch_set_trace: hipSetDevice failed");
+    if (rc == VT_OK && nb != 0) {
+        std::lock_guard<std::mutex> host_lock(e->host_mu);
+        // ONE merged launch over all batches (one grid start, one drain: launch_batches); then per batch the download of its hit
+        // records (VT_BATCH_FETCH_HITS) and its result kernels
+        std::vector<BatchReq> reqs(nb);
+        for (uint32_t k = 0; k < nb; ++k) reqs[k] = BatchReq{set->batches[k]->d_mem, set->batches[k]->d_hits, set->batches[k]->n, set->widths[k]};
+        rc = launch_batches(s, reqs.data(), nb, nullptr, false, false, e->stream);
+        if (rc == VT_OK && (set->flags & VT_BATCH_FETCH_HITS)) {
+            hipError_t err = hipEventRecord(e->ev_k[0], e->stream);
+            if (err == hipSuccess) err = hipStreamWaitEvent(e->s_out, e->ev_k[0], 0);
+            for (uint32_t k = 0; k < nb && err == hipSuccess; ++k) {
+                vt_batch* b = set->batches[k];
+                if (b->n == 0) continue;
+                err = hipMemcpyAsync(b->h_hits.p, b->d_hits, b->n * sizeof(vt_hit), hipMemcpyDeviceToHost, e->s_out);
+                if (err == hipSuccess) err = hipEventRecord(b->hits_down, e->s_out);
+                b->hits_in_flight = err == hipSuccess;
+            }
+            if (err != hipSuccess) rc = fail(VT_ERR_HIP, std::string("vt_batch_set_trace: ") + hipGetErrorString(err));
+        }
+        for (uint32_t k = 0; k < nb && rc == VT_OK; ++k) rc = batch_finish(s, set->batches[k]);
+    }
+    if (rc != VT_OK) { vt_batch_set_abort(set); return rc; }
+    {
+        std::lock_guard<std::mutex> lock(e->launch_mu);
+        for (vt_batch* b : set->batches) e->batches.push_back(b);
+    }
+    for (uint32_t k = 0; k < nb; ++k) out[k] = set->batches[k];
+    delete set;
+    return VT_OK;
+}
+
+int vt_batch_trace_closest_set(vt_scene* s, const vt_ray* const* rays, const uint64_t* n, const uint32_t* ray_image_widths, uint32_t nbatches,
+                               uint32_t flags, uint32_t* bad_batch, uint64_t* bad_ray, vt_batch** out)
+{
+    if (!out && nbatches) return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest_set: out is NULL");
+    for (uint32_t k = 0; k < nbatches; ++k) out[k] = nullptr;
+    if (bad_batch) *bad_batch = nbatches;
+    if (nbatches != 0 && (!rays || !n)) return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest_set: NULL argument");
+    if ((flags & VT_BATCH_CHECK_RANGES) && (!bad_ray || !bad_batch)) return fail(VT_ERR_INVALID_ARG, "vt_batch_trace_closest_set: VT_BATCH_CHECK_RANGES needs bad_batch and bad_ray");
+    vt_batch_set* set = nullptr;
+    int rc = vt_batch_set_begin(s, flags, &set);
+    if (rc != VT_OK) return rc;
+    for (uint32_t k = 0; k < nbatches; ++k) {
+        uint64_t bad = n[k];
+        rc = vt_batch_set_add(set, rays[k], n[k], ray_image_widths ? ray_image_widths[k] : 0, &bad);
+        if (rc != VT_OK) {
+            if (bad < n[k] && bad_batch) { *bad_batch = k; *bad_ray = bad; }
+            vt_batch_set_abort(set);
+            return rc;
+        }
+    }
+    return vt_batch_set_trace(set, out);
 }
 
 int vt_batch_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_batch** out)
@@ -1190,9 +1360,9 @@ void vt_batch_free(vt_batch* b)
         if (b->done) { (void)hipEventSynchronize(b->done); (void)hipEventDestroy(b->done); }
         if (b->hits_down) { if (b->hits_in_flight) (void)hipEventSynchronize(b->hits_down); (void)hipEventDestroy(b->hits_down); }
         std::lock_guard<std::mutex> lock(e->launch_mu);
-        if (b->d_mem) {                                  // kept for the next batch; the previous spare goes
-            if (e->d_batch_spare) (void)hipFree(e->d_batch_spare);
-            e->d_batch_spare = b->d_mem; e->d_batch_spare_bytes = b->d_mem_bytes;
+        if (b->d_mem) {                                  // kept for the next batches that fit; the oldest spare goes when the list is full
+            if (e->device_spare.size() >= 32) { (void)hipFree(e->device_spare.front().first); e->device_spare.erase(e->device_spare.begin()); }
+            e->device_spare.push_back({b->d_mem, b->d_mem_bytes});
         }
         for (vt_batch::HostArray* h : {&b->h_rays, &b->h_hits, &b->h_attrs, &b->h_shade}) {
             if (!h->p) continue;

@@ -101,8 +101,7 @@ struct vt_engine {
     // scenes uploaded through this engine: closing the engine releases their device memory and detaches them
     std::vector<vt_scene*> scenes;
     std::vector<vt_batch*> batches;          // live vt_batch objects (their device arrays go with the engine)
-    char*  d_batch_spare = nullptr;          // the device block of the batch freed last, for the next one that fits
-    size_t d_batch_spare_bytes = 0;
+    std::vector<std::pair<char*, size_t>> device_spare;   // device blocks of freed batches, for the next ones that fit (at most 32)
     std::vector<std::pair<void*, size_t>> pinned_spare;   // pinned host blocks of freed batches (their downloaded arrays)
 
     bool alpha_regs_checked = false;         // ALPHA kernels: hipFuncGetAttributes agreed with the build-time ISA check

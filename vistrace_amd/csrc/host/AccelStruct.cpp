@@ -273,6 +273,13 @@ int AccelStruct::TraverseBatch(ILuaBase* LUA)
         LUA->ThrowError("Unable to perform traversal, acceleration structure invalid (use AccelStruct:Rebuild to rebuild it)");
     if (LUA->IsType(2, Type::String)) return TraverseBatchBuffer(LUA);
     LUA->CheckType(2, Type::Table);
+    {   // a table of packed buffers = a SET of batches (one merged launch), a table of ray tables = the per-ray form below
+        LUA->PushNumber(1.0);
+        LUA->GetTable(2);
+        const bool buffers = LUA->IsType(-1, Type::String);
+        LUA->Pop();
+        if (buffers) return TraverseBatchBuffers(LUA);
+    }
     // rays[i] = { origin, direction, tMin?, tMax? } with the defaults and checks of Traverse.  Fields are read BY INDEX
     // (rays[i][k]): lua_next skips nil values and promises no order, so {o, d, nil, tMax} must not shift tMax to field 3.
     // First pass validates and counts (every raise happens before the ray array exists), second pass fills.
@@ -364,6 +371,79 @@ int AccelStruct::TraverseBatchBuffer(ILuaBase* LUA)
     }
     LUA->Pop(LUA->Top());
     LUA->PushUserType_Value(new TraceResultBatch(batch, mT), TraceResultBatch::id);
+    return 1;
+}
+
+// accel:TraverseBatch({buffer1, buffer2, ...}[, {imageWidth1, ...}]): several packed ray buffers (a frame's ray sets: per light,
+// per tile, per entity) -> a table of TraceResultBatch objects, traced by ONE merged launch (vt_batch_trace_closest_set): a
+// launch costs ~0.3 ms beyond its rays, which a script with 16 small sets would otherwise pay 16 times.
+int AccelStruct::TraverseBatchBuffers(ILuaBase* LUA)
+{
+    // Buffer by buffer: a string is staged and uploaded while it sits on the stack, then popped (a C function owns few stack
+    // slots, and only a string on the stack is certain to stay).  A Lua error must not leak the set: it is aborted first.
+    vt_batch_set* set = nullptr;
+    if (vt_batch_set_begin(mpScene, VT_BATCH_CHECK_RANGES | VT_BATCH_FETCH_HITS, &set) != VT_OK) {
+        static thread_local char msg[512];
+        std::snprintf(msg, sizeof(msg), "VisTrace: traversal failed: %s", vt_last_error());
+        LUA->ThrowError(msg);
+    }
+    const bool have_widths = LUA->IsType(3, Type::Table);
+    for (size_t i = 0;; ++i) {
+        LUA->PushNumber(double(i + 1));
+        LUA->GetTable(2);
+        if (LUA->IsType(-1, Type::Nil)) { LUA->Pop(); break; }
+        const char* problem = nullptr;
+        int problem_arg = 2;
+        unsigned int len = 0;
+        const char* bytes = nullptr;
+        uint32_t width = 0;
+        if (!LUA->IsType(-1, Type::String)) problem = "a table of ray buffers must hold strings only";
+        else {
+            bytes = LUA->GetString(-1, &len);
+            if (!bytes || len % sizeof(vt_ray) != 0) problem = "ray buffer must hold whole 32-byte records {origin, direction, tMin, tMax}";
+        }
+        if (!problem && have_widths) {
+            LUA->PushNumber(double(i + 1));
+            LUA->GetTable(3);
+            if (!LUA->IsType(-1, Type::Nil)) {
+                const double w = LUA->IsType(-1, Type::Number) ? LUA->GetNumber(-1) : -1.0;
+                if (!(w >= 0.0 && w <= 1048576.0) || w != std::floor(w)) { problem = "imageWidth must be a whole number of rays per row"; problem_arg = 3; }
+                else width = uint32_t(w);
+            }
+            LUA->Pop();
+        }
+        if (problem) { vt_batch_set_abort(set); LUA->ArgError(problem_arg, problem); }
+        const uint64_t n = len / sizeof(vt_ray);
+        uint64_t bad = n;
+        const int rc = vt_batch_set_add(set, reinterpret_cast<const vt_ray*>(bytes), n, width, &bad);
+        if (rc != VT_OK) {
+            vt_batch_set_abort(set);
+            if (bad < n) {                                       // Lua strings carry no alignment promise: copy the two fields out
+                float range[2];
+                std::memcpy(range, bytes + bad * sizeof(vt_ray) + 24, sizeof(range));
+                if (range[0] < 0.f) LUA->ThrowError("tMin cannot be less than 0");
+                LUA->ThrowError("tMax must be greater than tMin");
+            }
+            static thread_local char msg[512];
+            std::snprintf(msg, sizeof(msg), "VisTrace: traversal failed: %s", vt_last_error());
+            LUA->ThrowError(msg);
+        }
+        LUA->Pop();
+    }
+    std::vector<vt_batch*>& batches = mBatchSet;                 // a member: a Lua error must not skip a destructor
+    batches.assign(vt_batch_set_count(set), nullptr);
+    if (vt_batch_set_trace(set, batches.data()) != VT_OK) {      // consumes the set either way
+        static thread_local char msg[512];
+        std::snprintf(msg, sizeof(msg), "VisTrace: traversal failed: %s", vt_last_error());
+        LUA->ThrowError(msg);
+    }
+    LUA->Pop(LUA->Top());
+    LUA->CreateTable();
+    for (size_t i = 0; i < batches.size(); ++i) {
+        LUA->PushNumber(double(i + 1));
+        LUA->PushUserType_Value(new TraceResultBatch(batches[i], mT), TraceResultBatch::id);
+        LUA->SetTable(-3);
+    }
     return 1;
 }
 

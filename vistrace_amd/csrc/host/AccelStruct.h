@@ -34,6 +34,8 @@ public:
     //          array they need once (TraceResultBatch.h).  No per-ray table parsing, no per-hit allocation.
     //          accel:TraverseBatch(buffer, imageWidth): the rays are an image of imageWidth rays per row (camera rays) --
     //          a hint for the device's scheduling, results are the same with and without it.
+    //   rays = array of such strings[, array of image widths] -> array of TraceResultBatch, all traced by ONE launch (a frame's
+    //          small ray sets share one grid start and one drain: vt_batch_trace_closest_set).
     int TraverseBatch(GarrysMod::Lua::ILuaBase* LUA);
 
     const Material& GetMaterial(size_t i) const;
@@ -59,6 +61,7 @@ private:
     vt_host_scene* mpHostScene;             // the same records on the host: single rays are walked here (config 1)
     std::vector<vt_ray> mBatchRays;         // TraverseBatch scratch (members: a Lua error must not skip a destructor)
     std::vector<vt_hit> mBatchHits;
+    std::vector<vt_batch*> mBatchSet;       // TraverseBatch({buffers}) scratch: the handles on their way into Lua userdata
     std::shared_ptr<SceneTables> mT;        // mTriangles / mEntities / mMaterials of the reference (AccelStruct.h:64-66); replaced per build
 
     void ReleaseDevice();
@@ -66,6 +69,7 @@ private:
     int  BuildAndUpload(vt_engine* eng);
     int  UploadSideTables(const std::vector<uint8_t>& flags);
     int  TraverseBatchBuffer(GarrysMod::Lua::ILuaBase* LUA);
+    int  TraverseBatchBuffers(GarrysMod::Lua::ILuaBase* LUA);
     TraceResult* MakeResult(const vt_ray& ray, const vt_hit& hit, float coneWidth, float coneAngle) const;
 };
 

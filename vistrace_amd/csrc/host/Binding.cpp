@@ -286,6 +286,7 @@ LUA_FUNCTION(TraceResultBatch_Hits)                                    // the pa
     if (!h && b->Count()) BatchFetchError(LUA);
     if (b->Count() * sizeof(vt_hit) > 0xFFFFFFFFull)             // PushString takes an unsigned length
         LUA->ThrowError("VisTraceResultBatch:Hits: more than 4 GiB of hit records do not fit one Lua string (read them through the getters)");
+    if (b->Count() == 0) { LUA->PushString(""); return 1; }       // an empty batch: there is no array (and length 0 would mean strlen)
     LUA->PushString(reinterpret_cast<const char*>(h), unsigned(b->Count() * sizeof(vt_hit)));
     return 1;
 }
