@@ -72,6 +72,50 @@ int main()
             }
         }
     }
+    {   // registration of a large caller buffer on the fly, DMA straight from / to it on two streams (no staging copies at all)
+        const size_t big_n = size_t(1) << 24, bin = big_n * 32, bout = big_n * 16;
+        char* bi = (char*)std::malloc(bin); char* bo = (char*)std::malloc(bout);
+        std::memset(bi, 1, bin);                                  // the rays were written by the caller; the result array is fresh
+        char *dbi, *dbo; hipMalloc(&dbi, bin); hipMalloc(&dbo, bout);
+        hipStream_t s1; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking);
+        for (int rep = 0; rep < 3; ++rep) {
+            double t0 = now();
+            hipError_t e1 = hipHostRegister(bi, bin, hipHostRegisterDefault), e2 = hipHostRegister(bo, bout, hipHostRegisterDefault);
+            double t1 = now();
+            const size_t chunk = size_t(1) << 20;
+            for (size_t off = 0; off < big_n; off += chunk) {
+                hipMemcpyAsync(dbi + off * 32, bi + off * 32, chunk * 32, hipMemcpyHostToDevice, s0);
+                hipMemcpyAsync(bo + off * 16, dbo + off * 16, chunk * 16, hipMemcpyDeviceToHost, s1);
+            }
+            double t2 = now();
+            hipStreamSynchronize(s0); hipStreamSynchronize(s1);
+            double t3 = now();
+            hipHostUnregister(bi); hipHostUnregister(bo);
+            double t4 = now();
+            printf("(f) 16 Mi rays: register 512 + 256 MB %6.2f ms (%s, %s), enqueue %6.2f ms, copies both ways %6.2f ms, unregister %6.2f ms\n",
+                   (t1 - t0) * 1e3, hipGetErrorString(e1), hipGetErrorString(e2), (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3);
+        }
+        std::free(bi); std::free(bo); hipFree(dbi); hipFree(dbo);
+    }
+    {   // do an upload and a download overlap (full duplex), issued on two streams from pinned memory?
+        hipStream_t s1; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking);
+        for (int rep = 0; rep < 3; ++rep) {
+            double t0 = now();
+            for (int k = 0; k < 8; ++k) {
+                hipMemcpyAsync(d_in, pin, in_b, hipMemcpyHostToDevice, s0);
+                hipMemcpyAsync(pin_out, d_out, out_b, hipMemcpyDeviceToHost, s1);
+            }
+            hipStreamSynchronize(s0); hipStreamSynchronize(s1);
+            double t1 = now();
+            for (int k = 0; k < 8; ++k) {
+                hipMemcpyAsync(d_in, pin, in_b, hipMemcpyHostToDevice, s0);
+                hipMemcpyAsync(pin_out, d_out, out_b, hipMemcpyDeviceToHost, s0);
+            }
+            hipStreamSynchronize(s0);
+            double t2 = now();
+            if (rep) printf("(e) 8 x (H2D 32 MB + D2H 16 MB): two streams %6.2f ms, one stream %6.2f ms (sum of the parts: %.2f)\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3, 8 * 0.89);
+        }
+    }
     for (int rep = 0; rep < 3; ++rep) {
         double t0 = now();
         std::memcpy(pin, in, in_b);

@@ -950,3 +950,27 @@ def test_refit_with_non_finite_vertices_is_refused(va, engine, make_bundle):
         scene.trace_any(rays)
     scene.skin_refit(bones, binds)
     scene.trace_closest(rays)
+
+
+def test_page_locked_host_arrays_skip_the_staging(va, engine, make_bundle):
+    """vt_host_register: host arrays the caller has page-locked are read and written in place by the copy engines (no staging
+    copies); same bytes as the staged path, for a ragged batch above the pipelining threshold, closest hit and any hit."""
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    scene = upload(va, engine, b)
+    n = (1 << 21) + (1 << 20) + 4321                                          # > 2 chunks of 1 Mi rays, ragged tail
+    rays = np.ascontiguousarray(np.concatenate([W.primary_rays(1024, 1024), W.sphere_rays(n - (1 << 20), 31, origin=(1.0, 2.0, 3.0))]))
+    staged = scene.trace_closest(rays)
+    occ_staged = scene.trace_any(rays)
+    hits = np.zeros(n, va.HIT)
+    va.host_register(rays)
+    va.host_register(hits)
+    try:
+        scene.trace_closest(rays, out=hits)
+        assert hits.tobytes() == staged.tobytes()
+        assert (scene.trace_any(rays) == occ_staged).all()                     # rays locked, result array not: staged path again
+    finally:
+        va.host_unregister(rays)
+        va.host_unregister(hits)
+    assert_hits_equal(staged[:30000], b.oracle(rays[:30000]))
+    scene.free()

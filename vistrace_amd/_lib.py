@@ -94,6 +94,8 @@ SYMBOLS = {
     "vt_scene_upload": (C.c_int, [_vp, _vp, _pp]),
     "vt_scene_free": (None, [_vp]),
     "vt_scene_device_bytes": (_u64, [_vp]),
+    "vt_host_register": (C.c_int, [_vp, C.c_size_t]),
+    "vt_host_unregister": (C.c_int, [_vp]),
     "vt_trace_closest": (C.c_int, [_vp, _vp, _u64, _vp]),
     "vt_trace_any": (C.c_int, [_vp, _vp, _u64, _vp]),
     "vt_trace_closest_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),

@@ -150,6 +150,15 @@ class HostScene:
         return _copy_from(lib.vt_host_scene_tris(self._h), self.tri_count, TRI64)
 
 
+def host_register(arr: np.ndarray) -> None:
+    """Page-lock a host array that is reused across calls (vt_host_register): trace_closest / trace_any then copy without staging."""
+    check(lib.vt_host_register(ptr(arr), arr.nbytes))
+
+
+def host_unregister(arr: np.ndarray) -> None:
+    check(lib.vt_host_unregister(ptr(arr)))
+
+
 def device_count() -> int:
     n = C.c_int(0)
     check(lib.vt_device_count(C.byref(n)))
@@ -479,6 +488,6 @@ def build_scene(engine: Engine, verts: np.ndarray, flags: Optional[np.ndarray] =
 
 
 __all__ = ["Engine", "Scene", "HostBvh", "HostScene", "tris_setup", "build_scene", "make_rays", "device_count",
-           "shard_capacity", "shard_bounds", "gather_chunk_bounds", "comm_unique_id",
+           "shard_capacity", "shard_bounds", "gather_chunk_bounds", "comm_unique_id", "host_register", "host_unregister",
            "RAY", "HIT", "TRI64", "BVH_NODE", "NODE_PAIR", "RAY_STATS", "HIT_ATTRS", "TRI_ATTRIBS", "HIT_SHADE", "SKIN_VERTEX", "ALPHA_MATERIAL",
            "FLT_MAX", "_lib"]

@@ -923,6 +923,38 @@ static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, si
     if (rc != VT_OK) return rc;
     VT_HIP(hipStreamSynchronize(e->stream));                 // earlier work on the engine's stream owns the staging buffers
     const uint64_t nchunks = (n + C - 1) / C;
+    // Caller arrays that are page-locked already (vt_host_register, hipHostMalloc, a pinned torch tensor) need no staging at all:
+    // the copy engines read and write them directly, uploads and downloads overlap, and no host thread touches a byte
+    // (16 Mi rays: 9.6 instead of 14 ms on the round-4 box; registering a buffer costs ~70 us per MB once, which is why
+    // pageable arrays -- a fresh Lua string per call -- are staged instead)
+    auto page_locked = [](const void* p) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return at.type == hipMemoryTypeHost;
+    };
+    if (page_locked(rays) && page_locked(reinterpret_cast<const char*>(rays) + n * sizeof(vt_ray) - 1) && page_locked(out) &&
+        page_locked(static_cast<const char*>(out) + n * out_elem - 1)) {
+        for (uint64_t c = 0; c < nchunks; ++c) {
+            const int b = int(c & 1);
+            const uint64_t m = std::min(C, n - c * C);
+            char* d_in = static_cast<char*>(e->d_rays) + size_t(b) * C * sizeof(vt_ray);
+            char* d_res = static_cast<char*>(e->d_out) + size_t(b) * C * sizeof(vt_hit);
+            if (c >= 2) VT_HIP(hipStreamWaitEvent(e->s_in, e->ev_k[b], 0));   // chunk c-2 has read device buffer b
+            VT_HIP(hipMemcpyAsync(d_in, rays + c * C, m * sizeof(vt_ray), hipMemcpyHostToDevice, e->s_in));
+            VT_HIP(hipEventRecord(e->ev_in[b], e->s_in));
+            VT_HIP(hipStreamWaitEvent(e->stream, e->ev_in[b], 0));
+            if (c >= 2) VT_HIP(hipStreamWaitEvent(e->stream, e->ev_out[b], 0)); // chunk c-2's results have left device buffer b
+            rc = launch(s, d_in, m, any_hit ? nullptr : d_res, any_hit ? d_res : nullptr, nullptr, any_hit, false, e->stream);
+            if (rc != VT_OK) return rc;
+            VT_HIP(hipEventRecord(e->ev_k[b], e->stream));
+            VT_HIP(hipStreamWaitEvent(e->s_out, e->ev_k[b], 0));
+            VT_HIP(hipMemcpyAsync(static_cast<char*>(out) + c * C * out_elem, d_res, m * out_elem, hipMemcpyDeviceToHost, e->s_out));
+            VT_HIP(hipEventRecord(e->ev_out[b], e->s_out));
+        }
+        VT_HIP(hipStreamSynchronize(e->s_out));
+        VT_HIP(hipStreamSynchronize(e->stream));
+        return VT_OK;
+    }
     auto drain = [&](uint64_t c) -> int {                    // chunk c's results: pinned -> caller
         const int b = int(c & 1);
         const uint64_t m = std::min(C, n - c * C);
@@ -952,6 +984,23 @@ static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, si
     }
     if ((rc = drain(nchunks - 1)) != VT_OK) return rc;
     VT_HIP(hipStreamSynchronize(e->stream));
+    return VT_OK;
+}
+
+int vt_host_register(void* p, size_t bytes)
+{
+    if (!p || bytes == 0) return fail(VT_ERR_INVALID_ARG, "vt_host_register: empty range");
+    const hipError_t err = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (err == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return VT_OK; }
+    if (err != hipSuccess) { (void)hipGetLastError(); return fail(VT_ERR_HIP, std::string("vt_host_register: ") + hipGetErrorString(err)); }
+    return VT_OK;
+}
+
+int vt_host_unregister(void* p)
+{
+    if (!p) return fail(VT_ERR_INVALID_ARG, "vt_host_unregister: NULL");
+    const hipError_t err = hipHostUnregister(p);
+    if (err != hipSuccess) { (void)hipGetLastError(); return fail(VT_ERR_HIP, std::string("vt_host_unregister: ") + hipGetErrorString(err)); }
     return VT_OK;
 }
 

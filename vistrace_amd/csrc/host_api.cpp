@@ -28,7 +28,8 @@ void parallel_copy(void* dst, const void* src, size_t bytes)
 {
     const long long piece = 1 << 20;
     const long long pieces = (static_cast<long long>(bytes) + piece - 1) / piece;
-    const int threads = int(std::max<long long>(1, std::min<long long>({8, pieces, omp_get_max_threads()})));
+    static const long long cap = std::getenv("VT_COPY_THREADS") ? std::atoll(std::getenv("VT_COPY_THREADS")) : 8;
+    const int threads = int(std::max<long long>(1, std::min<long long>({cap, pieces, omp_get_max_threads()})));
 #pragma omp parallel for num_threads(threads) schedule(static)
     for (long long k = 0; k < pieces; ++k) {
         const size_t off = size_t(k) * size_t(piece);
