@@ -803,7 +803,9 @@ def main() -> None:
         "l1_gather_ceiling": [66, 73],
         "l1_gather_frac": round(gp["l1_gb_s_per_cu"] / 73.0, 3) if gp.get("l1_gb_s_per_cu") else None,
         "l1_gather_note": "64-B record accesses of every CU's vector L1 per second x 64 B / CUs, against 66-73 GB/s per CU (L2-resident random "
-                          "gather, MI355X_MICROARCH.md); frac is taken against 73",
+                          "gather, MI355X_MICROARCH.md); frac is taken against 73.  That ceiling is for accesses that MISS the L1: a workload "
+                          "whose records mostly hit it (camera rays: l1_hit_rate ~0.98) can exceed 1 -- its bound is the L1's own 64 B per cycle",
+        "l1_hit_rate": gp.get("l1_hit_rate"),
         "valu_busy_frac": ba.get("valu_busy_frac"),
         "lane_utilisation": ba.get("lane_utilisation"),
     })
