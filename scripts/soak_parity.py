@@ -103,6 +103,29 @@ for seed in range(first, first + count):
                 scene.trace_closest_dev(d_rays.data_ptr(), m, h2.data_ptr(), s2.cuda_stream)
             torch.cuda.synchronize()
             ok = ok and (tp.to_host(h1, va.HIT).view(np.uint8) == ref.view(np.uint8)).all() and (tp.to_host(h2, va.HIT).view(np.uint8) == ref.view(np.uint8)).all()
+        if seed % 2 == 0:                                     # round 4: the same rays cut into random batches, ONE merged launch (closest + any)
+            ncut = int(rng.integers(1, 24))
+            cuts = np.sort(rng.integers(0, m + 1, ncut))
+            bounds = np.concatenate([[0], cuts, [m]])
+            hm = torch.zeros(m * 16, dtype=torch.uint8, device=dev)
+            om = torch.full((m,), 9, dtype=torch.uint8, device=dev)
+            wid = [int(rng.integers(1, 40)) * 4 if rng.random() < 0.3 else 0 for _ in range(len(bounds) - 1)]
+            scene.trace_multi_dev([(d_rays.data_ptr() + 32 * int(lo), hm.data_ptr() + 16 * int(lo), int(hi - lo), w)
+                                   for lo, hi, w in zip(bounds[:-1], bounds[1:], wid)], tp.current_stream_handle(dev))
+            scene.trace_multi_dev([(d_rays.data_ptr() + 32 * int(lo), om.data_ptr() + int(lo), int(hi - lo), w)
+                                   for lo, hi, w in zip(bounds[:-1], bounds[1:], wid)], tp.current_stream_handle(dev), any_hit=True)
+            torch.cuda.synchronize()
+            ok = ok and (tp.to_host(hm, va.HIT).view(np.uint8) == ref.view(np.uint8)).all()
+            ok = ok and (om.cpu().numpy() == (any_ref["prim"] != O.MISS)).all()
+        if mode == 2 and seed % 6 == 0:                       # round 4: the batch object through the chunked pipeline, and a set of three
+            bt = scene.trace_batch(rays, fetch_hits=True, image_width=int(rng.choice([0, 8, 20])))
+            ok = ok and (bt.hits().view(np.uint8) == ref.view(np.uint8)).all()
+            bt.free()
+            third = m // 3
+            st3 = scene.trace_batch_set([rays[:third], rays[third:third], rays[third:]], fetch_hits=True)
+            ok = ok and (np.concatenate([b3.hits() for b3 in st3]).view(np.uint8) == ref.view(np.uint8)).all()
+            for b3 in st3:
+                b3.free()
         if mode == 1 and seed % 3 == 0:
             eng.set_option("reserved_cus", 32)
             ok = ok and (scene.trace_closest(rays).view(np.uint8) == ref.view(np.uint8)).all()

@@ -158,3 +158,22 @@ def test_gather_schedule_on_a_simulated_group():
     out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "_build", "test_gather_schedule")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout
+
+
+def test_gather_chunk_bounds_tile_a_shard():
+    """vt_gather_chunk_bounds (the pieces a shard is traced and gathered in, round 4): contiguous, in order, multiples of 64 records
+    except the last, covering the shard exactly -- for every rank the same, since all ranks pass the same count."""
+    import vistrace_amd as va
+    for count in (0, 1, 63, 64, 65, 1000, 1 << 20, (1 << 24) + 77, va.shard_capacity(134217728, 8)):
+        for K in (1, 2, 3, 4, 8, 16):
+            covered = 0
+            for c in range(K):
+                lo, hi = va.gather_chunk_bounds(count, K, c)
+                assert lo == covered and lo <= hi <= count
+                assert lo % 64 == 0 or lo == count
+                covered = hi
+            assert covered == count
+        assert va.gather_chunk_bounds(count, 4, 4) == (0, 0) and va.gather_chunk_bounds(count, 4, -1) == (0, 0)   # out of range: empty
+    # configs[4] over 8 ranks in 4 pieces: every piece 4 Mi rays
+    cap = va.shard_capacity(134217728, 8)
+    assert [va.gather_chunk_bounds(cap, 4, c) for c in range(4)] == [(k << 22, (k + 1) << 22) for k in range(4)]

@@ -237,7 +237,7 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
         // the batch table travels in the slot's pinned block -> its device block, in stream order ahead of the kernel; the
         // pinned block is only rewritten once the launch that last read it is over
         if (nreq > slot.segs_cap) {
-            if (slot.used) VT_HIP(hipEventSynchronize(slot.done));
+            if (slot.used) VT_HIP(hipEventSynchronize(slot.done));   // its kernel may still read the device block
             if (slot.d_segs) { VT_HIP(hipFree(slot.d_segs)); slot.d_segs = nullptr; }
             if (slot.h_segs) { VT_HIP(hipHostFree(slot.h_segs)); slot.h_segs = nullptr; }
             slot.segs_cap = 0;
@@ -245,8 +245,8 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
             VT_HIP(hipMalloc(reinterpret_cast<void**>(&slot.d_segs), cap * sizeof(TraceSeg)));
             VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&slot.h_segs), cap * sizeof(TraceSeg)));
             slot.segs_cap = cap;
-        } else if (slot.segs_in_flight) {
-            VT_HIP(hipEventSynchronize(slot.done));
+        } else if (slot.segs_copied_valid) {
+            VT_HIP(hipEventSynchronize(slot.segs_copied));   // the table copy of the merged launch that last used this slot (long over)
         }
         {   // result ranges of one launch must not overlap (they are written in no particular order)
             std::vector<std::pair<const char*, const char*>> ranges;
@@ -267,8 +267,10 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
         a.segs = slot.d_segs;
         a.nseg = nreq;
         VT_HIP(hipMemcpyAsync(slot.d_segs, slot.h_segs, size_t(nreq) * sizeof(TraceSeg), hipMemcpyHostToDevice, stream));
+        if (!slot.segs_copied) VT_HIP(hipEventCreateWithFlags(&slot.segs_copied, hipEventDisableTiming));
+        VT_HIP(hipEventRecord(slot.segs_copied, stream));    // from here on the pinned block may be rewritten
+        slot.segs_copied_valid = true;
     }
-    slot.segs_in_flight = nreq > 1;
     a.nblocks = uint32_t(nblocks);
     if (!p.persistent) p.grid_blocks = uint32_t(nblocks);
     // 0 = by scene size: cheap rays (small trees) finish fast enough for the single cursor word to become the limit
@@ -652,6 +654,7 @@ void vt_engine_close(vt_engine* e)
         if (sl.d_overflow) (void)hipFree(sl.d_overflow);
         if (sl.d_segs) (void)hipFree(sl.d_segs);
         if (sl.h_segs) (void)hipHostFree(sl.h_segs);
+        if (sl.segs_copied) (void)hipEventDestroy(sl.segs_copied);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (e->d_slot_ctl) (void)hipFree(e->d_slot_ctl);

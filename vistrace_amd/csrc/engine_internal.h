@@ -64,7 +64,8 @@ struct vt_engine {
         vt::TraceSeg* h_segs = nullptr;
         vt::TraceSeg* d_segs = nullptr;
         size_t        segs_cap = 0;
-        bool          segs_in_flight = false; // the slot's latest launch read h_segs (it must be over before h_segs changes)
+        hipEvent_t    segs_copied = nullptr;  // behind the latest copy h_segs -> d_segs: h_segs may be rewritten once it has passed
+        bool          segs_copied_valid = false;
     };
     LaunchSlot slots[kLaunchSlots];
     char*      d_slot_ctl = nullptr;
