@@ -208,3 +208,37 @@ def test_batch_set_equals_single_batches(va, engine, make_bundle):
     assert scene.trace_batch_set([]) == []
     assert len(scene.trace_batch_set([arrs[0][:0]])[0]) == 0
     scene.free()
+
+
+def test_merged_launch_on_degenerate_scenes(va, engine):
+    """empty scene (every ray misses), a scene whose root is a leaf (no node step at all) and one triangle: merged launches give what
+    separate calls give, for closest hit and any hit"""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    dev = torch.device("cuda", 0)
+    rays = W.sphere_rays(5000, 17, origin=(0.3, 0.2, -4.0))
+    rays["dir"][:2500] = (0.0, 0.0, 1.0)
+    d_rays = tp.to_device(rays, dev)
+    tri = np.array([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]]], np.float32)
+    quad = np.array([[[-1, -1, 0], [1, -1, 0], [1, 1, 0]], [[-1, -1, 0], [1, 1, 0], [-1, 1, 0]], [[-1, -1, 1], [1, -1, 1], [1, 1, 1]]], np.float32)
+    for verts in (np.zeros((0, 3, 3), np.float32), tri, quad):
+        tris = va.tris_setup(verts)
+        scene = va.Scene(engine, va.HostScene(va.HostBvh(tris)))
+        whole = tp.to_host(tp.trace_closest(scene, d_rays, len(rays)), va.HIT)
+        occ = tp.trace_any(scene, d_rays, len(rays)).cpu().numpy()
+        d_hits = tp.empty_records(len(rays), va.HIT, dev)
+        d_occ = torch.zeros(len(rays), dtype=torch.uint8, device=dev)
+        cuts = [0, 7, 7, 2500, 2501, 5000]
+        scene.trace_multi_dev([(d_rays.data_ptr() + 32 * lo, d_hits.data_ptr() + 16 * lo, hi - lo) for lo, hi in zip(cuts[:-1], cuts[1:])],
+                              tp.current_stream_handle(dev))
+        scene.trace_multi_dev([(d_rays.data_ptr() + 32 * lo, d_occ.data_ptr() + lo, hi - lo) for lo, hi in zip(cuts[:-1], cuts[1:])],
+                              tp.current_stream_handle(dev), any_hit=True)
+        torch.cuda.synchronize()
+        assert tp.to_host(d_hits, va.HIT).tobytes() == whole.tobytes()
+        assert (d_occ.cpu().numpy() == occ).all()
+        if len(verts):
+            assert (whole["prim"][:2500] != O_MISS).sum() > 0            # the parallel rays do hit the triangle(s)
+        else:
+            assert (whole["prim"] == O_MISS).all()
+        scene.free()
