@@ -417,7 +417,7 @@ int ensure_host_pipeline(vt_engine* e)
     const uint64_t C = vt_engine::kHostChunk;
     VT_HIP(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
     VT_HIP(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < vt_engine::kStageBufs; ++k) {
         VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage_in[k]), C * sizeof(vt_ray)));
         VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage_out[k]), C * sizeof(vt_hit)));
         VT_HIP(hipEventCreateWithFlags(&e->ev_in[k], hipEventDisableTiming));
@@ -459,9 +459,9 @@ int batch_pipeline(vt_scene* s, vt_batch* b, const void* rays, uint64_t n, uint3
     // batch may still have in flight on the engine's stream work on that batch's own device block)
     const uint64_t nchunks = (n + C - 1) / C;
     for (uint64_t c = 0; c < nchunks; ++c, ++turn) {
-        const int k = int(turn & 1);
+        const int k = int(turn % vt_engine::kStageBufs);
         const uint64_t lo = c * C, m = std::min(C, n - lo);
-        if (turn >= 2) VT_HIP(hipEventSynchronize(e->ev_in[k]));          // pinned input buffer k is free again
+        if (turn >= uint64_t(vt_engine::kStageBufs)) VT_HIP(hipEventSynchronize(e->ev_in[k]));   // pinned input buffer k is free again
         vt_ray* stage = reinterpret_cast<vt_ray*>(e->h_stage_in[k]);
         if (check) {
             const uint64_t bad = parallel_copy_checked(stage, static_cast<const char*>(rays) + lo * sizeof(vt_ray), m);
@@ -664,7 +664,7 @@ void vt_engine_close(vt_engine* e)
     if (e->d_loop) (void)hipFree(e->d_loop);
     if (e->d_reserved) (void)hipFree(e->d_reserved);
     if (e->h_live) (void)hipHostFree(e->h_live);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < vt_engine::kStageBufs; ++k) {
         if (e->h_stage_in[k]) (void)hipHostFree(e->h_stage_in[k]);
         if (e->h_stage_out[k]) (void)hipHostFree(e->h_stage_out[k]);
         if (e->ev_in[k]) (void)hipEventDestroy(e->ev_in[k]);
@@ -906,7 +906,7 @@ static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, si
         return VT_OK;
     }
     const uint64_t C = vt_engine::kHostChunk;
-    if (n <= 2 * C) {   // small batch: one copy each way around one launch
+    if (n <= 2 * C) {   // small batch: one copy each way around one launch (256 Ki-ray chunks were measured for 1 - 4 Mi rays: no gain)
         int rc = ensure_bytes(&e->d_rays, &e->d_rays_bytes, n * sizeof(vt_ray));
         if (rc == VT_OK) rc = ensure_bytes(&e->d_out, &e->d_out_bytes, n * out_elem);
         if (rc != VT_OK) return rc;
@@ -921,8 +921,9 @@ static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, si
     // Large batch: chunks of C rays flow through pinned double buffers -- while chunk c is traced, chunk c+1 is
     // staged and uploaded and chunk c-1 comes back and is copied out to the caller's (pageable) memory.
     if (int prc = ensure_host_pipeline(e); prc != VT_OK) return prc;
-    int rc = ensure_bytes(&e->d_rays, &e->d_rays_bytes, 2 * C * sizeof(vt_ray));
-    if (rc == VT_OK) rc = ensure_bytes(&e->d_out, &e->d_out_bytes, 2 * C * sizeof(vt_hit));
+    constexpr uint64_t NB = vt_engine::kStageBufs, LAG = vt_engine::kStageLag;
+    int rc = ensure_bytes(&e->d_rays, &e->d_rays_bytes, NB * C * sizeof(vt_ray));
+    if (rc == VT_OK) rc = ensure_bytes(&e->d_out, &e->d_out_bytes, NB * C * sizeof(vt_hit));
     if (rc != VT_OK) return rc;
     VT_HIP(hipStreamSynchronize(e->stream));                 // earlier work on the engine's stream owns the staging buffers
     const uint64_t nchunks = (n + C - 1) / C;
@@ -938,15 +939,15 @@ static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, si
     if (page_locked(rays) && page_locked(reinterpret_cast<const char*>(rays) + n * sizeof(vt_ray) - 1) && page_locked(out) &&
         page_locked(static_cast<const char*>(out) + n * out_elem - 1)) {
         for (uint64_t c = 0; c < nchunks; ++c) {
-            const int b = int(c & 1);
+            const int b = int(c % NB);
             const uint64_t m = std::min(C, n - c * C);
             char* d_in = static_cast<char*>(e->d_rays) + size_t(b) * C * sizeof(vt_ray);
             char* d_res = static_cast<char*>(e->d_out) + size_t(b) * C * sizeof(vt_hit);
-            if (c >= 2) VT_HIP(hipStreamWaitEvent(e->s_in, e->ev_k[b], 0));   // chunk c-2 has read device buffer b
+            if (c >= NB) VT_HIP(hipStreamWaitEvent(e->s_in, e->ev_k[b], 0));   // chunk c-NB has read device buffer b
             VT_HIP(hipMemcpyAsync(d_in, rays + c * C, m * sizeof(vt_ray), hipMemcpyHostToDevice, e->s_in));
             VT_HIP(hipEventRecord(e->ev_in[b], e->s_in));
             VT_HIP(hipStreamWaitEvent(e->stream, e->ev_in[b], 0));
-            if (c >= 2) VT_HIP(hipStreamWaitEvent(e->stream, e->ev_out[b], 0)); // chunk c-2's results have left device buffer b
+            if (c >= NB) VT_HIP(hipStreamWaitEvent(e->stream, e->ev_out[b], 0)); // chunk c-NB's results have left device buffer b
             rc = launch(s, d_in, m, any_hit ? nullptr : d_res, any_hit ? d_res : nullptr, nullptr, any_hit, false, e->stream);
             if (rc != VT_OK) return rc;
             VT_HIP(hipEventRecord(e->ev_k[b], e->stream));
@@ -959,33 +960,34 @@ static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, si
         return VT_OK;
     }
     auto drain = [&](uint64_t c) -> int {                    // chunk c's results: pinned -> caller
-        const int b = int(c & 1);
+        const int b = int(c % NB);
         const uint64_t m = std::min(C, n - c * C);
         VT_HIP(hipEventSynchronize(e->ev_out[b]));
         parallel_copy(static_cast<char*>(out) + c * C * out_elem, e->h_stage_out[b], m * out_elem);
         return VT_OK;
     };
     for (uint64_t c = 0; c < nchunks; ++c) {
-        const int b = int(c & 1);
+        const int b = int(c % NB);
         const uint64_t m = std::min(C, n - c * C);
         char* d_in = static_cast<char*>(e->d_rays) + size_t(b) * C * sizeof(vt_ray);
         char* d_res = static_cast<char*>(e->d_out) + size_t(b) * C * sizeof(vt_hit);
-        if (c >= 2) VT_HIP(hipEventSynchronize(e->ev_in[b]));            // pinned input buffer b is free again
+        if (c >= NB) VT_HIP(hipEventSynchronize(e->ev_in[b]));           // pinned input buffer b is free again
         parallel_copy(e->h_stage_in[b], rays + c * C, m * sizeof(vt_ray));
-        if (c >= 2) VT_HIP(hipStreamWaitEvent(e->s_in, e->ev_k[b], 0));   // chunk c-2 has read device buffer b
+        if (c >= NB) VT_HIP(hipStreamWaitEvent(e->s_in, e->ev_k[b], 0));   // chunk c-NB has read device buffer b
         VT_HIP(hipMemcpyAsync(d_in, e->h_stage_in[b], m * sizeof(vt_ray), hipMemcpyHostToDevice, e->s_in));
         VT_HIP(hipEventRecord(e->ev_in[b], e->s_in));
         VT_HIP(hipStreamWaitEvent(e->stream, e->ev_in[b], 0));
-        if (c >= 2) VT_HIP(hipStreamWaitEvent(e->stream, e->ev_out[b], 0)); // chunk c-2's results have left device buffer b
+        if (c >= NB) VT_HIP(hipStreamWaitEvent(e->stream, e->ev_out[b], 0)); // chunk c-NB's results have left device buffer b
         rc = launch(s, d_in, m, any_hit ? nullptr : d_res, any_hit ? d_res : nullptr, nullptr, any_hit, false, e->stream);
         if (rc != VT_OK) return rc;
         VT_HIP(hipEventRecord(e->ev_k[b], e->stream));
         VT_HIP(hipStreamWaitEvent(e->s_out, e->ev_k[b], 0));
         VT_HIP(hipMemcpyAsync(e->h_stage_out[b], d_res, m * out_elem, hipMemcpyDeviceToHost, e->s_out));
         VT_HIP(hipEventRecord(e->ev_out[b], e->s_out));
-        if (c >= 1 && (rc = drain(c - 1)) != VT_OK) return rc;
+        if (c >= LAG && (rc = drain(c - LAG)) != VT_OK) return rc;     // pinned output buffer (c - LAG) % NB is free again before chunk c - LAG + NB needs it
     }
-    if ((rc = drain(nchunks - 1)) != VT_OK) return rc;
+    for (uint64_t c = nchunks > LAG ? nchunks - LAG : 0; c < nchunks; ++c)
+        if ((rc = drain(c)) != VT_OK) return rc;
     VT_HIP(hipStreamSynchronize(e->stream));
     return VT_OK;
 }
