@@ -2,7 +2,9 @@
 // linearise) under AddressSanitizer + UBSan on the CPU (GPU sanitizers are not available on this pool).
 // Built by `make -C tests/cpp sanitize`; exits non-zero on any sanitizer report or failed check.
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -89,8 +91,44 @@ static void shards()
     CHECK(vt_shard_capacity(100, 0) == 0);
 }
 
+// the staging copy of the batch boundary (vt_batch_trace_closest_ex, VT_BATCH_CHECK_RANGES): copies n rays from a source of ANY
+// alignment and names the first ray whose range fails the checks of AccelStruct::Traverse
+namespace vt { uint64_t parallel_copy_checked(vt_ray* dst, const void* src, uint64_t n); void parallel_copy(void* dst, const void* src, size_t bytes); }
+static void staging_copy()
+{
+    for (uint64_t n : {0ull, 1ull, 5ull, 32768ull, 32769ull, 200000ull}) {
+        std::vector<char> raw(n * sizeof(vt_ray) + 3);
+        char* src = raw.data() + 3;                              // misaligned on purpose (a Lua string carries no alignment promise)
+        std::vector<vt_ray> rays(n), dst(n), plain(n);
+        for (uint64_t i = 0; i < n; ++i) rays[i] = vt_ray{{float(i), 1.f, 2.f}, {0.f, 0.f, 1.f}, float(i % 7), float(i % 7) + 1.f};
+        if (n) std::memcpy(src, rays.data(), n * sizeof(vt_ray));
+        CHECK(vt::parallel_copy_checked(dst.data(), src, n) == n);
+        CHECK(n == 0 || std::memcmp(dst.data(), rays.data(), n * sizeof(vt_ray)) == 0);
+        vt::parallel_copy(plain.data(), src, n * sizeof(vt_ray));
+        CHECK(n == 0 || std::memcmp(plain.data(), rays.data(), n * sizeof(vt_ray)) == 0);
+        for (uint64_t bad : {uint64_t(0), n / 2, n ? n - 1 : 0}) {
+            if (bad >= n) continue;
+            for (int rule = 0; rule < 3; ++rule) {
+                vt_ray r = rays[bad];
+                if (rule == 0) r.tmin = -0.5f; else if (rule == 1) r.tmax = r.tmin; else r.tmax = std::nanf("");   // NaN ranges pass, as in the reference
+                std::memcpy(src + bad * sizeof(vt_ray), &r, sizeof(r));
+                const uint64_t got = vt::parallel_copy_checked(dst.data(), src, n);
+                CHECK(got == (rule == 2 ? n : bad));
+                std::memcpy(src + bad * sizeof(vt_ray), &rays[bad], sizeof(vt_ray));
+            }
+        }
+        if (n > 40000) {                                         // two offenders in different pieces: the FIRST is named
+            vt_ray r = rays[100]; r.tmin = -1.f;
+            std::memcpy(src + 39000 * sizeof(vt_ray), &r, sizeof(r));
+            std::memcpy(src + 100 * sizeof(vt_ray), &r, sizeof(r));
+            CHECK(vt::parallel_copy_checked(dst.data(), src, n) == 100);
+        }
+    }
+}
+
 int main()
 {
+    staging_copy();
     for (uint32_t n : {0u, 1u, 2u, 3u, 17u, 1000u, 20000u, 70000u}) { run(n, 7 + n, false); run(n, 11 + n, true); }
     shards();
     vt_bvh* b = nullptr;
