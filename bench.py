@@ -979,6 +979,19 @@ def main() -> None:
         except Exception as exc:   # a secondary figure must never cost the headline line
             log(f"[bench] beyond-cache leg failed: {exc}")
 
+    # the legs' figures flat in `roofline` as well (scalars only: what a parser that drops nested objects still keeps)
+    if rank == 0:
+        hi_, bc_, ts_ = result.get("host_inclusive") or {}, result.get("beyond_cache") or {}, result.get("two_streams") or {}
+        result["roofline"].update({
+            "l1_gather_ceiling_lo": 66, "l1_gather_ceiling_hi": 73,
+            "host_inclusive_mrays_s": hi_.get("value"), "host_inclusive_ms": hi_.get("ms_per_call"),
+            "host_inclusive_page_locked_mrays_s": (hi_.get("page_locked_arrays") or {}).get("value"),
+            "host_inclusive_page_locked_ms": (hi_.get("page_locked_arrays") or {}).get("ms_per_call"),
+            "beyond_cache_workload": bc_.get("workload"), "beyond_cache_mrays_s": bc_.get("value"), "beyond_cache_kernel_ms": bc_.get("kernel_ms"),
+            "beyond_cache_frac": bc_.get("frac"), "beyond_cache_alg_over_peak": bc_.get("alg_over_peak"),
+            "two_streams_mrays_s": ts_.get("value"),
+        })
+
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) -------------------
     if rank == 0 and world == 1 and not args.no_cpu and n > 0:
         from oracle import binding as O
