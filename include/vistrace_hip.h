@@ -23,6 +23,11 @@
  * staging, run one at a time per engine).  Calls that rewrite a scene in place (vt_scene_refit,
  * vt_scene_skin_refit, vt_scene_set_alpha, vt_scene_free) first wait for every launch in flight on the
  * device.  vt_engine_set_timing / vt_engine_last_kernel_ms describe the last launch only.
+ *
+ * Errors: a launch that cannot be enqueued fails its call and leaves the engine usable (the launch slot's ray cursors are cleared
+ * before its next use).  After a device-side fault (an illegal address, a hung queue: VT_ERR_HIP from a synchronising call) the
+ * HIP context is unusable: close the engine and open a new one -- persistent launches count on the last wave of the previous
+ * launch on a slot having put the slot's cursors back, which a launch that died did not do.
  */
 #ifndef VISTRACE_HIP_H
 #define VISTRACE_HIP_H
