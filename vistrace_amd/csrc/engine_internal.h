@@ -1,4 +1,4 @@
-// engine_internal.h -- what engine.hip and multi_gpu.hip share: the objects behind the opaque vt_engine / vt_scene
+// engine_internal.h -- what engine.hip, batch.hip and multi_gpu.hip share: the objects behind the opaque vt_engine / vt_scene
 // handles of include/vistrace_hip.h and the two internal entry points every trace goes through.
 #pragma once
 
@@ -208,6 +208,10 @@ struct DeviceGuard {
 namespace vt {
 
 int ensure_bytes(void** ptr, size_t* have, size_t need);
+// one batch of a launch: d_out = its vt_hit array (closest hit) or its byte array (any hit); image_width as vt_batch_desc
+struct BatchReq { const void* d_rays; void* d_out; uint64_t n; uint32_t image_width; };
+// ONE launch over nreq batches on `stream` (per-launch scratch from the engine's slot ring); d_stats: counters kernels, one batch
+int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_stats, bool any_hit, bool stats, hipStream_t stream);
 // enqueue one trace of n device-resident rays on `stream` (per-launch scratch from the engine's slot ring)
 int engine_launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_occ, void* d_stats, bool any_hit, bool stats,
                   hipStream_t stream);
