@@ -66,3 +66,11 @@ def test_plain_c_example_on_gpu():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
     out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "_build", "trace_batch")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_batch_sets_on_gpu():
+    """examples/trace_sets.c: three host ray sets through vt_batch_set_begin / _add / _trace (one merged launch), from plain C."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "_build", "trace_sets")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
