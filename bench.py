@@ -876,6 +876,52 @@ def main() -> None:
         except Exception as exc:   # a secondary figure must never cost the headline line
             log(f"[bench] two-stream leg failed: {exc}")
 
+    # ---- many small batches (rank 0, N = 1): the same rays as 16 sets, 16 launches against ONE merged launch ----------------------
+    # What a caller with many small ray sets per frame pays: a launch costs ~0.3 ms beyond its rays (grid start + drain), 16 sets pay
+    # it 16 times unless they share a launch (vt_trace_closest_multi_dev: one cursor over all sets, one drain).  Never `value`.
+    if rank == 0 and world == 1 and not dist_on and n >= 16 * 4096 and not under_profiler() and args.legs != "off":
+        try:
+            sets = 16
+            per = (n // sets) // (16 * image_width) * (16 * image_width) if image_width else (n // sets) // 64 * 64
+            if per > 0:
+                esz = 1 if any_hit else HIT.itemsize
+                out_a, out_b = torch.zeros_like(d_hits), torch.zeros_like(d_hits)
+                descs = [(d_rays.data_ptr() + k * per * RAY.itemsize, out_b.data_ptr() + k * per * esz, per, image_width) for k in range(sets)]
+
+                def separate():
+                    for k in range(sets):
+                        if any_hit:
+                            scene.trace_any_dev(d_rays.data_ptr() + k * per * RAY.itemsize, per, out_a.data_ptr() + k * per * esz, stream)
+                        else:
+                            scene.trace_closest_dev(d_rays.data_ptr() + k * per * RAY.itemsize, per, out_a.data_ptr() + k * per * esz, stream)
+
+                def merged():
+                    scene.trace_multi_dev(descs, stream, any_hit=any_hit)
+
+                times = {}
+                for name, fn in (("separate", separate), ("merged", merged)):
+                    for _ in range(3):
+                        fn()
+                    torch.cuda.synchronize(device)
+                    reps = max(3, min(50, int(0.25 / max(ms_per_step * 1e-3, 1e-5))))
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        fn()
+                    torch.cuda.synchronize(device)
+                    times[name] = (time.perf_counter() - t0) / reps * 1e3
+                same = bool(torch.equal(out_a[: sets * per * esz], out_b[: sets * per * esz]))
+                result["merged_launch"] = {
+                    "sets": sets, "rays_per_set": per,
+                    "separate_launches_ms": round(times["separate"], 4), "separate_launches_value": round(sets * per / times["separate"] / 1e3, 2),
+                    "one_merged_launch_ms": round(times["merged"], 4), "one_merged_launch_value": round(sets * per / times["merged"] / 1e3, 2),
+                    "unit": result["unit"], "results_equal": same,
+                    "note": "the workload's rays cut into 16 equal sets (whole bands of 16 image rows for camera rays): 16 launches on one stream "
+                            "against vt_trace_*_multi_dev (one grid start, one drain); the results must be byte-equal",
+                }
+                del out_a, out_b
+        except Exception as exc:   # a secondary figure must never cost the headline line
+            log(f"[bench] merged-launch leg failed: {exc}")
+
     # ---- the transfer-inclusive figure of SURVEY 8(d) (rank 0, N = 1): never `value` ------------------------------------------
     # vt_trace_closest on HOST buffers: the same rays from pageable caller memory, every copy inside the call (the engine's chunked
     # pinned pipeline: upload of chunk c + 1, trace of chunk c and download of chunk c - 1 overlap)
@@ -990,6 +1036,8 @@ def main() -> None:
             "beyond_cache_workload": bc_.get("workload"), "beyond_cache_mrays_s": bc_.get("value"), "beyond_cache_kernel_ms": bc_.get("kernel_ms"),
             "beyond_cache_frac": bc_.get("frac"), "beyond_cache_alg_over_peak": bc_.get("alg_over_peak"),
             "two_streams_mrays_s": ts_.get("value"),
+            "sets16_separate_launches_mrays_s": (result.get("merged_launch") or {}).get("separate_launches_value"),
+            "sets16_one_merged_launch_mrays_s": (result.get("merged_launch") or {}).get("one_merged_launch_value"),
         })
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) -------------------
