@@ -419,6 +419,8 @@ def main() -> None:
     ap.add_argument("--pmc-passes", default="fetch,write,sq,mix,tcp,l2")
     ap.add_argument("--pmc-timeout", type=float, default=240.0)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pieces-timeout", type=float, default=60.0,
+                    help="N > 1: seconds the closing measurement of one batch in 2 / 4 / 8 pieces may take before it is abandoned")
     ap.add_argument("--legs", default=None, choices=["all", "host", "off"],
                     help="extra figures beside `value` at N = 1: host = host_inclusive (vt_trace_closest on host arrays: PCIe inside the call); "
                          "all = + beyond_cache (the same ray kind into S10M).  Default: all for the default workload, host otherwise")
@@ -662,20 +664,22 @@ def main() -> None:
         # ONE batch from idle to "every record on rank 0", cut into K pieces: trace + gather for K = 1, about max(trace, gather) +
         # one piece when the pieces overlap (each extra piece costs one more launch's drain)
         single = {}
+
+        def single_batch(K):
+            ts = []
+            for _ in range(4):
+                torch.cuda.synchronize(device)
+                dist.barrier()
+                t0 = time.perf_counter()
+                native.submit(trace_into, stream, K)
+                native.drain()
+                torch.cuda.synchronize(device)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            tk = torch.tensor([float(np.mean(ts[1:]))], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+            single[str(K)] = round(float(tk.item()), 4)
         if native is not None:
-            for K in (1, 2, 4, 8):
-                ts = []
-                for _ in range(4):
-                    torch.cuda.synchronize(device)
-                    dist.barrier()
-                    t0 = time.perf_counter()
-                    native.submit(trace_into, stream, K)
-                    native.drain()
-                    torch.cuda.synchronize(device)
-                    ts.append((time.perf_counter() - t0) * 1e3)
-                tk = torch.tensor([float(np.mean(ts[1:]))], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-                dist.all_reduce(tk, op=dist.ReduceOp.MAX)
-                single[str(K)] = round(float(tk.item()), 4)
+            single_batch(1)          # the path the timed steps used; K > 1 runs at the very end, behind a watchdog (see below)
         t_mean, g_mean = float(np.mean(tr)), (float(np.mean(ga)) if ga else 0.0)
         dev_t = device if args.backend == "nccl" else "cpu"
         hi = torch.tensor([t_mean, g_mean], dtype=torch.float64, device=dev_t)
@@ -1141,6 +1145,28 @@ def main() -> None:
             O.set_alpha()
         if not (same_prim and same_tuv):
             log("[bench] PARITY FAILURE on the sample")
+    # ---- N > 1: ONE batch in K pieces (grouped ncclSend / ncclRecv per piece) -- last, and behind a watchdog: this path has run on
+    # hardware with one rank only, and a collective that never completes must not cost the line its measured figures
+    pieces_hung = False
+    if dist_on and native is not None and n > 0 and dist_breakdown is not None:
+        import threading
+
+        def pieces():
+            torch.cuda.set_device(device)
+            for K in (2, 4, 8):
+                single_batch(K)
+        th = threading.Thread(target=pieces, daemon=True)
+        th.start()
+        th.join(timeout=args.pieces_timeout)
+        pieces_hung = th.is_alive()
+        dist_breakdown["single_batch_ms"] = dict(single)
+        if pieces_hung:
+            dist_breakdown["single_batch_note"] = f"the measurement in pieces did not finish within {args.pieces_timeout} s and was abandoned (K = 1 is the path of the timed steps)"
+            log(f"[bench] rank {rank}: single batch in pieces timed out; leaving without collective teardown")
+            if rank == 0:
+                print(json.dumps(result), flush=True)
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
     if dist_on:
         # RCCL writes a version banner to the C stdout of rank 0; when stdout is a pipe it sits in the stdio buffer until
         # exit and would land BEHIND the result.  Push it out first so that the JSON line is the last line of the run.
