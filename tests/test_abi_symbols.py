@@ -69,3 +69,37 @@ def test_multi_gpu_entry_points_validate_arguments(va):
     if not torch.cuda.is_available():
         one = (C.c_int * 1)(0)
         assert L.lib.vt_engine_open_multi(one, 1, C.byref(h)) == L.VT_ERR_HIP
+
+
+def test_round4_entry_points_validate_arguments(va):
+    """The entry points added in round 4 (merged launches, batch options and sets, pieces of a gather, host registration) refuse
+    NULL handles and malformed arguments before they touch a device, with a message -- no GPU needed."""
+    L = va._lib
+    lib = L.lib
+    h = C.c_void_p()
+    bad = C.c_uint64(0)
+    badb = C.c_uint32(0)
+    desc = np.zeros(1, L.BATCH_DESC)
+    assert lib.vt_trace_closest_multi_dev(None, L.ptr(desc), 1, None) == L.VT_ERR_INVALID_ARG and b"scene is NULL" in lib.vt_last_error()
+    assert lib.vt_trace_any_multi_dev(None, L.ptr(desc), 1, None) == L.VT_ERR_INVALID_ARG
+    assert lib.vt_batch_trace_closest_ex(None, None, 0, 0, 0, C.byref(bad), C.byref(h)) == L.VT_ERR_INVALID_ARG
+    assert lib.vt_batch_trace_closest_ex(None, None, 0, 0, 0, C.byref(bad), None) == L.VT_ERR_INVALID_ARG
+    assert lib.vt_batch_set_begin(None, 0, C.byref(h)) == L.VT_ERR_INVALID_ARG and h.value is None
+    assert lib.vt_batch_set_begin(None, 0, None) == L.VT_ERR_INVALID_ARG
+    assert lib.vt_batch_set_add(None, None, 0, 0, C.byref(bad)) == L.VT_ERR_INVALID_ARG
+    assert lib.vt_batch_set_trace(None, None) == L.VT_ERR_INVALID_ARG
+    assert lib.vt_batch_set_count(None) == 0
+    lib.vt_batch_set_abort(None)                                            # a no-op
+    outs = (C.c_void_p * 1)()
+    assert lib.vt_batch_trace_closest_set(None, None, None, None, 0, 0, C.byref(badb), C.byref(bad), outs) == L.VT_ERR_INVALID_ARG
+    assert lib.vt_gather_hits_part_dev(None, None, 1, 0, 1, None, 0, None) == L.VT_ERR_INVALID_ARG
+    assert lib.vt_host_register(None, 16) == L.VT_ERR_INVALID_ARG and lib.vt_host_unregister(None) == L.VT_ERR_INVALID_ARG
+    buf = np.zeros(16, np.uint8)
+    assert lib.vt_host_register(L.ptr(buf), 0) == L.VT_ERR_INVALID_ARG
+    # the pieces of a shard are pure arithmetic
+    lo, hi = C.c_uint64(7), C.c_uint64(7)
+    lib.vt_gather_chunk_bounds(1000, 4, 1, C.byref(lo), C.byref(hi))
+    assert (lo.value, hi.value) == (256, 512)
+    lib.vt_gather_chunk_bounds(1000, 4, 9, C.byref(lo), C.byref(hi))
+    assert (lo.value, hi.value) == (0, 0)
+    lib.vt_gather_chunk_bounds(1000, 4, 1, None, None)                      # NULL outputs are tolerated
