@@ -304,10 +304,12 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
 typedef struct vt_batch vt_batch;
 int      vt_batch_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_batch** out);
 /* The same with what a scripting front end needs on the way in and out (round 4: accel:TraverseBatch(buffer) went from 106 to
- * > 400 Mrays/s end to end at 1 Mi rays).  The batch flows in chunks of 256 Ki rays through pinned staging buffers: chunk c is
- * copied out of the caller's memory by a few host threads and uploaded while chunk c - 1 is traced.
+ * > 500 Mrays/s end to end at 1 Mi rays).  The batch flows in chunks of 256 Ki rays: chunk c is uploaded while chunk c - 1 is
+ * traced -- straight from the caller's memory where the runtime copies pageable memory at the pinned rate (measured once per
+ * process; VT_BATCH_UPLOAD=staged|direct in the environment decides instead), else through pinned staging buffers filled by a few
+ * host threads.
  *   ray_image_width        as vt_batch_desc::ray_image_width (vt_batch_trace_closest takes the engine option instead);
- *   VT_BATCH_CHECK_RANGES  the staging copy looks at every ray's range: tMin < 0 or tMax <= tMin (the checks of
+ *   VT_BATCH_CHECK_RANGES  the upload looks at every ray's range (a device kernel behind each chunk, or the staging copy): tMin < 0 or tMax <= tMin (the checks of
  *                          AccelStruct::Traverse, source/objects/AccelStruct.cpp:805-806) fails the call with
  *                          VT_ERR_INVALID_ARG and *bad_ray = the first such ray (else *bad_ray = n); no batch is returned;
  *   VT_BATCH_FETCH_HITS    the hit records of chunk c - 2 come back into pinned host memory while chunk c - 1 is traced:

@@ -58,6 +58,56 @@ int ensure_host_pipeline(vt_engine* e)
     return VT_OK;
 }
 
+// the range checks of AccelStruct::Traverse (source/objects/AccelStruct.cpp:805-806) over rays that are already on the device:
+// first_bad = min(first_bad, index of a ray with tMin < 0 or tMax <= tMin); NaN ranges pass, as in the reference
+__global__ __launch_bounds__(256) void check_ranges_kernel(const vt_ray* rays, uint64_t n, uint64_t base, unsigned long long* first_bad)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float tmin = rays[i].tmin, tmax = rays[i].tmax;
+    if (tmin < 0.f || tmax <= tmin) atomicMin(first_bad, static_cast<unsigned long long>(base + i));
+}
+
+constexpr size_t kBatchTail = 256;       // bytes behind a batch's arrays in its device block: the first-bad-ray word of its upload
+
+// Does this host's runtime copy PAGEABLE memory to the device at the rate of pinned memory?  (On the round-4 boxes it does: 56 GB/s
+// either way, profiles/r4/upload_probe.txt -- then staging a caller's buffer through pinned memory with host threads only adds
+// work.)  Measured once per process, 8 MB each way, on the engine's upload stream.
+bool pageable_copies_are_fast(vt_engine* e)
+{
+    static std::atomic<int> known{-1};
+    int k = known.load(std::memory_order_acquire);
+    if (k >= 0) return k != 0;
+    if (const char* env = std::getenv("VT_BATCH_UPLOAD")) {                 // "staged" / "direct": skip the measurement
+        k = std::strcmp(env, "direct") == 0 ? 1 : 0;
+        known.store(k, std::memory_order_release);
+        return k != 0;
+    }
+    const size_t bytes = size_t(8) << 20;
+    k = 0;
+    void* d = nullptr;
+    char* pageable = static_cast<char*>(std::malloc(bytes));
+    if (pageable && hipMalloc(&d, bytes) == hipSuccess) {
+        std::memset(pageable, 1, bytes);
+        auto timed = [&](const void* src) {
+            double best = 1e30;
+            for (int rep = 0; rep < 3; ++rep) {
+                const auto t0 = std::chrono::steady_clock::now();
+                if (hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, e->s_in) != hipSuccess || hipStreamSynchronize(e->s_in) != hipSuccess) return 1e30;
+                best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            }
+            return best;
+        };
+        const double t_pinned = timed(e->h_stage_in[0]), t_pageable = timed(pageable);
+        k = t_pageable <= 1.4 * t_pinned ? 1 : 0;
+    }
+    if (d) (void)hipFree(d);
+    std::free(pageable);
+    (void)hipGetLastError();
+    known.store(k, std::memory_order_release);
+    return k != 0;
+}
+
 // The batch's rays -> device, traced, hit records -> the batch's pinned host block, chunk by chunk: while chunk c is staged (a few
 // host threads copy it from the caller's bytes into a pinned buffer, looking at every ray's range on the way if asked to) and
 // uploaded, chunk c - 1 is traced and the hit records of chunk c - 2 come back.  The caller's memory is free when this returns;
@@ -86,23 +136,40 @@ int batch_pipeline(vt_scene* s, vt_batch* b, const void* rays, uint64_t n, uint3
     }
     uint64_t own_turn = 0;
     uint64_t& turn = stage_turn ? *stage_turn : own_turn;
+    // Where the runtime moves pageable memory at the pinned rate the chunks go up straight from the caller's bytes (no staging
+    // copy, no host thread touches a ray) and the range checks run on the device behind each upload: 1 Mi rays 1.1 -> 0.8 ms.
+    const bool direct = pageable_copies_are_fast(e);
+    unsigned long long* const d_first_bad = reinterpret_cast<unsigned long long*>(b->d_mem + b->d_mem_bytes - kBatchTail);
+    if (direct && check) {
+        if (!e->h_live) VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_live), 64));
+        VT_HIP(hipMemsetAsync(d_first_bad, 0xFF, sizeof(unsigned long long), e->s_in));
+    }
     // (the pinned staging buffers are free: every host-pointer call leaves them so, and e->host_mu is held; the kernels an earlier
     // batch may still have in flight on the engine's stream work on that batch's own device block)
     const uint64_t nchunks = (n + C - 1) / C;
     for (uint64_t c = 0; c < nchunks; ++c, ++turn) {
         const int k = int(turn % vt_engine::kStageBufs);
         const uint64_t lo = c * C, m = std::min(C, n - lo);
-        if (turn >= uint64_t(vt_engine::kStageBufs)) VT_HIP(hipEventSynchronize(e->ev_in[k]));   // pinned input buffer k is free again
-        vt_ray* stage = reinterpret_cast<vt_ray*>(e->h_stage_in[k]);
-        if (check) {
-            const uint64_t bad = parallel_copy_checked(stage, static_cast<const char*>(rays) + lo * sizeof(vt_ray), m);
-            if (bad < m) { *bad_ray = lo + bad; return VT_OK; }
-        } else {
-            parallel_copy(stage, static_cast<const char*>(rays) + lo * sizeof(vt_ray), m * sizeof(vt_ray));
-        }
         char* d_in = b->d_mem + lo * sizeof(vt_ray);
         char* d_res = static_cast<char*>(b->d_hits) + lo * sizeof(vt_hit);
-        VT_HIP(hipMemcpyAsync(d_in, stage, m * sizeof(vt_ray), hipMemcpyHostToDevice, e->s_in));
+        const void* src = static_cast<const char*>(rays) + lo * sizeof(vt_ray);
+        if (!direct) {
+            if (turn >= uint64_t(vt_engine::kStageBufs)) VT_HIP(hipEventSynchronize(e->ev_in[k]));   // pinned input buffer k is free again
+            vt_ray* stage = reinterpret_cast<vt_ray*>(e->h_stage_in[k]);
+            if (check) {
+                const uint64_t bad = parallel_copy_checked(stage, src, m);
+                if (bad < m) { *bad_ray = lo + bad; return VT_OK; }
+            } else {
+                parallel_copy(stage, src, m * sizeof(vt_ray));
+            }
+            src = stage;
+        }
+        VT_HIP(hipMemcpyAsync(d_in, src, m * sizeof(vt_ray), hipMemcpyHostToDevice, e->s_in));
+        if (direct && check) {
+            hipLaunchKernelGGL(check_ranges_kernel, dim3(uint32_t((m + 255) / 256)), dim3(256), 0, e->s_in,
+                               reinterpret_cast<const vt_ray*>(d_in), m, lo, d_first_bad);
+            VT_HIP(hipGetLastError());
+        }
         VT_HIP(hipEventRecord(e->ev_in[k], e->s_in));
         VT_HIP(hipStreamWaitEvent(e->stream, e->ev_in[k], 0));
         if (!trace_chunks) continue;
@@ -114,6 +181,13 @@ int batch_pipeline(vt_scene* s, vt_batch* b, const void* rays, uint64_t n, uint3
             VT_HIP(hipStreamWaitEvent(e->s_out, e->ev_k[k], 0));
             VT_HIP(hipMemcpyAsync(static_cast<char*>(b->h_hits.p) + lo * sizeof(vt_hit), d_res, m * sizeof(vt_hit), hipMemcpyDeviceToHost, e->s_out));
         }
+    }
+    if (direct && check) {                                   // the verdict of the device-side checks: behind the last upload, not behind a trace
+        VT_HIP(hipMemcpyAsync(e->h_live, d_first_bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->s_in));
+        VT_HIP(hipStreamSynchronize(e->s_in));
+        unsigned long long first_bad;
+        std::memcpy(&first_bad, e->h_live, sizeof(first_bad));
+        if (first_bad < n) *bad_ray = first_bad;
     }
     if (!trace_chunks) return VT_OK;                         // the set's caller traces, downloads and waits for the uploads
     if (fetch) { VT_HIP(hipEventRecord(b->hits_down, e->s_out)); b->hits_in_flight = true; }
@@ -133,7 +207,7 @@ int batch_new(vt_scene* s, uint64_t n, vt_batch** out)
     auto al = [](uint64_t x) { return (x + 255) & ~uint64_t(255); };
     const uint64_t ray_b = al(n * sizeof(vt_ray)), hit_b = al(n * sizeof(vt_hit)), att_b = al(n * sizeof(vt_hit_attrs));
     const uint64_t sha_b = s->d_attribs ? al(n * sizeof(vt_hit_shade)) : 0;
-    const size_t need = ray_b + hit_b + att_b + sha_b;
+    const size_t need = ray_b + hit_b + att_b + sha_b + kBatchTail;
     hipError_t err = hipSuccess;
     {
         std::lock_guard<std::mutex> lock(e->launch_mu);
