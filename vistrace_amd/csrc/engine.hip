@@ -241,10 +241,29 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
     } else {
         // the batch table travels in the slot's pinned block -> its device block, in stream order ahead of the kernel; the
         // pinned block is only rewritten once the launch that last read it is over
+        if (slot.segs_cap == 0 && !e->d_segs_all && nreq <= vt_engine::kSlotSegs) {
+            // first merged launch of the engine: tables of kSlotSegs batches for ALL slots from one allocation each -- otherwise every
+            // slot would allocate its own on its first merged launch (16 launches of ~0.2 ms extra: profiles/r4/notes.md section 1)
+            const size_t per = vt_engine::kSlotSegs * sizeof(TraceSeg), all = vt_engine::kLaunchSlots * per;
+            VT_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_segs_all), all));
+            if (hipHostMalloc(reinterpret_cast<void**>(&e->h_segs_all), all) != hipSuccess) {
+                (void)hipGetLastError(); (void)hipFree(e->d_segs_all); e->d_segs_all = nullptr;
+                return fail(VT_ERR_HIP, "trace launch: no pinned memory for the batch tables");
+            }
+            for (uint32_t k = 0; k < vt_engine::kLaunchSlots; ++k) {
+                vt_engine::LaunchSlot& sl = e->slots[k];
+                if (sl.segs_cap != 0) continue;
+                sl.d_segs = reinterpret_cast<TraceSeg*>(e->d_segs_all + k * per);
+                sl.h_segs = reinterpret_cast<TraceSeg*>(e->h_segs_all + k * per);
+                sl.segs_cap = vt_engine::kSlotSegs;
+                sl.segs_shared = true;
+            }
+        }
         if (nreq > slot.segs_cap) {
             if (slot.used) VT_HIP(hipEventSynchronize(slot.done));   // its kernel may still read the device block
-            if (slot.d_segs) { VT_HIP(hipFree(slot.d_segs)); slot.d_segs = nullptr; }
-            if (slot.h_segs) { VT_HIP(hipHostFree(slot.h_segs)); slot.h_segs = nullptr; }
+            if (slot.d_segs && !slot.segs_shared) VT_HIP(hipFree(slot.d_segs));
+            if (slot.h_segs && !slot.segs_shared) VT_HIP(hipHostFree(slot.h_segs));
+            slot.d_segs = nullptr; slot.h_segs = nullptr; slot.segs_shared = false;
             slot.segs_cap = 0;
             const size_t cap = std::max<size_t>(64, size_t(nreq) * 2);
             VT_HIP(hipMalloc(reinterpret_cast<void**>(&slot.d_segs), cap * sizeof(TraceSeg)));
@@ -499,11 +518,13 @@ void vt_engine_close(vt_engine* e)
     e->pinned_spare.clear();
     for (vt_engine::LaunchSlot& sl : e->slots) {
         if (sl.d_overflow) (void)hipFree(sl.d_overflow);
-        if (sl.d_segs) (void)hipFree(sl.d_segs);
-        if (sl.h_segs) (void)hipHostFree(sl.h_segs);
+        if (sl.d_segs && !sl.segs_shared) (void)hipFree(sl.d_segs);
+        if (sl.h_segs && !sl.segs_shared) (void)hipHostFree(sl.h_segs);
         if (sl.segs_copied) (void)hipEventDestroy(sl.segs_copied);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    if (e->d_segs_all) (void)hipFree(e->d_segs_all);
+    if (e->h_segs_all) (void)hipHostFree(e->h_segs_all);
     if (e->d_slot_ctl) (void)hipFree(e->d_slot_ctl);
     if (e->ev_loop) (void)hipEventDestroy(e->ev_loop);
     if (e->d_rays) (void)hipFree(e->d_rays);

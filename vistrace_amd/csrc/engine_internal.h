@@ -66,7 +66,11 @@ struct vt_engine {
         size_t        segs_cap = 0;
         hipEvent_t    segs_copied = nullptr;  // behind the latest copy h_segs -> d_segs: h_segs may be rewritten once it has passed
         bool          segs_copied_valid = false;
+        bool          segs_shared = false;    // h_segs / d_segs lie in the engine's one block for all slots (not freed per slot)
     };
+    static constexpr uint32_t kSlotSegs = 64;   // batches per merged launch served from the shared table block (more: the slot grows its own)
+    char*      d_segs_all = nullptr;            // kLaunchSlots x kSlotSegs batch descriptors, device / pinned host: allocated at the
+    char*      h_segs_all = nullptr;            //   engine's first merged launch
     LaunchSlot slots[kLaunchSlots];
     char*      d_slot_ctl = nullptr;
     uint32_t   next_slot = 0;
