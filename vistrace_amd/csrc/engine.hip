@@ -165,13 +165,27 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
     ++e->next_slot;
     const size_t ovf_words = size_t(p.ovf_entries) * p.grid_blocks * kBlockThreads;
     if (ovf_words > slot.overflow_words) {
-        // grow this slot's overflow area (rare: first launches on a deeper tree); only the launch that last used
-        // THIS slot has to be over -- nothing else on the device is waited for
+        // Grow the overflow area (rare: first launches on a deeper tree or with a larger one-ray-per-lane grid).  Only the launch that
+        // last used THIS slot has to be over -- nothing else on the device is waited for.  Every other slot that is idle right now
+        // and would need the same growth on its next turn gets its area from the same allocation: one hipMalloc instead of one per
+        // slot over the next 16 launches (0.2 ms each: profiles/r4/notes.md section 1).  A block is freed when its last slot moves on.
         if (slot.used) VT_HIP(hipEventSynchronize(slot.done));
-        if (slot.d_overflow) VT_HIP(hipFree(slot.d_overflow));
-        slot.d_overflow = nullptr; slot.overflow_words = 0;
-        VT_HIP(hipMalloc(reinterpret_cast<void**>(&slot.d_overflow), ovf_words * sizeof(uint32_t)));
-        slot.overflow_words = ovf_words;
+        std::vector<vt_engine::LaunchSlot*> takers{&slot};
+        for (vt_engine::LaunchSlot& other : e->slots)
+            if (&other != &slot && other.overflow_words < ovf_words && (!other.used || hipEventQuery(other.done) == hipSuccess)) takers.push_back(&other);
+        (void)hipGetLastError();                             // hipEventQuery of a launch in flight reports hipErrorNotReady
+        void* block = nullptr;
+        if (hipMalloc(&block, takers.size() * ovf_words * sizeof(uint32_t)) != hipSuccess) {   // not enough room for all: this slot alone
+            (void)hipGetLastError();
+            takers.resize(1);
+            VT_HIP(hipMalloc(&block, ovf_words * sizeof(uint32_t)));
+        }
+        std::shared_ptr<void> owner(block, [](void* p) { (void)hipFree(p); });
+        for (size_t k = 0; k < takers.size(); ++k) {
+            takers[k]->ovf_block = owner;
+            takers[k]->d_overflow = static_cast<uint32_t*>(block) + k * ovf_words;
+            takers[k]->overflow_words = ovf_words;
+        }
     } else if (slot.used) {
         VT_HIP(hipStreamWaitEvent(stream, slot.done, 0));    // kLaunchSlots launches ago: normally long finished
     }
@@ -517,7 +531,7 @@ void vt_engine_close(vt_engine* e)
     for (auto& ps : e->pinned_spare) (void)hipHostFree(ps.first);
     e->pinned_spare.clear();
     for (vt_engine::LaunchSlot& sl : e->slots) {
-        if (sl.d_overflow) (void)hipFree(sl.d_overflow);
+        sl.ovf_block.reset(); sl.d_overflow = nullptr;
         if (sl.d_segs && !sl.segs_shared) (void)hipFree(sl.d_segs);
         if (sl.h_segs && !sl.segs_shared) (void)hipHostFree(sl.h_segs);
         if (sl.segs_copied) (void)hipEventDestroy(sl.segs_copied);

@@ -55,7 +55,8 @@ struct vt_engine {
     static constexpr size_t   kSlotCtlBytes = 8192;   // 512 B of cursors (8 x 64 B), then 4 KB of reserved-CU counters
     struct LaunchSlot {
         uint32_t*  d_ctl = nullptr;          // into d_slot_ctl
-        uint32_t*  d_overflow = nullptr;     // grown on demand, per slot
+        uint32_t*  d_overflow = nullptr;     // grown on demand: a piece of ovf_block
+        std::shared_ptr<void> ovf_block;     // the allocation d_overflow lies in (shared by the slots that grew together)
         size_t     overflow_words = 0;
         hipEvent_t done = nullptr;
         bool       used = false;
