@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 4   /* 2: launch-slot ring, host walk, multi-GPU entries; 3: vt_batch, any-hit counters, gather timing; 4: merged launches, chunked gather, batch sets (all additive) */
+#define VT_ABI_VERSION 4   /* 2: launch-slot ring, host walk, multi-GPU entries; 3: vt_batch, any-hit counters, gather timing; 4: merged launches, chunked gather, batch sets, vertex frames + vt_hit_tbn (all additive) */
 
 enum vt_status {
     VT_OK              = 0,
@@ -102,6 +102,19 @@ typedef struct vt_tri_attribs { float uv[3][2]; float alpha[3]; uint32_t ent_id;
 /* texUV, blendFactor, entIdx, submatIdx of a hit (source/objects/TraceResult.cpp:73-78). 32 B.
  * A miss yields zeros with ent_id = material = VT_MISS. */
 typedef struct vt_hit_shade { float tex_uv[2]; float blend; uint32_t ent_id; uint32_t material; uint32_t pad[3]; } vt_hit_shade;
+
+/* Per-vertex normals and tangents of a triangle (Triangle::normals / tangents, source/objects/Primitives.h:62-63), original
+ * triangle order, as the mesh or the world loader produced them (not re-normalised here either).  72 B. */
+typedef struct vt_tri_frame { float normal[3][3]; float tangent[3][3]; } vt_tri_frame;
+/* What TraceResult::CalcTBN (source/objects/TraceResult.cpp:132-186) leaves in normal / tangent / binormal for a material
+ * WITHOUT a normal map -- the interpolated, normalised vertex frame with vB = cross(vT, vN) per vertex (:59-61) and the
+ * grazing-angle correction towards the geometric normal (:175-184) -- and TraceResult::CalcFootprint's textureLodInfo
+ * (:89-103: x = the triangle's lod, Primitives.h:93-105, y = coneWidth^2 / dot(wo, geometricNormal)^2 with the cone
+ * propagated to the hit).  lod_set = 0 and lod_info = 0 when the cone is switched off (coneWidth < 0 or coneAngle <= 0,
+ * the mipOverride of TraceResult.cpp:54 -- the defaults of accel:Traverse).  The normal-map branch (:139-173) needs
+ * IVTFTexture::Sample of the absent VTFParser submodule and is out of scope; a caller with a normal map perturbs the frame
+ * returned here.  A miss yields zeros.  48 B. */
+typedef struct vt_hit_tbn { float normal[3]; float tangent[3]; float binormal[3]; float lod_info[2]; uint32_t lod_set; } vt_hit_tbn;
 
 /* Pinhole camera of the synthetic workloads (pixel-centre rays, row-major, top row first). */
 typedef struct vt_camera { float pos[3]; float forward[3]; float up[3]; float vfov_deg; uint32_t width; uint32_t height; } vt_camera;
@@ -342,6 +355,7 @@ int      vt_batch_rays(vt_batch* b, const vt_ray** rays);     /* the rays as upl
 int      vt_batch_hits(vt_batch* b, const vt_hit** hits);
 int      vt_batch_attrs(vt_batch* b, const vt_hit_attrs** attrs);
 int      vt_batch_shade(vt_batch* b, const vt_hit_shade** shade);     /* VT_ERR_INVALID_ARG without vt_scene_set_tri_attribs */
+int      vt_batch_tbn(vt_batch* b, const vt_hit_tbn** tbn);           /* VT_ERR_INVALID_ARG without vt_scene_set_tri_frames + _attribs; cone off */
 void     vt_batch_free(vt_batch* b);
 
 /* Launch configuration (also readable from VT_* environment variables at vt_engine_open).  Keys:
@@ -477,6 +491,18 @@ int vt_host_scene_set_alpha(vt_host_scene* hs, const vt_tri_attribs* attribs, ui
 
 /* entIdx / texUV / blendFactor / submatIdx per hit (needs vt_scene_set_tri_attribs). d_out: n x vt_hit_shade. */
 int vt_hit_shade_dev(vt_scene* s, const void* d_hits, uint64_t n, void* d_out, void* stream);
+
+/* ---- shading frame of a hit: TraceResult::GetNormal / GetTangent / GetBinormal in bulk (vt_tri_frame, vt_hit_tbn above) ---- */
+/* Optional side table (n must equal the scene's triangle count); copied to the device.  With skin data present
+ * (vt_scene_set_skin) these are the BIND-pose frames: every vt_scene_skin_refit also moves them by TransformToBone with
+ * angleOnly = true (source/objects/AccelStruct.cpp:82-92), as SkinTriangle does. */
+int vt_scene_set_tri_frames(vt_scene* s, const vt_tri_frame* frames, uint32_t n);
+/* d_out: n x vt_hit_tbn.  Needs vt_scene_set_tri_frames and (for lod_info.x, which is derived from the uvs)
+ * vt_scene_set_tri_attribs.  cone_width / cone_angle as accel:Traverse's coneWidth / coneAngle (one pair per batch). */
+int vt_hit_tbn_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64_t n, float cone_width, float cone_angle,
+                   void* d_out, void* stream);
+/* Copy the current (skinned) frames back, original triangle order.  For inspection and tests. */
+int vt_scene_read_tri_frames(vt_scene* s, vt_tri_frame* frames_out);
 
 /* Device-side ray generation for wavefront-style callers; nothing is traced.
  * vt_gen_primary_dev: width*height normalised pinhole rays, range [0, FLT_MAX].

@@ -24,6 +24,7 @@ HIT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
 ALPHA_MATERIAL = np.dtype([("tex_mat", "<f4", (2, 4)), ("tex_scale", "<f4"), ("alpha_ref", "<f4"), ("width", "<u4"),
                            ("height", "<u4"), ("filter", "<u4"), ("pad", "<u4"), ("offset", "<u8")])
 SKIN_VERTEX = np.dtype([("weight", "<f4", 3), ("bone", "i1", 3), ("num_bones", "u1")])
+TBN = np.dtype([("normal", "<f4", 3), ("tangent", "<f4", 3), ("binormal", "<f4", 3), ("lod_info", "<f4", 2), ("lod_set", "<u4")])
 ATTRS = np.dtype([("pos", "<f4", 3), ("uvw", "<f4", 3), ("ngeo", "<f4", 3), ("wo", "<f4", 3), ("front", "<u4")])
 
 
@@ -140,6 +141,8 @@ def lib() -> C.CDLL:
         L.vto_alpha_pass.restype = C.c_int
         L.vto_skin_matrices.argtypes = [vp, vp, u32, vp]
         L.vto_skin_verts.argtypes = [vp, vp, vp, u32, vp, vp]
+        L.vto_hit_tbn.argtypes = [vp, vp, C.c_float, C.c_float, C.c_float, vp, vp, vp, C.c_float, C.c_float, vp]
+        L.vto_skin_frames.argtypes = [vp, vp, vp, u32, vp, vp]
         _lib = L
     return _lib
 
@@ -252,6 +255,37 @@ def skin_verts(bind_verts: np.ndarray, skin: np.ndarray, matrix_base: np.ndarray
     out = np.zeros((n, 9), np.float32)
     lib().vto_skin_verts(bind_verts.ctypes.data, skin.ctypes.data, matrix_base.ctypes.data, n, mats.ctypes.data,
                          out.ctypes.data)
+    return out
+
+
+def hit_tbn(tris: np.ndarray, rays: np.ndarray, hits: np.ndarray, frames: np.ndarray, uvs: np.ndarray,
+            cone_width: float = -1.0, cone_angle: float = -1.0) -> np.ndarray:
+    """TraceResult::CalcTBN (no normal map) + CalcFootprint per hit; frames: ntris x 18 floats (normals[3][3],
+    tangents[3][3]), uvs: ntris x 6.  Misses stay zero."""
+    frames = np.ascontiguousarray(frames, np.float32).reshape(-1, 18)
+    uvs = np.ascontiguousarray(uvs, np.float32).reshape(-1, 6)
+    out = np.zeros(len(hits), TBN)
+    L = lib()
+    for i in range(len(hits)):
+        p = int(hits["prim"][i])
+        if p == MISS:
+            continue
+        L.vto_hit_tbn(tris[p:].ctypes.data, rays["dir"][i].ctypes.data, float(hits["t"][i]), float(hits["u"][i]),
+                      float(hits["v"][i]), frames[p].ctypes.data, frames[p, 9:].ctypes.data, uvs[p].ctypes.data,
+                      float(cone_width), float(cone_angle), out[i:i + 1].ctypes.data)
+    return out
+
+
+def skin_frames(bind_frames: np.ndarray, skin: np.ndarray, matrix_base: np.ndarray, mats: np.ndarray) -> np.ndarray:
+    """SkinTriangle's normals / tangents (AccelStruct.cpp:82-92, angleOnly): n x 18 floats."""
+    bind_frames = np.ascontiguousarray(bind_frames, np.float32).reshape(-1, 18)
+    n = bind_frames.shape[0]
+    skin = np.ascontiguousarray(skin, SKIN_VERTEX).reshape(n * 3)
+    matrix_base = np.ascontiguousarray(matrix_base, np.uint32).reshape(n)
+    mats = np.ascontiguousarray(mats, np.float32).reshape(-1, 16)
+    out = np.zeros((n, 18), np.float32)
+    lib().vto_skin_frames(bind_frames.ctypes.data, skin.ctypes.data, matrix_base.ctypes.data, n, mats.ctypes.data,
+                          out.ctypes.data)
     return out
 
 

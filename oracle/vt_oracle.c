@@ -569,3 +569,84 @@ void vto_skin_verts(const float* bind_verts, const vto_skin_vertex* skin, const 
             vto_transform_to_bone(pos[vi], &skin[(size_t)t * 3 + vi], mats_t, out_verts + (size_t)t * 9 + vi * 3);
     }
 }
+
+/* ---- TraceResult.cpp:58-62, 89-103, 132-137, 175-186 -------------------------------------------*/
+static inline void normalize3(float v[3])          /* glm::normalize: v * inversesqrt(dot(v, v)) */
+{
+    const float inv = 1.0f / sqrtf(dot3(v, v));
+    v[0] = v[0] * inv; v[1] = v[1] * inv; v[2] = v[2] * inv;
+}
+
+void vto_hit_tbn(const vto_tri* tri, const float dir[3], float distance, float u, float v,
+                 const float normals[9], const float tangents[9], const float uvs[6],
+                 float cone_width, float cone_angle, vto_tbn* out)
+{
+    vto_attrs at;
+    vto_hit_attrs(tri, dir, u, v, &at);                       /* wo (:56), geometricNormal (:71), uvw (:70) */
+    const float w = at.uvw[2];
+    float vB[3][3];
+    for (int i = 0; i < 3; ++i) cross3(tangents + 3 * i, normals + 3 * i, vB[i]);      /* :60 */
+    float n[3], t[3], b[3];
+    for (int a = 0; a < 3; ++a) {                             /* :134-136 uvw[2]*v[0] + uvw[0]*v[1] + uvw[1]*v[2] */
+        n[a] = (w * normals[a] + u * normals[3 + a]) + v * normals[6 + a];
+        t[a] = (w * tangents[a] + u * tangents[3 + a]) + v * tangents[6 + a];
+        b[a] = (w * vB[0][a] + u * vB[1][a]) + v * vB[2][a];
+    }
+    normalize3(n); normalize3(t); normalize3(b);
+    /* material.normalMap == nullptr: :139-173 skipped */
+    const float kCosThetaThreshold = 0.1f;                    /* :175 */
+    const float cosTheta = fabsf(dot3(at.wo, n));
+    if (cosTheta <= kCosThetaThreshold) {
+        float s = cosTheta * (1.f / kCosThetaThreshold);      /* :178 saturate */
+        s = s < 0.f ? 0.f : s; s = s > 1.f ? 1.f : s;
+        for (int a = 0; a < 3; ++a) n[a] = at.ngeo[a] * (1.f - s) + n[a] * s;          /* :179 lerp(geometricNormal, normal, t) */
+        normalize3(n);
+        const float tn = dot3(t, n);                          /* :181 */
+        for (int a = 0; a < 3; ++a) t[a] = t[a] - n[a] * tn;
+        normalize3(t);
+        cross3(t, n, b);                                      /* :182 */
+    }
+    for (int a = 0; a < 3; ++a) { out->normal[a] = n[a]; out->tangent[a] = t[a]; out->binormal[a] = b[a]; }
+    out->lod_info[0] = out->lod_info[1] = 0.f;
+    out->lod_set = 0;
+    if (!(cone_width < 0.f || cone_angle <= 0.f)) {           /* :54 mipOverride, :91 */
+        const float cw = cone_angle * distance + cone_width;  /* :95 */
+        const float normalTerm = dot3(at.wo, at.ngeo);        /* :97 */
+        /* Primitives.h:97-103 */
+        const float uv10x = uvs[2] - uvs[0], uv10y = uvs[3] - uvs[1];
+        const float uv20x = uvs[4] - uvs[0], uv20y = uvs[5] - uvs[1];
+        const float triUVArea = fabsf(uv10x * uv20y - uv20x * uv10y);
+        const float len = sqrtf(dot3(tri->n, tri->n));
+        out->lod_info[0] = 0.5f * log2f(triUVArea / len);
+        out->lod_info[1] = (cw * cw) / (normalTerm * normalTerm);                       /* :99-102 */
+        out->lod_set = 1;
+    }
+}
+
+/* TransformToBone :35-47 with angleOnly = true: vertex = (vec, 0) */
+static void vto_rotate_to_bone(const float v[3], const vto_skin_vertex* sv, const float* mats, float out[3])
+{
+    float fin[4] = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t i = 0; i < sv->num_bones; ++i) {
+        const float* M = mats + (size_t)(int)sv->bone[i] * 16;
+        for (int r = 0; r < 4; ++r) {
+            const float a0 = M[0 * 4 + r] * v[0] + M[1 * 4 + r] * v[1];
+            const float a1 = M[2 * 4 + r] * v[2] + M[3 * 4 + r] * 0.f;
+            fin[r] = fin[r] + (a0 + a1) * sv->weight[i];
+        }
+    }
+    out[0] = fin[0]; out[1] = fin[1]; out[2] = fin[2];
+}
+
+void vto_skin_frames(const float* bind_frames, const vto_skin_vertex* skin, const uint32_t* matrix_base,
+                     uint32_t n, const float* mats, float* out_frames)
+{
+    for (uint32_t t = 0; t < n; ++t) {
+        const float* mats_t = mats + (size_t)matrix_base[t] * 16;
+        for (int vi = 0; vi < 3; ++vi) {
+            const vto_skin_vertex* sv = &skin[(size_t)t * 3 + vi];
+            vto_rotate_to_bone(bind_frames + (size_t)t * 18 + vi * 3, sv, mats_t, out_frames + (size_t)t * 18 + vi * 3);           /* :82 normals */
+            vto_rotate_to_bone(bind_frames + (size_t)t * 18 + 9 + vi * 3, sv, mats_t, out_frames + (size_t)t * 18 + 9 + vi * 3);   /* :88 tangents */
+        }
+    }
+}

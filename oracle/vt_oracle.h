@@ -16,7 +16,8 @@
  *     submodule under /root/reference (.gitmodules:4-6), so that part follows
  *     the library's published algorithm as recorded in SURVEY.md section 3.2
  *     ("UPSTREAM-RECALL").
- *   - the hit-record derivations of source/objects/TraceResult.cpp:45-86,255-262
+ *   - the hit-record derivations of source/objects/TraceResult.cpp:45-86,255-262 and the
+ *     texture-free part of its shading frame (:89-103, :132-137, :175-186)
  *   - the two helpers that define the bounce-ray workload:
  *       vistrace.CalcRayOrigin  source/VisTrace.cpp:1495-1517
  *       hemisphere_cos          source/libraries/BSDF.cpp:69-77
@@ -175,6 +176,26 @@ void vto_skin_matrices(const float* bones, const float* binds, uint32_t nmat, fl
  * TransformToBone (:35-47) with the matrices mats[matrix_base[t] + bone], out_verts n x 9. */
 void vto_skin_verts(const float* bind_verts, const vto_skin_vertex* skin, const uint32_t* matrix_base,
                     uint32_t n, const float* mats, float* out_verts);
+
+/* ---- shading frame of a hit: TraceResult::CalcTBN without a normal map + CalcFootprint -------------
+ * source/objects/TraceResult.cpp:58-62 (vN, vT, vB = cross(vT, vN)), :89-103 (CalcFootprint), :132-137 and
+ * :175-186 (CalcTBN: interpolate, normalise, grazing-angle correction); the triangle's lod is
+ * Primitives.h:97-104 (0.5 * log2(triUVArea / length(n))).  glm's normalize / dot / cross / lerp / saturate are
+ * restated in their generic scalar forms (glm is un-vendored and unpinned):
+ *   normalize(v) = v * (1 / sqrt(dot(v, v)));  dot = (x + y) + z;  lerp(x, y, a) = x * (1 - a) + y * a;
+ *   saturate(x) = min(max(x, 0), 1).
+ * normals / tangents: 3 x 3 floats (vertex-major), uvs: 3 x 2.  distance = the hit's t.  lod_set = 0 (and
+ * lod_info = 0) when mipOverride holds (coneWidth < 0 || coneAngle <= 0, TraceResult.cpp:54). */
+typedef struct vto_tbn { float normal[3]; float tangent[3]; float binormal[3]; float lod_info[2]; uint32_t lod_set; } vto_tbn;
+void vto_hit_tbn(const vto_tri* tri, const float dir[3], float distance, float u, float v,
+                 const float normals[9], const float tangents[9], const float uvs[6],
+                 float cone_width, float cone_angle, vto_tbn* out);
+
+/* SkinTriangle's normals / tangents (AccelStruct.cpp:82-92): TransformToBone with angleOnly = true, i.e. the
+ * vertex is (vec, 0).  frames: n x 18 floats (normals[3][3], tangents[3][3]); not re-normalised (the reference
+ * does not either). */
+void vto_skin_frames(const float* bind_frames, const vto_skin_vertex* skin, const uint32_t* matrix_base,
+                     uint32_t n, const float* mats, float* out_frames);
 
 #ifdef __cplusplus
 }

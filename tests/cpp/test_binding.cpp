@@ -46,6 +46,9 @@ static Triangle make_tri(Vec3 a, Vec3 b, Vec3 c, bool oneSided, size_t material)
     t.material = material;
     t.uvs[0] = Vec2{0, 0}; t.uvs[1] = Vec2{1, 0}; t.uvs[2] = Vec2{0, 1};
     t.alphas[0] = 0.f; t.alphas[1] = 1.f; t.alphas[2] = 0.5f;
+    // a bent vertex frame (unit vectors, tangent perpendicular to normal at every vertex)
+    t.normals[0] = Vec3{0, 0, 1};  t.normals[1] = Vec3{0.6f, 0, 0.8f};   t.normals[2] = Vec3{0, 0.6f, 0.8f};
+    t.tangents[0] = Vec3{1, 0, 0}; t.tangents[1] = Vec3{0.8f, 0, -0.6f}; t.tangents[2] = Vec3{1, 0, 0};
     return t;
 }
 
@@ -69,7 +72,7 @@ static void test_cpu_side()
     CHECK(AccelStruct_id >= LT::Count && TraceResult::id >= LT::Count && AccelStruct_id != TraceResult::id);
     CHECK(L.Top() == 0);
     // the registered surface, by name: the reference's Tracing API (VisTrace.cpp:1693-1720, 1745-1751, 1820) + TraverseBatch
-    for (const char* m : {"__gc", "__tostring", "Pos", "Incident", "Distance", "Entity", "GeometricNormal", "Barycentric", "TextureUV",
+    for (const char* m : {"__gc", "__tostring", "Pos", "Incident", "Distance", "Entity", "GeometricNormal", "Normal", "Tangent", "Binormal", "Barycentric", "TextureUV",
                           "SubMaterialIndex", "MaterialFlags", "SurfaceFlags", "HitSky", "HitWater", "FrontFacing"})
         CHECK(L.find_method(TraceResult::id, m) != nullptr);
     for (const char* m : {"__gc", "__tostring", "Traverse", "Rebuild", "TraverseBatch"})
@@ -239,6 +242,23 @@ static void test_gpu_side()
         g_entityByIndex[42] = &dummyEntity;
         CHECK(call_method(L, res, "GeometricNormal") == 1 && L.GetVector(-1).z == -1.f);
         CHECK(call_method(L, res, "FrontFacing") == 1 && L.GetBool(-1) == false);
+        {   // TraceResult:Normal / Tangent / Binormal (VisTrace.cpp:524-549; CalcTBN, TraceResult.cpp:132-186, no normal map):
+            // uvw = (.25, .25, .5): normal = normalize(.5 n0 + .25 n1 + .25 n2) = normalize(.15, .15, .9); head-on ray: no correction
+            const float l = std::sqrt(0.15f * 0.15f + 0.15f * 0.15f + 0.9f * 0.9f);
+            auto near = [](float a, float b) { return std::fabs(a - b) < 2e-6f; };
+            CHECK(call_method(L, res, "Normal") == 1);
+            ::Vector n = L.GetVector(-1);
+            CHECK(near(n.x, 0.15f / l) && near(n.y, 0.15f / l) && near(n.z, 0.9f / l));
+            CHECK(call_method(L, res, "Tangent") == 1);
+            ::Vector tg = L.GetVector(-1);
+            const float tl = std::sqrt(0.95f * 0.95f + 0.15f * 0.15f);
+            CHECK(near(tg.x, 0.95f / tl) && tg.y == 0.f && near(tg.z, -0.15f / tl));
+            CHECK(call_method(L, res, "Binormal") == 1);
+            ::Vector bn = L.GetVector(-1);          // vB = cross(vT, vN) per vertex: (0,-1,0), (0,-1,0), (0,-.8,.6) -> normalize(0, -.95, .15)
+            CHECK(bn.x == 0.f && near(bn.y, -0.95f / tl) && near(bn.z, 0.15f / tl));
+            Vec2 lod;
+            CHECK(r->GetTextureLodInfo(lod) == false);           // cone off by default (coneWidth = coneAngle = -1)
+        }
         CHECK(call_method(L, res, "SubMaterialIndex") == 1 && L.GetNumber(-1) == 3);   // 2 world mats + 0, 1-based
         CHECK(call_method(L, res, "MaterialFlags") == 1 && L.GetNumber(-1) == double(MATFLAG_NONE));
         CHECK(call_method(L, res, "SurfaceFlags") == 1 && L.GetNumber(-1) == 0.0);
@@ -276,6 +296,16 @@ static void test_gpu_side()
     CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1), State::Nil(), State::Num(3.0)}) == 1);
     delete L.GetUserType<TraceResult>(1, TraceResult::id);
     CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1), State::Num(3.5), State::Nil()}) == 0);
+
+    {   // a valid cone (coneWidth 0.5, coneAngle 0.25) reaches CalcFootprint (TraceResult.cpp:89-103): at distance 3 the cone is
+        // 0.25 * 3 + 0.5 = 1.25 wide, dot(wo, ngeo) = -1; tri.lod = 0.5 * log2(uv area 1 / |n| 16) = -2 (Primitives.h:97-103)
+        CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1), State::Nil(), State::Nil(), State::Num(0.5), State::Num(0.25)}) == 1);
+        TraceResult* r = L.GetUserType<TraceResult>(1, TraceResult::id);
+        Vec2 lod;
+        CHECK(r->GetTextureLodInfo(lod) && lod.x == -2.f && lod.y == 1.5625f);
+        CHECK(r->GetTextureLodInfo(lod) && lod.y == 1.5625f);     // computed once (textureLodSet)
+        delete r;
+    }
 
     // validation messages and argument numbers (AccelStruct.cpp:802-806)
     int arg = 0;
@@ -425,6 +455,7 @@ static void test_gpu_side()
             CHECK(call_method(L, rb, "Hit", {idx}) == 1 && L.GetBool(-1) == (got == 1));
             if (got != 1) {
                 CHECK(call_method(L, rb, "Pos", {idx}) == 0 && call_method(L, rb, "Distance", {idx}) == 0 && call_method(L, rb, "Get", {idx}) == 0);
+                CHECK(call_method(L, rb, "Normal", {idx}) == 0 && call_method(L, rb, "Binormal", {idx}) == 0);
                 continue;
             }
             ++bhit;
@@ -437,6 +468,18 @@ static void test_gpu_side()
             CHECK(call_method(L, rb, "Barycentric", {idx}) == 1 && L.GetVector(-1).x == a->uvw.x && L.GetVector(-1).y == a->uvw.y);
             CHECK(call_method(L, rb, "GeometricNormal", {idx}) == 1 && close(L.GetVector(-1).z, a->geometricNormal.z));
             CHECK(call_method(L, rb, "Incident", {idx}) == 1 && close(L.GetVector(-1).z, a->wo.z) && close(L.GetVector(-1).x, a->wo.x));
+            {   // the batch's frame comes from the device kernel, the single result's from the host class: same expression tree
+                const Vec3 hn = a->GetNormal(), ht = a->GetTangent(), hb = a->GetBinormal();
+                CHECK(call_method(L, rb, "Normal", {idx}) == 1);
+                const ::Vector dn = L.GetVector(-1);
+                CHECK(dn.x == hn.x && dn.y == hn.y && dn.z == hn.z);
+                CHECK(call_method(L, rb, "Tangent", {idx}) == 1);
+                const ::Vector dt = L.GetVector(-1);
+                CHECK(dt.x == ht.x && dt.y == ht.y && dt.z == ht.z);
+                CHECK(call_method(L, rb, "Binormal", {idx}) == 1);
+                const ::Vector db = L.GetVector(-1);
+                CHECK(db.x == hb.x && db.y == hb.y && db.z == hb.z);
+            }
             CHECK(call_method(L, rb, "FrontFacing", {idx}) == 1 && L.GetBool(-1) == a->frontFacing);
             CHECK(call_method(L, rb, "SubMaterialIndex", {idx}) == 1 && L.GetNumber(-1) == double(a->submatIdx + 1));
             CHECK(call_method(L, rb, "MaterialFlags", {idx}) == 1 && L.GetNumber(-1) == double(a->GetMaterialFlags()));

@@ -96,6 +96,12 @@ def test_round4_entry_points_validate_arguments(va):
     assert lib.vt_host_register(None, 16) == L.VT_ERR_INVALID_ARG and lib.vt_host_unregister(None) == L.VT_ERR_INVALID_ARG
     buf = np.zeros(16, np.uint8)
     assert lib.vt_host_register(L.ptr(buf), 0) == L.VT_ERR_INVALID_ARG
+    # vertex frames / shading frame of a hit
+    fr = np.zeros(1, L.TRI_FRAME)
+    assert lib.vt_scene_set_tri_frames(None, L.ptr(fr), 1) == L.VT_ERR_INVALID_ARG and b"scene is NULL" in lib.vt_last_error()
+    assert lib.vt_scene_read_tri_frames(None, L.ptr(fr)) == L.VT_ERR_INVALID_ARG
+    assert lib.vt_hit_tbn_dev(None, None, None, 1, -1.0, -1.0, None, None) == L.VT_ERR_INVALID_ARG
+    assert lib.vt_batch_tbn(None, C.byref(h)) == L.VT_ERR_INVALID_ARG
     # the pieces of a shard are pure arithmetic
     lo, hi = C.c_uint64(7), C.c_uint64(7)
     lib.vt_gather_chunk_bounds(1000, 4, 1, C.byref(lo), C.byref(hi))

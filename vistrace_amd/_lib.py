@@ -35,6 +35,8 @@ RAY_STATS = np.dtype([("steps", "<u4"), ("tests", "<u4")])
 HIT_ATTRS = np.dtype([("pos", "<f4", 3), ("t", "<f4"), ("ngeo", "<f4", 3), ("prim", "<u4"),
                       ("uvw", "<f4", 3), ("front", "<u4"), ("wo", "<f4", 3), ("hit", "<u4")])
 TRI_ATTRIBS = np.dtype([("uv", "<f4", (3, 2)), ("alpha", "<f4", 3), ("ent_id", "<u4"), ("material", "<u4"), ("pad", "<u4")])
+TRI_FRAME = np.dtype([("normal", "<f4", (3, 3)), ("tangent", "<f4", (3, 3))])
+HIT_TBN = np.dtype([("normal", "<f4", 3), ("tangent", "<f4", 3), ("binormal", "<f4", 3), ("lod_info", "<f4", 2), ("lod_set", "<u4")])
 HIT_SHADE = np.dtype([("tex_uv", "<f4", 2), ("blend", "<f4"), ("ent_id", "<u4"), ("material", "<u4"), ("pad", "<u4", 3)])
 CAMERA = np.dtype([("pos", "<f4", 3), ("forward", "<f4", 3), ("up", "<f4", 3), ("vfov_deg", "<f4"), ("width", "<u4"), ("height", "<u4")])
 ALPHA_MATERIAL = np.dtype([("tex_mat", "<f4", (2, 4)), ("tex_scale", "<f4"), ("alpha_ref", "<f4"), ("width", "<u4"),
@@ -42,6 +44,7 @@ ALPHA_MATERIAL = np.dtype([("tex_mat", "<f4", (2, 4)), ("tex_scale", "<f4"), ("a
 SKIN_VERTEX = np.dtype([("weight", "<f4", 3), ("bone", "i1", 3), ("num_bones", "u1")])
 BATCH_DESC = np.dtype([("d_rays", "<u8"), ("d_out", "<u8"), ("n", "<u8"), ("ray_image_width", "<u4"), ("reserved", "<u4")])
 assert BATCH_DESC.itemsize == 32
+assert TRI_FRAME.itemsize == 72 and HIT_TBN.itemsize == 48
 assert TRI_ATTRIBS.itemsize == 48 and HIT_SHADE.itemsize == 32 and SKIN_VERTEX.itemsize == 16 and ALPHA_MATERIAL.itemsize == 64
 assert RAY.itemsize == 32 and HIT.itemsize == 16 and BVH_NODE.itemsize == 32
 assert NODE_PAIR.itemsize == 64 and TRI64.itemsize == 64 and HIT_ATTRS.itemsize == 64
@@ -118,6 +121,7 @@ SYMBOLS = {
     "vt_batch_hits": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
     "vt_batch_attrs": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
     "vt_batch_shade": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
+    "vt_batch_tbn": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
     "vt_batch_free": (None, [_vp]),
     "vt_hit_attrs_dev": (C.c_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     "vt_scene_refit": (C.c_int, [_vp, _vp, _vp, _u32]),
@@ -127,6 +131,9 @@ SYMBOLS = {
     "vt_scene_read_records": (C.c_int, [_vp, _vp, _vp]),
     "vt_scene_set_tri_attribs": (C.c_int, [_vp, _vp, _u32]),
     "vt_hit_shade_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
+    "vt_scene_set_tri_frames": (C.c_int, [_vp, _vp, _u32]),
+    "vt_scene_read_tri_frames": (C.c_int, [_vp, _vp]),
+    "vt_hit_tbn_dev": (C.c_int, [_vp, _vp, _vp, _u64, C.c_float, C.c_float, _vp, _vp]),
     "vt_gen_primary_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
     "vt_gen_bounce_dev": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "vt_bounce_loop_dev": (C.c_int, [_vp, _vp, _u64, _u32, _u64, _vp, _vp, _vp]),

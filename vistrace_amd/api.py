@@ -14,7 +14,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from ._lib import (ALPHA_MATERIAL, BVH_NODE, HIT, HIT_ATTRS, HIT_SHADE, NODE_PAIR, RAY, RAY_STATS, SKIN_VERTEX, TRI64, TRI_ATTRIBS, check, lib,
+from ._lib import (ALPHA_MATERIAL, BVH_NODE, HIT, HIT_ATTRS, HIT_SHADE, HIT_TBN, TRI_FRAME, NODE_PAIR, RAY, RAY_STATS, SKIN_VERTEX, TRI64, TRI_ATTRIBS, check, lib,
                    ptr)
 
 FLT_MAX = float(np.finfo(np.float32).max)
@@ -208,6 +208,10 @@ class Batch:
 
     def shade(self) -> np.ndarray:
         return self._fetch(lib.vt_batch_shade, HIT_SHADE)
+
+    def tbn(self) -> np.ndarray:
+        """Shading frame per hit (TraceResult::GetNormal / GetTangent / GetBinormal without a normal map), cone off."""
+        return self._fetch(lib.vt_batch_tbn, HIT_TBN)
 
     def free(self) -> None:
         if self._h:
@@ -480,6 +484,22 @@ class Scene:
     def hit_shade_dev(self, d_hits: int, n: int, d_out: int, stream: int = 0) -> None:
         check(lib.vt_hit_shade_dev(self._h, d_hits, n, d_out, stream or None))
 
+    def set_tri_frames(self, frames: np.ndarray) -> None:
+        """Per-vertex normals / tangents (original order; the bind pose when the scene is skinned) for hit_tbn_dev."""
+        assert frames.dtype == TRI_FRAME
+        frames = np.ascontiguousarray(frames)
+        check(lib.vt_scene_set_tri_frames(self._h, ptr(frames) if len(frames) else None, len(frames)))
+
+    def read_tri_frames(self) -> np.ndarray:
+        frames = np.zeros(self.host_scene.tri_count, dtype=TRI_FRAME)
+        check(lib.vt_scene_read_tri_frames(self._h, ptr(frames) if len(frames) else None))
+        return frames
+
+    def hit_tbn_dev(self, d_rays: int, d_hits: int, n: int, d_out: int, cone_width: float = -1.0, cone_angle: float = -1.0,
+                    stream: int = 0) -> None:
+        """n x HIT_TBN: TraceResult::CalcTBN (no normal map) + CalcFootprint (TraceResult.cpp:89-103, 132-186)."""
+        check(lib.vt_hit_tbn_dev(self._h, d_rays, d_hits, n, cone_width, cone_angle, d_out, stream or None))
+
 
 def build_scene(engine: Engine, verts: np.ndarray, flags: Optional[np.ndarray] = None, nthreads: int = 0) -> Scene:
     """verts (n,3,3) -> setup -> build (default builder) -> linearise -> upload."""
@@ -489,5 +509,5 @@ def build_scene(engine: Engine, verts: np.ndarray, flags: Optional[np.ndarray] =
 
 __all__ = ["Engine", "Scene", "HostBvh", "HostScene", "tris_setup", "build_scene", "make_rays", "device_count",
            "shard_capacity", "shard_bounds", "gather_chunk_bounds", "comm_unique_id", "host_register", "host_unregister",
-           "RAY", "HIT", "TRI64", "BVH_NODE", "NODE_PAIR", "RAY_STATS", "HIT_ATTRS", "TRI_ATTRIBS", "HIT_SHADE", "SKIN_VERTEX", "ALPHA_MATERIAL",
+           "RAY", "HIT", "TRI64", "BVH_NODE", "NODE_PAIR", "RAY_STATS", "HIT_ATTRS", "TRI_ATTRIBS", "HIT_SHADE", "HIT_TBN", "TRI_FRAME", "SKIN_VERTEX", "ALPHA_MATERIAL",
            "FLT_MAX", "_lib"]

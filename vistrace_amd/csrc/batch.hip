@@ -195,7 +195,7 @@ int batch_pipeline(vt_scene* s, vt_batch* b, const void* rays, uint64_t n, uint3
     return VT_OK;
 }
 
-// a batch object with its device block (rays | hits | attrs | shade) from the engine's spare blocks or a new allocation
+// a batch object with its device block (rays | hits | attrs | shade | tbn) from the engine's spare blocks or a new allocation
 int batch_new(vt_scene* s, uint64_t n, vt_batch** out)
 {
     vt_engine* e = s->engine;
@@ -207,7 +207,8 @@ int batch_new(vt_scene* s, uint64_t n, vt_batch** out)
     auto al = [](uint64_t x) { return (x + 255) & ~uint64_t(255); };
     const uint64_t ray_b = al(n * sizeof(vt_ray)), hit_b = al(n * sizeof(vt_hit)), att_b = al(n * sizeof(vt_hit_attrs));
     const uint64_t sha_b = s->d_attribs ? al(n * sizeof(vt_hit_shade)) : 0;
-    const size_t need = ray_b + hit_b + att_b + sha_b + kBatchTail;
+    const uint64_t tbn_b = s->d_attribs && s->d_frames ? al(n * sizeof(vt_hit_tbn)) : 0;
+    const size_t need = ray_b + hit_b + att_b + sha_b + tbn_b + kBatchTail;
     hipError_t err = hipSuccess;
     {
         std::lock_guard<std::mutex> lock(e->launch_mu);
@@ -231,6 +232,7 @@ int batch_new(vt_scene* s, uint64_t n, vt_batch** out)
     b->d_hits = b->d_mem + ray_b;
     b->d_attrs = b->d_mem + ray_b + hit_b;
     b->d_shade = sha_b ? b->d_mem + ray_b + hit_b + att_b : nullptr;
+    b->d_tbn = tbn_b ? b->d_mem + ray_b + hit_b + att_b + sha_b : nullptr;
     return VT_OK;
 }
 
@@ -246,6 +248,8 @@ int batch_finish(vt_scene* s, vt_batch* b)
         HitShadeArgs sa{s->d_attribs, static_cast<const vt_hit*>(b->d_hits), static_cast<vt_hit_shade*>(b->d_shade), b->n};
         err = launch_hit_shade(sa, e->stream);
     }
+    // the shading frame, cone switched off as by accel:Traverse's defaults (coneWidth = coneAngle = -1, AccelStruct.cpp:796-806)
+    if (err == hipSuccess && b->d_tbn) err = launch_hit_tbn(s, b->d_mem, b->d_hits, b->n, -1.f, -1.f, b->d_tbn, e->stream);
     if (err == hipSuccess) err = hipEventRecord(b->done, e->stream);
     if (err != hipSuccess) return fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err));
     return VT_OK;
@@ -672,6 +676,14 @@ int vt_batch_shade(vt_batch* b, const vt_hit_shade** shade)
     return batch_fetch(b, b->d_shade, sizeof(vt_hit_shade), b->h_shade, reinterpret_cast<const void**>(shade), "vt_batch_shade");
 }
 
+int vt_batch_tbn(vt_batch* b, const vt_hit_tbn** tbn)
+{
+    if (!b || !tbn) return fail(VT_ERR_INVALID_ARG, "vt_batch_tbn: NULL");
+    if (b->n != 0 && !b->h_tbn.have && b->engine && !b->d_tbn)
+        return fail(VT_ERR_INVALID_ARG, "vt_batch_tbn: the scene had no vertex frames (vt_scene_set_tri_frames) or no triangle attributes when the batch was traced");
+    return batch_fetch(b, b->d_tbn, sizeof(vt_hit_tbn), b->h_tbn, reinterpret_cast<const void**>(tbn), "vt_batch_tbn");
+}
+
 void vt_batch_free(vt_batch* b)
 {
     if (!b) return;
@@ -684,7 +696,7 @@ void vt_batch_free(vt_batch* b)
             if (e->device_spare.size() >= 32) { (void)hipFree(e->device_spare.front().first); e->device_spare.erase(e->device_spare.begin()); }
             e->device_spare.push_back({b->d_mem, b->d_mem_bytes});
         }
-        for (vt_batch::HostArray* h : {&b->h_rays, &b->h_hits, &b->h_attrs, &b->h_shade}) {
+        for (vt_batch::HostArray* h : {&b->h_rays, &b->h_hits, &b->h_attrs, &b->h_shade, &b->h_tbn}) {
             if (!h->p) continue;
             if (e->pinned_spare.size() < 8) e->pinned_spare.push_back({h->p, h->bytes});
             else (void)hipHostFree(h->p);
@@ -692,7 +704,7 @@ void vt_batch_free(vt_batch* b)
         }
         e->batches.erase(std::remove(e->batches.begin(), e->batches.end(), b), e->batches.end());
     }
-    for (vt_batch::HostArray* h : {&b->h_rays, &b->h_hits, &b->h_attrs, &b->h_shade})
+    for (vt_batch::HostArray* h : {&b->h_rays, &b->h_hits, &b->h_attrs, &b->h_shade, &b->h_tbn})
         if (h->p) (void)hipHostFree(h->p);              // the engine is gone: nothing to hand the blocks back to
     delete b;
 }

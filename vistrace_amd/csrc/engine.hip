@@ -711,7 +711,7 @@ static void release_scene_device(vt_scene* s)
                      reinterpret_cast<void**>(&s->d_alpha_mats), reinterpret_cast<void**>(&s->d_alpha_texels),
                      reinterpret_cast<void**>(&s->d_bind_verts), reinterpret_cast<void**>(&s->d_skin),
                      reinterpret_cast<void**>(&s->d_matrix_base), reinterpret_cast<void**>(&s->d_skin_mats),
-                     reinterpret_cast<void**>(&s->d_bad)};
+                     reinterpret_cast<void**>(&s->d_bad), reinterpret_cast<void**>(&s->d_frames_bind)};
     for (void** b : bufs) {
         if (*b) (void)hipFree(*b);
         *b = nullptr;
@@ -719,6 +719,7 @@ static void release_scene_device(vt_scene* s)
     if (s->refit_graph) (void)hipGraphExecDestroy(s->refit_graph);
     s->refit_graph = nullptr;
     s->d_tris = nullptr;
+    s->d_frames = nullptr;
 }
 
 void vt_scene_free(vt_scene* s)
@@ -1037,6 +1038,7 @@ int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uin
     if (rc != VT_OK) return rc;
     SkinTrisArgs ta{s->d_bind_verts, s->d_skin, s->d_matrix_base, d_prod, s->d_prim_to_slot, s->d_tris, s->ntris, nmat, s->d_bad};
     VT_HIP(launch_skin_tris(ta, e->stream));
+    VT_HIP(skin_frames(s, d_prod, nmat, e->stream));                     // normals / tangents, AccelStruct.cpp:82-92
     if (s->host_stale) s->host_stale->store(1, std::memory_order_release);
     rc = refit_levels(s);
     return rc != VT_OK ? rc : end_finite_check(s, "vt_scene_skin_refit");

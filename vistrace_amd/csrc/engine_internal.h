@@ -149,6 +149,8 @@ struct vt_scene {
     uint32_t      tri_base = 0;
     uint32_t*     d_prim_to_slot = nullptr;
     vt_tri_attribs* d_attribs = nullptr;   // optional side table, original triangle order
+    vt_tri_frame*   d_frames_bind = nullptr; // optional: per-vertex normals / tangents as handed over (vt_scene_set_tri_frames), and ...
+    vt_tri_frame*   d_frames = nullptr;      // ... as the last vt_scene_skin_refit moved them (second half of the same block)
     // refit: pair indices sorted by depth (deepest level first) and where each level starts
     uint32_t*     d_level_pairs = nullptr;
     std::vector<uint32_t> level_begin;     // level_begin[k] .. level_begin[k+1]) = k-th deepest level
@@ -185,12 +187,12 @@ struct vt_scene {
 struct vt_batch {
     vt_engine* engine = nullptr;             // NULL once the engine was closed
     uint64_t   n = 0;
-    char*      d_mem = nullptr;              // rays | hits | attrs | shade
+    char*      d_mem = nullptr;              // rays | hits | attrs | shade | tbn
     size_t     d_mem_bytes = 0;
     // host copies, each fetched on first use into pinned memory (taken from / returned to the engine's spare list)
     struct HostArray { void* p = nullptr; size_t bytes = 0; bool have = false; };
-    HostArray h_rays, h_hits, h_attrs, h_shade;
-    void *d_hits = nullptr, *d_attrs = nullptr, *d_shade = nullptr;
+    HostArray h_rays, h_hits, h_attrs, h_shade, h_tbn;
+    void *d_hits = nullptr, *d_attrs = nullptr, *d_shade = nullptr, *d_tbn = nullptr;
     hipEvent_t done = nullptr;               // behind the last kernel of the batch
     hipEvent_t hits_down = nullptr;          // VT_BATCH_FETCH_HITS: behind the last download of hit records into h_hits
     bool       hits_in_flight = false;       // ... which vt_batch_hits still has to wait for
@@ -222,6 +224,13 @@ int engine_launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, voi
                   hipStream_t stream);
 // the host-pointer path of ONE device: staging copies + launch(es) + copy-out, synchronous
 int engine_trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, size_t out_elem, bool any_hit);
+
+// shading.hip
+// TraceResult::CalcTBN (no normal map) + CalcFootprint for n hits; the scene holds frames and attribs
+hipError_t launch_hit_tbn(vt_scene* s, const void* d_rays, const void* d_hits, uint64_t n, float cone_width, float cone_angle,
+                          void* d_out, hipStream_t stream);
+// the per-vertex frames follow the bones (no-op without vt_scene_set_tri_frames); d_prod = this frame's bones x binds products
+hipError_t skin_frames(vt_scene* s, const float* d_prod, uint32_t nmat, hipStream_t stream);
 
 // multi_gpu.hip
 // a host ray array split into contiguous shards, one per device of the scene's group, traced side by side

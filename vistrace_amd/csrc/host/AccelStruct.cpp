@@ -154,7 +154,8 @@ int AccelStruct::BuildAndUpload(vt_engine* eng)
 }
 
 // Per-triangle side table (uvs, vertex alphas, entity id, material index): what the device needs for the shading part of
-// a batch's results (TraceResult.cpp:73-78, vt_hit_shade) -- always.  The side data of the in-kernel alpha test
+// a batch's results (TraceResult.cpp:73-78, vt_hit_shade) and the per-vertex normals / tangents of its shading frame
+// (TraceResult.cpp:132-186, vt_hit_tbn) -- always.  The side data of the in-kernel alpha test
 // (Primitives.h:196-208: per-material transform / reference / alpha plane) only when a material carries the flag.
 int AccelStruct::UploadSideTables(const std::vector<uint8_t>& flags)
 {
@@ -170,6 +171,17 @@ int AccelStruct::UploadSideTables(const std::vector<uint8_t>& flags)
         a.pad = 0;
     }
     int rc = vt_scene_set_tri_attribs(mpScene, attribs.data(), uint32_t(attribs.size()));
+    if (rc == VT_OK) {                                       // per-vertex normals / tangents: the shading frame of a batch's hits
+        std::vector<vt_tri_frame> frames(mT->triangles.size());
+        for (size_t i = 0; i < mT->triangles.size(); ++i) {
+            const Triangle& t = mT->triangles[i];
+            for (int k = 0; k < 3; ++k) {
+                frames[i].normal[k][0] = t.normals[k].x; frames[i].normal[k][1] = t.normals[k].y; frames[i].normal[k][2] = t.normals[k].z;
+                frames[i].tangent[k][0] = t.tangents[k].x; frames[i].tangent[k][1] = t.tangents[k].y; frames[i].tangent[k][2] = t.tangents[k].z;
+            }
+        }
+        rc = vt_scene_set_tri_frames(mpScene, frames.data(), uint32_t(frames.size()));
+    }
     if (rc != VT_OK || !any) return rc;
     std::vector<vt_alpha_material> mats(mT->materials.size());
     std::vector<uint8_t> texels;

@@ -161,6 +161,30 @@ LUA_FUNCTION(TraceResult_GeometricNormal)                              // VisTra
     return 1;
 }
 
+LUA_FUNCTION(TraceResult_Normal)                                       // VisTrace.cpp:524-531
+{
+    TraceResult* r = Self(LUA);
+    const Vec3& v = r->GetNormal();
+    LUA->PushVector(MakeVector(v.x, v.y, v.z));
+    return 1;
+}
+
+LUA_FUNCTION(TraceResult_Tangent)                                      // VisTrace.cpp:533-540
+{
+    TraceResult* r = Self(LUA);
+    const Vec3& v = r->GetTangent();
+    LUA->PushVector(MakeVector(v.x, v.y, v.z));
+    return 1;
+}
+
+LUA_FUNCTION(TraceResult_Binormal)                                     // VisTrace.cpp:542-549
+{
+    TraceResult* r = Self(LUA);
+    const Vec3& v = r->GetBinormal();
+    LUA->PushVector(MakeVector(v.x, v.y, v.z));
+    return 1;
+}
+
 LUA_FUNCTION(TraceResult_Barycentric)                                  // VisTrace.cpp:552-559
 {
     TraceResult* r = Self(LUA);
@@ -338,6 +362,22 @@ LUA_FUNCTION(TraceResultBatch_GeometricNormal)
     return 1;
 }
 
+// Normal / Tangent / Binormal of ray i's hit: the frame the device materialised for the whole batch (vt_hit_tbn)
+static int PushBatchFrameVector(ILuaBase* LUA, int which)
+{
+    TraceResultBatch* b = BatchSelf(LUA);
+    const uint64_t i = BatchIndex(LUA, b);
+    if (BatchHit(LUA, b, i).prim == VT_MISS) return 0;
+    const vt_hit_tbn* t = b->Tbn();
+    if (!t) BatchFetchError(LUA);
+    const float* v = which == 0 ? t[i].normal : which == 1 ? t[i].tangent : t[i].binormal;
+    LUA->PushVector(MakeVector(v[0], v[1], v[2]));
+    return 1;
+}
+LUA_FUNCTION(TraceResultBatch_Normal) { return PushBatchFrameVector(LUA, 0); }
+LUA_FUNCTION(TraceResultBatch_Tangent) { return PushBatchFrameVector(LUA, 1); }
+LUA_FUNCTION(TraceResultBatch_Binormal) { return PushBatchFrameVector(LUA, 2); }
+
 LUA_FUNCTION(TraceResultBatch_Barycentric)
 {
     TraceResultBatch* b = BatchSelf(LUA);
@@ -484,6 +524,9 @@ void RegisterTracingApi(ILuaBase* LUA)
     Method(LUA, "Distance", TraceResult_Distance);
     Method(LUA, "Entity", TraceResult_Entity);
     Method(LUA, "GeometricNormal", TraceResult_GeometricNormal);
+    Method(LUA, "Normal", TraceResult_Normal);
+    Method(LUA, "Tangent", TraceResult_Tangent);
+    Method(LUA, "Binormal", TraceResult_Binormal);
     Method(LUA, "Barycentric", TraceResult_Barycentric);
     Method(LUA, "TextureUV", TraceResult_TextureUV);
     Method(LUA, "SubMaterialIndex", TraceResult_SubMaterialIndex);
@@ -508,6 +551,9 @@ void RegisterTracingApi(ILuaBase* LUA)
     Method(LUA, "Distance", TraceResultBatch_Distance);
     Method(LUA, "Entity", TraceResultBatch_Entity);
     Method(LUA, "GeometricNormal", TraceResultBatch_GeometricNormal);
+    Method(LUA, "Normal", TraceResultBatch_Normal);
+    Method(LUA, "Tangent", TraceResultBatch_Tangent);
+    Method(LUA, "Binormal", TraceResultBatch_Binormal);
     Method(LUA, "Barycentric", TraceResultBatch_Barycentric);
     Method(LUA, "TextureUV", TraceResultBatch_TextureUV);
     Method(LUA, "SubMaterialIndex", TraceResultBatch_SubMaterialIndex);

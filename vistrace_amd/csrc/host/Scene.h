@@ -44,7 +44,8 @@ struct Material {
 
 struct Triangle {
     Vec3     p0, p1, p2;                  // world-space vertices (the device record re-derives e1, e2, n)
-    Vec3     normals[3];
+    Vec3     normals[3];                  // Primitives.h:62
+    Vec3     tangents[3];                 // Primitives.h:63
     Vec2     uvs[3];
     float    alphas[3] = {1, 1, 1};
     bool     oneSided = false;            // Primitives.h:57 (world brushes: AccelStruct.cpp:408-410)

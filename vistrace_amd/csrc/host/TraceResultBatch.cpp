@@ -30,6 +30,12 @@ const vt_hit_shade* TraceResultBatch::Shade()
     return vt_batch_shade(mBatch, &p) == VT_OK ? p : nullptr;
 }
 
+const vt_hit_tbn* TraceResultBatch::Tbn()
+{
+    const vt_hit_tbn* p = nullptr;
+    return vt_batch_tbn(mBatch, &p) == VT_OK ? p : nullptr;
+}
+
 const Entity& TraceResultBatch::EntityOf(const vt_hit& h) const
 {
     static const Entity kNoEntity{};

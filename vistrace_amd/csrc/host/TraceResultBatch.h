@@ -5,7 +5,7 @@
 // calls and N allocations on the host around a trace that takes a fraction of a millisecond per million rays.  Here
 // the batch stays where it was traced (vt_batch, include/vistrace_hip.h): hit records, the TraceResult core
 // (Pos, Distance, GeometricNormal, Barycentric, Incident, FrontFacing: vt_hit_attrs) and the shading part (TextureUV,
-// blend factor, entity id, material: vt_hit_shade) are materialised by device kernels, and a getter downloads the one
+// blend factor, entity id, material: vt_hit_shade; Normal, Tangent, Binormal: vt_hit_tbn) are materialised by device kernels, and a getter downloads the one
 // array it reads on first use.  Getters mirror TraceResult's, with the ray's 1-based index as their argument.
 #pragma once
 
@@ -34,6 +34,7 @@ public:
     const vt_hit*       Hits();
     const vt_hit_attrs* Attrs();
     const vt_hit_shade* Shade();
+    const vt_hit_tbn*   Tbn();                          // shading frame (no normal map), cone off
     const SceneTables&  Tables() const { return *mTables; }
     // the triangle / entity / material behind hit i (i must be a hit)
     const Triangle& TriangleOf(const vt_hit& h) const { return mTables->triangles[h.prim]; }

@@ -363,6 +363,29 @@ def rig_pose(nmat: int, frame: int, seed: int = SEED + 10):
     return cm(bone), cm(bind)
 
 
+def vertex_frames(verts: np.ndarray, seed: int = SEED + 12, bend: float = 0.35):
+    """Seeded per-vertex shading frames for triangles (n,3,3): normals = the face normal bent by up to ~`bend` rad per vertex
+    (as a smoothed mesh has them), tangents = a seeded direction made perpendicular to the vertex normal; unit length in fp32
+    up to rounding, a few triangles with un-normalised vectors (the reference takes the mesh's as they come).
+    Returns an (n,) structured array compatible with TRI_FRAME."""
+    rng = np.random.default_rng(seed)
+    n = len(verts)
+    v = np.asarray(verts, np.float64).reshape(n, 3, 3)
+    face = np.cross(v[:, 0] - v[:, 1], v[:, 2] - v[:, 0])                       # Primitives.h:95 cross(e1, e2)
+    ln = np.linalg.norm(face, axis=1, keepdims=True)
+    face = np.where(ln > 0, face / np.where(ln > 0, ln, 1), np.array([0.0, 0.0, 1.0]))
+    nrm = face[:, None, :] + rng.normal(scale=bend, size=(n, 3, 3))
+    nrm /= np.linalg.norm(nrm, axis=2, keepdims=True)
+    tan = rng.normal(size=(n, 3, 3))
+    tan -= nrm * (tan * nrm).sum(axis=2, keepdims=True)
+    tan /= np.linalg.norm(tan, axis=2, keepdims=True)
+    scale = np.where(rng.random((n, 1, 1)) < 0.02, rng.uniform(0.25, 4.0, (n, 1, 1)), 1.0)
+    out = np.zeros(n, np.dtype([("normal", "<f4", (3, 3)), ("tangent", "<f4", (3, 3))]))
+    out["normal"] = (nrm * scale).astype(np.float32)
+    out["tangent"] = (tan * scale).astype(np.float32)
+    return out
+
+
 def alpha_test_rig(ntris: int, nmats: int = 6, alpha_fraction: float = 0.4, seed: int = SEED + 11):
     """Seeded alpha-test inputs: (flags u8 with bit 1 = VT_TRI_ALPHATEST on ~alpha_fraction of the triangles,
     TRI_ATTRIBS-compatible array with uvs + material, ALPHA_MATERIAL-compatible array, texels u8).
