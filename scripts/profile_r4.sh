@@ -28,4 +28,5 @@ python3 scripts/merged_launch_rate.py > $OUT/merged_s100k_primary.txt 2>&1
 python3 scripts/merged_launch_rate.py --scene S1M --side 512 > $OUT/merged_s1m_primary_512.txt 2>&1
 python3 scripts/merged_launch_rate.py --scene S1M --side 1024 --kind bounce > $OUT/merged_s1m_bounce_1024.txt 2>&1
 timeout 300 tests/cpp/_build/test_binding --bench > $OUT/binding_bench.txt 2>&1
+timeout 300 python3 scripts/shading_frame_rate.py 2>&1 | grep -vE 'RCCL|NCCL|amdgpu.ids' > $OUT/shading_frame.txt
 head -4 $OUT/kernel_stats.csv | cut -c1-200

@@ -87,33 +87,39 @@ __global__ __launch_bounds__(kBlockThreads) void hit_tbn_kernel(HitTbnArgs a)
 }
 
 // SkinTriangle's normals and tangents (AccelStruct.cpp:82-92): TransformToBone with angleOnly = true -- the vertex is (vec, 0);
-// the matrices are the per-frame products skin_matrices_kernel has just formed.  One thread per triangle.
+// the matrices are the per-frame products skin_matrices_kernel has just formed.  One thread per VERTEX (its normal and its
+// tangent share bones and weights), matrix columns fetched as four 16-B loads per bone: the kernel is bound by the vector L1's
+// gather rate on the 128-KB matrix table, not by the 144 MB of frames it streams (one thread per vector with scalar matrix
+// loads: 97 us for 1 M triangles).
 __global__ __launch_bounds__(kBlockThreads) void skin_frames_kernel(SkinFramesArgs a)
 {
-    const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
-    if (i >= a.n) return;
-    const vt_tri_frame B = a.bind[i];
-    vt_tri_frame o;
-    const uint32_t base = a.matrix_base[i];
-    for (int vi = 0; vi < 3; ++vi) {
-        const vt_skin_vertex sv = a.skin[size_t(i) * 3 + vi];
-        float fn[3] = {0.f, 0.f, 0.f}, ft[3] = {0.f, 0.f, 0.f};
-        for (uint32_t q = 0; q < sv.num_bones && q < 3u; ++q) {
-            uint32_t mi = base + uint32_t(int(sv.bone[q]));
-            mi = mi < a.nmat ? mi : 0u;                            // as skin_tris_kernel: stay inside the table
-            const float* M = a.mats + size_t(mi) * 16;
-            for (int r = 0; r < 3; ++r) {
-                const float n0 = M[r] * B.normal[vi][0] + M[4 + r] * B.normal[vi][1];
-                const float n1 = M[8 + r] * B.normal[vi][2] + M[12 + r] * 0.f;
-                fn[r] = fn[r] + (n0 + n1) * sv.weight[q];
-                const float t0 = M[r] * B.tangent[vi][0] + M[4 + r] * B.tangent[vi][1];
-                const float t1 = M[8 + r] * B.tangent[vi][2] + M[12 + r] * 0.f;
-                ft[r] = ft[r] + (t0 + t1) * sv.weight[q];
-            }
+    const uint64_t j = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
+    if (j >= uint64_t(a.n) * 3) return;
+    const uint32_t tri = uint32_t(j / 3), vi = uint32_t(j % 3);
+    const float* nsrc = reinterpret_cast<const float*>(a.bind) + size_t(tri) * 18 + vi * 3;
+    const float n0 = nsrc[0], n1 = nsrc[1], n2 = nsrc[2];
+    const float t0 = nsrc[9], t1 = nsrc[10], t2 = nsrc[11];
+    const vt_skin_vertex sv = a.skin[j];
+    const uint32_t base = a.matrix_base[tri];
+    float fn[3] = {0.f, 0.f, 0.f}, ft[3] = {0.f, 0.f, 0.f};
+    for (uint32_t q = 0; q < sv.num_bones && q < 3u; ++q) {
+        uint32_t mi = base + uint32_t(int(sv.bone[q]));
+        mi = mi < a.nmat ? mi : 0u;                            // as skin_tris_kernel: stay inside the table
+        const float4* M = reinterpret_cast<const float4*>(a.mats + size_t(mi) * 16);
+        const float4 c0 = M[0], c1 = M[1], c2 = M[2], c3 = M[3];
+        const float m0[3] = {c0.x, c0.y, c0.z}, m1[3] = {c1.x, c1.y, c1.z}, m2[3] = {c2.x, c2.y, c2.z}, m3[3] = {c3.x, c3.y, c3.z};
+        for (int r = 0; r < 3; ++r) {
+            const float a0 = m0[r] * n0 + m1[r] * n1;
+            const float a1 = m2[r] * n2 + m3[r] * 0.f;
+            fn[r] = fn[r] + (a0 + a1) * sv.weight[q];
+            const float b0 = m0[r] * t0 + m1[r] * t1;
+            const float b1 = m2[r] * t2 + m3[r] * 0.f;
+            ft[r] = ft[r] + (b0 + b1) * sv.weight[q];
         }
-        for (int r = 0; r < 3; ++r) { o.normal[vi][r] = fn[r]; o.tangent[vi][r] = ft[r]; }
     }
-    a.out[i] = o;
+    float* dst = reinterpret_cast<float*>(a.out) + size_t(tri) * 18 + vi * 3;
+    dst[0] = fn[0]; dst[1] = fn[1]; dst[2] = fn[2];
+    dst[9] = ft[0]; dst[10] = ft[1]; dst[11] = ft[2];
 }
 
 hipError_t launch_hit_tbn(vt_scene* s, const void* d_rays, const void* d_hits, uint64_t n, float cone_width, float cone_angle,
@@ -132,7 +138,8 @@ hipError_t skin_frames(vt_scene* s, const float* d_prod, uint32_t nmat, hipStrea
 {
     if (!s->d_frames_bind) return hipSuccess;
     SkinFramesArgs a{s->d_frames_bind, s->d_skin, s->d_matrix_base, d_prod, s->d_frames, s->ntris, nmat};
-    hipLaunchKernelGGL(skin_frames_kernel, dim3((s->ntris + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, stream, a);
+    const uint64_t vertices = uint64_t(s->ntris) * 3;
+    hipLaunchKernelGGL(skin_frames_kernel, dim3(uint32_t((vertices + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream, a);
     return hipGetLastError();
 }
 
