@@ -133,6 +133,30 @@ for seed in range(first, first + count):
         if not ok:
             bad += 1
             print(f"MISMATCH seed {seed} mode {mode} n {n} m {m}", flush=True)
+    if seed % 5 == 2 and rig is None and not poisoned:        # round 4: the shading frame of every hit (CalcTBN without a normal map + CalcFootprint)
+        from vistrace_amd import workloads as W
+        attribs = np.zeros(n, va.TRI_ATTRIBS)
+        attribs["uv"] = rng.uniform(-4, 4, (n, 3, 2)).astype(np.float32)
+        frames = W.vertex_frames(verts, seed).view(va.TRI_FRAME)
+        scene.set_tri_attribs(attribs)
+        scene.set_tri_frames(frames)
+        cone = (float(rng.uniform(0, 1)), float(rng.uniform(1e-4, 0.05))) if seed % 2 else (-1.0, -1.0)
+        d_rays = tp.to_device(rays, dev)
+        d_hits = tp.trace_closest(scene, d_rays, m)
+        d_tbn = tp.empty_records(m, va.HIT_TBN, dev)
+        scene.hit_tbn_dev(d_rays.data_ptr(), d_hits.data_ptr(), m, d_tbn.data_ptr(), cone[0], cone[1], tp.current_stream_handle(dev))
+        torch.cuda.synchronize()
+        got = tp.to_host(d_tbn, va.HIT_TBN)
+        exp = O.hit_tbn(otris, rays, ref, frames.view(np.float32).reshape(-1, 18), attribs["uv"].reshape(-1, 6), cone[0], cone[1])
+        same = lambda a, b: ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()     # NaN payloads may differ
+        ok = all(same(got[k], exp[k]) for k in ("normal", "tangent", "binormal")) and same(got["lod_info"][:, 1], exp["lod_info"][:, 1])
+        ok = ok and (got["lod_set"] == exp["lod_set"]).all()
+        la, lb = got["lod_info"][:, 0], exp["lod_info"][:, 0]
+        fin = np.isfinite(lb)
+        ok = ok and (np.abs(la[fin] - lb[fin]) <= 4e-6 + 2e-6 * np.abs(lb[fin])).all() and same(la[~fin], lb[~fin])
+        if not ok:
+            bad += 1
+            print(f"SHADING FRAME MISMATCH seed {seed} n {n} m {m}", flush=True)
     if seed % 5 == 1 and rig is None and not poisoned:                         # device refit against the host pipeline, then trace parity
         moved = (verts + rng.normal(scale=0.05 * spread, size=verts.shape)).astype(np.float32)
         scene.refit(moved, flags)
