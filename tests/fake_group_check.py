@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Child process of tests/test_gpu_fake_group.py: the N > 1 control flow of the product on ONE GPU.
+
+Environment (set by the test): VT_RCCL_LIB = tests/cpp/_build/libfake_rccl.so (a test double: transfers between ranks are
+stream-ordered device copies, see tests/cpp/fake_rccl.cpp) and VT_TEST_ALLOW_DEVICE_ALIASES=1 (device 0 stands for every member
+of a group).  Everything else is the shipped library: vt_engine_open_multi, scene replication, the per-device host threads,
+vt_trace_closest_gather_dev's schedule (double-buffered send buffers, K pieces per batch), and the one-process-per-GPU form
+(vt_engine_comm_init_rank + vt_gather_hits[_part]_dev) with one thread per rank as bench.py --gpus N runs one process per rank.
+Every result is compared with the CPU oracle bit for bit.  Prints "fake group: ok ..." and exits 0, or raises."""
+import os
+import sys
+import threading
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+assert os.environ.get("VT_RCCL_LIB", "").endswith("libfake_rccl.so") and os.environ.get("VT_TEST_ALLOW_DEVICE_ALIASES") == "1"
+import vistrace_amd as va
+from oracle import binding as O
+from vistrace_amd import torch_plumbing as tp
+from vistrace_amd import workloads as W
+
+dev = torch.device("cuda", 0)
+verts = np.ascontiguousarray(W.make_scene("S10k"), np.float32)
+tris = va.tris_setup(verts)
+bvh = va.HostBvh(tris)
+host_scene = va.HostScene(bvh)
+otris = O.tris_from_tri64(tris)
+
+
+def oracle(rays):
+    return O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays)[0]
+
+
+def same(got, ref):
+    return bool((got.view(np.uint8) == ref.view(np.uint8)).all())
+
+
+checks = 0
+
+# ---- one process, N devices: vt_engine_open_multi + vt_trace_closest_gather_dev -------------------------------------------------
+n = 300_007                                   # ragged: shards of different sizes, the last one short of its capacity
+NB = 5                                        # batches in flight back to back, each with its OWN rays: a send buffer that is
+batch_rays = [W.sphere_rays(n, 5 + j, origin=(4.0 - j, 5.0, 6.0 + j)) for j in range(NB)]   # reused too early shows as a mismatch
+batch_ref = [oracle(r) for r in batch_rays]
+rays, ref = batch_rays[0], batch_ref[0]
+for ndev in (2, 3, 4, 8):
+    eng = va.Engine([0] * ndev)
+    assert eng.device_count == ndev
+    eng.set_option("persistent", 1 if ndev in (3, 8) else 2)      # persistent waves on the small shards too
+    scene = va.Scene(eng, host_scene)         # replicated to every member
+    cap = va.shard_capacity(n, ndev)
+    shards, ptrs = [], []
+    for j in range(NB):
+        per_dev = []
+        for g in range(ndev):
+            lo, hi = va.shard_bounds(n, ndev, g)
+            per_dev.append(tp.to_device(batch_rays[j][lo:hi], dev) if hi > lo else None)
+        shards.append(per_dev)
+        ptrs.append([s.data_ptr() if s is not None else 0 for s in per_dev])
+    outs = [torch.zeros(ndev * cap * 16, dtype=torch.uint8, device=dev) for _ in range(NB)]
+    for K in (1, 2, 4, 3):
+        eng.set_option("gather_chunks", K)
+        for o in outs:
+            o.fill_(0xEE)
+        for j, o in enumerate(outs):           # five batches back to back: both send buffers of every peer are reused
+            scene.trace_closest_gather_dev(ptrs[j], n, o.data_ptr())
+        eng.synchronize()
+        for j, o in enumerate(outs):
+            assert same(tp.to_host(o[: n * 16], va.HIT), batch_ref[j]), f"gather_dev ndev {ndev} K {K} batch {j}"
+            checks += 1
+    # with room reserved for a collective's kernels beside the persistent grids
+    eng.set_option("gather_chunks", 2)
+    eng.set_option("reserved_cus", 32)
+    outs[0].fill_(0xEE)
+    scene.trace_closest_gather_dev(ptrs[0], n, outs[0].data_ptr())
+    eng.synchronize()
+    assert same(tp.to_host(outs[0][: n * 16], va.HIT), ref), f"gather_dev reserved CUs ndev {ndev}"
+    eng.set_option("reserved_cus", 0)
+    checks += 1
+    # host rays: one staging pipeline per member, side by side on their own threads (needs >= 1 Mi rays)
+    if ndev in (2, 4):
+        big = W.sphere_rays((1 << 20) + 4099, 9, origin=(-3.0, 2.0, 1.0))
+        big_ref = oracle(big)
+        assert same(scene.trace_closest(big), big_ref), f"host rays ndev {ndev}"
+        assert (scene.trace_any(big) == (big_ref["prim"] != O.MISS)).all()
+        checks += 2
+    scene.free()
+    eng.close()
+
+# ---- one engine per rank, one thread per rank: vt_engine_comm_init_rank + vt_gather_hits[_part]_dev -------------------------------
+for nranks in (2, 4):
+    uid = va.comm_unique_id()
+    cap = va.shard_capacity(n, nranks)
+    recv = [torch.zeros(nranks * cap * 16, dtype=torch.uint8, device=dev) for _ in range(4)]    # one receive buffer per batch, two send buffers per rank
+    errors = []
+    barrier = threading.Barrier(nranks)
+
+    def rank_main(rank):
+        try:
+            eng = va.Engine(0)
+            eng.comm_init_rank(nranks, rank, uid)
+            eng.set_option("reserved_cus", 32)
+            scene = va.Scene(eng, host_scene)
+            lo, hi = va.shard_bounds(n, nranks, rank)
+            d_batch = [tp.to_device(batch_rays[j][lo:hi], dev) for j in range(4)]
+            stream = torch.cuda.Stream(dev)
+            sh = stream.cuda_stream
+            send = [torch.zeros(cap * 16, dtype=torch.uint8, device=dev) for _ in range(2)]
+            torch.cuda.synchronize()
+            for K in (1, 4, 2):
+                for batch in range(4):
+                    k = batch % 2
+                    d_rays = d_batch[batch]
+                    eng.gather_wait(1, sh)                                 # the gather of two batches ago has read send[k]
+                    for c in range(K):
+                        clo, chi = va.gather_chunk_bounds(cap, K, c)
+                        m = min(chi, hi - lo) - clo
+                        if m > 0:
+                            scene.trace_closest_dev(d_rays.data_ptr() + 32 * clo, m, send[k].data_ptr() + 16 * clo, sh)
+                        if K == 1:
+                            eng.gather_hits_dev(send[k].data_ptr(), cap, recv[batch].data_ptr() if rank == 0 else 0, 0, sh)
+                        else:
+                            eng.gather_hits_part_dev(send[k].data_ptr(), cap, c, K, recv[batch].data_ptr() if rank == 0 else 0, 0, sh)
+                eng.gather_wait(0)
+                torch.cuda.synchronize()
+                barrier.wait()
+                if rank == 0:
+                    for j in range(4):
+                        if not same(tp.to_host(recv[j][: n * 16], va.HIT), batch_ref[j]):
+                            errors.append(f"per-rank gather nranks {nranks} K {K} batch {j}")
+                        recv[j].fill_(0xEE)
+                    torch.cuda.synchronize()
+                barrier.wait()
+            scene.free()
+            eng.close()
+        except Exception as exc:                                            # noqa: BLE001
+            errors.append(f"rank {rank}: {exc!r}")
+            barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+        assert not t.is_alive(), "a rank thread hangs"
+    assert not errors, errors
+    checks += 12
+
+print(f"fake group: ok, {checks} checks")
