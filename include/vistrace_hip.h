@@ -211,10 +211,12 @@ void     vt_shard_bounds(uint64_t n, int ndev, int g, uint64_t* lo, uint64_t* hi
  * buffer belongs to the engine -- the root device traces straight into its first `capacity` records (ncclGather in
  * place) and the other shards arrive later.  To overlap batches pass a DIFFERENT buffer to the next call (alternate two)
  * and consume a buffer only after a synchronisation that covers its batch; passing the same buffer again lets batch
- * b + 1 overwrite shard 0 while batch b is still arriving.
- * STATUS: experimental for ndev > 1 -- exercised on hardware with one device per group only (no multi-GPU node was
- * available); the order of traces, waits and gathers is the one tests/cpp/test_gather_schedule.cpp checks on a
- * simulated group of 2, 4 and 8 devices (vistrace_amd/csrc/gather_schedule.h).  The engine must come from
+ * b + 1 overwrite shard 0 while batch b is still arriving.  The engines' streams are not ordered against the caller's: what
+ * produced d_rays and whatever last wrote d_hits_root (a memset on another stream, say) must have COMPLETED before the call.
+ * STATUS: experimental for ndev > 1 -- no multi-GPU node was available.  Exercised: one device per group with real RCCL; groups
+ * of 2 - 8 members on one GPU against a test double for RCCL (tests/test_gpu_fake_group.py: every step below runs, the transfers
+ * are stream-ordered device copies); the order of traces, waits and gathers on a simulated group
+ * (tests/cpp/test_gather_schedule.cpp, vistrace_amd/csrc/gather_schedule.h).  The engine must come from
  * vt_engine_open_multi: an engine whose communicator was made by vt_engine_comm_init_rank is refused. */
 int vt_trace_closest_gather_dev(vt_scene* s, const void* const* d_rays, uint64_t n, void* d_hits_root);
 /* One process per GPU (e.g. under torch.distributed.run): the same gather with one communicator per process.

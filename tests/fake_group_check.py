@@ -34,15 +34,23 @@ def oracle(rays):
 
 
 def same(got, ref):
-    return bool((got.view(np.uint8) == ref.view(np.uint8)).all())
+    eq = (got.view(np.uint8).reshape(-1, 16) == ref.view(np.uint8).reshape(-1, 16)).all(axis=1)
+    if not eq.all():                           # where: runs of differing records
+        bad = np.nonzero(~eq)[0]
+        cuts = np.nonzero(np.diff(bad) > 1)[0]
+        runs = [(int(a), int(b) + 1) for a, b in zip(np.concatenate([[bad[0]], bad[cuts + 1]]), np.concatenate([bad[cuts], [bad[-1]]]))]
+        print(f"mismatch: {len(bad)} of {len(eq)} records differ, runs {runs[:12]}{' ...' if len(runs) > 12 else ''}; first got {got[bad[0]]} expected {ref[bad[0]]}", flush=True)
+    return bool(eq.all())
 
 
 checks = 0
+ROUND = int(os.environ.get("FAKE_GROUP_ROUND", "0"))      # scripts/fake_group_soak.sh: other sizes and rays per round
+rng = np.random.default_rng(1000 + ROUND)
 
 # ---- one process, N devices: vt_engine_open_multi + vt_trace_closest_gather_dev -------------------------------------------------
-n = 300_007                                   # ragged: shards of different sizes, the last one short of its capacity
+n = 300_007 if ROUND == 0 else int(rng.integers(5_000, 700_000))   # ragged: shards of different sizes, the last one short of its capacity
 NB = 5                                        # batches in flight back to back, each with its OWN rays: a send buffer that is
-batch_rays = [W.sphere_rays(n, 5 + j, origin=(4.0 - j, 5.0, 6.0 + j)) for j in range(NB)]   # reused too early shows as a mismatch
+batch_rays = [W.sphere_rays(n, 5 + j + 10 * ROUND, origin=(4.0 - j, 5.0, 6.0 + j)) for j in range(NB)]   # reused too early shows as a mismatch
 batch_ref = [oracle(r) for r in batch_rays]
 rays, ref = batch_rays[0], batch_ref[0]
 for ndev in (2, 3, 4, 8):
@@ -64,16 +72,20 @@ for ndev in (2, 3, 4, 8):
         eng.set_option("gather_chunks", K)
         for o in outs:
             o.fill_(0xEE)
+        torch.cuda.synchronize()               # the fills run on torch's stream, the group on the engines' own streams
         for j, o in enumerate(outs):           # five batches back to back: both send buffers of every peer are reused
             scene.trace_closest_gather_dev(ptrs[j], n, o.data_ptr())
         eng.synchronize()
         for j, o in enumerate(outs):
-            assert same(tp.to_host(o[: n * 16], va.HIT), batch_ref[j]), f"gather_dev ndev {ndev} K {K} batch {j}"
+            if not same(tp.to_host(o[: n * 16], va.HIT), batch_ref[j]):
+                print(f"n {n} ndev {ndev} cap {cap} K {K} batch {j}; shards {[va.shard_bounds(n, ndev, g) for g in range(ndev)]}; pieces {[va.gather_chunk_bounds(cap, K, c) for c in range(K)]}", flush=True)
+                raise AssertionError(f"gather_dev ndev {ndev} K {K} batch {j}")
             checks += 1
     # with room reserved for a collective's kernels beside the persistent grids
     eng.set_option("gather_chunks", 2)
     eng.set_option("reserved_cus", 32)
     outs[0].fill_(0xEE)
+    torch.cuda.synchronize()
     scene.trace_closest_gather_dev(ptrs[0], n, outs[0].data_ptr())
     eng.synchronize()
     assert same(tp.to_host(outs[0][: n * 16], va.HIT), ref), f"gather_dev reserved CUs ndev {ndev}"
@@ -148,4 +160,4 @@ for nranks in (2, 4):
     assert not errors, errors
     checks += 12
 
-print(f"fake group: ok, {checks} checks")
+print(f"fake group: ok, {checks} checks (round {ROUND}, {n} rays per batch)")

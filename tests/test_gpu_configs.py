@@ -283,6 +283,8 @@ def test_multi_gpu_abi_with_one_device(va, make_bundle):
         assert eng.get_option("gather_chunks") == K
         for o in outs:
             o.zero_()
+        torch.cuda.synchronize()               # zero_ runs on torch's stream, the group on the engine's own
+        for o in outs:
             scene.trace_closest_gather_dev([d_rays.data_ptr()], n, o.data_ptr())
         eng.synchronize()
         for o in outs:
@@ -292,6 +294,7 @@ def test_multi_gpu_abi_with_one_device(va, make_bundle):
     # the diagnostic mode (no overlap) falls back to one piece per batch
     eng.set_option("gather_overlap", 0)
     outs[0].zero_()
+    torch.cuda.synchronize()
     scene.trace_closest_gather_dev([d_rays.data_ptr()], n, outs[0].data_ptr())
     eng.synchronize()
     assert bool((outs[0][: n * 16] == whole).all())
