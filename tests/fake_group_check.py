@@ -126,15 +126,18 @@ for nranks in (2, 4):
                     k = batch % 2
                     d_rays = d_batch[batch]
                     eng.gather_wait(1, sh)                                 # the gather of two batches ago has read send[k]
+                    # 4 ranks: the root traces straight into its slice of the result, as bench.py's NativeGather does (in place:
+                    # d_send == d_recv_root + root * count records, no local copy); 2 ranks: from a send buffer of its own
+                    mine = recv[batch] if (rank == 0 and nranks == 4) else send[k]
                     for c in range(K):
                         clo, chi = va.gather_chunk_bounds(cap, K, c)
                         m = min(chi, hi - lo) - clo
                         if m > 0:
-                            scene.trace_closest_dev(d_rays.data_ptr() + 32 * clo, m, send[k].data_ptr() + 16 * clo, sh)
+                            scene.trace_closest_dev(d_rays.data_ptr() + 32 * clo, m, mine.data_ptr() + 16 * clo, sh)
                         if K == 1:
-                            eng.gather_hits_dev(send[k].data_ptr(), cap, recv[batch].data_ptr() if rank == 0 else 0, 0, sh)
+                            eng.gather_hits_dev(mine.data_ptr(), cap, recv[batch].data_ptr() if rank == 0 else 0, 0, sh)
                         else:
-                            eng.gather_hits_part_dev(send[k].data_ptr(), cap, c, K, recv[batch].data_ptr() if rank == 0 else 0, 0, sh)
+                            eng.gather_hits_part_dev(mine.data_ptr(), cap, c, K, recv[batch].data_ptr() if rank == 0 else 0, 0, sh)
                 eng.gather_wait(0)
                 torch.cuda.synchronize()
                 barrier.wait()
