@@ -974,3 +974,74 @@ def test_page_locked_host_arrays_skip_the_staging(va, engine, make_bundle):
         va.host_unregister(hits)
     assert_hits_equal(staged[:30000], b.oracle(rays[:30000]))
     scene.free()
+
+
+@pytest.mark.parametrize("with_alpha", [False, True])
+def test_records_beyond_4_gib(va, engine, O, with_alpha):
+    """Maximum sizes: a scene whose triangle records (and AlphaRecs) lie beyond 4 GiB.  Building one takes 45 M triangles; the
+    upload's test hook VT_TEST_RECORD_GAP leaves an unused gap of 2^26 records (4 GiB) between the pairs and the triangles of a
+    10 k-triangle scene instead, which moves every triangle fetch, the refit's record writes, the TraceResult kernels' reads and
+    the AlphaRec table past the 32-bit byte offsets the DMA-fetch kernel uses -- so the engine must pick the kernels that form
+    64-bit addresses, and their results must not change: hits, any-hit, counters, hit attributes, device refit."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    verts = W.make_scene("S10k")
+    n = len(verts)
+    flags = None
+    if with_alpha:
+        flags, attribs, mats, texels = W.alpha_test_rig(n)
+    tris = va.tris_setup(verts, flags)
+    bvh = va.HostBvh(tris)
+    host_scene = va.HostScene(bvh)
+    os.environ["VT_TEST_RECORD_GAP"] = str((1 << 26) + 1000)
+    try:
+        scene = va.Scene(engine, host_scene)
+    finally:
+        del os.environ["VT_TEST_RECORD_GAP"]
+    assert scene.device_bytes > (1 << 32)
+    otris = O.tris_from_tri64(tris)
+    rays = np.concatenate([W.primary_rays(96, 96), W.sphere_rays(30000, 41, origin=(-120.0, 80.0, 15.0))])
+    try:
+        if with_alpha:
+            scene.set_tri_attribs(attribs.view(va.TRI_ATTRIBS))
+            scene.set_alpha(mats.view(va.ALPHA_MATERIAL), texels)
+            O.set_alpha(otris, attribs["uv"].reshape(n, 6), attribs["material"], mats.view(O.ALPHA_MATERIAL), texels)
+        ref, ref_st, _, _, _ = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays, want_stats=True)
+        any_ref = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays, any_hit=True)[0]
+    finally:
+        O.set_alpha()
+    saved = {k: engine.get_option(k) for k in ("persistent", "fetch_dma")}
+    try:
+        for cfg in (dict(persistent=0), dict(persistent=1, fetch_dma=1), dict(persistent=2)):
+            for k, v in cfg.items():
+                engine.set_option(k, v)
+            assert_hits_equal(scene.trace_closest(rays), ref)
+            if cfg.get("persistent") == 1:
+                assert engine.get_option("last_persistent") == 1 and engine.get_option("last_fetch_dma") == 0, "DMA fetch beyond 4 GiB"
+            assert (scene.trace_any(rays) == (any_ref["prim"] != O_MISS)).all()
+            got, st = stats_on_device(va, scene, rays)
+            assert_hits_equal(got, ref)
+            assert (st["steps"] == ref_st[:, 0]).all() and (st["tests"] == ref_st[:, 1]).all()
+    finally:
+        for k, v in saved.items():
+            engine.set_option(k, v)
+    # the records are where the gap says, and the TraceResult kernel reads them there
+    pairs, dtris = scene.read_records()
+    assert (dtris.view(np.uint8) == host_scene.tris().view(np.uint8)).all() and (pairs.view(np.uint8) == host_scene.pairs().view(np.uint8)).all()
+    dev = torch.device("cuda", 0)
+    d_rays = tp.to_device(rays, dev)
+    d_hits = tp.trace_closest(scene, d_rays, len(rays))
+    attrs = tp.to_host(tp.hit_attrs(scene, d_rays, d_hits, len(rays)), va.HIT_ATTRS)
+    oa = O.hit_attrs(otris, rays, ref)
+    hit = ref["prim"] != O_MISS
+    assert np.allclose(attrs["pos"][hit], oa["pos"][hit], rtol=REL_TOL, atol=1e-4) and (attrs["hit"] == hit).all()
+    if not with_alpha:
+        # device refit writes the moved triangles' records beyond 4 GiB too
+        moved = (verts + np.float32(0.125)).astype(np.float32)
+        scene.refit(moved)
+        mtris = va.tris_setup(moved)
+        bvh.refit(mtris)
+        ref2 = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(mtris), rays)[0]
+        assert_hits_equal(scene.trace_closest(rays), ref2)
+    scene.free()

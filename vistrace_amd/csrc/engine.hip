@@ -649,9 +649,14 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
 
     // Record layout: pairs first, triangles behind them on a 128-B boundary.
     hipError_t err = hipSuccess;
-    if (uint64_t(s->npairs) + 2 * uint64_t(s->ntris) + 4 >= 0xFFFFFFFFull) { delete s; return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: scene too large"); }
+    // (test hook: VT_TEST_RECORD_GAP=<records> leaves that many unused records between the pairs and the triangles, so that a
+    // small scene has triangle and AlphaRec records beyond 4 GiB -- the 64-bit addressing and the kernel choice of scenes with
+    // more than 67 M records, without building one: tests/test_gpu_configs.py)
+    uint64_t gap = 0;
+    if (const char* env = std::getenv("VT_TEST_RECORD_GAP")) gap = std::strtoull(env, nullptr, 10) & ~uint64_t(1);
+    if (uint64_t(s->npairs) + gap + 2 * uint64_t(s->ntris) + 4 >= 0xFFFFFFFFull) { delete s; return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: scene too large"); }
     {
-        s->tri_base = (s->npairs + 1u) & ~1u;
+        s->tri_base = ((s->npairs + 1u) & ~1u) + uint32_t(gap);
         const size_t pair_bytes = hs.pairs.size() * sizeof(vt_node_pair);
         const size_t tri_off = size_t(s->tri_base) * 64, tri_bytes = hs.tris.size() * sizeof(vt_tri64);
         // a scene with alpha-tested triangles keeps one AlphaRec per triangle slot behind the triangles (filled once
