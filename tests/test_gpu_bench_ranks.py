@@ -1,0 +1,49 @@
+"""bench.py with more than one rank on the one-GPU box: its N > 1 control flow (rendezvous, ray sharding, per-rank scene build,
+the chunked double-buffered trace -> gather pipeline, barrier + max-over-ranks timing, rank 0's single JSON line) under
+torch.distributed.run exactly as the driver launches it -- with `--backend gloo`, bench.py's test mode in which every rank uses
+device 0 and the hit records travel through torch.distributed.gather over host memory.  The native RCCL gather of the real
+N > 1 run (vt_gather_hits_dev) is exercised with one rank in test_native_gather_single_rank and with 2 - 8 ranks against the test
+double in tests/test_gpu_fake_group.py; what only a multi-GPU node can add are RCCL's kernels and the links."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(nranks, extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--no-cpu", "--no-pmc", "--alt-builder", "none", "--legs", "off"] + extra
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line"
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_weak_scaling_line_with_several_ranks(nranks):
+    d = _run(nranks, ["--side", "512"])
+    assert d["n_gpus"] == nranks and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["config"]["rays_per_gpu"] == 512 * 512 and d["config"]["rays_total"] == nranks * 512 * 512
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["rays_total"] / d["ms_per_step"] / 1e3) <= 1e-2 * d["value"]
+    assert d["vs_baseline"] is None and d["unit"] == "Mrays/s" and "gather" in json.dumps(d["config"])
+
+
+def test_strong_scaling_line_with_two_ranks():
+    """configs[4]'s shape (camera tiles split over the ranks) on a small scene."""
+    d = _run(2, ["--scaling", "strong", "--scene", "S100k", "--tiles", "4"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rays_total"] == 4 * 1024 * 1024 and d["value"] > 0
