@@ -74,3 +74,11 @@ def test_plain_c_batch_sets_on_gpu():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
     out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "_build", "trace_sets")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_shading_frame_on_gpu():
+    """examples/shading_frame.c: vertex frames, vt_batch_tbn and frames that follow a bone, from plain C."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "_build", "shading_frame")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
