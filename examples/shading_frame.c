@@ -42,8 +42,9 @@ int main(void)
     CHECK(vt_scene_upload(eng, hs, &scene));
     vt_bvh_free(bvh);
 
-    /* side tables: uvs (the triangle's lod is derived from them) and the vertex frames -- normals lean outwards along x as on a
-     * gently curved panel: (-0.6, 0, 0.8) on the x = 0 edge, (+0.6, 0, 0.8) on the x = 2 edge; tangents perpendicular to them */
+    /* side tables: uvs (only the cone footprint needs them: the triangle's lod is derived from the uvs) and the vertex frames --
+     * normals lean outwards along x as on a gently curved panel: (-0.6, 0, 0.8) on the x = 0 edge, (+0.6, 0, 0.8) on the
+     * x = 2 edge; tangents perpendicular to them */
     vt_tri_attribs attribs[2];
     vt_tri_frame frames[2];
     memset(attribs, 0, sizeof attribs);

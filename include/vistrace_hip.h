@@ -357,7 +357,7 @@ int      vt_batch_rays(vt_batch* b, const vt_ray** rays);     /* the rays as upl
 int      vt_batch_hits(vt_batch* b, const vt_hit** hits);
 int      vt_batch_attrs(vt_batch* b, const vt_hit_attrs** attrs);
 int      vt_batch_shade(vt_batch* b, const vt_hit_shade** shade);     /* VT_ERR_INVALID_ARG without vt_scene_set_tri_attribs */
-int      vt_batch_tbn(vt_batch* b, const vt_hit_tbn** tbn);           /* VT_ERR_INVALID_ARG without vt_scene_set_tri_frames + _attribs; cone off */
+int      vt_batch_tbn(vt_batch* b, const vt_hit_tbn** tbn);           /* VT_ERR_INVALID_ARG without vt_scene_set_tri_frames; cone off */
 void     vt_batch_free(vt_batch* b);
 
 /* Launch configuration (also readable from VT_* environment variables at vt_engine_open).  Keys:
@@ -499,7 +499,7 @@ int vt_hit_shade_dev(vt_scene* s, const void* d_hits, uint64_t n, void* d_out, v
  * (vt_scene_set_skin) these are the BIND-pose frames: every vt_scene_skin_refit also moves them by TransformToBone with
  * angleOnly = true (source/objects/AccelStruct.cpp:82-92), as SkinTriangle does. */
 int vt_scene_set_tri_frames(vt_scene* s, const vt_tri_frame* frames, uint32_t n);
-/* d_out: n x vt_hit_tbn.  Needs vt_scene_set_tri_frames and (for lod_info.x, which is derived from the uvs)
+/* d_out: n x vt_hit_tbn.  Needs vt_scene_set_tri_frames and, with the cone on (lod_info.x is derived from the uvs),
  * vt_scene_set_tri_attribs.  cone_width / cone_angle as accel:Traverse's coneWidth / coneAngle (one pair per batch). */
 int vt_hit_tbn_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64_t n, float cone_width, float cone_angle,
                    void* d_out, void* stream);

@@ -112,14 +112,20 @@ def test_hit_tbn_needs_its_tables(va, engine, make_bundle):
         scene.read_tri_frames()
     with pytest.raises(va._lib.VisTraceError, match="triangle count"):
         scene.set_tri_frames(frames[:-1])
-    scene.set_tri_frames(frames)
-    with pytest.raises(va._lib.VisTraceError, match="vt_scene_set_tri_attribs"):
-        scene.hit_tbn_dev(d_rays.data_ptr(), d_hits.data_ptr(), len(rays), d_out.data_ptr())
-    assert (scene.read_tri_frames().view(np.uint8) == frames.view(np.uint8)).all()
-    scene.hit_tbn_dev(d_rays.data_ptr(), d_hits.data_ptr(), 0, 0)              # n = 0: nothing to do, no buffers needed
-    bt = scene.trace_batch(rays)
+    bt = scene.trace_batch(rays)                                                 # traced before the frames were there
     with pytest.raises(va._lib.VisTraceError, match="vertex frames"):
         bt.tbn()
+    bt.free()
+    scene.set_tri_frames(frames)
+    with pytest.raises(va._lib.VisTraceError, match="vt_scene_set_tri_attribs"):    # the cone asks for the triangle's lod: uvs
+        scene.hit_tbn_dev(d_rays.data_ptr(), d_hits.data_ptr(), len(rays), d_out.data_ptr(), 0.5, 0.01)
+    assert (scene.read_tri_frames().view(np.uint8) == frames.view(np.uint8)).all()
+    scene.hit_tbn_dev(d_rays.data_ptr(), d_hits.data_ptr(), 0, 0)              # n = 0: nothing to do, no buffers needed
+    # cone off (accel:Traverse's defaults): the frame alone needs no uvs -- and the batch object carries it
+    scene.hit_tbn_dev(d_rays.data_ptr(), d_hits.data_ptr(), len(rays), d_out.data_ptr())
+    torch.cuda.synchronize()
+    bt = scene.trace_batch(rays)
+    assert (bt.tbn().view(np.uint8) == tp.to_host(d_out, va.HIT_TBN).view(np.uint8)).all() and (bt.tbn()["lod_set"] == 0).all()
     bt.free()
 
 

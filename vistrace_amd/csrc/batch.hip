@@ -207,7 +207,7 @@ int batch_new(vt_scene* s, uint64_t n, vt_batch** out)
     auto al = [](uint64_t x) { return (x + 255) & ~uint64_t(255); };
     const uint64_t ray_b = al(n * sizeof(vt_ray)), hit_b = al(n * sizeof(vt_hit)), att_b = al(n * sizeof(vt_hit_attrs));
     const uint64_t sha_b = s->d_attribs ? al(n * sizeof(vt_hit_shade)) : 0;
-    const uint64_t tbn_b = s->d_attribs && s->d_frames ? al(n * sizeof(vt_hit_tbn)) : 0;
+    const uint64_t tbn_b = s->d_frames ? al(n * sizeof(vt_hit_tbn)) : 0;
     const size_t need = ray_b + hit_b + att_b + sha_b + tbn_b + kBatchTail;
     hipError_t err = hipSuccess;
     {
@@ -680,7 +680,7 @@ int vt_batch_tbn(vt_batch* b, const vt_hit_tbn** tbn)
 {
     if (!b || !tbn) return fail(VT_ERR_INVALID_ARG, "vt_batch_tbn: NULL");
     if (b->n != 0 && !b->h_tbn.have && b->engine && !b->d_tbn)
-        return fail(VT_ERR_INVALID_ARG, "vt_batch_tbn: the scene had no vertex frames (vt_scene_set_tri_frames) or no triangle attributes when the batch was traced");
+        return fail(VT_ERR_INVALID_ARG, "vt_batch_tbn: the scene had no vertex frames (vt_scene_set_tri_frames) when the batch was traced");
     return batch_fetch(b, b->d_tbn, sizeof(vt_hit_tbn), b->h_tbn, reinterpret_cast<const void**>(tbn), "vt_batch_tbn");
 }
 

@@ -195,7 +195,8 @@ int vt_hit_tbn_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64_t
     if (n == 0) return VT_OK;
     if (!d_rays || !d_hits || !d_out) return fail(VT_ERR_INVALID_ARG, "vt_hit_tbn_dev: NULL device buffer");
     if (!s->d_frames) return fail(VT_ERR_INVALID_ARG, "vt_hit_tbn_dev: call vt_scene_set_tri_frames first");
-    if (!s->d_attribs) return fail(VT_ERR_INVALID_ARG, "vt_hit_tbn_dev: call vt_scene_set_tri_attribs first (the triangle's lod is derived from its uvs)");
+    const bool cone_on = !(cone_width < 0.f || cone_angle <= 0.f);
+    if (cone_on && !s->d_attribs) return fail(VT_ERR_INVALID_ARG, "vt_hit_tbn_dev: call vt_scene_set_tri_attribs first (with a cone the triangle's lod is asked for, which is derived from its uvs)");
     DeviceGuard guard(s->engine->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_hit_tbn_dev: hipSetDevice failed");
     VT_HIP(launch_hit_tbn(s, d_rays, d_hits, n, cone_width, cone_angle, d_out, static_cast<hipStream_t>(stream)));
