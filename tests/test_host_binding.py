@@ -48,6 +48,15 @@ def test_host_code_under_asan_ubsan():
     assert "0 failed" in out.stdout
 
 
+def test_host_trace_result_class_equals_the_oracle():
+    """host/TraceResult.cpp (what one accel:Traverse call hands to Lua) against the oracle on the CPU, under ASan + UBSan: ctor
+    fields, GetPos, texUV / blend, Normal / Tangent / Binormal (CalcTBN without a normal map, grazing branch included) and the
+    cone footprint on 20 000 random triangles, frames and hit points -- bit for bit."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "trace_result"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "_build", "test_trace_result")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and " 0 failed" in out.stdout, out.stdout + out.stderr
+
+
 def test_plain_c_example_builds_and_fails_loudly_without_gpu():
     """examples/trace_batch.c compiles as C11 against the header; without a device it reports
     VT_ERR_HIP (exit 2) instead of falling back to anything."""
