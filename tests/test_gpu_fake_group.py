@@ -50,3 +50,15 @@ def test_device_aliases_are_refused_without_the_test_hook(va):
     assert os.environ.get("VT_TEST_ALLOW_DEVICE_ALIASES") is None
     with pytest.raises(va._lib.VisTraceError, match="listed twice"):
         va.Engine([0, 0])
+
+
+def test_host_binding_through_a_two_member_group():
+    """The reference-shaped host classes (tests/cpp/test_binding: AccelStruct, TraceResult, TraceResultBatch behind a fake Lua
+    state) with VISTRACE_DEVICES=0,0: the accel opens a two-member group, scenes and side tables are replicated, batches go
+    through the group's root -- all 3 064 checks as with one device."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "fake_rccl"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, VT_RCCL_LIB=os.path.join(ROOT, "tests", "cpp", "_build", "libfake_rccl.so"), VT_TEST_ALLOW_DEVICE_ALIASES="1",
+               VISTRACE_DEVICES="0,0")
+    p = subprocess.run([os.path.join(ROOT, "tests", "cpp", "_build", "test_binding")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and " 0 failed" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
