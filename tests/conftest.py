@@ -73,7 +73,10 @@ def make_bundle(va, O):
 def engine(va, request):
     """Every GPU parity test runs against both kernels: persistent waves (LDS-DMA fetch, lane re-fill,
     coherence probe) and the one-ray-per-lane kernel that the default auto mode picks for small batches."""
-    eng = va.Engine(0)
+    # VT_TEST_GROUP_MEMBERS=N (with VT_TEST_ALLOW_DEVICE_ALIASES=1 and the RCCL test double): the whole parity suite through the
+    # root of an N-member group -- scenes, refits, skins, alpha tables and frames are then replicated to every member
+    members = int(os.environ.get("VT_TEST_GROUP_MEMBERS", "0"))
+    eng = va.Engine([0] * members) if members > 1 else va.Engine(0)
     eng.set_option("persistent", 1 if request.param == "persistent" else 0)
     eng.set_option("static_overflow_mb", 2048)
     return eng

@@ -101,6 +101,67 @@ for ndev in (2, 3, 4, 8):
     scene.free()
     eng.close()
 
+# ---- calls that rewrite a scene reach every member: host rays (>= 1 Mi: sharded over the members) see the same scene everywhere --
+eng = va.Engine([0, 0, 0])
+flags, attribs, mats, texels = W.alpha_test_rig(len(verts))
+atris = va.tris_setup(verts, flags)
+abvh = va.HostBvh(atris)
+scene = va.Scene(eng, va.HostScene(abvh))
+scene.set_tri_attribs(attribs.view(va.TRI_ATTRIBS))
+scene.set_alpha(mats.view(va.ALPHA_MATERIAL), texels)
+big = W.sphere_rays((1 << 20) + 777, 21 + ROUND, origin=(2.0, -3.0, 4.0))
+
+
+def alpha_oracle(tris64, rays_):
+    ot = O.tris_from_tri64(tris64)
+    try:
+        O.set_alpha(ot, attribs["uv"].reshape(len(verts), 6), attribs["material"], mats.view(O.ALPHA_MATERIAL), texels)
+        return O.traverse_batch(abvh.nodes().view(O.NODE), abvh.prim_indices(), ot, rays_)[0]
+    finally:
+        O.set_alpha()
+
+
+assert same(scene.trace_closest(big), alpha_oracle(atris, big)), "alpha tables on every member"
+moved = (verts + np.float32(0.375)).astype(np.float32)
+scene.refit(moved, flags)                                        # vt_scene_refit on every member
+mtris = va.tris_setup(moved, flags)
+abvh.refit(mtris)
+assert same(scene.trace_closest(big), alpha_oracle(mtris, big)), "refit on every member"
+# a refit that is refused (non-finite vertices) leaves EVERY member refusing to trace, not just the first one asked
+bad = moved.copy(); bad[5, 1, 1] = np.nan
+try:
+    scene.refit(bad, flags)
+    raise AssertionError("a refit with a NaN vertex must fail")
+except va._lib.VisTraceError:
+    pass
+for rays_ in (big, big[:1000]):                                  # through the members, and through the root alone
+    try:
+        scene.trace_closest(rays_)
+        raise AssertionError("a poisoned group must refuse to trace")
+    except va._lib.VisTraceError:
+        pass
+scene.refit(moved, flags)                                        # a clean refit heals every member
+assert same(scene.trace_closest(big), alpha_oracle(mtris, big)), "clean refit after a refused one"
+checks += 5
+scene.free()
+eng.close()
+# skinning: matrices to every member, positions and vertex frames follow
+eng = va.Engine([0, 0])
+pbvh = va.HostBvh(tris)
+scene = va.Scene(eng, va.HostScene(pbvh))
+skin, base, nmat = W.skinned_rig(len(verts))
+scene.set_skin(verts, skin, base)
+bones, binds = W.rig_pose(nmat, 1 + ROUND)
+scene.skin_refit(bones, binds)
+posed = O.skin_verts(verts.reshape(len(verts), 9), skin, base, O.skin_matrices(bones, binds)).reshape(len(verts), 3, 3)
+ptris = va.tris_setup(posed)
+pbvh.refit(ptris)
+pref = O.traverse_batch(pbvh.nodes().view(O.NODE), pbvh.prim_indices(), O.tris_from_tri64(ptris), big)[0]
+assert same(scene.trace_closest(big), pref), "skin refit on every member"
+checks += 1
+scene.free()
+eng.close()
+
 # ---- one engine per rank, one thread per rank: vt_engine_comm_init_rank + vt_gather_hits[_part]_dev -------------------------------
 for nranks in (2, 4):
     uid = va.comm_unique_id()

@@ -62,3 +62,19 @@ def test_host_binding_through_a_two_member_group():
                VISTRACE_DEVICES="0,0")
     p = subprocess.run([os.path.join(ROOT, "tests", "cpp", "_build", "test_binding")], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and " 0 failed" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
+
+
+def test_parity_suites_through_the_root_of_a_group():
+    """tests/test_gpu_parity.py, test_gpu_shading_frame.py and test_gpu_multi_batch.py once more with the `engine` fixture opened
+    as a two-member group (VT_TEST_GROUP_MEMBERS=2, tests/conftest.py): every scene, refit, skin, alpha table and frame table is
+    replicated, host batches of >= 1 Mi rays are sharded over the members, everything else runs on the root.  (This is how a
+    refused refit was found to leave the members of a group with different geometry: vt_scene_refit / vt_scene_skin_refit now go
+    to every member before the first failure is reported.)"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "fake_rccl"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, VT_RCCL_LIB=os.path.join(ROOT, "tests", "cpp", "_build", "libfake_rccl.so"), VT_TEST_ALLOW_DEVICE_ALIASES="1",
+               VT_TEST_GROUP_MEMBERS="2")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_shading_frame.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_multi_batch.py")], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    tail = [ln for ln in p.stdout.splitlines() if "passed" in ln or "failed" in ln]
+    assert p.returncode == 0 and tail and "failed" not in tail[-1], (p.stdout[-3000:], p.stderr[-2000:])

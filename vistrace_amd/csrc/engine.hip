@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -949,9 +950,24 @@ static int refit_levels(vt_scene* s)
     return VT_OK;
 }
 
-int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32_t n)
+// A call that moves a scene's geometry goes to EVERY member of its group, also when one of them fails: a refit that is refused
+// for non-finite vertices has rewritten that member's records by then (and left it refusing to trace), and the members of a group
+// must not end up with different geometry.  The caller sees the first failure.
+static int for_every_member(vt_scene* s, const std::function<int(vt_scene*)>& member_call)
 {
-    if (s) for (vt_scene* rep : s->replicas) { const int rc = vt_scene_refit(rep, verts, flags, n); if (rc != VT_OK) return rc; }
+    int first_rc = VT_OK;
+    std::string first_msg;
+    if (s) for (vt_scene* rep : s->replicas) {
+        const int rc = member_call(rep);
+        if (rc != VT_OK && first_rc == VT_OK) { first_rc = rc; first_msg = vt_last_error(); }
+    }
+    const int rc = member_call(s);
+    if (rc != VT_OK) return rc;
+    return first_rc == VT_OK ? VT_OK : fail(first_rc, first_msg);
+}
+
+static int refit_member(vt_scene* s, const float* verts, const uint8_t* flags, uint32_t n)
+{
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: scene is NULL");
     if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: the scene\'s engine has been closed");
     if (n != s->ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: n differs from the scene's triangle count");
@@ -985,6 +1001,11 @@ int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32
     return rc != VT_OK ? rc : end_finite_check(s, "vt_scene_refit");
 }
 
+int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32_t n)
+{
+    return for_every_member(s, [&](vt_scene* member) { return refit_member(member, verts, flags, n); });
+}
+
 int vt_scene_set_skin(vt_scene* s, const float* bind_verts, const vt_skin_vertex* skin, const uint32_t* matrix_base, uint32_t n)
 {
     if (s) for (vt_scene* rep : s->replicas) { const int rc = vt_scene_set_skin(rep, bind_verts, skin, matrix_base, n); if (rc != VT_OK) return rc; }
@@ -1015,9 +1036,8 @@ int vt_scene_set_skin(vt_scene* s, const float* bind_verts, const vt_skin_vertex
     return VT_OK;
 }
 
-int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uint32_t nmat)
+static int skin_refit_member(vt_scene* s, const float* bones, const float* binds, uint32_t nmat)
 {
-    if (s) for (vt_scene* rep : s->replicas) { const int rc = vt_scene_skin_refit(rep, bones, binds, nmat); if (rc != VT_OK) return rc; }
     if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: scene is NULL");
     if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: the scene\'s engine has been closed");
     if (s->ntris == 0) return VT_OK;
@@ -1047,6 +1067,11 @@ int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uin
     if (s->host_stale) s->host_stale->store(1, std::memory_order_release);
     rc = refit_levels(s);
     return rc != VT_OK ? rc : end_finite_check(s, "vt_scene_skin_refit");
+}
+
+int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uint32_t nmat)
+{
+    return for_every_member(s, [&](vt_scene* member) { return skin_refit_member(member, bones, binds, nmat); });
 }
 
 int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_out)
