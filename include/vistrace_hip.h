@@ -424,7 +424,8 @@ int vt_engine_synchronize(vt_engine* e);
  * exactly the records vt_tris_setup + vt_bvh_refit + vt_scene_linearise would.  Vertices must be finite: NaN boxes
  * pass every slab test, so every ray would walk the poisoned subtree -- the call then fails with VT_ERR_INVALID_ARG
  * (the message counts the triangles) and the scene refuses to trace until a refit with finite data (the same holds
- * for vt_scene_skin_refit, e.g. with a NaN bone matrix). */
+ * for vt_scene_skin_refit, e.g. with a NaN bone matrix).  In a multi-GPU group both calls reach EVERY member before a failure is
+ * reported, so the members never hold different geometry: a refused refit leaves the whole group refusing to trace. */
 int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32_t n);
 
 /* Device-side skinning + refit (the per-frame half of AccelStruct::Rebuild for animated entities,
