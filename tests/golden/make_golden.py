@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/s1k_golden.npz.
+"""Generates tests/golden/s1k_golden.npz, terrain_golden.npz and shading_frame_golden.npz.
 
 The reference has no golden vectors for this path and cannot be built here (SURVEY.md 0.2,
 0.4), so these vectors are produced by the CPU oracle (oracle/vt_oracle.c) after it has been
@@ -71,6 +71,21 @@ def main():
     assert ((tbrute["prim"] == O.MISS) == (thits["prim"] == O.MISS)).all()
     tout = os.path.join(os.path.dirname(os.path.abspath(__file__)), "terrain_golden.npz")
     np.savez_compressed(tout, verts=tverts, flags=tflags, nodes=tnodes, prim_indices=tpidx, rays=trays, hits=thits, stats=tstats)
+    # ---- third fixture: the shading frame of the s1k fixture's hits (TraceResult::CalcTBN without a normal map +
+    # CalcFootprint) from seeded vertex frames and uvs, cone on; and those frames skinned by one seeded pose ----
+    frames = W.vertex_frames(verts, W.SEED + 31)
+    uv = np.random.default_rng(W.SEED + 32).uniform(-2, 2, (len(verts), 3, 2)).astype(np.float32)
+    cone = (0.25, 0.004)
+    sel = np.arange(0, len(rays), 4)                         # every fourth ray of the s1k fixture keeps the file small
+    tbn = O.hit_tbn(otris, rays[sel], hits[sel], frames.view(np.float32).reshape(-1, 18), uv.reshape(-1, 6), cone[0], cone[1])
+    tbn_off = O.hit_tbn(otris, rays[sel], hits[sel], frames.view(np.float32).reshape(-1, 18), uv.reshape(-1, 6))
+    skin, base, nmat = W.skinned_rig(len(verts), nents=4, bones_per_ent=6, seed=W.SEED + 33)
+    bones, binds = W.rig_pose(nmat, 2, seed=W.SEED + 34)
+    skinned = O.skin_frames(frames.view(np.float32).reshape(-1, 18), skin, base, O.skin_matrices(bones, binds))
+    fout = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shading_frame_golden.npz")
+    np.savez_compressed(fout, ray_index=sel, frames=frames.view(np.float32).reshape(-1, 18), uv=uv, cone=np.array(cone, np.float32), tbn=tbn, tbn_cone_off=tbn_off,
+                        skin=skin, matrix_base=base, bones=bones, binds=binds, skinned_frames=skinned)
+    print(f"wrote {fout}: {int((hits['prim'][sel] != O.MISS).sum())} frames of hits, {len(verts)} skinned triangle frames, {os.path.getsize(fout) / 1024:.0f} KiB")
     print(f"wrote {tout}: {len(trays)} rays, {int((thits['prim'] != O.MISS).sum())} hits, {os.path.getsize(tout) / 1024:.0f} KiB")
     print(f"wrote {out}: {len(rays)} rays, {int((hits['prim'] != O.MISS).sum())} hits, {ties} tie-broken indices, "
           f"{os.path.getsize(out) / 1024:.0f} KiB")

@@ -182,3 +182,34 @@ def test_batch_object_carries_the_frame(va, engine, make_bundle, O):
     assert (np.concatenate([s.tbn() for s in sets]).view(np.uint8) == dev_tbn.view(np.uint8)).all()
     for s in sets:
         s.free()
+
+
+def test_shading_frame_golden_fixture(va, engine):
+    """The committed fixture (tests/golden/shading_frame_golden.npz, generator beside it) on the device: the frame of every fourth
+    hit of the s1k fixture, cone on and off, and the vertex frames after one skinning pose."""
+    import os
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gold, sf = np.load(os.path.join(gdir, "s1k_golden.npz")), np.load(os.path.join(gdir, "shading_frame_golden.npz"))
+    verts = gold["verts"]
+    scene = va.Scene(engine, va.HostScene(va.HostBvh(va.tris_setup(verts), builder="ploc")))
+    attribs = np.zeros(len(verts), va.TRI_ATTRIBS)
+    attribs["uv"] = sf["uv"]
+    scene.set_tri_attribs(attribs)
+    frames = np.ascontiguousarray(sf["frames"]).view(va.TRI_FRAME).reshape(-1)
+    scene.set_tri_frames(frames)
+    sel = sf["ray_index"]
+    rays, hits = np.ascontiguousarray(gold["rays"].view(va.RAY)[sel]), np.ascontiguousarray(gold["hits"].view(va.HIT)[sel])
+    dev = torch.device("cuda", 0)
+    d_rays, d_hits = tp.to_device(rays, dev), tp.to_device(hits, dev)            # the fixture's own hit records
+    assert (scene.trace_closest(rays).view(np.uint8) == hits.view(np.uint8)).all()
+    d_out = tp.empty_records(len(rays), va.HIT_TBN, dev)
+    hit = hits["prim"] != O_MISS
+    for key, cone in (("tbn", tuple(float(x) for x in sf["cone"])), ("tbn_cone_off", (-1.0, -1.0))):
+        scene.hit_tbn_dev(d_rays.data_ptr(), d_hits.data_ptr(), len(rays), d_out.data_ptr(), cone[0], cone[1], tp.current_stream_handle(dev))
+        torch.cuda.synchronize()
+        _assert_tbn(tp.to_host(d_out, va.HIT_TBN), sf[key].view(va.HIT_TBN).reshape(-1), hit)
+    scene.set_skin(verts, sf["skin"].view(va.SKIN_VERTEX), sf["matrix_base"])
+    scene.skin_refit(sf["bones"], sf["binds"])
+    assert (scene.read_tri_frames().view(np.uint32).reshape(-1, 18) == sf["skinned_frames"].view(np.uint32)).all()

@@ -79,3 +79,19 @@ def test_terrain_golden_cull_flags(va, O):
     assert n_above != n_below and n_above > 0 and n_below > 0        # the cull bit changes the answer
     bvh = va.HostBvh(va.tris_setup(g["verts"], g["flags"]), builder="ploc")
     assert (bvh.nodes().view(np.uint8) == g["nodes"].view(np.uint8)).all()
+
+
+def test_oracle_reproduces_the_shading_frame_fixture(O, gold):
+    """tests/golden/shading_frame_golden.npz: the shading frame (CalcTBN without a normal map + CalcFootprint) of every fourth
+    hit of the s1k fixture, cone on and off, and the vertex frames skinned by one pose -- the oracle must reproduce them bit for bit
+    (the log2 inside the triangle's lod included: same libm on the same inputs)."""
+    sf = np.load(os.path.join(os.path.dirname(GOLDEN), "shading_frame_golden.npz"))
+    tris = O.tris_setup(gold["verts"])
+    sel = sf["ray_index"]
+    rays, hits = gold["rays"].view(O.RAY)[sel], gold["hits"].view(O.HIT)[sel]
+    for key, cone in (("tbn", tuple(float(x) for x in sf["cone"])), ("tbn_cone_off", (-1.0, -1.0))):
+        got = O.hit_tbn(tris, rays, hits, sf["frames"], sf["uv"].reshape(-1, 6), cone[0], cone[1])
+        assert (got.view(np.uint8) == sf[key].view(O.TBN).view(np.uint8)).all(), key
+    assert (sf["tbn"].view(O.TBN)["lod_set"][hits["prim"] != O.MISS] == 1).all() and not sf["tbn_cone_off"].view(O.TBN)["lod_set"].any()
+    skinned = O.skin_frames(sf["frames"], sf["skin"].view(O.SKIN_VERTEX), sf["matrix_base"], O.skin_matrices(sf["bones"], sf["binds"]))
+    assert (skinned.view(np.uint32) == sf["skinned_frames"].view(np.uint32)).all()
