@@ -899,8 +899,11 @@ static int begin_finite_check(vt_scene* s)
 // after the (synchronous) refit: how many triangles had a non-finite vertex?
 static int end_finite_check(vt_scene* s, const char* who)
 {
+    // (on the engine's stream, not the legacy stream: another member of the group may be capturing its refit graph on this
+    // device right now, and a legacy-stream copy would depend on that capturing stream)
     uint32_t bad = 0;
-    VT_HIP(hipMemcpy(&bad, s->d_bad, 4, hipMemcpyDeviceToHost));
+    VT_HIP(hipMemcpyAsync(&bad, s->d_bad, 4, hipMemcpyDeviceToHost, s->engine->stream));
+    VT_HIP(hipStreamSynchronize(s->engine->stream));
     s->poisoned = bad != 0;
     if (bad != 0)
         return fail(VT_ERR_INVALID_ARG, std::string(who) + ": " + std::to_string(bad) + " triangles have a non-finite (NaN / inf) vertex; "
@@ -944,7 +947,8 @@ static int refit_levels(vt_scene* s)
     VT_HIP(hipStreamSynchronize(e->stream));
     if (s->npairs != 0) {                                // the scene's extent moved with the vertices: keep the packet probe's radius current
         vt_node_pair root;
-        VT_HIP(hipMemcpy(&root, s->d_records, sizeof(root), hipMemcpyDeviceToHost));
+        VT_HIP(hipMemcpyAsync(&root, s->d_records, sizeof(root), hipMemcpyDeviceToHost, e->stream));
+        VT_HIP(hipStreamSynchronize(e->stream));
         s->coherent_radius2 = packet_radius2(root);
     }
     return VT_OK;
@@ -952,7 +956,10 @@ static int refit_levels(vt_scene* s)
 
 // A call that moves a scene's geometry goes to EVERY member of its group, also when one of them fails: a refit that is refused
 // for non-finite vertices has rewritten that member's records by then (and left it refusing to trace), and the members of a group
-// must not end up with different geometry.  The caller sees the first failure.
+// must not end up with different geometry.  The caller sees the root's failure, else the first replica's.
+// One member after the other: running them side by side (one host thread per member) was tried and taken out again -- with
+// several engines on ONE device the members' calls (allocations, device synchronisation) invalidate the stream capture of another
+// member's refit graph, and with one device per member the gain (0.3 ms per member and frame) could not be measured here.
 static int for_every_member(vt_scene* s, const std::function<int(vt_scene*)>& member_call)
 {
     int first_rc = VT_OK;
