@@ -59,3 +59,22 @@ def test_checker_recognises_foreign_uses_of_the_texel_registers(checker):
     assert not checker.touches_texel_regs("v_fma_f32 v75, -v71, v70, v74")
     assert not checker.touches_texel_regs("global_load_dwordx4 v[72:75], v1, s[2:3]")
     assert not checker.touches_texel_regs("s_mov_b32 s76, s77")
+
+
+def test_no_auxiliary_kernel_spills_or_uses_scratch(checker):
+    """Every other kernel of the library (TraceResult materialisation, shading frame, refit, skinning, ray generation, the bounce
+    loop's queue, the batch range check): no VGPR / SGPR spills, no private segment, and room for full occupancy (<= 64 VGPRs)."""
+    import tempfile
+    seen = 0
+    for name in ("trace_kernels.o", "shading.o", "batch.o"):
+        obj = os.path.join(CSRC, "_build", name)
+        with tempfile.TemporaryDirectory() as tmp:
+            meta = checker.kernel_metadata(checker.device_code_object(obj, tmp))
+        for kernel, m in meta.items():
+            if "trace_kernel" in kernel:
+                continue                                  # the traversal kernels have their own contract (above)
+            seen += 1
+            assert int(m.get("vgpr_spill_count", 0)) == 0 and int(m.get("sgpr_spill_count", 0)) == 0, kernel
+            assert int(m.get("private_segment_fixed_size", 0)) == 0, kernel
+            assert int(m["vgpr_count"]) <= 64, (kernel, m["vgpr_count"])
+    assert seen >= 15
