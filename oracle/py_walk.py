@@ -114,3 +114,59 @@ def walk(nodes, prim_indices, tris, ray, any_hit=False):
                     break
                 left = stack.pop()
     return (*best, steps, tests)
+
+
+# ---- the shading frame, restated a second time from the reference's text (source/objects/TraceResult.cpp:45-103, 132-186 and
+# ---- source/objects/Primitives.h:93-104), not from vt_oracle.c: vector expressions as glm evaluates them component-wise -----------
+def _v(x):
+    return [F(x[0]), F(x[1]), F(x[2])]
+
+
+def _dot(a, b):                      # glm::dot(vec3): tmp = a * b; tmp.x + tmp.y + tmp.z
+    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
+
+
+def _cross(x, y):                    # glm::cross
+    return [x[1] * y[2] - y[1] * x[2], x[2] * y[0] - y[2] * x[0], x[0] * y[1] - y[0] * x[1]]
+
+
+def _normalize(v):                   # glm::normalize: v * inversesqrt(dot(v, v)), inversesqrt(x) = 1 / sqrt(x)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        inv = F(1.0) / np.sqrt(_dot(v, v))
+        return [v[0] * inv, v[1] * inv, v[2] * inv]
+
+
+def _bary(uvw, a):                   # uvw[2] * a[0] + uvw[0] * a[1] + uvw[1] * a[2], per component, left to right
+    return [(uvw[2] * a[0][k] + uvw[0] * a[1][k]) + uvw[1] * a[2][k] for k in range(3)]
+
+
+def hit_tbn(tri, direction, distance, u, v, normals, tangents, uvs, cone_width, cone_angle):
+    """tri = (p0, e1, e2, n) as fp32 triples; normals / tangents: 3 x 3, uvs: 3 x 2.  Returns (normal, tangent, binormal,
+    lod_info or None) -- TraceResult's GetNormal / GetTangent / GetBinormal and textureLodInfo for a material without a normal map."""
+    p0, e1, e2, n = (_v(x) for x in tri)
+    u, v, distance, cone_width, cone_angle = F(u), F(v), F(distance), F(cone_width), F(cone_angle)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        wo = [-c for c in _normalize(_v(direction))]                        # AccelStruct.cpp:826, TraceResult.cpp:56
+        vN, vT = [_v(x) for x in normals], [_v(x) for x in tangents]         # :58-59
+        vB = [_cross(vT[i], vN[i]) for i in range(3)]                        # :60
+        uvw = [u, v, F(1.0) - u - v]                                         # :70
+        length = np.sqrt((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2])          # Primitives.h:102 length(n)
+        ngeo = [n[0] / length, n[1] / length, n[2] / length]                 # :104, TraceResult.cpp:71
+        normal, tangent, binormal = _normalize(_bary(uvw, vN)), _normalize(_bary(uvw, vT)), _normalize(_bary(uvw, vB))   # :134-136
+        k_threshold = F(0.1)                                                 # :175
+        cos_theta = abs(_dot(wo, normal))
+        if cos_theta <= k_threshold:
+            t = min(max(cos_theta * (F(1.0) / k_threshold), F(0.0)), F(1.0))                   # saturate
+            normal = _normalize([ngeo[k] * (F(1.0) - t) + normal[k] * t for k in range(3)])     # lerp(geometricNormal, normal, t)
+            tn = _dot(tangent, normal)
+            tangent = _normalize([tangent[k] - normal[k] * tn for k in range(3)])
+            binormal = _cross(tangent, normal)
+        lod = None
+        if not (cone_width < 0 or cone_angle <= 0):                          # :54 mipOverride
+            cw = cone_angle * distance + cone_width                          # :95
+            normal_term = _dot(wo, ngeo)
+            uv = [[F(a), F(b)] for a, b in uvs]
+            uv10, uv20 = [uv[1][0] - uv[0][0], uv[1][1] - uv[0][1]], [uv[2][0] - uv[0][0], uv[2][1] - uv[0][1]]
+            area = abs(uv10[0] * uv20[1] - uv20[0] * uv10[1])                # Primitives.h:99
+            lod = (F(0.5) * np.log2(area / length), (cw * cw) / (normal_term * normal_term))    # :103, TraceResult.cpp:99-102
+    return normal, tangent, binormal, lod

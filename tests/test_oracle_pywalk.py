@@ -40,3 +40,37 @@ def test_c_oracle_equals_python_walk(va, O, seed, ntris, any_hit):
         ties += prim in (4, 5, 6)
     if ntris > 10 and not any_hit:
         assert ties >= 1
+
+
+def test_shading_frame_restated_twice(O):
+    """oracle/py_walk.py::hit_tbn (numpy fp32 scalars, written from the reference's text) against vto_hit_tbn: normal / tangent /
+    binormal and the cone term bit for bit, both branches of CalcTBN; the triangle's lod within an ulp of log2 (numpy's and libm's
+    log2 need not round alike)."""
+    from oracle import py_walk as P
+    rng = np.random.default_rng(77)
+    grazing = 0
+    for it in range(1500):
+        p = rng.normal(scale=20, size=(3, 3)).astype(np.float32)
+        tri = O.tris_setup(p[None])
+        normals, tangents = rng.normal(size=(3, 3)).astype(np.float32), rng.normal(size=(3, 3)).astype(np.float32)
+        uvs = rng.uniform(-3, 3, (3, 2)).astype(np.float32)
+        u = np.float32(rng.random() * 0.7); v = np.float32(rng.random() * (1 - u) * 0.9)
+        d = rng.normal(size=3).astype(np.float32)
+        if it % 4 == 0:                                    # almost inside the plane: the grazing branch
+            d = ((p[1] - p[0]) + np.float32(0.03) * rng.normal(size=3)).astype(np.float32)
+        dist = np.float32(rng.random() * 50)
+        cone = (np.float32(rng.random()), np.float32(0.001 + rng.random() * 0.05)) if it % 3 else (np.float32(-1), np.float32(-1))
+        ray = np.zeros(1, O.RAY); ray["dir"] = d
+        hit = np.zeros(1, O.HIT); hit["prim"], hit["t"], hit["u"], hit["v"] = 0, dist, u, v
+        ref = O.hit_tbn(tri, ray, hit, np.concatenate([normals.reshape(9), tangents.reshape(9)])[None], uvs.reshape(1, 6), float(cone[0]), float(cone[1]))[0]
+        n, t, b, lod = P.hit_tbn((tri["p0"][0], tri["e1"][0], tri["e2"][0], tri["n"][0]), d, dist, u, v, normals, tangents, uvs, cone[0], cone[1])
+        same = lambda a, c: np.array_equal(np.array(a, np.float32).view(np.uint32), np.asarray(c, np.float32).view(np.uint32)) or \
+            (np.isnan(np.array(a, np.float32)) == np.isnan(np.asarray(c, np.float32))).all() and np.isnan(np.array(a, np.float32)).any()
+        assert same(n, ref["normal"]) and same(t, ref["tangent"]) and same(b, ref["binormal"]), it
+        assert (lod is not None) == bool(ref["lod_set"])
+        if lod is not None:
+            assert same([lod[1]], [ref["lod_info"][1]]) and abs(float(lod[0]) - float(ref["lod_info"][0])) <= 4e-7 * max(1.0, abs(float(lod[0])))
+        wo = -d / np.linalg.norm(d)
+        nn = (1 - u - v) * normals[0] + u * normals[1] + v * normals[2]
+        grazing += abs(float(np.dot(wo, nn / np.linalg.norm(nn)))) <= 0.1
+    assert grazing > 100
