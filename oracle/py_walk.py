@@ -170,3 +170,33 @@ def hit_tbn(tri, direction, distance, u, v, normals, tangents, uvs, cone_width, 
             area = abs(uv10[0] * uv20[1] - uv20[0] * uv10[1])                # Primitives.h:99
             lod = (F(0.5) * np.log2(area / length), (cw * cw) / (normal_term * normal_term))    # :103, TraceResult.cpp:99-102
     return normal, tangent, binormal, lod
+
+
+# ---- skinning, restated a second time from source/objects/AccelStruct.cpp:34-92 (glm mat4 * mat4, mat4 * vec4, vec4 * scalar in
+# ---- their generic scalar forms: columns scaled and added left to right) ------------------------------------------------------------
+def mat4_mul(a, b):
+    """glm: Result[c] = A[0] * B[c][0] + A[1] * B[c][1] + A[2] * B[c][2] + A[3] * B[c][3]; a, b: 16 floats, column-major."""
+    a, b = np.asarray(a, F), np.asarray(b, F)
+    out = np.zeros(16, F)
+    for c in range(4):
+        for r in range(4):
+            acc = a[0 * 4 + r] * b[c * 4 + 0]
+            acc = acc + a[1 * 4 + r] * b[c * 4 + 1]
+            acc = acc + a[2 * 4 + r] * b[c * 4 + 2]
+            acc = acc + a[3 * 4 + r] * b[c * 4 + 3]
+            out[c * 4 + r] = acc
+    return out
+
+
+def transform_to_bone(vec, mats, num_bones, weights, bone_ids, angle_only=False):
+    """TransformToBone (:35-47): final += bones[id] * binds[id] * vertex * weight, vertex = (vec, angle_only ? 0 : 1);
+    mats[k] = the product bones[k] * binds[k] (16 floats, column-major).  glm mat4 * vec4 = (m0 * x + m1 * y) + (m2 * z + m3 * w)."""
+    x, y, z, w = F(vec[0]), F(vec[1]), F(vec[2]), F(0.0 if angle_only else 1.0)
+    fin = [F(0.0)] * 4
+    with np.errstate(invalid="ignore", over="ignore"):
+        for i in range(int(num_bones)):
+            m = np.asarray(mats[int(bone_ids[i])], F)
+            for r in range(4):
+                col = (m[0 * 4 + r] * x + m[1 * 4 + r] * y) + (m[2 * 4 + r] * z + m[3 * 4 + r] * w)
+                fin[r] = fin[r] + col * F(weights[i])
+    return np.array(fin[:3], F)

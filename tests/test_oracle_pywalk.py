@@ -74,3 +74,34 @@ def test_shading_frame_restated_twice(O):
         nn = (1 - u - v) * normals[0] + u * normals[1] + v * normals[2]
         grazing += abs(float(np.dot(wo, nn / np.linalg.norm(nn)))) <= 0.1
     assert grazing > 100
+
+
+def test_skinning_restated_twice(O):
+    """py_walk.mat4_mul / transform_to_bone (numpy fp32, from AccelStruct.cpp:34-92) against vto_skin_matrices, vto_skin_verts and
+    vto_skin_frames: bit for bit on a seeded rig (positions through the p0 / e1 / e2 round trip of SkinTriangle :68-72)."""
+    from oracle import py_walk as P
+    from vistrace_amd import workloads as W
+    rng = np.random.default_rng(12)
+    n = 120
+    verts = rng.normal(scale=40, size=(n, 9)).astype(np.float32)
+    frames = rng.normal(size=(n, 18)).astype(np.float32)
+    skin, base, nmat = W.skinned_rig(n, nents=3, bones_per_ent=5)
+    bones, binds = W.rig_pose(nmat, frame=3)
+    mats = O.skin_matrices(bones, binds)
+    for k in range(nmat):
+        assert np.array_equal(P.mat4_mul(bones[k], binds[k]).view(np.uint32), mats[k].view(np.uint32))
+    got_v = O.skin_verts(verts, skin, base, mats)
+    got_f = O.skin_frames(frames, skin, base, mats)
+    for t in range(n):
+        ent = mats[base[t]:]
+        b = verts[t]
+        p0 = b[0:3]; e1 = b[0:3] - b[3:6]; e2 = b[6:9] - b[0:3]
+        pos = [p0, p0 - e1, p0 + e2]
+        for vi in range(3):
+            sv = skin[t, vi]
+            exp = P.transform_to_bone(pos[vi], ent, sv["num_bones"], sv["weight"], sv["bone"])
+            assert np.array_equal(exp.view(np.uint32), got_v[t, vi * 3: vi * 3 + 3].view(np.uint32)), (t, vi)
+            for half in range(2):
+                vec = frames[t, half * 9 + vi * 3: half * 9 + vi * 3 + 3]
+                exp = P.transform_to_bone(vec, ent, sv["num_bones"], sv["weight"], sv["bone"], angle_only=True)
+                assert np.array_equal(exp.view(np.uint32), got_f[t, half * 9 + vi * 3: half * 9 + vi * 3 + 3].view(np.uint32)), (t, vi, half)
