@@ -110,7 +110,8 @@ typedef struct vt_tri_frame { float normal[3][3]; float tangent[3][3]; } vt_tri_
  * WITHOUT a normal map -- the interpolated, normalised vertex frame with vB = cross(vT, vN) per vertex (:59-61) and the
  * grazing-angle correction towards the geometric normal (:175-184) -- and TraceResult::CalcFootprint's textureLodInfo
  * (:89-103: x = the triangle's lod, Primitives.h:93-105, y = coneWidth^2 / dot(wo, geometricNormal)^2 with the cone
- * propagated to the hit).  lod_set = 0 and lod_info = 0 when the cone is switched off (coneWidth < 0 or coneAngle <= 0,
+ * propagated to the hit: coneAngle * distance + coneWidth, distance = the hit's t in units of the direction AS GIVEN, which is what
+ * the reference passes, AccelStruct.cpp:826).  lod_set = 0 and lod_info = 0 when the cone is switched off (coneWidth < 0 or coneAngle <= 0,
  * the mipOverride of TraceResult.cpp:54 -- the defaults of accel:Traverse).  The normal-map branch (:139-173) needs
  * IVTFTexture::Sample of the absent VTFParser submodule and is out of scope; a caller with a normal map perturbs the frame
  * returned here.  A miss yields zeros.  48 B. */
