@@ -200,3 +200,24 @@ def transform_to_bone(vec, mats, num_bones, weights, bone_ids, angle_only=False)
                 col = (m[0 * 4 + r] * x + m[1 * 4 + r] * y) + (m[2 * 4 + r] * z + m[3 * 4 + r] * w)
                 fin[r] = fin[r] + col * F(weights[i])
     return np.array(fin[:3], F)
+
+
+# ---- the TraceResult constructor's derived fields and GetPos, restated a second time (source/objects/TraceResult.cpp:56-85, 255-262) ----
+def hit_attrs(tri, direction, u, v, uvs=None, alphas=None):
+    """tri = (p0, e1, e2, n).  Returns dict(wo, uvw, ngeo, pos, front[, tex_uv, blend])."""
+    p0, e1, e2, n = (_v(x) for x in tri)
+    u, v = F(u), F(v)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        wo = [-c for c in _normalize(_v(direction))]                         # :56 with AccelStruct.cpp:826
+        uvw = [u, v, F(1.0) - u - v]                                          # :70
+        length = np.sqrt((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2])
+        ngeo = [n[k] / length for k in range(3)]                              # :71, Primitives.h:104
+        verts = [p0, [p0[k] - e1[k] for k in range(3)], [p0[k] + e2[k] for k in range(3)]]   # :65-68: p0, p1() = p0 - e1, p2() = p0 + e2
+        pos = _bary(uvw, verts)                                               # :258
+        out = dict(wo=wo, uvw=uvw, ngeo=ngeo, pos=pos, front=bool(_dot(wo, ngeo) >= 0))          # :85
+        if uvs is not None:
+            uv = [[F(a), F(b)] for a, b in uvs]
+            out["tex_uv"] = [(uvw[2] * uv[0][k] + uvw[0] * uv[1][k]) + uvw[1] * uv[2][k] for k in range(2)]   # :74
+            al = [F(a) for a in alphas]
+            out["blend"] = (uvw[2] * al[0] + uvw[0] * al[1]) + uvw[1] * al[2]   # :73
+    return out

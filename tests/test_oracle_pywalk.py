@@ -105,3 +105,24 @@ def test_skinning_restated_twice(O):
                 vec = frames[t, half * 9 + vi * 3: half * 9 + vi * 3 + 3]
                 exp = P.transform_to_bone(vec, ent, sv["num_bones"], sv["weight"], sv["bone"], angle_only=True)
                 assert np.array_equal(exp.view(np.uint32), got_f[t, half * 9 + vi * 3: half * 9 + vi * 3 + 3].view(np.uint32)), (t, vi, half)
+
+
+def test_trace_result_fields_restated_twice(O):
+    """py_walk.hit_attrs (numpy fp32, from TraceResult.cpp:56-85, 255-262) against vto_hit_attrs / vto_hit_shade, bit for bit."""
+    from oracle import py_walk as P
+    rng = np.random.default_rng(5)
+    eq = lambda a, b: np.array_equal(np.array(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
+    for it in range(800):
+        p = rng.normal(scale=10.0 ** rng.uniform(-2, 2), size=(3, 3)).astype(np.float32)
+        tri = O.tris_setup(p[None])
+        u = np.float32(rng.random() * 0.8); v = np.float32(rng.random() * (1 - u))
+        d = (rng.normal(size=3) * 10.0 ** rng.uniform(-3, 3)).astype(np.float32)
+        uvs, alphas = rng.uniform(-2, 2, (3, 2)).astype(np.float32), rng.random(3).astype(np.float32)
+        ray = np.zeros(1, O.RAY); ray["dir"] = d
+        hit = np.zeros(1, O.HIT); hit["prim"], hit["u"], hit["v"] = 0, u, v
+        ref = O.hit_attrs(tri, ray, hit)[0]
+        got = P.hit_attrs((tri["p0"][0], tri["e1"][0], tri["e2"][0], tri["n"][0]), d, u, v, uvs, alphas)
+        assert eq(got["wo"], ref["wo"]) and eq(got["uvw"], ref["uvw"]) and eq(got["ngeo"], ref["ngeo"]) and eq(got["pos"], ref["pos"]), it
+        assert got["front"] == bool(ref["front"])
+        tex, blend = O.hit_shade(u, v, uvs, alphas)
+        assert eq(got["tex_uv"], tex) and eq([got["blend"]], [blend])
