@@ -396,6 +396,56 @@ def verify_gather(dist, rank, world, n, local_hits, recv, device, backend):
     return bool(flag.item())
 
 
+def launch_ranks(args) -> int:
+    """`python3 bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, exactly as the driver's
+    N > 1 command does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <the same arguments>`), as a CHILD process -- this process has not touched HIP (torch is not even imported yet) and
+    never will: it relays rank 0's JSON line to stdout (everything else the ranks print on stdout goes to stderr, so the line
+    is the only thing on stdout) and returns the child's exit code.  No fallback: a child that fails, or ends without a line,
+    is a non-zero exit with a one-line reason on stderr."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.pop("OMP_PROC_BIND", None)          # set above for the N = 1 cpu_baseline leg only: N ranks must not all pin to the same cores
+    env.pop("OMP_PLACES", None)
+    log(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks as a child process ({' '.join(cmd[1:9])} bench.py ...)")
+    try:
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    except OSError as exc:
+        print(f"[bench] FATAL: could not start the ranks: {exc}", file=sys.stderr, flush=True)
+        return 127
+
+    def forward(signum, _frame):            # the driver's timeout reaches the ranks too
+        try:
+            os.killpg(child.pid, signum)
+        except OSError:
+            pass
+    old = {sig: signal.signal(sig, forward) for sig in (signal.SIGTERM, signal.SIGINT)}
+    lines = []
+    try:
+        for line in child.stdout:
+            if line.startswith("{") and line.rstrip().endswith("}"):
+                lines.append(line.rstrip("\n"))
+            else:
+                sys.stderr.write(line)
+        rc = child.wait()
+    finally:
+        for sig, handler in old.items():
+            signal.signal(sig, handler)
+    if rc != 0:
+        print(f"[bench] FATAL: the ranks exited with code {rc} (torch.distributed.run, {args.gpus} ranks); no result line", file=sys.stderr, flush=True)
+        return rc if 0 < rc < 256 else 1
+    if len(lines) != 1:
+        print(f"[bench] FATAL: the ranks exited cleanly but printed {len(lines)} result lines instead of one", file=sys.stderr, flush=True)
+        return 5
+    print(lines[0], flush=True)
+    return 0
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -450,6 +500,14 @@ def main() -> None:
                     help="N > 1: pieces a rank's batch is traced and gathered in (piece c crosses the links while piece c + 1 is traced; "
                          "native: vt_gather_hits_part_dev, 1 .. 16).  1 = one trace + one ncclGather per step: in a stream of steps the gather "
                          "of step b already overlaps the trace of step b + 1; pieces pay for a one-shot batch (dist_breakdown.single_batch_ms)")
+    ap.add_argument("--form", default="ranks", choices=["ranks", "group"],
+                    help="N > 1: ranks = one process per GPU (vt_engine_comm_init_rank; what the driver launches, and what a bare "
+                         "`bench.py --gpus N` starts by itself); group = ONE process drives all N devices (vt_engine_open_multi + "
+                         "vt_trace_closest_gather_dev: the form a Lua state would use, INTEGRATION.md 3b)")
+    ap.add_argument("--group-devices", default=None,
+                    help="--form group: comma-separated device ids of the members (default 0 .. N-1).  A device listed twice needs "
+                         "the test hooks (VT_ENABLE_TEST_HOOKS=1 VT_TEST_ALLOW_DEVICE_ALIASES=1) and the RCCL test double (VT_RCCL_LIB): "
+                         "the line is then labelled simulated")
     ap.add_argument("--mode", default=None, choices=[None, "persistent", "static"])
     ap.add_argument("--image-hint", default="on", choices=["on", "off"],
                     help="camera-ray workloads (--kind primary, --scaling strong): pass the image's row length to the engine "
@@ -457,6 +515,10 @@ def main() -> None:
     args = ap.parse_args()
     if args.legs is None:   # the S10M leg only beside the default (headline) workload: the other configs are lines of their own
         args.legs = "all" if (args.scene == "S1M" and args.kind == "bounce" and args.side == 4096 and args.scaling == "weak" and args.alpha_frac == 0) else "host"
+
+    if args.gpus > 1 and args.form == "ranks" and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        # before torch is imported and before anything touches HIP: the ranks are a child process, never an exec of this one
+        sys.exit(launch_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -470,8 +532,9 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if args.form == "ranks" and args.gpus != world and args.gpus > 1:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python3 bench.py --gpus {args.gpus}` without a launcher: it starts its ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the traversal has no CPU path)")
     ndev = torch.cuda.device_count()

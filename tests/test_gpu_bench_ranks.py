@@ -47,3 +47,26 @@ def test_strong_scaling_line_with_two_ranks():
     """configs[4]'s shape (camera tiles split over the ranks) on a small scene."""
     d = _run(2, ["--scaling", "strong", "--scene", "S100k", "--tiles", "4"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rays_total"] == 4 * 1024 * 1024 and d["value"] > 0
+
+
+def test_bare_command_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` exactly as the driver runs N = 1 -- no launcher: bench.py starts the two ranks as a child
+    process before it touches HIP and relays rank 0's line (the only thing on stdout)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--no-cpu", "--no-pmc", "--alt-builder", "none", "--legs", "off", "--side", "512"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1, "stdout carries the result line and nothing else"
+    d = json.loads(out[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["rays_total"] == 2 * 512 * 512 and d["value"] > 0
+
+
+def test_bare_command_reports_a_crashed_rank():
+    """A rank that dies (here: an unknown scene name) is a non-zero exit code and a one-line reason, never a line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--no-cpu", "--no-pmc",
+                        "--scene", "no_such_scene"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    assert [ln for ln in p.stderr.splitlines() if ln.strip()][-1].startswith("[bench] FATAL: the ranks exited with code")
