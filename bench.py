@@ -446,6 +446,210 @@ def launch_ranks(args) -> int:
     return 0
 
 
+def run_group(args) -> None:
+    """--form group: ONE process drives all N devices -- vt_engine_open_multi, the scene replicated by vt_scene_upload, every member's
+    shard of the rays resident on its device, one vt_trace_closest_gather_dev per step (traces on the members' streams, ONE gather of
+    the hit records to the root over RCCL, double-buffered across steps).  This is the form a Lua state would use (one thread of one
+    process: INTEGRATION.md 3b, ref call site source/objects/AccelStruct.cpp:818).  Same workloads, same line as the one-process-
+    per-GPU form; `config.form` says which one ran, `config.simulated` whether members shared a device / RCCL was the test double."""
+    import torch
+
+    import vistrace_amd as va
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    from vistrace_amd._lib import HIT, RAY, RAY_STATS
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the traversal has no CPU path)")
+    if args.kind == "shadow":
+        raise SystemExit("--kind shadow is a single-GPU workload (BASELINE configs[3])")
+    ndev = args.gpus
+    devices = [int(x) for x in args.group_devices.split(",")] if args.group_devices else list(range(ndev))
+    if len(devices) != ndev:
+        raise SystemExit(f"--group-devices names {len(devices)} devices, --gpus {ndev}")
+    aliased = len(set(devices)) < ndev
+    fake_rccl = "fake_rccl" in os.environ.get("VT_RCCL_LIB", "")
+    simulated = None
+    if aliased or fake_rccl:
+        simulated = ("members share device(s) %s" % sorted(set(devices)) if aliased else "one device per member") + (
+            "; RCCL replaced by the test double tests/cpp/fake_rccl.cpp (transfers = stream-ordered device copies)" if fake_rccl else "") + \
+            ": the control flow and what ONE GPU needs for N members' work -- NOT a scaling number"
+    if args.scaling == "strong" and args.tiles % ndev != 0:
+        raise SystemExit("--form group --scaling strong needs --tiles divisible by --gpus")
+    root_dev = torch.device("cuda", devices[0])
+    torch.cuda.set_device(root_dev)
+
+    # ---- scene: CPU build once, replicated to every member by vt_scene_upload ----------------------------------------------------
+    t0 = time.time()
+    verts = W.make_scene(args.scene)
+    tris = va.tris_setup(verts)
+    host_threads = max(1, len(os.sched_getaffinity(0)))
+    bvh = va.HostBvh(tris, nthreads=min(16, host_threads), builder=args.builder)
+    host_scene = va.HostScene(bvh)
+    t1 = time.time()
+    engine = va.Engine(devices)
+    if args.mode is not None:
+        engine.set_option("persistent", 1 if args.mode == "persistent" else 0)
+    scene = va.Scene(engine, host_scene)
+    log(f"[bench] group of {ndev} members on devices {devices}: scene {args.scene} ({len(tris)} tris) built in {t1 - t0:.2f}s, "
+        f"replicated in {time.time() - t1:.2f}s ({scene.device_bytes / 1e6:.1f} MB per member)")
+
+    # ---- every member's rays on its own device (made with a single-device engine of that device; also the gather's reference) -----
+    tile = 1024 * 1024
+    singles = {}
+    def single_for(d):
+        if d not in singles:
+            e1 = va.Engine(d)
+            singles[d] = (e1, va.Scene(e1, host_scene))
+        return singles[d]
+    member_rays, member_n, ref_sums, tot_steps, tot_tests = [], [], [], 0, 0
+    workload = None
+    image_width = 0                 # camera-ray workloads are images in row-major order: the engines learn the row length
+    if args.image_hint == "on" and (args.kind == "primary" or args.scaling == "strong"):
+        image_width = 1024 if args.scaling == "strong" else args.side
+    for g, d in enumerate(devices):
+        dev = torch.device("cuda", d)
+        with torch.cuda.device(dev):
+            e1, s1 = single_for(d)
+            r, n_g, n_total, workload, _ = make_rays(args, g, ndev, va, W, tp, e1, s1, dev)
+            _, d_stats = tp.trace_stats(s1, r, n_g)                       # algorithmic bytes: exact counters, untimed
+            st = d_stats.view(torch.int32).view(n_g, 2).sum(dim=0, dtype=torch.int64).cpu().numpy()
+            tot_steps, tot_tests = tot_steps + int(st[0]), tot_tests + int(st[1])
+            del d_stats
+            e1.set_option("ray_image_width", image_width)
+            ref = tp.trace_closest(s1, r, n_g)                                # the member's shard traced alone: what must arrive on the root
+            torch.cuda.synchronize(dev)
+            ref_sums.append(int(ref.view(torch.int64).sum().item()))
+            del ref
+        member_rays.append(r)
+        member_n.append(n_g)
+    for e1, s1 in singles.values():
+        s1.free(); e1.close()
+    singles.clear()
+    if len(set(member_n)) != 1:
+        raise SystemExit(f"members got shards of different sizes {member_n}: the group form needs equal shards")
+    n = member_n[0]
+    cap = va.shard_capacity(n_total, ndev)
+    assert cap == n and n_total == n * ndev, (cap, n, n_total)
+    engine.set_option("ray_image_width", image_width)
+    alg_bytes = n_total * 48 + 64 * (tot_steps + tot_tests)
+    log(f"[bench] workload {workload}: {n} rays per member, {n_total} in the job; steps/ray {tot_steps / n_total:.2f} tests/ray {tot_tests / n_total:.2f}")
+
+    engine.set_timing(True)
+    if args.reserve_cus > 0 and ndev > 1:
+        engine.set_option("reserved_cus", args.reserve_cus)
+    if args.overlap == "off":
+        engine.set_option("gather_overlap", 0)
+    engine.set_option("gather_chunks", max(1, args.chunks))
+    ptrs = [r.data_ptr() for r in member_rays]
+    outs = [torch.empty(ndev * cap * 16, dtype=torch.uint8, device=root_dev) for _ in range(2)]
+    for o in outs:
+        o.fill_(0xEE)
+
+    def sync_all():
+        for d in set(devices):
+            torch.cuda.synchronize(torch.device("cuda", d))
+        engine.synchronize()
+
+    sync_all()
+    batch = [0]
+
+    def step():
+        scene.trace_closest_gather_dev(ptrs, n_total, outs[batch[0] % 2].data_ptr())
+        batch[0] += 1
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    engine.synchronize()
+    # the proof that the gather delivered every member's records to the root unchanged (64-bit word sums per shard)
+    last = outs[(batch[0] - 1) % 2].view(torch.int64).view(ndev, -1).sum(dim=1).cpu().numpy()
+    gather_verified = bool(all(int(last[g]) == ref_sums[g] for g in range(ndev)))
+    if not gather_verified:
+        print("[bench] FATAL: the group's gather did NOT deliver every member's records to the root intact", file=sys.stderr, flush=True)
+        sys.exit(4)
+
+    sync_all()
+    start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    engine.synchronize()                                   # every hit record of every step is on the root
+    sync_all()
+    elapsed = time.perf_counter() - start
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- where the step time goes (untimed, synchronised batches behind the timed region) ------------------------------------------
+    tr, ga = [[] for _ in range(ndev)], []
+    for _ in range(6):
+        step()
+        engine.synchronize()
+        for g in range(ndev):
+            tr[g].append(engine.member_kernel_ms(g))
+        if ndev > 1:
+            ga.append(engine.last_gather_ms())
+    t_mean = [float(np.mean(x)) for x in tr]
+    g_mean = float(np.mean(ga)) if ga else 0.0
+    single = {}
+    for K in (1, 2, 4, 8):
+        engine.set_option("gather_chunks", K)
+        ts = []
+        for _ in range(4):
+            sync_all()
+            t0 = time.perf_counter()
+            step()
+            engine.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        single[str(K)] = round(float(np.mean(ts[1:])), 4)
+    engine.set_option("gather_chunks", max(1, args.chunks))
+    engine.set_timing(False)
+    t_max = max(t_mean)
+    hidden = max(0.0, t_max + g_mean - ms_per_step)
+    value = n_total * args.steps / elapsed / 1e6
+    k_ms = float(np.mean(t_mean))
+    result = {
+        "metric": ("Mrays/s closest-hit, 1M-triangle scene" if args.scene == "S1M" else "Mrays/s closest-hit, scene %s" % args.scene),
+        "value": round(value, 2), "unit": "Mrays/s", "n_gpus": ndev, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (seeded; rays generated on the device)",
+        "config": {
+            "workload": workload, "scene_triangles": int(len(tris)), "bvh_builder": BUILDER_NAMES[args.builder],
+            "rays_per_gpu": n, "rays_total": n_total, "query": "closest-hit",
+            "ray_kind": "pinhole primary" if (args.kind == "primary" or args.scaling == "strong") else "cosine-hemisphere bounce (incoherent)",
+            "form": "group: ONE process, vt_engine_open_multi over %d members, vt_trace_closest_gather_dev per step" % ndev,
+            "group_devices": devices,
+            "simulated": simulated,
+            "parallelism": f"rays sharded x{ndev}, BVH replicated, hits gathered to the root inside the step (ncclGather on the members' "
+                           f"communication streams, double-buffered across steps); {engine.get_option('reserved_cus')} CUs keep room for its kernels",
+            "gather_verified": gather_verified,
+            "dist_breakdown": {
+                "trace_ms_per_rank": {"min": round(min(t_mean), 4), "max": round(t_max, 4)},
+                "gather_ms_per_rank": {"min": round(g_mean, 4), "max": round(g_mean, 4)} if ga else None,
+                "gather_ms_how": "HIP events on the root's communication stream around one batch's gather (vt_engine_last_gather_ms); with members "
+                                 "sharing a device the 'transfer' is device copies competing with the other members' traces",
+                "step_ms": round(ms_per_step, 4), "chunks": max(1, args.chunks),
+                "single_batch_ms": single,
+                "single_batch_how": "one isolated batch (devices idle before, every record on the root after; wall clock) traced and gathered in K "
+                                    "pieces (engine option gather_chunks), K = the keys",
+                "overlap": args.overlap,
+                "overlap_frac": round(min(1.0, hidden / min(t_max, g_mean)), 3) if ga and min(t_max, g_mean) > 0 else None,
+                "overlap_note": "(trace + gather - step) / min(trace, gather): 1 = the shorter of the two is fully hidden, 0 = they run back to back",
+                "gather_kind": "native ncclGather issued by vt_trace_closest_gather_dev (single-process group, ncclCommInitAll)",
+                "bytes_into_root_per_step": int((ndev - 1) * cap * 16),
+            },
+            "launch_options": {k: engine.get_option(k) for k in ("lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold", "reserved_cus", "reserved_limit", "ray_image_width", "gather_chunks")},
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+            "traffic_source": "PMC passes are taken at N = 1 only (the kernel is the same)",
+            "alg_achieved": round(alg_bytes / ndev / (k_ms * 1e-3) / 1e9, 1),
+            "alg_note": "algorithmic bytes (SURVEY 8(d)) of one member's shard / that member's mean launch duration",
+            "kernel_ms": round(k_ms, 4), "kernel_ms_how": "mean over the members of vt_engine_last_kernel_ms (HIP events on each member's trace stream), 6 synchronised batches",
+            "alg_bytes_per_ray": round(alg_bytes / n_total, 1), "steps_per_ray": round(tot_steps / n_total, 2), "tests_per_ray": round(tot_tests / n_total, 2),
+            "kernel_sources_sha": kernel_sources_sha(),
+        },
+    }
+    print(json.dumps(result), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -519,6 +723,10 @@ def main() -> None:
     if args.gpus > 1 and args.form == "ranks" and "WORLD_SIZE" not in os.environ and not args.pmc_child:
         # before torch is imported and before anything touches HIP: the ranks are a child process, never an exec of this one
         sys.exit(launch_ranks(args))
+
+    if args.form == "group":
+        run_group(args)
+        return
 
     import torch
     import torch.distributed as dist

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 4   /* 2: launch-slot ring, host walk, multi-GPU entries; 3: vt_batch, any-hit counters, gather timing; 4: merged launches, chunked gather, batch sets, vertex frames + vt_hit_tbn (all additive) */
+#define VT_ABI_VERSION 5   /* 2: launch-slot ring, host walk, multi-GPU entries; 3: vt_batch, any-hit counters, gather timing; 4: merged launches, chunked gather, batch sets, vertex frames + vt_hit_tbn; 5: vt_engine_member, vt_scene_upload_stats (all additive) */
 
 enum vt_status {
     VT_OK              = 0,
@@ -199,6 +199,10 @@ void vt_engine_close(vt_engine* e);
 int vt_engine_open_multi(const int* devices, int ndev, vt_engine** out);
 int vt_engine_device_count(const vt_engine* e);          /* 1 for vt_engine_open */
 int vt_engine_device(const vt_engine* e, int g);         /* HIP device of group member g (0 = root), -1 if out of range */
+/* Member g of a group (0 = the root itself), NULL if out of range: a BORROWED handle, owned by the root, for the per-engine
+ * queries (vt_engine_last_kernel_ms, vt_engine_last_gather_ms, vt_engine_launch_info, vt_engine_get_option).  Never close it,
+ * never set options on it (options go to the root and reach every member), never upload scenes through it. */
+vt_engine* vt_engine_member(vt_engine* e, int g);
 /* Contiguous sharding (keeps the coherence of primary rays inside a shard): capacity = ceil(n / ndev) rounded up to
  * 64 rays, shard g = [g * capacity, min(n, (g + 1) * capacity)) -- the last shards may be short or empty. */
 uint64_t vt_shard_capacity(uint64_t n, int ndev);
@@ -229,8 +233,10 @@ int vt_trace_closest_gather_dev(vt_scene* s, const void* const* d_rays, uint64_t
  * `stream` wait until at most ONE gather is still in flight (call it before overwriting the older of two alternating
  * send buffers); vt_gather_wait(e, 0, NULL): host-wait for every gather.  Engine option "gather_overlap" = 0 makes
  * vt_gather_wait(e, 1, stream) wait for the latest gather too (diagnostic: step = trace + gather).  With
- * vt_engine_set_timing on, vt_engine_last_gather_ms reports the duration of the latest gather on the communication
- * stream (HIP events around the ncclGather). */
+ * vt_engine_set_timing on, vt_engine_last_gather_ms reports the duration of the latest batch's gather on the communication
+ * stream: HIP events in front of the batch's first piece and behind its last one (one ncclGather when the batch is one piece;
+ * with K > 1 pieces the span includes the waits for the traces of pieces 1 .. K-1).  Single-process group: the root's figure
+ * (it receives every shard). */
 int vt_comm_unique_id(void* id128);
 int vt_engine_comm_init_rank(vt_engine* e, int nranks, int rank, const void* id128);
 int vt_gather_hits_dev(vt_engine* e, const void* d_send, uint64_t count, void* d_recv_root, int root, void* stream);
@@ -243,6 +249,9 @@ int vt_gather_wait(vt_engine* e, int batches_in_flight, void* stream);
  *   one process per GPU: after vt_gather_wait(e, 1, stream), for c = 0 .. K-1: trace the rays of piece c into d_send + lo
  *     records on `stream`, then vt_gather_hits_part_dev(e, d_send, count, c, K, d_recv_root, root, stream).  Every rank
  *     passes the same count and K; the pieces of a batch are handed over in order.  vt_gather_hits_dev = one piece.
+ *     Piece 0 always starts a new batch: a batch that was abandoned between two pieces (the caller's own trace failed) is
+ *     dropped by the next piece 0 (or vt_gather_hits_dev) -- on EVERY rank, or the ranks' send / receive counts no longer
+ *     match.  With count == 0 every piece is a no-op.
  * A piece of every shard cannot land at its final place through ncclGather (it puts rank r's data at r * piece size), so
  * pieces move as the sends and receives ncclGather consists of, one group per piece; K = 1 is the single ncclGather.
  * Each extra piece costs one more launch (~0.3 ms of drain): worth it for a one-shot batch whose gather is as long as its
@@ -535,6 +544,19 @@ int vt_engine_set_timing(vt_engine* e, int enabled);
 int vt_engine_last_kernel_ms(vt_engine* e, float* ms);
 /* Launch geometry actually used (for DESIGN.md / bench reporting). */
 int vt_engine_launch_info(vt_engine* e, uint32_t* blocks, uint32_t* threads, uint32_t* lds_bytes);
+
+/* ---- Test hooks ------------------------------------------------------------------------------------------------------
+ * Environment switches compiled into the library so that a box with ONE GPU can execute code that a product run reaches
+ * only on other hardware.  They are DEAD unless VT_ENABLE_TEST_HOOKS=1 is set beside them, and an active hook announces
+ * itself on stderr once ("[vistrace_hip] TEST HOOK active: ...").  Never set them in production.
+ *   VT_TEST_ALLOW_DEVICE_ALIASES=1   vt_engine_open_multi accepts a device listed several times (device 0 standing for every
+ *                                    member of a group).  Real RCCL refuses such a group: use with VT_RCCL_LIB pointing at
+ *                                    tests/cpp/_build/libfake_rccl.so (tests/test_gpu_fake_group.py, bench.py --form group).
+ *   VT_TEST_RECORD_GAP=<records>     vt_scene_upload leaves that many unused 64-B records between the pairs and the
+ *                                    triangles (a multi-GiB allocation): the 64-bit record addressing of scenes with more than
+ *                                    67 M records on a 10 k-triangle scene (tests/test_gpu_parity.py::test_records_beyond_4_gib).
+ * Not hooks but configuration, always honoured: VT_RCCL_LIB (path of the RCCL library to dlopen instead of librccl.so),
+ * VT_BUILDER (default builder of vt_bvh_build), VT_BATCH_UPLOAD (staged | direct), VT_COPY_THREADS (staging-copy threads). */
 
 #ifdef __cplusplus
 }

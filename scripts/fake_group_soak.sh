@@ -3,7 +3,7 @@
 # delays: races in a schedule are a matter of timing.   bash scripts/fake_group_soak.sh [seconds]   (GPU box, repo root)
 cd "$(dirname "$0")/.."
 make -C tests/cpp fake_rccl > /dev/null || exit 1
-export VT_RCCL_LIB=$PWD/tests/cpp/_build/libfake_rccl.so VT_TEST_ALLOW_DEVICE_ALIASES=1
+export VT_RCCL_LIB=$PWD/tests/cpp/_build/libfake_rccl.so VT_ENABLE_TEST_HOOKS=1 VT_TEST_ALLOW_DEVICE_ALIASES=1
 budget=${1:-300}; t0=$(date +%s); round=1; bad=0
 while [ $(( $(date +%s) - t0 )) -lt $budget ]; do
     for delay in 0 200 1500 6000; do

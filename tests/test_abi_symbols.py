@@ -29,7 +29,7 @@ def test_pod_sizes(va):
     L = va._lib
     assert (L.RAY.itemsize, L.HIT.itemsize, L.BVH_NODE.itemsize, L.NODE_PAIR.itemsize, L.TRI64.itemsize,
             L.RAY_STATS.itemsize, L.HIT_ATTRS.itemsize) == (32, 16, 32, 64, 64, 8, 64)
-    assert L.lib.vt_abi_version() == 4
+    assert L.lib.vt_abi_version() == 5
 
 
 def test_no_product_import_of_oracle():

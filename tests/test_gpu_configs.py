@@ -357,7 +357,37 @@ def test_native_gather_single_rank(va, make_bundle):
         eng.gather_hits_part_dev(send[0].data_ptr(), n, c, 4, recv[0].data_ptr(), 0, stream)
     with pytest.raises(va._lib.VisTraceError):
         eng.gather_hits_part_dev(send[0].data_ptr(), n, 0, 17, recv[0].data_ptr(), 0, stream)
+    # a batch abandoned between two pieces (the caller's own trace failed, say) must not wedge the engine: piece 0 of the next
+    # batch -- or a plain vt_gather_hits_dev -- starts afresh, and the results of the batches behind it are right
+    eng.gather_hits_part_dev(send[0].data_ptr(), n, 0, 4, recv[0].data_ptr(), 0, stream)
+    eng.gather_hits_part_dev(send[0].data_ptr(), n, 1, 4, recv[0].data_ptr(), 0, stream)       # ... and never pieces 2, 3
+    for r in recv:
+        r.zero_()
+    torch.cuda.synchronize()
+    for batch in range(3):
+        k = batch % 2
+        eng.gather_wait(1, stream)
+        scene.trace_closest_dev(d_rays.data_ptr(), n, send[k].data_ptr(), stream)
+        eng.gather_hits_dev(send[k].data_ptr(), n, recv[k].data_ptr(), 0, stream)
     eng.gather_wait(0)
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert_hits_equal(tp.to_host(recv[k], va.HIT), ref)
+    # an empty batch in pieces: every piece is a no-op, whatever the order state
+    for c in range(3):
+        eng.gather_hits_part_dev(send[0].data_ptr(), 0, c, 3, recv[0].data_ptr(), 0, stream)
+    # the gather's timing spans all pieces of a batch (first piece .. behind the last)
+    eng.set_timing(True)
+    for c in range(4):
+        lo, hi = va.gather_chunk_bounds(n, 4, c)
+        scene.trace_closest_dev(d_rays.data_ptr() + 32 * lo, hi - lo, send[0].data_ptr() + 16 * lo, stream)
+        eng.gather_hits_part_dev(send[0].data_ptr(), n, c, 4, recv[0].data_ptr(), 0, stream)
+    eng.gather_wait(0)
+    whole = eng.last_gather_ms()
+    eng.gather_hits_dev(send[0].data_ptr(), n, recv[0].data_ptr(), 0, stream)
+    eng.gather_wait(0)
+    assert whole > 0 and eng.last_gather_ms() > 0
+    eng.set_timing(False)
     scene.free()
     eng.close()
 

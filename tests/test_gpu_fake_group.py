@@ -23,7 +23,7 @@ def _run_child(**extra):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "fake_rccl"], stdout=subprocess.DEVNULL)
     fake = os.path.join(ROOT, "tests", "cpp", "_build", "libfake_rccl.so")
     assert os.path.exists(fake)
-    env = dict(os.environ, VT_RCCL_LIB=fake, VT_TEST_ALLOW_DEVICE_ALIASES="1", **extra)
+    env = dict(os.environ, VT_RCCL_LIB=fake, VT_ENABLE_TEST_HOOKS="1", VT_TEST_ALLOW_DEVICE_ALIASES="1", **extra)
     # a child process: the library binds its RCCL entry points once per process, and the other tests want the real one
     return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fake_group_check.py")], env=env, capture_output=True, text=True, timeout=900)
 
@@ -47,9 +47,15 @@ def test_the_fake_group_check_detects_a_send_that_completes_early():
 
 def test_device_aliases_are_refused_without_the_test_hook(va):
     """Outside that test a device listed twice is an error (real RCCL cannot form such a group)."""
-    assert os.environ.get("VT_TEST_ALLOW_DEVICE_ALIASES") is None
+    assert os.environ.get("VT_TEST_ALLOW_DEVICE_ALIASES") is None and os.environ.get("VT_ENABLE_TEST_HOOKS") is None
     with pytest.raises(va._lib.VisTraceError, match="listed twice"):
         va.Engine([0, 0])
+    os.environ["VT_TEST_ALLOW_DEVICE_ALIASES"] = "1"        # the hook alone is dead: VT_ENABLE_TEST_HOOKS=1 must stand beside it
+    try:
+        with pytest.raises(va._lib.VisTraceError, match="listed twice"):
+            va.Engine([0, 0])
+    finally:
+        del os.environ["VT_TEST_ALLOW_DEVICE_ALIASES"]
 
 
 def test_host_binding_through_a_two_member_group():
@@ -58,7 +64,7 @@ def test_host_binding_through_a_two_member_group():
     through the group's root -- all 3 064 checks as with one device."""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "fake_rccl"], stdout=subprocess.DEVNULL)
-    env = dict(os.environ, VT_RCCL_LIB=os.path.join(ROOT, "tests", "cpp", "_build", "libfake_rccl.so"), VT_TEST_ALLOW_DEVICE_ALIASES="1",
+    env = dict(os.environ, VT_RCCL_LIB=os.path.join(ROOT, "tests", "cpp", "_build", "libfake_rccl.so"), VT_ENABLE_TEST_HOOKS="1", VT_TEST_ALLOW_DEVICE_ALIASES="1",
                VISTRACE_DEVICES="0,0")
     p = subprocess.run([os.path.join(ROOT, "tests", "cpp", "_build", "test_binding")], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and " 0 failed" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
@@ -71,10 +77,31 @@ def test_parity_suites_through_the_root_of_a_group():
     refused refit was found to leave the members of a group with different geometry: vt_scene_refit / vt_scene_skin_refit now go
     to every member before the first failure is reported.)"""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "fake_rccl"], stdout=subprocess.DEVNULL)
-    env = dict(os.environ, VT_RCCL_LIB=os.path.join(ROOT, "tests", "cpp", "_build", "libfake_rccl.so"), VT_TEST_ALLOW_DEVICE_ALIASES="1",
+    env = dict(os.environ, VT_RCCL_LIB=os.path.join(ROOT, "tests", "cpp", "_build", "libfake_rccl.so"), VT_ENABLE_TEST_HOOKS="1", VT_TEST_ALLOW_DEVICE_ALIASES="1",
                VT_TEST_GROUP_MEMBERS="2")
     p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_shading_frame.py"),
                         os.path.join(ROOT, "tests", "test_gpu_multi_batch.py")], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     tail = [ln for ln in p.stdout.splitlines() if "passed" in ln or "failed" in ln]
     assert p.returncode == 0 and tail and "failed" not in tail[-1], (p.stdout[-3000:], p.stderr[-2000:])
+
+
+def test_bench_group_form_on_a_simulated_group():
+    """bench.py --form group: ONE process, vt_engine_open_multi over three members (device 0 three times, RCCL test double),
+    vt_trace_closest_gather_dev per step -- the form a Lua state would use.  The line must be well-formed, labelled simulated,
+    with the gather verified against each member's shard traced alone."""
+    import json
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "fake_rccl"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, VT_RCCL_LIB=os.path.join(ROOT, "tests", "cpp", "_build", "libfake_rccl.so"), VT_ENABLE_TEST_HOOKS="1",
+               VT_TEST_ALLOW_DEVICE_ALIASES="1")
+    for extra, total in ((["--side", "512"], 3 * 512 * 512), (["--scaling", "strong", "--scene", "S100k", "--tiles", "3"], 3 * 1024 * 1024)):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--form", "group", "--gpus", "3", "--group-devices", "0,0,0",
+                            "--steps", "3", "--warmup", "1"] + extra, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 3 and d["config"]["rays_total"] == total and d["value"] > 0
+        assert d["config"]["gather_verified"] is True and d["config"]["simulated"] and "group" in d["config"]["form"]
+        bd = d["config"]["dist_breakdown"]
+        assert set(bd["single_batch_ms"]) == {"1", "2", "4", "8"} and bd["trace_ms_per_rank"]["max"] > 0 and bd["gather_ms_per_rank"]["max"] > 0

@@ -242,3 +242,62 @@ def test_merged_launch_on_degenerate_scenes(va, engine):
         else:
             assert (whole["prim"] == O_MISS).all()
         scene.free()
+
+
+def test_batch_set_of_empty_buffers_on_a_fresh_engine(va, make_bundle):
+    """accel:TraverseBatch({""}) as an accel's FIRST call: a set of empty buffers only, with the hit records asked for, on an engine
+    that has never traced a host batch (its staging pipeline and events do not exist yet) -- empty batches come back, no HIP error."""
+    b = make_bundle("S10k")
+    eng = va.Engine(0)
+    scene = va.Scene(eng, b.host_scene)
+    empty = np.zeros(0, va.RAY)
+    got = scene.trace_batch_set([empty, empty], check_ranges=True, fetch_hits=True)
+    assert [len(g) for g in got] == [0, 0] and len(got[0].hits()) == 0 and len(got[1].attrs()) == 0
+    for g in got:
+        g.free()
+    scene.free()
+    eng.close()
+
+
+def test_open_batch_set_survives_its_engine_and_its_scene(va, make_bundle):
+    """A set that is still open (buffers added, not traced) when its engine is closed or its scene freed: the batches' device memory
+    goes with the engine, later calls on the set fail with a message, and abort / trace free the shells (no dangling pointers: this
+    test crashes or trips the allocator otherwise)."""
+    import ctypes as C
+    from vistrace_amd import workloads as W
+    L = va._lib
+    b = make_bundle("S10k")
+    rays = np.ascontiguousarray(W.sphere_rays(5000, 3))
+    bad = C.c_uint64(0)
+    for how in ("close_engine_then_trace", "close_engine_then_abort", "free_scene_then_trace", "free_scene_then_add"):
+        eng = va.Engine(0)
+        scene = va.Scene(eng, b.host_scene)
+        h = C.c_void_p()
+        assert L.lib.vt_batch_set_begin(scene._h, 0, C.byref(h)) == L.VT_OK
+        assert L.lib.vt_batch_set_add(h, L.ptr(rays), len(rays), 0, C.byref(bad)) == L.VT_OK
+        assert L.lib.vt_batch_set_add(h, L.ptr(rays), len(rays), 0, C.byref(bad)) == L.VT_OK
+        outs = (C.c_void_p * 2)()
+        if how.startswith("close_engine"):
+            eng.close()
+            if how.endswith("trace"):
+                assert L.lib.vt_batch_set_trace(h, outs) == L.VT_ERR_INVALID_ARG and b"engine has been closed" in L.lib.vt_last_error()
+            else:
+                L.lib.vt_batch_set_abort(h)
+            scene.free()
+        else:
+            scene.free()
+            if how.endswith("add"):
+                assert L.lib.vt_batch_set_add(h, L.ptr(rays), len(rays), 0, C.byref(bad)) == L.VT_ERR_INVALID_ARG
+                assert b"scene has been freed" in L.lib.vt_last_error()
+                L.lib.vt_batch_set_abort(h)
+            else:
+                assert L.lib.vt_batch_set_trace(h, outs) == L.VT_ERR_INVALID_ARG and b"scene has been freed" in L.lib.vt_last_error()
+            eng.close()
+    # and the engine is as usable as before
+    eng = va.Engine(0)
+    scene = va.Scene(eng, b.host_scene)
+    got = scene.trace_batch_set([rays])
+    assert_hits_equal(got[0].hits(), b.oracle(rays))
+    got[0].free()
+    scene.free()
+    eng.close()

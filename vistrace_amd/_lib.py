@@ -84,6 +84,7 @@ SYMBOLS = {
     "vt_engine_open_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, _pp]),
     "vt_engine_device_count": (C.c_int, [_vp]),
     "vt_engine_device": (C.c_int, [_vp, C.c_int]),
+    "vt_engine_member": (_vp, [_vp, C.c_int]),
     "vt_shard_capacity": (_u64, [_u64, C.c_int]),
     "vt_shard_bounds": (None, [_u64, C.c_int, C.c_int, C.POINTER(_u64), C.POINTER(_u64)]),
     "vt_trace_closest_gather_dev": (C.c_int, [_vp, C.POINTER(C.c_void_p), _u64, _vp]),

@@ -251,6 +251,15 @@ class Engine:
     def device_count(self) -> int:
         return int(lib.vt_engine_device_count(self._h))
 
+    def member_kernel_ms(self, g: int) -> float:
+        """Duration of the latest timed trace launch of group member g (vt_engine_member + vt_engine_last_kernel_ms)."""
+        m = lib.vt_engine_member(self._h, g)
+        if not m:
+            raise IndexError(f"group member {g} out of range")
+        ms = C.c_float(0)
+        check(lib.vt_engine_last_kernel_ms(C.c_void_p(m), C.byref(ms)))
+        return float(ms.value)
+
     # one process per GPU: native RCCL gather of hit records (vt_gather_hits_dev)
     def comm_init_rank(self, nranks: int, rank: int, unique_id: bytes) -> None:
         assert len(unique_id) == 128

@@ -500,8 +500,24 @@ int vt_batch_set_begin(vt_scene* s, uint32_t flags, vt_batch_set** out)
     vt_batch_set* set = new vt_batch_set();
     set->scene = s;
     set->flags = flags;
+    s->open_sets.push_back(set);                 // vt_scene_free detaches it: the set must not keep a dangling scene
     *out = set;
     return VT_OK;
+}
+
+// the set leaves its scene's list (it is about to be deleted)
+static void set_unlink(vt_batch_set* set)
+{
+    if (vt_scene* s = set->scene) s->open_sets.erase(std::remove(s->open_sets.begin(), s->open_sets.end(), set), s->open_sets.end());
+    set->scene = nullptr;
+}
+
+// the batches of a set whose engine or scene has gone: the engine released their device memory when it closed (they were
+// registered with it when they were added); what is left are the shells and their pinned host arrays
+static void set_free_batches(vt_batch_set* set)
+{
+    for (vt_batch* b : set->batches) vt_batch_free(b);
+    set->batches.clear();
 }
 
 void vt_batch_set_abort(vt_batch_set* set)
@@ -510,9 +526,11 @@ void vt_batch_set_abort(vt_batch_set* set)
     if (vt_scene* s = set->scene; s && s->engine) {
         vt_engine* e = s->engine;
         DeviceGuard guard(e->device);
-        (void)hipStreamSynchronize(e->s_in); (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->s_out);
-        for (vt_batch* b : set->batches) batch_discard(e, b);
+        if (e->s_in) { (void)hipStreamSynchronize(e->s_in); (void)hipStreamSynchronize(e->s_out); }
+        (void)hipStreamSynchronize(e->stream);
     }
+    set_free_batches(set);                       // with or without an engine: vt_batch_free knows both
+    set_unlink(set);
     delete set;
 }
 
@@ -521,6 +539,7 @@ int vt_batch_set_add(vt_batch_set* set, const vt_ray* rays, uint64_t n, uint32_t
     if (!set) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_add: set is NULL");
     if (bad_ray) *bad_ray = n;
     vt_scene* s = set->scene;
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_add: the set's scene has been freed");
     if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_add: the scene\'s engine has been closed");
     if (n != 0 && !rays) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_add: rays is NULL");
     if (n >= (uint64_t(1) << 32)) return fail(VT_ERR_INVALID_ARG, "vt_batch_set_add: a batch of a set holds at most 2^32 - 1 rays");
@@ -546,6 +565,12 @@ int vt_batch_set_add(vt_batch_set* set, const vt_ray* rays, uint64_t n, uint32_t
         *bad_ray = bad;
         return fail(VT_ERR_INVALID_ARG, "vt_batch_set_add: ray " + std::to_string(bad) + " fails the range checks (tMin < 0 or tMax <= tMin)");
     }
+    {
+        // registered with the engine from now on: should the engine be closed while the set is open, it releases the batch's
+        // device memory and detaches it like any other live batch
+        std::lock_guard<std::mutex> lock(e->launch_mu);
+        e->batches.push_back(b);
+    }
     set->batches.push_back(b);
     set->widths.push_back(ray_image_width);
     return VT_OK;
@@ -559,11 +584,19 @@ int vt_batch_set_trace(vt_batch_set* set, vt_batch** out)
     const uint32_t nb = uint32_t(set->batches.size());
     if (nb != 0 && !out) { vt_batch_set_abort(set); return fail(VT_ERR_INVALID_ARG, "vt_batch_set_trace: out is NULL"); }
     vt_scene* s = set->scene;
-    if (!s->engine) { delete set; return fail(VT_ERR_INVALID_ARG, "vt_batch_set_trace: the scene\'s engine has been closed"); }
+    if (!s || !s->engine) {
+        const bool freed = !s;
+        vt_batch_set_abort(set);
+        return fail(VT_ERR_INVALID_ARG, freed ? "vt_batch_set_trace: the set's scene has been freed" : "vt_batch_set_trace: the scene\'s engine has been closed");
+    }
     vt_engine* e = s->engine;
     DeviceGuard guard(e->device);
     int rc = guard.ok ? VT_OK : fail(VT_ERR_HIP, "vt_batch_set_trace: hipSetDevice failed");
-    if (rc == VT_OK && nb != 0) {
+    uint64_t total = 0;
+    for (const vt_batch* b : set->batches) total += b->n;
+    // (a set of empty buffers only -- accel:TraverseBatch({""}) -- launches nothing and fetches nothing: the engine's host pipeline,
+    // whose events the fetch uses, is only created by the first non-empty add)
+    if (rc == VT_OK && nb != 0 && total != 0) {
         std::lock_guard<std::mutex> host_lock(e->host_mu);
         // ONE merged launch over all batches (one grid start, one drain: launch_batches); then per batch the download of its hit
         // records (VT_BATCH_FETCH_HITS) and its result kernels
@@ -585,11 +618,8 @@ int vt_batch_set_trace(vt_batch_set* set, vt_batch** out)
         for (uint32_t k = 0; k < nb && rc == VT_OK; ++k) rc = batch_finish(s, set->batches[k]);
     }
     if (rc != VT_OK) { vt_batch_set_abort(set); return rc; }
-    {
-        std::lock_guard<std::mutex> lock(e->launch_mu);
-        for (vt_batch* b : set->batches) e->batches.push_back(b);
-    }
-    for (uint32_t k = 0; k < nb; ++k) out[k] = set->batches[k];
+    for (uint32_t k = 0; k < nb; ++k) out[k] = set->batches[k];     // already registered with the engine (vt_batch_set_add)
+    set_unlink(set);
     delete set;
     return VT_OK;
 }
@@ -714,6 +744,12 @@ void* vt_engine_stream(vt_engine* e) { return e ? static_cast<void*>(e->stream) 
 } // extern "C"
 
 namespace vt {
+
+void batch_sets_detach(vt_scene* s)
+{
+    for (vt_batch_set* set : s->open_sets) set->scene = nullptr;
+    s->open_sets.clear();
+}
 
 int engine_trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, size_t out_elem, bool any_hit)
 {

@@ -654,7 +654,7 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
     // small scene has triangle and AlphaRec records beyond 4 GiB -- the 64-bit addressing and the kernel choice of scenes with
     // more than 67 M records, without building one: tests/test_gpu_configs.py)
     uint64_t gap = 0;
-    if (const char* env = std::getenv("VT_TEST_RECORD_GAP")) gap = std::strtoull(env, nullptr, 10) & ~uint64_t(1);
+    if (const char* env = test_hook("VT_TEST_RECORD_GAP")) gap = std::strtoull(env, nullptr, 10) & ~uint64_t(1);
     if (uint64_t(s->npairs) + gap + 2 * uint64_t(s->ntris) + 4 >= 0xFFFFFFFFull) { delete s; return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: scene too large"); }
     {
         s->tri_base = ((s->npairs + 1u) & ~1u) + uint32_t(gap);
@@ -731,6 +731,7 @@ static void release_scene_device(vt_scene* s)
 void vt_scene_free(vt_scene* s)
 {
     if (!s) return;
+    batch_sets_detach(s);
     for (vt_scene* rep : s->replicas) vt_scene_free(rep);
     s->replicas.clear();
     if (vt_engine* e = s->engine) {             // NULL once the engine was closed: only the shell is left
@@ -1217,6 +1218,7 @@ int vt_engine_synchronize(vt_engine* e)
 int vt_engine_set_timing(vt_engine* e, int enabled)
 {
     if (!e) return fail(VT_ERR_INVALID_ARG, "vt_engine_set_timing: NULL");
+    for (vt_engine* p : e->peers) (void)vt_engine_set_timing(p, enabled);      // a group is timed as a whole
     e->timing = enabled != 0;
     e->ev_valid = false;
     return VT_OK;

@@ -142,8 +142,11 @@ struct vt_engine {
     vt::GatherSchedule sched;                      // batches issued + which sent events exist (group state lives on the root)
 };
 
+struct vt_batch_set;
+
 struct vt_scene {
     vt_engine*    engine = nullptr;
+    std::vector<vt_batch_set*> open_sets;  // vt_batch_set_begin .. _trace / _abort: detached when the scene is freed
     char*         d_records = nullptr; // pairs, then (128-B aligned) the leaf-ordered triangles
     vt_tri64*     d_tris = nullptr;    // = d_records + tri_base * 64
     uint32_t      tri_base = 0;
@@ -222,6 +225,8 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
 // enqueue one trace of n device-resident rays on `stream` (per-launch scratch from the engine's slot ring)
 int engine_launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_occ, void* d_stats, bool any_hit, bool stats,
                   hipStream_t stream);
+// batch.hip: the open batch sets of a scene that is being freed lose their scene (their later calls fail, abort still frees them)
+void batch_sets_detach(vt_scene* s);
 // the host-pointer path of ONE device: staging copies + launch(es) + copy-out, synchronous
 int engine_trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, size_t out_elem, bool any_hit);
 

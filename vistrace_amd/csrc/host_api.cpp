@@ -7,9 +7,11 @@
 #include <omp.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <mutex>
 #include <new>
 
 namespace vt {
@@ -22,6 +24,25 @@ int fail(int code, const std::string& msg)
 {
     g_last_error = msg;
     return code;
+}
+
+// Test hooks (include/vistrace_hip.h, "Test hooks"): environment switches that change what the library does so that a one-GPU box
+// can reach code a product run reaches only on other hardware.  They are dead unless VT_ENABLE_TEST_HOOKS=1 is set as well, and
+// an active hook says so on stderr once -- a stray variable in a user's environment never changes product behaviour silently.
+const char* test_hook(const char* name)
+{
+    const char* on = std::getenv("VT_ENABLE_TEST_HOOKS");
+    if (!on || on[0] != '1' || on[1] != '\0') return nullptr;
+    const char* v = std::getenv(name);
+    if (!v || !*v) return nullptr;
+    static std::mutex mu;
+    static std::vector<std::string> announced;
+    std::lock_guard<std::mutex> lock(mu);
+    if (std::find(announced.begin(), announced.end(), name) == announced.end()) {
+        announced.emplace_back(name);
+        std::fprintf(stderr, "[vistrace_hip] TEST HOOK active: %s=%s (VT_ENABLE_TEST_HOOKS=1) -- not a product configuration\n", name, v);
+    }
+    return v;
 }
 
 void parallel_copy(void* dst, const void* src, size_t bytes)

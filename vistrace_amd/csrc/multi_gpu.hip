@@ -252,9 +252,9 @@ int vt_engine_open_multi(const int* devices, int ndev, vt_engine** out)
     if (!out) return fail(VT_ERR_INVALID_ARG, "vt_engine_open_multi: out is NULL");
     *out = nullptr;
     if (!devices || ndev <= 0) return fail(VT_ERR_INVALID_ARG, "vt_engine_open_multi: no devices");
-    // (test hook: with VT_TEST_ALLOW_DEVICE_ALIASES=1 a device may stand for several members of the group, so that the N > 1
+    // (test hook, dead without VT_ENABLE_TEST_HOOKS=1: with VT_TEST_ALLOW_DEVICE_ALIASES=1 a device may stand for several members of the group, so that the N > 1
     // control flow runs on a box with one GPU -- against tests/cpp/fake_rccl.cpp, real RCCL refuses such a group)
-    const char* aliases = std::getenv("VT_TEST_ALLOW_DEVICE_ALIASES");
+    const char* aliases = test_hook("VT_TEST_ALLOW_DEVICE_ALIASES");
     const bool allow_aliases = aliases && aliases[0] == '1';
     for (int a = 0; a < ndev && !allow_aliases; ++a)
         for (int b = a + 1; b < ndev; ++b)
@@ -274,6 +274,12 @@ int vt_engine_open_multi(const int* devices, int ndev, vt_engine** out)
 }
 
 int vt_engine_device_count(const vt_engine* e) { return e ? int(e->peers.size()) + 1 : 0; }
+
+vt_engine* vt_engine_member(vt_engine* e, int g)
+{
+    if (!e || g < 0 || g > int(e->peers.size())) return nullptr;
+    return g == 0 ? e : e->peers[size_t(g) - 1];
+}
 
 int vt_engine_device(const vt_engine* e, int g)
 {
@@ -358,6 +364,9 @@ int vt_trace_closest_gather_dev(vt_scene* s, const void* const* d_rays, uint64_t
             VT_HIP(hipStreamWaitEvent(e->s_comm, e->ev_traced[st.chunk], 0));
             break;
         case GatherOp::Gather: {
+            // with timing on: the root's communication stream, from where the batch's first piece may start to behind its last
+            // piece (the root receives every shard, so this is the gather's duration; vt_engine_last_gather_ms)
+            if (root->timing && st.dev == 0 && st.chunk == 0) VT_HIP(hipEventRecord(root->ev_g0, root->s_comm));
             if (!in_group) { VT_NCCL(R->GroupStart()); in_group = true; }
             uint64_t clo = 0, chi = 0;
             gather_chunk_bounds(cap, K, st.chunk, &clo, &chi);
@@ -367,6 +376,7 @@ int vt_trace_closest_gather_dev(vt_scene* s, const void* const* d_rays, uint64_t
         }
         case GatherOp::RecordSent:
             VT_HIP(hipEventRecord(e->ev_sent[st.buf], e->s_comm));
+            if (root->timing && st.dev == 0) { VT_HIP(hipEventRecord(root->ev_g1, root->s_comm)); root->gather_timed = true; }
             break;
         }
     }
@@ -424,13 +434,23 @@ int vt_gather_hits_part_dev(vt_engine* e, const void* d_send, uint64_t count, in
     if (e->comm_rank == root && !d_recv_root) return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_dev: the root needs a receive buffer");
     if (nchunks < 1 || nchunks > kMaxGatherChunks || chunk < 0 || chunk >= nchunks)
         return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_part_dev: chunk / nchunks out of range (1 .. 16 pieces)");
-    // the pieces of one batch come in order, every rank with the same nchunks: the batch's steps are planned at its first piece
-    if (chunk == 0 ? !e->part_steps.empty() : (e->part_steps.empty() || e->part_next != chunk || e->part_chunks != nchunks))
-        return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_part_dev: the pieces of a batch must be handed over in order, 0 .. nchunks - 1");
+    // an empty batch has no pieces to order and nothing to send (every rank passes the same count): all its calls are no-ops
     if (count == 0) return VT_OK;
     RcclApi* R = rccl();
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_gather_hits_dev: hipSetDevice failed");
+    // The pieces of one batch come in order, every rank with the same nchunks: the batch's steps are planned at its first piece.
+    // Piece 0 always starts a NEW batch: a batch the caller abandoned between two pieces (its own trace of piece c failed, say)
+    // is dropped here -- the pieces it did hand over are on the communication stream, so its `sent` event is recorded behind them
+    // and the next user of that send buffer waits for them as for a whole batch.
+    if (chunk == 0 && !e->part_steps.empty()) {
+        const int stale_buf = e->part_steps.back().buf;
+        e->part_steps.clear(); e->part_next = 0; e->part_chunks = 0;
+        VT_HIP(hipEventRecord(e->ev_sent[stale_buf], e->s_comm));
+    }
+    if (chunk != 0 && (e->part_steps.empty() || e->part_next != chunk || e->part_chunks != nchunks))
+        return fail(VT_ERR_INVALID_ARG, "vt_gather_hits_part_dev: the pieces of a batch must be handed over in order, 0 .. nchunks - 1 "
+                                        "(piece 0 starts a new batch and drops an unfinished one)");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (chunk == 0) {
         if (e->sched.effective_chunks(nchunks) != nchunks)
@@ -452,12 +472,12 @@ int vt_gather_hits_part_dev(vt_engine* e, const void* d_send, uint64_t count, in
         case GatherOp::RecordTraced: if (hipEventRecord(e->ev_traced[chunk], stream) != hipSuccess) rc = fail(VT_ERR_HIP, "vt_gather_hits_dev: hipEventRecord failed"); break;
         case GatherOp::WaitTraced:   if (hipStreamWaitEvent(e->s_comm, e->ev_traced[chunk], 0) != hipSuccess) rc = fail(VT_ERR_HIP, "vt_gather_hits_dev: hipStreamWaitEvent failed"); break;
         case GatherOp::Gather: {
-            if (e->timing) (void)hipEventRecord(e->ev_g0, e->s_comm);
+            if (e->timing && chunk == 0) (void)hipEventRecord(e->ev_g0, e->s_comm);     // around ALL pieces of the batch
             ncclResult_t r = nchunks == 1 ? ncclSuccess : R->GroupStart();
             if (r == ncclSuccess) r = move_part(R, e, d_send, d_recv_root, count, lo, hi, nchunks == 1, root);
             if (nchunks != 1) { const ncclResult_t r2 = R->GroupEnd(); if (r == ncclSuccess) r = r2; }
             if (r != ncclSuccess) rc = rccl_fail("gather", r);
-            if (e->timing) { (void)hipEventRecord(e->ev_g1, e->s_comm); e->gather_timed = true; }
+            if (e->timing && chunk + 1 == nchunks) { (void)hipEventRecord(e->ev_g1, e->s_comm); e->gather_timed = true; }
             break;
         }
         case GatherOp::RecordSent:   if (hipEventRecord(e->ev_sent[st.buf], e->s_comm) != hipSuccess) rc = fail(VT_ERR_HIP, "vt_gather_hits_dev: hipEventRecord failed"); break;

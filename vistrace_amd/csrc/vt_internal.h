@@ -51,6 +51,9 @@ void parallel_copy(void* dst, const void* src, size_t bytes);
 // ... of n rays, returning the first ray whose range fails the checks of AccelStruct::Traverse (n = none)
 uint64_t parallel_copy_checked(vt_ray* dst, const void* src, uint64_t n);
 
+// value of a test-hook environment variable, NULL unless VT_ENABLE_TEST_HOOKS=1 (announced on stderr once per hook)
+const char* test_hook(const char* name);
+
 void set_error(const std::string& msg);
 int  fail(int code, const std::string& msg);
 
