@@ -127,6 +127,8 @@ scene.refit(moved, flags)                                        # vt_scene_refi
 mtris = va.tris_setup(moved, flags)
 abvh.refit(mtris)
 assert same(scene.trace_closest(big), alpha_oracle(mtris, big)), "refit on every member"
+# ... in phases: no member was waited for before the LAST member's work had been enqueued (engine.hip: update_every_member)
+assert eng.get_option("last_update_members") == 3 and eng.get_option("last_update_early_waits") == 0
 # a refit that is refused (non-finite vertices) leaves EVERY member refusing to trace, not just the first one asked
 bad = moved.copy(); bad[5, 1, 1] = np.nan
 try:
@@ -158,6 +160,7 @@ ptris = va.tris_setup(posed)
 pbvh.refit(ptris)
 pref = O.traverse_batch(pbvh.nodes().view(O.NODE), pbvh.prim_indices(), O.tris_from_tri64(ptris), big)[0]
 assert same(scene.trace_closest(big), pref), "skin refit on every member"
+assert eng.get_option("last_update_members") == 2 and eng.get_option("last_update_early_waits") == 0
 checks += 1
 scene.free()
 eng.close()

@@ -618,6 +618,10 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
     else if (k == "last_fetch_dma") *value = e->last_dma;
     else if (k == "device") *value = e->device;
     else if (k == "device_count") *value = int64_t(e->peers.size()) + 1;
+    // the latest vt_scene_refit / vt_scene_skin_refit of a scene of this (root) engine: members it went to, and how many of them
+    // were waited for before the last member's work had been enqueued (0 by construction; tests/fake_group_check.py)
+    else if (k == "last_update_members") *value = e->last_update_members;
+    else if (k == "last_update_early_waits") *value = e->last_update_early_waits;
     else return fail(VT_ERR_INVALID_ARG, "vt_engine_get_option: unknown key: " + k);
     return VT_OK;
 }
@@ -724,6 +728,8 @@ static void release_scene_device(vt_scene* s)
     }
     if (s->refit_graph) (void)hipGraphExecDestroy(s->refit_graph);
     s->refit_graph = nullptr;
+    if (s->h_verdict) (void)hipHostFree(s->h_verdict);
+    s->h_verdict = nullptr;
     s->d_tris = nullptr;
     s->d_frames = nullptr;
 }
@@ -890,30 +896,44 @@ int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t dep
     return VT_OK;
 }
 
-static int begin_finite_check(vt_scene* s)
+// ---- calls that move a scene's geometry: refit and skin refit, in three phases over ALL members of the scene's group ----------
+// A group's scene lives on every member (replicas); a call that moves its geometry goes to every one of them, also when one
+// of them fails: a refit that is refused for non-finite vertices has rewritten that member's records by then (and left it refusing
+// to trace), and the members of a group must not end up with different geometry.  One host thread, three phases:
+//   prepare  every member: argument checks, the device synchronisation (records are rewritten in place: traces in flight on
+//            caller streams must finish first), allocations -- everything that may block or allocate;
+//   enqueue  every member: copies, kernels, the level-by-level refit (a hipGraph, captured on first use), the read-back of the
+//            verdict -- asynchronous calls only, so member k + 1's work is enqueued while member k's runs;
+//   finish   every member: wait for its stream, read the verdict (non-finite triangles poison the scene), refresh the packet radius.
+// No member is waited for before the last member's work has been enqueued: a frame costs one member's device time plus the
+// enqueue time of the others instead of their sum (round 4: members one after the other, 0.3 - 0.4 ms each for a skinned
+// 1 M-triangle scene).  Side by side on host THREADS was tried in round 4 and taken out: a member's allocations / device
+// synchronisation invalidate the stream capture of another member's refit graph when members share a device; with the
+// allocations and synchronisations in their own phase no capture runs beside them.
+struct UpdateJob {
+    vt_scene* s = nullptr;
+    int rc = VT_OK;              // first failure of this member (a failed member skips its later phases)
+    std::string msg;
+    bool active = false;         // prepare passed and there is work to do
+};
+
+static int job_fail(UpdateJob& j, int rc)
+{
+    if (j.rc == VT_OK) { j.rc = rc; j.msg = vt_last_error(); }
+    j.active = false;
+    return rc;
+}
+
+// pinned read-back block of a scene: the finite check's counter and the root pair behind a refit
+static int ensure_verdict_block(vt_scene* s)
 {
     if (!s->d_bad) VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_bad), 64));
-    VT_HIP(hipMemsetAsync(s->d_bad, 0, 4, s->engine->stream));
+    if (!s->h_verdict) VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_verdict), 128));
     return VT_OK;
 }
 
-// after the (synchronous) refit: how many triangles had a non-finite vertex?
-static int end_finite_check(vt_scene* s, const char* who)
-{
-    // (on the engine's stream, not the legacy stream: another member of the group may be capturing its refit graph on this
-    // device right now, and a legacy-stream copy would depend on that capturing stream)
-    uint32_t bad = 0;
-    VT_HIP(hipMemcpyAsync(&bad, s->d_bad, 4, hipMemcpyDeviceToHost, s->engine->stream));
-    VT_HIP(hipStreamSynchronize(s->engine->stream));
-    s->poisoned = bad != 0;
-    if (bad != 0)
-        return fail(VT_ERR_INVALID_ARG, std::string(who) + ": " + std::to_string(bad) + " triangles have a non-finite (NaN / inf) vertex; "
-                                        "the scene cannot be traced until it is refitted with finite data");
-    return VT_OK;
-}
-
-// all pair bounds from the (already rewritten) triangle records, deepest level first; waits for the result
-static int refit_levels(vt_scene* s)
+// enqueue: all pair bounds from the (already rewritten) triangle records, deepest level first, then the read-back of the verdict
+static int enqueue_levels_and_verdict(vt_scene* s)
 {
     vt_engine* e = s->engine;
     const size_t levels = s->level_begin.empty() ? 0 : s->level_begin.size() - 1;
@@ -945,73 +965,119 @@ static int refit_levels(vt_scene* s)
         const int rc = enqueue();
         if (rc != VT_OK) return rc;
     }
-    VT_HIP(hipStreamSynchronize(e->stream));
-    if (s->npairs != 0) {                                // the scene's extent moved with the vertices: keep the packet probe's radius current
-        vt_node_pair root;
-        VT_HIP(hipMemcpyAsync(&root, s->d_records, sizeof(root), hipMemcpyDeviceToHost, e->stream));
-        VT_HIP(hipStreamSynchronize(e->stream));
-        s->coherent_radius2 = packet_radius2(root);
-    }
+    // the verdict: how many triangles had a non-finite vertex, and the root pair (the scene's extent moved with the vertices:
+    // the packet probe's radius follows) -- into pinned memory, read in the finish phase
+    VT_HIP(hipMemcpyAsync(s->h_verdict, s->d_bad, 4, hipMemcpyDeviceToHost, e->stream));
+    if (s->npairs != 0) VT_HIP(hipMemcpyAsync(s->h_verdict + 64, s->d_records, sizeof(vt_node_pair), hipMemcpyDeviceToHost, e->stream));
     return VT_OK;
 }
 
-// A call that moves a scene's geometry goes to EVERY member of its group, also when one of them fails: a refit that is refused
-// for non-finite vertices has rewritten that member's records by then (and left it refusing to trace), and the members of a group
-// must not end up with different geometry.  The caller sees the root's failure, else the first replica's.
-// One member after the other: running them side by side (one host thread per member) was tried and taken out again -- with
-// several engines on ONE device the members' calls (allocations, device synchronisation) invalidate the stream capture of another
-// member's refit graph, and with one device per member the gain (0.3 ms per member and frame) could not be measured here.
-static int for_every_member(vt_scene* s, const std::function<int(vt_scene*)>& member_call)
-{
-    int first_rc = VT_OK;
-    std::string first_msg;
-    if (s) for (vt_scene* rep : s->replicas) {
-        const int rc = member_call(rep);
-        if (rc != VT_OK && first_rc == VT_OK) { first_rc = rc; first_msg = vt_last_error(); }
-    }
-    const int rc = member_call(s);
-    if (rc != VT_OK) return rc;
-    return first_rc == VT_OK ? VT_OK : fail(first_rc, first_msg);
-}
+// the order of enqueues ('E', one per member, logged when the member's last asynchronous call has returned) and host waits ('W',
+// logged where the update path waits for a member's stream) of the latest group-wide update: a 'W' in front of the last 'E'
+// means a member was waited for while another still had work to enqueue
+static thread_local std::string t_update_log;
 
-static int refit_member(vt_scene* s, const float* verts, const uint8_t* flags, uint32_t n)
+static int finish_update(vt_scene* s, const char* who)
 {
-    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: scene is NULL");
-    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: the scene\'s engine has been closed");
-    if (n != s->ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: n differs from the scene's triangle count");
-    if (n == 0) return VT_OK;
-    if (!verts) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: verts is NULL");
-    if (flags) {                                         // new flags replace the old ones: so does the scene's alpha-test state
-        bool any = false;
-        for (uint32_t i = 0; i < n && !any; ++i) any = (flags[i] & VT_TRI_ALPHATEST) != 0;
-        s->has_alpha = any;
-    }
     vt_engine* e = s->engine;
     DeviceGuard guard(e->device);
-    if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_refit: hipSetDevice failed");
-    std::lock_guard<std::mutex> host_lock(e->host_mu);
-    // records and bounds are rewritten in place: traces of this scene still in flight on caller streams must finish
-    // first (vt_trace_*_dev is asynchronous), or rays would read half-updated boxes
-    VT_HIP(hipDeviceSynchronize());
-    int rc = ensure_bytes(&e->d_rays, &e->d_rays_bytes, size_t(n) * 9 * sizeof(float));
-    if (rc == VT_OK && flags) rc = ensure_bytes(&e->d_out, &e->d_out_bytes, n);
-    if (rc != VT_OK) return rc;
-    VT_HIP(hipMemcpyAsync(e->d_rays, verts, size_t(n) * 9 * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    if (flags) VT_HIP(hipMemcpyAsync(e->d_out, flags, n, hipMemcpyHostToDevice, e->stream));
-    rc = begin_finite_check(s);
-    if (rc != VT_OK) return rc;
-    RefitTrisArgs ta{static_cast<const float*>(e->d_rays), flags ? static_cast<const uint8_t*>(e->d_out) : nullptr,
-                     s->d_prim_to_slot, s->d_tris, n, s->d_bad};
-    VT_HIP(launch_refit_tris(ta, e->stream));
-    if (s->host_stale) s->host_stale->store(1, std::memory_order_release);   // the host copy (single-ray path) is now out of date
-    rc = refit_levels(s);
-    if (rc == VT_OK && flags && s->has_alpha && !s->alpha_ready) rc = build_alpha_records(s);   // the flags switched the test on
-    return rc != VT_OK ? rc : end_finite_check(s, "vt_scene_refit");
+    if (!guard.ok) return fail(VT_ERR_HIP, std::string(who) + ": hipSetDevice failed");
+    t_update_log.push_back('W');
+    VT_HIP(hipStreamSynchronize(e->stream));
+    uint32_t bad = 0;
+    std::memcpy(&bad, s->h_verdict, 4);
+    if (s->npairs != 0) {
+        vt_node_pair root;
+        std::memcpy(&root, s->h_verdict + 64, sizeof(root));
+        s->coherent_radius2 = packet_radius2(root);
+    }
+    s->poisoned = bad != 0;
+    if (bad != 0)
+        return fail(VT_ERR_INVALID_ARG, std::string(who) + ": " + std::to_string(bad) + " triangles have a non-finite (NaN / inf) vertex; "
+                                        "the scene cannot be traced until it is refitted with finite data");
+    return VT_OK;
+}
+
+// The three phases over every member (replicas first, the root last, as before); the caller sees the root's failure, else the
+// first replica's.  g_update_* : what tests/fake_group_check.py reads through engine option "last_update_early_waits".
+static int update_every_member(vt_scene* root, const char* who, const std::function<int(vt_scene*)>& prepare,
+                               const std::function<int(vt_scene*)>& enqueue, const std::function<int(vt_scene*)>& after)
+{
+    std::vector<UpdateJob> jobs;
+    if (root) for (vt_scene* rep : root->replicas) { UpdateJob j; j.s = rep; jobs.push_back(j); }
+    { UpdateJob j; j.s = root; jobs.push_back(j); }
+    t_update_log.clear();
+    for (UpdateJob& j : jobs) {                          // prepare: may block, may allocate
+        const int rc = prepare(j.s);
+        if (rc == VT_OK) j.active = true;
+        else if (rc > 0) job_fail(j, rc);                // rc < 0: nothing to do for this member (empty scene), not a failure
+    }
+    for (UpdateJob& j : jobs) {                          // enqueue: asynchronous calls only
+        if (!j.active) continue;
+        DeviceGuard guard(j.s->engine->device);
+        if (!guard.ok) { job_fail(j, fail(VT_ERR_HIP, std::string(who) + ": hipSetDevice failed")); continue; }
+        const int rc = enqueue(j.s);
+        t_update_log.push_back('E');
+        if (rc != VT_OK) job_fail(j, rc);
+    }
+    for (UpdateJob& j : jobs) {                          // finish: the first host wait of the call
+        if (!j.active) continue;
+        int rc = finish_update(j.s, who);
+        if (rc == VT_OK && after) rc = after(j.s);
+        if (rc != VT_OK) job_fail(j, rc);
+    }
+    if (root && root->engine) {
+        const size_t last_e = t_update_log.rfind('E');
+        const uint32_t early_waits = last_e == std::string::npos ? 0 : uint32_t(std::count(t_update_log.begin(), t_update_log.begin() + long(last_e), 'W'));
+        root->engine->last_update_members = uint32_t(jobs.size());
+        root->engine->last_update_early_waits = early_waits;
+    }
+    for (UpdateJob& j : jobs)                            // a failed member that passed `prepare` left work on its stream: drain it
+        if (j.rc != VT_OK && j.s && j.s->engine) { DeviceGuard guard(j.s->engine->device); (void)hipStreamSynchronize(j.s->engine->stream); }
+    const UpdateJob& rj = jobs.back();
+    if (rj.rc != VT_OK) return fail(rj.rc, rj.msg);
+    for (const UpdateJob& j : jobs) if (j.rc != VT_OK) return fail(j.rc, j.msg);
+    return VT_OK;
 }
 
 int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32_t n)
 {
-    return for_every_member(s, [&](vt_scene* member) { return refit_member(member, verts, flags, n); });
+    std::vector<std::unique_lock<std::mutex>> locks;       // one call that rewrites a scene at a time, on every member
+    bool alpha_from_flags = false;
+    if (flags) for (uint32_t i = 0; i < n && !alpha_from_flags; ++i) alpha_from_flags = (flags[i] & VT_TRI_ALPHATEST) != 0;
+    auto prepare = [&](vt_scene* m) -> int {
+        if (!m) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: scene is NULL");
+        if (!m->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: the scene\'s engine has been closed");
+        if (n != m->ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: n differs from the scene's triangle count");
+        if (n == 0) return -1;
+        if (!verts) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: verts is NULL");
+        if (flags) m->has_alpha = alpha_from_flags;        // new flags replace the old ones: so does the scene's alpha-test state
+        vt_engine* e = m->engine;
+        DeviceGuard guard(e->device);
+        if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_refit: hipSetDevice failed");
+        locks.emplace_back(e->host_mu);
+        // records and bounds are rewritten in place: traces of this scene still in flight on caller streams must finish
+        // first (vt_trace_*_dev is asynchronous), or rays would read half-updated boxes
+        VT_HIP(hipDeviceSynchronize());
+        int rc = ensure_bytes(&e->d_rays, &e->d_rays_bytes, size_t(n) * 9 * sizeof(float));
+        if (rc == VT_OK && flags) rc = ensure_bytes(&e->d_out, &e->d_out_bytes, n);
+        return rc != VT_OK ? rc : ensure_verdict_block(m);
+    };
+    auto enqueue = [&](vt_scene* m) -> int {
+        vt_engine* e = m->engine;
+        VT_HIP(hipMemcpyAsync(e->d_rays, verts, size_t(n) * 9 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        if (flags) VT_HIP(hipMemcpyAsync(e->d_out, flags, n, hipMemcpyHostToDevice, e->stream));
+        VT_HIP(hipMemsetAsync(m->d_bad, 0, 4, e->stream));
+        RefitTrisArgs ta{static_cast<const float*>(e->d_rays), flags ? static_cast<const uint8_t*>(e->d_out) : nullptr,
+                         m->d_prim_to_slot, m->d_tris, n, m->d_bad};
+        VT_HIP(launch_refit_tris(ta, e->stream));
+        if (m->host_stale) m->host_stale->store(1, std::memory_order_release);   // the host copy (single-ray path) is now out of date
+        return enqueue_levels_and_verdict(m);
+    };
+    auto after = [&](vt_scene* m) -> int {                 // the flags switched the alpha test on: its records are built now
+        return flags && m->has_alpha && !m->alpha_ready ? build_alpha_records(m) : VT_OK;
+    };
+    return update_every_member(s, "vt_scene_refit", prepare, enqueue, after);
 }
 
 int vt_scene_set_skin(vt_scene* s, const float* bind_verts, const vt_skin_vertex* skin, const uint32_t* matrix_base, uint32_t n)
@@ -1044,42 +1110,43 @@ int vt_scene_set_skin(vt_scene* s, const float* bind_verts, const vt_skin_vertex
     return VT_OK;
 }
 
-static int skin_refit_member(vt_scene* s, const float* bones, const float* binds, uint32_t nmat)
-{
-    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: scene is NULL");
-    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: the scene\'s engine has been closed");
-    if (s->ntris == 0) return VT_OK;
-    if (!s->d_bind_verts) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: no skin data (call vt_scene_set_skin first)");
-    if (nmat == 0 || !bones || !binds) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: no matrices");
-    vt_engine* e = s->engine;
-    DeviceGuard guard(e->device);
-    if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_skin_refit: hipSetDevice failed");
-    std::lock_guard<std::mutex> host_lock(e->host_mu);
-    VT_HIP(hipDeviceSynchronize());          // in-flight traces of this scene read the records that are about to change
-    if (nmat > s->mats_cap) {
-        if (s->d_skin_mats) { VT_HIP(hipFree(s->d_skin_mats)); s->d_skin_mats = nullptr; s->mats_cap = 0; }
-        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_skin_mats), size_t(nmat) * 3 * 64));
-        s->mats_cap = nmat;
-    }
-    float* d_bones = s->d_skin_mats;
-    float* d_binds = d_bones + size_t(s->mats_cap) * 16;
-    float* d_prod = d_binds + size_t(s->mats_cap) * 16;
-    VT_HIP(hipMemcpyAsync(d_bones, bones, size_t(nmat) * 64, hipMemcpyHostToDevice, e->stream));
-    VT_HIP(hipMemcpyAsync(d_binds, binds, size_t(nmat) * 64, hipMemcpyHostToDevice, e->stream));
-    VT_HIP(launch_skin_matrices(SkinMatricesArgs{d_bones, d_binds, d_prod, nmat}, e->stream));
-    int rc = begin_finite_check(s);
-    if (rc != VT_OK) return rc;
-    SkinTrisArgs ta{s->d_bind_verts, s->d_skin, s->d_matrix_base, d_prod, s->d_prim_to_slot, s->d_tris, s->ntris, nmat, s->d_bad};
-    VT_HIP(launch_skin_tris(ta, e->stream));
-    VT_HIP(skin_frames(s, d_prod, nmat, e->stream));                     // normals / tangents, AccelStruct.cpp:82-92
-    if (s->host_stale) s->host_stale->store(1, std::memory_order_release);
-    rc = refit_levels(s);
-    return rc != VT_OK ? rc : end_finite_check(s, "vt_scene_skin_refit");
-}
-
 int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uint32_t nmat)
 {
-    return for_every_member(s, [&](vt_scene* member) { return skin_refit_member(member, bones, binds, nmat); });
+    std::vector<std::unique_lock<std::mutex>> locks;
+    auto prepare = [&](vt_scene* m) -> int {
+        if (!m) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: scene is NULL");
+        if (!m->engine) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: the scene\'s engine has been closed");
+        if (m->ntris == 0) return -1;
+        if (!m->d_bind_verts) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: no skin data (call vt_scene_set_skin first)");
+        if (nmat == 0 || !bones || !binds) return fail(VT_ERR_INVALID_ARG, "vt_scene_skin_refit: no matrices");
+        vt_engine* e = m->engine;
+        DeviceGuard guard(e->device);
+        if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_skin_refit: hipSetDevice failed");
+        locks.emplace_back(e->host_mu);
+        VT_HIP(hipDeviceSynchronize());          // in-flight traces of this scene read the records that are about to change
+        if (nmat > m->mats_cap) {
+            if (m->d_skin_mats) { VT_HIP(hipFree(m->d_skin_mats)); m->d_skin_mats = nullptr; m->mats_cap = 0; }
+            VT_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_skin_mats), size_t(nmat) * 3 * 64));
+            m->mats_cap = nmat;
+        }
+        return ensure_verdict_block(m);
+    };
+    auto enqueue = [&](vt_scene* m) -> int {
+        vt_engine* e = m->engine;
+        float* d_bones = m->d_skin_mats;
+        float* d_binds = d_bones + size_t(m->mats_cap) * 16;
+        float* d_prod = d_binds + size_t(m->mats_cap) * 16;
+        VT_HIP(hipMemcpyAsync(d_bones, bones, size_t(nmat) * 64, hipMemcpyHostToDevice, e->stream));
+        VT_HIP(hipMemcpyAsync(d_binds, binds, size_t(nmat) * 64, hipMemcpyHostToDevice, e->stream));
+        VT_HIP(launch_skin_matrices(SkinMatricesArgs{d_bones, d_binds, d_prod, nmat}, e->stream));
+        VT_HIP(hipMemsetAsync(m->d_bad, 0, 4, e->stream));
+        SkinTrisArgs ta{m->d_bind_verts, m->d_skin, m->d_matrix_base, d_prod, m->d_prim_to_slot, m->d_tris, m->ntris, nmat, m->d_bad};
+        VT_HIP(launch_skin_tris(ta, e->stream));
+        VT_HIP(skin_frames(m, d_prod, nmat, e->stream));                     // normals / tangents, AccelStruct.cpp:82-92
+        if (m->host_stale) m->host_stale->store(1, std::memory_order_release);
+        return enqueue_levels_and_verdict(m);
+    };
+    return update_every_member(s, "vt_scene_skin_refit", prepare, enqueue, nullptr);
 }
 
 int vt_scene_read_records(vt_scene* s, vt_node_pair* pairs_out, vt_tri64* tris_out)

@@ -114,6 +114,8 @@ struct vt_engine {
     std::vector<std::pair<char*, size_t>> device_spare;   // device blocks of freed batches, for the next ones that fit (at most 32)
     std::vector<std::pair<void*, size_t>> pinned_spare;   // pinned host blocks of freed batches (their downloaded arrays)
 
+    uint32_t last_update_members = 0, last_update_early_waits = 0;   // the latest group-wide refit / skin refit (diagnostic)
+
     bool alpha_regs_checked = false;         // ALPHA kernels: hipFuncGetAttributes agreed with the build-time ISA check
 
     // last launch geometry
@@ -177,6 +179,7 @@ struct vt_scene {
     // every ray -- the scene is refused until it has been refitted with finite data
     float           coherent_radius2 = 0.f;   // (2 % of the scene's diagonal)^2: how far apart the origins of a ray packet may lie
     uint32_t*       d_bad = nullptr;
+    char*           h_verdict = nullptr;     // pinned: [0] the finite check's count, [64] the root pair behind a refit
     bool            poisoned = false;
     hipGraphExec_t  refit_graph = nullptr;   // the level-by-level refit launches, captured once (launch-bound: ~30 tiny kernels)
     uint32_t      npairs = 0, ntris = 0, max_depth = 0, root_leaf_count = 0;
