@@ -93,19 +93,22 @@ def build_scene(args, va, W, dev_index, world):
     host_threads = max(1, len(os.sched_getaffinity(0)) // max(1, world))   # explicit: launchers may export OMP_NUM_THREADS=1
     bvh = va.HostBvh(tris, nthreads=min(16, host_threads), builder=args.builder)   # ranks build side by side
     t2 = time.time()
-    host_scene = va.HostScene(bvh)
     engine = va.Engine(dev_index)
     if args.mode is not None:
         engine.set_option("persistent", 1 if args.mode == "persistent" else 0)
-    scene = va.Scene(engine, host_scene)
+    t2b = time.time()
+    # Rebuild's upload step: the tree and the triangle records go up as they are, the device re-packs them (vt_scene_upload_tree)
+    scene = va.Scene.from_tree(engine, bvh)
+    t3 = time.time()
     if rig:
         scene.set_tri_attribs(rig[1].view(va.TRI_ATTRIBS))
         scene.set_alpha(rig[2].view(va.ALPHA_MATERIAL), rig[3])
     scene.alpha_rig = rig
-    t3 = time.time()
-    log(f"[bench] scene {args.scene}: {len(tris)} tris, {host_scene.pair_count} pairs, depth {host_scene.max_depth}, "
-        f"{scene.device_bytes / 1e6:.1f} MB on device; gen {t1 - t0:.2f}s build {t2 - t1:.2f}s upload {t3 - t2:.2f}s")
-    return tris, bvh, host_scene, engine, scene, host_threads
+    st = scene.upload_stats()
+    log(f"[bench] scene {args.scene}: {len(tris)} tris, {(len(bvh.nodes()) - 1) // 2} pairs, {scene.device_bytes / 1e6:.1f} MB on device; "
+        f"gen {t1 - t0:.2f}s build {t2 - t1:.2f}s engine {t2b - t2:.3f}s upload + device re-pack {(t3 - t2b) * 1e3:.1f} ms "
+        f"(copies issued {st['copy_ms']:.1f}, device {st['device_ms']:.1f})")
+    return tris, bvh, None, engine, scene, host_threads
 
 
 def make_rays(args, rank, world, va, W, tp, engine, scene, device):
@@ -396,6 +399,77 @@ def verify_gather(dist, rank, world, n, local_hits, recv, device, backend):
     return bool(flag.item())
 
 
+def rebuild_leg(args, va, W, engine, host_threads) -> dict:
+    """What accel:Rebuild costs (ref source/VisTrace.cpp:798-818 -> AccelStruct.cpp:762-775), step by step on this workload's
+    scene, each step the best of 3: triangle set-up, the CPU build, then the part that is NOT the build -- re-packing the tree for
+    the device and uploading it -- both ways: on the host (vt_scene_linearise + vt_scene_upload, rounds 1-4) and on the device
+    (vt_scene_upload_tree, round 5; byte-equal records), against what the same bytes cost on the link.  Refit / skin refit (the
+    per-frame alternative to a Rebuild) for contrast."""
+    def best(fn, reps=3):
+        ts, out = [], None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return min(ts), out
+    verts = W.make_scene(args.scene)
+    threads = min(16, host_threads)
+    setup_ms, tris = best(lambda: va.tris_setup(verts))
+    build_ms, bvh = best(lambda: va.HostBvh(tris, nthreads=threads, builder=args.builder), reps=2)
+    lin_ms, hs = best(lambda: va.HostScene(bvh))
+    up_ms, sc_host = best(lambda: va.Scene(engine, hs), reps=1)
+    ts = []
+    for _ in range(3):                                     # fresh scene each time, the previous one freed outside the timed part
+        sc_host.free()
+        t0 = time.perf_counter()
+        sc_host = va.Scene(engine, hs)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    up_ms = min(ts)
+    sc_dev, ts, stats = None, [], None
+    for _ in range(4):
+        if sc_dev is not None:
+            sc_dev.free()
+        t0 = time.perf_counter()
+        sc_dev = va.Scene.from_tree(engine, bvh)
+        ts.append((time.perf_counter() - t0) * 1e3)
+        stats = sc_dev.upload_stats()
+    tree_ms = min(ts[1:])                                  # the first call allocates the engine's staging block
+    hp, ht = sc_host.read_records()
+    t0 = time.perf_counter()
+    sc_dev.download_host_scene()
+    down_ms = (time.perf_counter() - t0) * 1e3
+    dp, dt = sc_dev.read_records()
+    equal = bool(hp.tobytes() == dp.tobytes() and ht.tobytes() == dt.tobytes())
+    del hp, ht, dp, dt
+    moved = (verts + np.float32(0.25)).astype(np.float32)
+    sc_dev.refit(moved)
+    refit_ms, _ = best(lambda: sc_dev.refit(moved))
+    skin, base, nmat = W.skinned_rig(len(verts), nents=64, bones_per_ent=32)
+    sc_dev.set_skin(verts, skin, base)
+    bones, binds = W.rig_pose(nmat, 0)
+    for _ in range(3):
+        sc_dev.skin_refit(bones, binds)
+    skin_ms, _ = best(lambda: sc_dev.skin_refit(bones, binds), reps=10)
+    h2d = stats["bytes_h2d"]
+    link_ms = h2d / 56e9 * 1e3                             # profiles/r4/upload_probe.txt: 56 GB/s host -> device on these boxes
+    out = {
+        "scene": args.scene, "triangles": int(len(tris)), "host_threads": threads,
+        "tris_setup_ms": round(setup_ms, 2), "bvh_build_ms": round(build_ms, 1), "bvh_builder": args.builder,
+        "host_repack": {"vt_scene_linearise_ms": round(lin_ms, 2), "vt_scene_upload_ms": round(up_ms, 2), "sum_ms": round(lin_ms + up_ms, 2)},
+        "device_repack": {"vt_scene_upload_tree_ms": round(tree_ms, 2), "first_call_ms": round(ts[0], 2),
+                          "copies_issued_ms": round(stats["copy_ms"], 2), "device_and_readback_ms": round(stats["device_ms"], 2),
+                          "bytes_h2d": int(h2d), "link_time_ms_at_56GBs": round(link_ms, 2), "over_link_time": round(tree_ms / link_ms, 2)},
+        "records_byte_equal": equal,
+        "vt_host_scene_download_ms": round(down_ms, 2),
+        "vt_scene_refit_ms": round(refit_ms, 2), "vt_scene_skin_refit_ms": round(skin_ms, 3),
+        "note": "Rebuild = tris_setup + bvh_build (CPU, as north_star prescribes) + the re-pack / upload step; rounds 1-4 re-packed on the host "
+                "(host_repack), round 5 on the device (device_repack: three plain copies + five kernels + one radix sort; the product path). "
+                "vt_host_scene_download is paid only by callers that walk single rays on the host, on first use.",
+    }
+    sc_host.free(); sc_dev.free()
+    return out
+
+
 def launch_ranks(args) -> int:
     """`python3 bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, exactly as the driver's
     N > 1 command does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
@@ -485,12 +559,11 @@ def run_group(args) -> None:
     tris = va.tris_setup(verts)
     host_threads = max(1, len(os.sched_getaffinity(0)))
     bvh = va.HostBvh(tris, nthreads=min(16, host_threads), builder=args.builder)
-    host_scene = va.HostScene(bvh)
     t1 = time.time()
     engine = va.Engine(devices)
     if args.mode is not None:
         engine.set_option("persistent", 1 if args.mode == "persistent" else 0)
-    scene = va.Scene(engine, host_scene)
+    scene = va.Scene.from_tree(engine, bvh)              # every member re-packs its own copy (vt_scene_upload_tree)
     log(f"[bench] group of {ndev} members on devices {devices}: scene {args.scene} ({len(tris)} tris) built in {t1 - t0:.2f}s, "
         f"replicated in {time.time() - t1:.2f}s ({scene.device_bytes / 1e6:.1f} MB per member)")
 
@@ -500,7 +573,7 @@ def run_group(args) -> None:
     def single_for(d):
         if d not in singles:
             e1 = va.Engine(d)
-            singles[d] = (e1, va.Scene(e1, host_scene))
+            singles[d] = (e1, va.Scene.from_tree(e1, bvh))
         return singles[d]
     member_rays, member_n, ref_sums, tot_steps, tot_tests = [], [], [], 0, 0
     workload = None
@@ -536,7 +609,10 @@ def run_group(args) -> None:
     log(f"[bench] workload {workload}: {n} rays per member, {n_total} in the job; steps/ray {tot_steps / n_total:.2f} tests/ray {tot_tests / n_total:.2f}")
 
     engine.set_timing(True)
-    if args.reserve_cus > 0 and ndev > 1:
+    # room for RCCL's kernels beside the resident trace grids -- but not when members SHARE a device: several persistent grids on
+    # one GPU with CUs reserved send each other's blocks to the reserved CUs (profiles/r4/notes.md section 3: 40 ms instead of 5),
+    # and the test double's transfers are copies that need no CUs
+    if args.reserve_cus > 0 and ndev > 1 and not aliased:
         engine.set_option("reserved_cus", args.reserve_cus)
     if args.overlap == "off":
         engine.set_option("gather_overlap", 0)
@@ -678,6 +754,8 @@ def main() -> None:
     ap.add_argument("--legs", default=None, choices=["all", "host", "off"],
                     help="extra figures beside `value` at N = 1: host = host_inclusive (vt_trace_closest on host arrays: PCIe inside the call); "
                          "all = + beyond_cache (the same ray kind into S10M).  Default: all for the default workload, host otherwise")
+    ap.add_argument("--rebuild-leg", default="auto", choices=["auto", "on", "off"],
+                    help="N = 1: time accel:Rebuild's steps on this workload's scene and report them as `rebuild` (auto: beside the default workload)")
     ap.add_argument("--beyond-cache-pmc", action="store_true", help="collect the beyond_cache leg's FETCH / WRITE counters live (two more child passes)")
     ap.add_argument("--builder", default="sah", choices=["ploc", "sah", "sah_refined"],
                     help="sah = binned SAH, the product's default builder (vt_bvh_build); ploc = the reference's algorithm "
@@ -808,7 +886,9 @@ def main() -> None:
 
     # ---- timed region -------------------------------------------------------------------
     engine.set_timing(True)
-    if dist_on and args.reserve_cus > 0:
+    if dist_on and args.reserve_cus > 0 and args.backend == "gloo" and world > torch.cuda.device_count():
+        log("[bench] gloo test mode with ranks sharing a GPU: no CUs reserved (several resident grids on one device)")
+    elif dist_on and args.reserve_cus > 0:
         # the gather of batch b runs while batch b+1 is traced: its kernels need somewhere to run
         try:
             engine.set_option("reserved_cus", args.reserve_cus)
@@ -1299,6 +1379,13 @@ def main() -> None:
             del b_rays, b_hits, b_scene, b_engine
         except Exception as exc:   # a secondary figure must never cost the headline line
             log(f"[bench] beyond-cache leg failed: {exc}")
+
+    # ---- what a Rebuild costs (rank 0, N = 1): never `value` -------------------------------------------------------------------
+    if rank == 0 and world == 1 and not dist_on and not under_profiler() and (args.rebuild_leg == "on" or (args.rebuild_leg == "auto" and args.legs == "all")):
+        try:
+            result["rebuild"] = rebuild_leg(args, va, W, engine, host_threads)
+        except Exception as exc:   # a secondary figure must never cost the headline line
+            log(f"[bench] rebuild leg failed: {exc}")
 
     # the legs' figures flat in `roofline` as well (scalars only: what a parser that drops nested objects still keeps)
     if rank == 0:

@@ -262,6 +262,21 @@ int vt_engine_last_gather_ms(vt_engine* e, float* ms);
 
 /* Upload once per Rebuild (north star: "uploaded once per Rebuild"). */
 int  vt_scene_upload(vt_engine* e, const vt_host_scene* hs, vt_scene** out);
+/* The same step with the re-packing done ON THE DEVICE (round 5): the tree as vt_bvh_build left it and the triangle records in
+ * original order go up as three plain copies; kernels number the pairs depth-first, shuffle the triangles into leaf order and
+ * derive the index tables.  Result byte-equal to vt_scene_linearise + vt_scene_upload (records, level lists, triangle -> slot),
+ * without the host walk (85-100 ms per million triangles on one core) -- stands where the reference constructs its intersector
+ * and traverser over the finished tree (source/objects/AccelStruct.cpp:772-773).  tris = the vt_tris_setup output the tree
+ * was built from, ntris = its length.  On a group's root the scene is built on every member. */
+int  vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvh, const vt_tri64* tris, uint32_t ntris, vt_scene** out);
+/* Where the time of a scene's upload went (host clock, ms): alloc = staging block, copy = issuing the host -> device copies,
+ * device = kernels + read-backs + waiting for them, total = the whole call (for a group's root: all members). */
+typedef struct vt_upload_stats { float alloc_ms, copy_ms, device_ms, total_ms; uint64_t bytes_h2d; uint32_t linearised_on_device; uint32_t pad; } vt_upload_stats;
+int  vt_scene_upload_stats(const vt_scene* s, vt_upload_stats* out);
+/* The host-side copy of a device scene (pairs, leaf-ordered triangles, depths): what vt_host_scene_trace_* and the accessors
+ * need when the scene came from vt_scene_upload_tree.  From then on a device-side refit marks the copy stale and
+ * vt_host_scene_sync refreshes it, exactly as for a host scene the device scene was uploaded from. */
+int  vt_host_scene_download(vt_scene* s, vt_host_scene** out);
 void vt_scene_free(vt_scene* s);
 uint64_t vt_scene_device_bytes(const vt_scene* s);
 

@@ -109,3 +109,17 @@ def test_round4_entry_points_validate_arguments(va):
     lib.vt_gather_chunk_bounds(1000, 4, 9, C.byref(lo), C.byref(hi))
     assert (lo.value, hi.value) == (0, 0)
     lib.vt_gather_chunk_bounds(1000, 4, 1, None, None)                      # NULL outputs are tolerated
+
+
+def test_round5_entry_points_validate_arguments(va):
+    """vt_scene_upload_tree / vt_scene_upload_stats / vt_host_scene_download / vt_engine_member refuse NULL handles with a message."""
+    L = va._lib
+    lib = L.lib
+    h = C.c_void_p()
+    assert lib.vt_scene_upload_tree(None, None, None, 0, C.byref(h)) == L.VT_ERR_INVALID_ARG and b"NULL argument" in lib.vt_last_error()
+    st = np.zeros(1, L.UPLOAD_STATS)
+    assert lib.vt_scene_upload_stats(None, L.ptr(st)) == L.VT_ERR_INVALID_ARG
+    assert lib.vt_host_scene_download(None, C.byref(h)) == L.VT_ERR_INVALID_ARG and h.value is None
+    assert lib.vt_host_scene_download(None, None) == L.VT_ERR_INVALID_ARG
+    assert lib.vt_engine_member(None, 0) is None
+    assert L.UPLOAD_STATS.itemsize == 32

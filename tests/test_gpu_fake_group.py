@@ -83,7 +83,7 @@ def test_parity_suites_through_the_root_of_a_group():
                         os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_shading_frame.py"),
                         os.path.join(ROOT, "tests", "test_gpu_multi_batch.py")], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     tail = [ln for ln in p.stdout.splitlines() if "passed" in ln or "failed" in ln]
-    assert p.returncode == 0 and tail and "failed" not in tail[-1], (p.stdout[-3000:], p.stderr[-2000:])
+    assert p.returncode == 0 and tail and "failed" not in tail[-1], (p.stdout[-12000:], p.stderr[-2000:])
 
 
 def test_bench_group_form_on_a_simulated_group():

@@ -996,14 +996,17 @@ def test_records_beyond_4_gib(va, engine, O, with_alpha):
     host_scene = va.HostScene(bvh)
     os.environ["VT_TEST_RECORD_GAP"] = str((1 << 26) + 1000)
     try:
-        small = va.Scene(engine, host_scene)          # the hook alone is dead: it needs VT_ENABLE_TEST_HOOKS=1 beside it
-        assert small.device_bytes < (1 << 30)
-        small.free()
-        os.environ["VT_ENABLE_TEST_HOOKS"] = "1"
+        hooks_were_on = os.environ.get("VT_ENABLE_TEST_HOOKS") == "1"      # (the group-fixture run of this suite has them on)
+        if not hooks_were_on:
+            small = va.Scene(engine, host_scene)      # the hook alone is dead: it needs VT_ENABLE_TEST_HOOKS=1 beside it
+            assert small.device_bytes < (1 << 30)
+            small.free()
+            os.environ["VT_ENABLE_TEST_HOOKS"] = "1"
         scene = va.Scene(engine, host_scene)
     finally:
         del os.environ["VT_TEST_RECORD_GAP"]
-        os.environ.pop("VT_ENABLE_TEST_HOOKS", None)
+        if not hooks_were_on:
+            os.environ.pop("VT_ENABLE_TEST_HOOKS", None)
     assert scene.device_bytes > (1 << 32)
     otris = O.tris_from_tri64(tris)
     rays = np.concatenate([W.primary_rays(96, 96), W.sphere_rays(30000, 41, origin=(-120.0, 80.0, 15.0))])

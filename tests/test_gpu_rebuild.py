@@ -1,0 +1,102 @@
+"""Rebuild's upload step with the re-packing done on the device (vt_scene_upload_tree, vistrace_amd/csrc/scene_build.hip) against the
+host lineariser (vt_scene_linearise + vt_scene_upload): the records on the device must be BYTE-EQUAL, the index tables must drive a
+refit to the same bytes, hits and counters must equal the oracle's, and the host copy fetched back (vt_host_scene_download) must
+equal the host lineariser's output.  Stands where the reference constructs its intersector / traverser over the finished tree
+(source/objects/AccelStruct.cpp:772-773)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scenes(W):
+    yield "S1k", W.make_scene("S1k"), None
+    yield "S10k", W.make_scene("S10k"), None
+    verts, flags = W.make_terrain()
+    yield "terrain", verts, flags
+    yield "S100k", W.make_scene("S100k"), None
+
+
+@pytest.mark.parametrize("builder", ["sah", "ploc", "sah_refined"])
+def test_device_linearise_is_byte_equal_to_the_host_lineariser(va, O, engine, builder):
+    from vistrace_amd import workloads as W
+    for name, verts, flags in _scenes(W):
+        tris = va.tris_setup(verts, flags)
+        bvh = va.HostBvh(tris, builder=builder)
+        host = va.Scene(engine, va.HostScene(bvh))
+        dev = va.Scene.from_tree(engine, bvh)
+        assert dev.upload_stats()["linearised_on_device"] == 1 and host.upload_stats()["linearised_on_device"] == 0
+        hp, ht = host.read_records()
+        dp, dt = dev.read_records()                       # (fetches the host copy: vt_host_scene_download)
+        assert hp.tobytes() == dp.tobytes(), f"{name}/{builder}: pair records differ"
+        assert ht.tobytes() == dt.tobytes(), f"{name}/{builder}: triangle records differ"
+        assert dev.device_bytes == host.device_bytes
+        # the downloaded host scene equals the host lineariser's output (pairs, triangles, depth, and its own single-ray walk)
+        assert dev.host_scene.pairs().tobytes() == host.host_scene.pairs().tobytes()
+        assert dev.host_scene.tris().tobytes() == host.host_scene.tris().tobytes()
+        assert (dev.host_scene.max_depth, dev.host_scene.pair_count, dev.host_scene.tri_count, dev.host_scene.root_leaf_count) == \
+               (host.host_scene.max_depth, host.host_scene.pair_count, host.host_scene.tri_count, host.host_scene.root_leaf_count)
+        rays = np.concatenate([W.primary_rays(64, 64), W.sphere_rays(20000, 5)])
+        ref, ref_stats = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris), rays, want_stats=True)[:2]
+        got = dev.trace_closest(rays)
+        assert got.tobytes() == ref.tobytes(), f"{name}/{builder}: hits differ from the oracle"
+        assert dev.host_scene.trace_closest_host(rays[:2000]).tobytes() == ref[:2000].tobytes()
+        # the index tables (triangle -> slot, pairs by level): a refit through them writes the same bytes as through the host-built ones
+        moved = (np.asarray(verts, np.float32) * np.float32(1.03125) + np.float32(0.5)).astype(np.float32)
+        host.refit(moved, flags)
+        dev.refit(moved, flags)
+        hp, ht = host.read_records()
+        dp, dt = dev.read_records()
+        assert hp.tobytes() == dp.tobytes() and ht.tobytes() == dt.tobytes(), f"{name}/{builder}: records differ after a refit"
+        # a host scene downloaded from the device can be uploaded again (it carries the pairs' depths)
+        again = va.Scene(engine, dev.host_scene)
+        dev.sync_host_scene()
+        ap, at = again.read_records()
+        assert len(ap) == len(dp)
+        again.free(); host.free(); dev.free()
+
+
+def test_device_linearise_on_degenerate_trees(va, engine):
+    """no triangles, one triangle (the root is a leaf), two triangles (one pair of leaves): the device path serves them all"""
+    from vistrace_amd import workloads as W
+    rays = W.sphere_rays(3000, 11, origin=(0.2, 0.1, -3.0))
+    rays["dir"][:1500] = (0.0, 0.0, 1.0)
+    one = np.array([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]]], np.float32)
+    far = np.array([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]], [[50, 50, 50], [51, 50, 50], [50, 51, 50]], [[-60, 2, 3], [-61, 2, 3], [-60, 3, 3]]], np.float32)
+    many = np.concatenate([one + np.float32(k) for k in range(40)])
+    for verts in (np.zeros((0, 3, 3), np.float32), one, far, many):
+        tris = va.tris_setup(verts)
+        bvh = va.HostBvh(tris)
+        host = va.Scene(engine, va.HostScene(bvh))
+        dev = va.Scene.from_tree(engine, bvh)
+        assert dev.trace_closest(rays).tobytes() == host.trace_closest(rays).tobytes()
+        assert (dev.trace_any(rays) == host.trace_any(rays)).all()
+        hp, ht = host.read_records()
+        dp, dt = dev.read_records()
+        assert hp.tobytes() == dp.tobytes() and ht.tobytes() == dt.tobytes()
+        host.free(); dev.free()
+
+
+def test_device_linearise_with_alpha_tested_triangles(va, O, engine):
+    """the alpha flag is found on the device (room for the AlphaRecs behind the triangles), tables set afterwards as usual"""
+    from vistrace_amd import workloads as W
+    verts = np.ascontiguousarray(W.make_scene("S10k"), np.float32)
+    flags, attribs, mats, texels = W.alpha_test_rig(len(verts))
+    tris = va.tris_setup(verts, flags)
+    bvh = va.HostBvh(tris)
+    host = va.Scene(engine, va.HostScene(bvh))
+    dev = va.Scene.from_tree(engine, bvh)
+    assert dev.device_bytes == host.device_bytes
+    for sc in (host, dev):
+        sc.set_tri_attribs(attribs.view(va.TRI_ATTRIBS))
+        sc.set_alpha(mats.view(va.ALPHA_MATERIAL), texels)
+    rays = W.sphere_rays(40000, 23, origin=(3.0, -2.0, 5.0))
+    assert dev.trace_closest(rays).tobytes() == host.trace_closest(rays).tobytes()
+    ot = O.tris_from_tri64(tris)
+    try:
+        O.set_alpha(ot, attribs["uv"].reshape(len(verts), 6), attribs["material"], mats.view(O.ALPHA_MATERIAL), texels)
+        ref = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), ot, rays)[0]
+    finally:
+        O.set_alpha()
+    assert dev.trace_closest(rays).tobytes() == ref.tobytes()
+    host.free(); dev.free()

@@ -42,6 +42,8 @@ CAMERA = np.dtype([("pos", "<f4", 3), ("forward", "<f4", 3), ("up", "<f4", 3), (
 ALPHA_MATERIAL = np.dtype([("tex_mat", "<f4", (2, 4)), ("tex_scale", "<f4"), ("alpha_ref", "<f4"), ("width", "<u4"),
                            ("height", "<u4"), ("filter", "<u4"), ("pad", "<u4"), ("offset", "<u8")])
 SKIN_VERTEX = np.dtype([("weight", "<f4", 3), ("bone", "i1", 3), ("num_bones", "u1")])
+UPLOAD_STATS = np.dtype([("alloc_ms", "<f4"), ("copy_ms", "<f4"), ("device_ms", "<f4"), ("total_ms", "<f4"), ("bytes_h2d", "<u8"),
+                         ("linearised_on_device", "<u4"), ("pad", "<u4")])
 BATCH_DESC = np.dtype([("d_rays", "<u8"), ("d_out", "<u8"), ("n", "<u8"), ("ray_image_width", "<u4"), ("reserved", "<u4")])
 assert BATCH_DESC.itemsize == 32
 assert TRI_FRAME.itemsize == 72 and HIT_TBN.itemsize == 48
@@ -96,6 +98,9 @@ SYMBOLS = {
     "vt_gather_hits_part_dev": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "vt_engine_last_gather_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "vt_scene_upload": (C.c_int, [_vp, _vp, _pp]),
+    "vt_scene_upload_tree": (C.c_int, [_vp, _vp, _vp, _u32, _pp]),
+    "vt_scene_upload_stats": (C.c_int, [_vp, _vp]),
+    "vt_host_scene_download": (C.c_int, [_vp, _pp]),
     "vt_scene_free": (None, [_vp]),
     "vt_scene_device_bytes": (_u64, [_vp]),
     "vt_host_register": (C.c_int, [_vp, C.c_size_t]),

@@ -341,6 +341,34 @@ class Scene:
         check(lib.vt_scene_upload(engine._h, host_scene._h, C.byref(h)))
         self._h = h
 
+    @classmethod
+    def from_tree(cls, engine: Engine, bvh: HostBvh) -> "Scene":
+        """vt_scene_upload_tree: the tree and the triangle records go up as they are, the device numbers the pairs, shuffles the
+        triangles into leaf order and derives the index tables (no host walk).  `host_scene` is fetched on first use."""
+        self = cls.__new__(cls)
+        self.engine = engine
+        self.host_scene = None
+        h = C.c_void_p()
+        check(lib.vt_scene_upload_tree(engine._h, bvh._h, ptr(bvh.tris) if len(bvh.tris) else None, len(bvh.tris), C.byref(h)))
+        self._h = h
+        self._bvh = bvh
+        return self
+
+    def download_host_scene(self) -> HostScene:
+        """vt_host_scene_download: the host-side copy of this scene (single-ray path, accessors)."""
+        h = C.c_void_p()
+        check(lib.vt_host_scene_download(self._h, C.byref(h)))
+        hs = HostScene.__new__(HostScene)
+        hs.bvh = getattr(self, "_bvh", None)
+        hs._h = h
+        self.host_scene = hs
+        return hs
+
+    def upload_stats(self) -> dict:
+        st = np.zeros(1, dtype=_lib.UPLOAD_STATS)
+        check(lib.vt_scene_upload_stats(self._h, ptr(st)))
+        return {k: (float(st[0][k]) if st.dtype[k].kind == "f" else int(st[0][k])) for k in st.dtype.names if k != "pad"}
+
     def free(self):
         if getattr(self, "_h", None):
             lib.vt_scene_free(self._h)
@@ -479,6 +507,8 @@ class Scene:
 
     def read_records(self):
         """(pairs, tris) as they currently are on the device."""
+        if self.host_scene is None:
+            self.download_host_scene()
         pairs = np.zeros(self.host_scene.pair_count, dtype=NODE_PAIR)
         tris = np.zeros(self.host_scene.tri_count, dtype=TRI64)
         check(lib.vt_scene_read_records(self._h, ptr(pairs) if len(pairs) else None, ptr(tris) if len(tris) else None))

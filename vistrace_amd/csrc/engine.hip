@@ -545,6 +545,8 @@ void vt_engine_close(vt_engine* e)
     if (e->d_rays) (void)hipFree(e->d_rays);
     if (e->d_out) (void)hipFree(e->d_out);
     if (e->d_loop) (void)hipFree(e->d_loop);
+    if (e->d_build) (void)hipFree(e->d_build);
+    if (e->h_build) (void)hipHostFree(e->h_build);
     if (e->d_reserved) (void)hipFree(e->d_reserved);
     if (e->h_live) (void)hipHostFree(e->h_live);
     for (int k = 0; k < vt_engine::kStageBufs; ++k) {
@@ -631,8 +633,10 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
     if (!e || !hsw || !out) return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: NULL argument");
     *out = nullptr;
     const HostScene& hs = hsw->hs;
-    bool has_alpha = false;                              // Primitives.h:196-208: needs vt_scene_set_alpha before tracing
-    for (const vt_tri64& t : hs.tris) has_alpha = has_alpha || (t.flags & VT_TRI_ALPHATEST) != 0;
+    // Primitives.h:196-208: alpha-tested triangles need vt_scene_set_alpha before tracing (the flag scan is vt_scene_linearise's,
+    // kept current by vt_host_scene_sync)
+    const bool has_alpha = hs.has_alpha;
+    if (hs.pair_depth.size() != hs.pairs.size()) return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: the host scene lacks its pair depths");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_upload: hipSetDevice failed");
 
@@ -646,17 +650,12 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
     s->max_depth = hs.max_depth;
     s->root_leaf_count = hs.root_leaf_count;
 
-    std::vector<uint32_t> prim_to_slot(hs.tris.size());
-    for (size_t i = 0; i < hs.tris.size(); ++i) {
-        if (hs.tris[i].prim >= hs.tris.size()) { delete s; return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: bad prim index"); }
-        prim_to_slot[hs.tris[i].prim] = uint32_t(i);
-    }
-
     // Record layout: pairs first, triangles behind them on a 128-B boundary.
+    const auto t_begin = std::chrono::steady_clock::now();
     hipError_t err = hipSuccess;
-    // (test hook: VT_TEST_RECORD_GAP=<records> leaves that many unused records between the pairs and the triangles, so that a
-    // small scene has triangle and AlphaRec records beyond 4 GiB -- the 64-bit addressing and the kernel choice of scenes with
-    // more than 67 M records, without building one: tests/test_gpu_configs.py)
+    // (test hook, dead without VT_ENABLE_TEST_HOOKS=1: VT_TEST_RECORD_GAP=<records> leaves that many unused records between the
+    // pairs and the triangles, so that a small scene has triangle and AlphaRec records beyond 4 GiB -- the 64-bit addressing and
+    // the kernel choice of scenes with more than 67 M records, without building one: tests/test_gpu_parity.py)
     uint64_t gap = 0;
     if (const char* env = test_hook("VT_TEST_RECORD_GAP")) gap = std::strtoull(env, nullptr, 10) & ~uint64_t(1);
     if (uint64_t(s->npairs) + gap + 2 * uint64_t(s->ntris) + 4 >= 0xFFFFFFFFull) { delete s; return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: scene too large"); }
@@ -671,37 +670,31 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
         // never empty: idle lanes of the DMA-fetch kernel read record 0, so it must exist (zeros for an empty scene)
         const size_t rec_bytes = s->record_capacity * 64;
         err = hipMalloc(reinterpret_cast<void**>(&s->d_records), rec_bytes);
-        if (err == hipSuccess) err = hipMemset(s->d_records, 0, rec_bytes);
-        if (err == hipSuccess && pair_bytes) err = hipMemcpy(s->d_records, hs.pairs.data(), pair_bytes, hipMemcpyHostToDevice);
-        if (err == hipSuccess && tri_bytes) err = hipMemcpy(s->d_records + tri_off, hs.tris.data(), tri_bytes, hipMemcpyHostToDevice);
+        // zeros only where no copy lands: the padding between pairs and triangles (+ the test gap), the AlphaRec room
+        if (err == hipSuccess && tri_off > pair_bytes) err = hipMemsetAsync(s->d_records + pair_bytes, 0, tri_off - pair_bytes, e->stream);
+        if (err == hipSuccess && rec_bytes > tri_off + tri_bytes) err = hipMemsetAsync(s->d_records + tri_off + tri_bytes, 0, rec_bytes - tri_off - tri_bytes, e->stream);
+        if (err == hipSuccess && pair_bytes) err = hipMemcpyAsync(s->d_records, hs.pairs.data(), pair_bytes, hipMemcpyHostToDevice, e->stream);
+        if (err == hipSuccess && tri_bytes) err = hipMemcpyAsync(s->d_records + tri_off, hs.tris.data(), tri_bytes, hipMemcpyHostToDevice, e->stream);
         s->d_tris = reinterpret_cast<vt_tri64*>(s->d_records + tri_off);
         s->bytes += rec_bytes;
+        s->upload_stats.bytes_h2d = pair_bytes + tri_bytes + hs.pair_depth.size() * 4;
     }
-    if (err == hipSuccess && !prim_to_slot.empty()) {
-        err = hipMalloc(reinterpret_cast<void**>(&s->d_prim_to_slot), prim_to_slot.size() * sizeof(uint32_t));
-        if (err == hipSuccess)
-            err = hipMemcpy(s->d_prim_to_slot, prim_to_slot.data(), prim_to_slot.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        s->bytes += prim_to_slot.size() * sizeof(uint32_t);
-    }
-    if (err == hipSuccess && !hs.pairs.empty()) {
-        // pairs grouped by depth, deepest first (counting sort), for the level-wise refit
-        std::vector<uint32_t> count(hs.max_depth + 2, 0);
-        for (uint32_t d : hs.pair_depth) ++count[d];
-        s->level_begin.assign(1, 0);
-        std::vector<uint32_t> start(hs.max_depth + 2, 0);
-        uint32_t acc = 0;
-        for (uint32_t d = hs.max_depth; d >= 1; --d) { start[d] = acc; acc += count[d]; s->level_begin.push_back(acc); }
-        std::vector<uint32_t> order(hs.pairs.size());
-        for (uint32_t p = 0; p < hs.pairs.size(); ++p) order[start[hs.pair_depth[p]]++] = p;
-        err = hipMalloc(reinterpret_cast<void**>(&s->d_level_pairs), order.size() * sizeof(uint32_t));
-        if (err == hipSuccess) err = hipMemcpy(s->d_level_pairs, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        s->bytes += order.size() * sizeof(uint32_t);
-    }
+    s->upload_stats.copy_ms = float(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     if (err != hipSuccess) {
+        e->scenes.push_back(s);
         vt_scene_free(s);
         return fail(VT_ERR_HIP, std::string("vt_scene_upload: ") + hipGetErrorString(err));
     }
     e->scenes.push_back(s);
+    {
+        // triangle -> slot (refits) and the pairs by depth, deepest first (level-wise refit): built on the device from the
+        // records just uploaded and the pairs' depths (scene_build.hip) -- round 4 made both on the host, serially
+        std::lock_guard<std::mutex> host_lock(e->host_mu);
+        const int rc = scene_index_tables(s, hs.pair_depth.data());
+        if (rc != VT_OK) { vt_scene_free(s); return rc; }
+    }
+    s->upload_stats.total_ms = float(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    s->upload_stats.device_ms = s->upload_stats.total_ms - s->upload_stats.copy_ms;
     // a group's scene lives on every device: the BVH is replicated, rays are what is sharded
     for (vt_engine* p : e->peers) {
         vt_scene* rep = nullptr;
@@ -1313,6 +1306,8 @@ int vt_engine_launch_info(vt_engine* e, uint32_t* blocks, uint32_t* threads, uin
 } // extern "C"
 
 namespace vt {
+
+float scene_packet_radius2(const vt_node_pair& root) { return packet_radius2(root); }
 
 int engine_launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_occ, void* d_stats, bool any_hit, bool stats,
                   hipStream_t stream)

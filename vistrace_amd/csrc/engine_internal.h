@@ -94,6 +94,9 @@ struct vt_engine {
     char* h_stage_out[kStageBufs] = {};
     hipStream_t s_in = nullptr, s_out = nullptr;
     hipEvent_t ev_in[kStageBufs] = {}, ev_k[kStageBufs] = {}, ev_out[kStageBufs] = {};
+    // Rebuild (scene_build.hip): staging block of the device lineariser / index tables, kept across Rebuilds; pinned read-back
+    void*  d_build = nullptr;  size_t d_build_bytes = 0;
+    char*  h_build = nullptr;
     // bounce loop: two ray queues, two path-id queues, the queue's hit records, block offsets, live counter
     void*  d_loop = nullptr;  size_t d_loop_bytes = 0;
     uint32_t* h_live = nullptr;           // pinned read-back of the live-path count
@@ -184,6 +187,7 @@ struct vt_scene {
     hipGraphExec_t  refit_graph = nullptr;   // the level-by-level refit launches, captured once (launch-bound: ~30 tiny kernels)
     uint32_t      npairs = 0, ntris = 0, max_depth = 0, root_leaf_count = 0;
     uint64_t      bytes = 0;
+    vt_upload_stats upload_stats{};         // where the time of this scene's upload went (vt_scene_upload_stats)
     std::shared_ptr<std::atomic<int>> host_stale;   // the vt_host_scene this scene was uploaded from: set by a device-side refit
     // multi-GPU group: the same scene on every peer device (replicas[g-1] lives on engine->peers[g-1]); owned by this scene
     std::vector<vt_scene*> replicas;
@@ -228,6 +232,10 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
 // enqueue one trace of n device-resident rays on `stream` (per-launch scratch from the engine's slot ring)
 int engine_launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_occ, void* d_stats, bool any_hit, bool stats,
                   hipStream_t stream);
+// engine.hip: (2 % of the scene's diagonal)^2 from the root pair: how far apart the origins of a ray packet may lie
+float scene_packet_radius2(const vt_node_pair& root);
+// scene_build.hip: prim_to_slot and the level lists of a scene whose records are on the device (h_pair_depth: depth of every pair)
+int scene_index_tables(vt_scene* s, const uint32_t* h_pair_depth);
 // batch.hip: the open batch sets of a scene that is being freed lose their scene (their later calls fail, abort still frees them)
 void batch_sets_detach(vt_scene* s);
 // the host-pointer path of ONE device: staging copies + launch(es) + copy-out, synchronous

@@ -71,6 +71,15 @@ void AccelStruct::ReleaseDevice()
     mpHostScene = nullptr;
 }
 
+// the records on the host (pairs, leaf-ordered triangles) for the rays that are walked here: fetched from the device the first time
+// one is asked for -- a caller that only traces batches never pays for the copy
+int AccelStruct::EnsureHostScene() const
+{
+    if (mpHostScene) return VT_OK;
+    if (!mpScene) return VT_ERR_INVALID_ARG;
+    return vt_host_scene_download(mpScene, &mpHostScene);
+}
+
 void AccelStruct::PopulateAccel(ILuaBase* LUA, const World* pWorld)
 {
     // ThrowError does not return and (in the real module: longjmp) does not unwind C++ frames, so every raise below
@@ -145,9 +154,10 @@ int AccelStruct::BuildAndUpload(vt_engine* eng)
     vt_bvh* bvh = nullptr;
     int rc = vt_tris_setup(verts.data(), flags.data(), n, recs.data());
     if (rc == VT_OK) rc = vt_bvh_build(recs.data(), n, 0, &bvh);
-    if (rc == VT_OK) rc = vt_scene_linearise(bvh, recs.data(), &mpHostScene);   // kept: single rays are walked on the host
+    // the tree and the records go up as they are; the device re-packs them (pairs in depth-first order, triangles in leaf order,
+    // index tables) on every device of the engine.  The host copy that single rays are walked on is fetched on first use.
+    if (rc == VT_OK) rc = vt_scene_upload_tree(eng, bvh, recs.data(), n, &mpScene);
     if (bvh) vt_bvh_free(bvh);
-    if (rc == VT_OK) rc = vt_scene_upload(eng, mpHostScene, &mpScene);           // replicated to every device of the engine
     if (rc == VT_OK) rc = UploadSideTables(flags);
     if (rc != VT_OK) ReleaseDevice();
     return rc;
@@ -201,7 +211,8 @@ int AccelStruct::UploadSideTables(const std::vector<uint8_t>& flags)
         if (has_plane) texels.insert(texels.end(), m.baseAlpha.begin(), m.baseAlpha.begin() + size_t(m.alphaWidth) * m.alphaHeight);
     }
     rc = vt_scene_set_alpha(mpScene, mats.data(), uint32_t(mats.size()), texels.data(), texels.size());
-    if (rc == VT_OK)                                        // the same tables for the host walk
+    if (rc == VT_OK) rc = EnsureHostScene();                // the same tables for the host walk: such a scene fetches its host copy now
+    if (rc == VT_OK)
         rc = vt_host_scene_set_alpha(mpHostScene, attribs.data(), uint32_t(attribs.size()), mats.data(), uint32_t(mats.size()),
                                      texels.data(), texels.size());
     return rc;
@@ -248,7 +259,7 @@ int AccelStruct::Traverse(ILuaBase* LUA)
     // of the linearised scene -- 1-2 us against ~20 us for a launch-bound lone ray on the device (BASELINE config 1).
     const vt_ray ray{{origin.x, origin.y, origin.z}, {direction.x, direction.y, direction.z}, tMin, tMax};
     vt_hit hit;
-    if (vt_host_scene_trace_closest(mpHostScene, &ray, 1, &hit) != VT_OK) {
+    if (EnsureHostScene() != VT_OK || vt_host_scene_trace_closest(mpHostScene, &ray, 1, &hit) != VT_OK) {
         static thread_local char msg[512];
         std::snprintf(msg, sizeof(msg), "VisTrace: traversal failed: %s", vt_last_error());
         LUA->ThrowError(msg);
@@ -270,7 +281,8 @@ int AccelStruct::TraceClosest(const vt_ray* rays, uint64_t n, vt_hit* hits) cons
 int AccelStruct::TraceClosestHost(const vt_ray* rays, uint64_t n, vt_hit* hits) const
 {
     if (!mAccelBuilt) return VT_ERR_INVALID_ARG;
-    return vt_host_scene_trace_closest(mpHostScene, rays, n, hits);
+    const int rc = EnsureHostScene();
+    return rc != VT_OK ? rc : vt_host_scene_trace_closest(mpHostScene, rays, n, hits);
 }
 
 int AccelStruct::TraceClosestDevice(const vt_ray* rays, uint64_t n, vt_hit* hits) const

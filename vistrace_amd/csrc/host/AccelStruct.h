@@ -58,7 +58,7 @@ public:
 private:
     bool mAccelBuilt;
     vt_scene* mpScene;                      // device-resident linearised BVH + triangles
-    vt_host_scene* mpHostScene;             // the same records on the host: single rays are walked here (config 1)
+    mutable vt_host_scene* mpHostScene;     // the same records on the host: single rays are walked here (config 1); fetched on first use
     std::vector<vt_ray> mBatchRays;         // TraverseBatch scratch (members: a Lua error must not skip a destructor)
     std::vector<vt_hit> mBatchHits;
     std::vector<vt_batch*> mBatchSet;       // TraverseBatch({buffers}) scratch: the handles on their way into Lua userdata
@@ -67,6 +67,7 @@ private:
     void ReleaseDevice();
     bool AppendEntity(void* entityUserData);   // false: the entity table is full (65535)
     int  BuildAndUpload(vt_engine* eng);
+    int  EnsureHostScene() const;
     int  UploadSideTables(const std::vector<uint8_t>& flags);
     int  TraverseBatchBuffer(GarrysMod::Lua::ILuaBase* LUA);
     int  TraverseBatchBuffers(GarrysMod::Lua::ILuaBase* LUA);

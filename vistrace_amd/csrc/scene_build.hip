@@ -1,0 +1,468 @@
+// scene_build.hip -- Rebuild's device half: from the CPU-built tree to the records the traversal kernels read.
+//
+// The reference constructs its intersector / traverser over the finished tree (source/objects/AccelStruct.cpp:772-773); this
+// project re-packs the tree for the device first: inner nodes become 64-B sibling-pair records in depth-first (left-first) order,
+// triangles are shuffled into leaf order, and two index tables are derived (triangle -> slot for refits, pairs by depth for the
+// level-wise refit).  Round 1-4 did that on the host (linearise.cpp: a serial walk, 85-100 ms per million triangles) and uploaded
+// the result; here the walk is replaced by five data-parallel kernels over the v1 node array, so a Rebuild's upload step is three
+// plain copies (nodes, primitive indices, triangle records as the builder saw them) plus well under a millisecond of device work:
+//
+//   lin_parents   node i -> parent of its two children
+//   lin_counts    bottom-up: inner nodes and triangles below every node (each leaf walks up; the second arrival at a node
+//                 continues -- the classic atomic-counter refit pattern)
+//   lin_offsets   every node walks up to the root and sums what precedes it in the depth-first order: its pair index, the
+//                 first triangle slot of its pair / of its leaf, its depth
+//   lin_emit      inner node -> its pair record (children's `first` re-targeted); leaf -> its triangle records + prim_to_slot
+//   radix sort    pairs by (max_depth - depth), stable: the level lists of the refit, deepest level first
+//
+// The result is BYTE-EQUAL to vt_scene_linearise + vt_scene_upload (tests/test_gpu_parity.py::test_device_linearise_*): same
+// numbering (a pair's leaf children are emitted when the pair is numbered, left before right; then the left subtree, then the
+// right), same level lists (ascending pair index inside a level).  vt_host_scene_download brings the records back for the callers
+// that walk single rays on the host.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <string.h>              // rocprim's texture iterator calls the global memset from host code
+#include <rocprim/rocprim.hpp>
+
+#include "engine_internal.h"
+
+using namespace vt;
+
+namespace {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kErrChild = 1, kErrDepth = 2, kErrPrim = 4;
+constexpr int kMaxWalk = 1 << 16;             // steps a walk to the root may take before the tree is declared malformed
+
+struct LinArgs {
+    const vt_bvh_node* nodes;  uint32_t n_nodes;
+    const uint32_t* prim_indices; uint32_t n_prims;
+    const vt_tri64* tris_in;   uint32_t ntris;
+    uint32_t *parent, *cnt, *tcount, *flag, *pidx, *tbase, *depth;
+    uint32_t* status;          // [0] error bits, [1] deepest pair, [2] a triangle carries VT_TRI_ALPHATEST
+};
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(256) void lin_alpha_flag(const vt_tri64* tris, uint32_t n, uint32_t* status)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n && (tris[i].flags & VT_TRI_ALPHATEST)) status[2] = 1;
+}
+
+__global__ __launch_bounds__(256) void lin_parents(LinArgs a)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.n_nodes) return;
+    if (i == 0) a.parent[0] = kNone;
+    const vt_bvh_node me = a.nodes[i];
+    if (me.prim_count != 0) {
+        if (uint64_t(me.first) + me.prim_count > a.n_prims) atomicOr(&a.status[0], kErrPrim);
+        return;
+    }
+    // children sit side by side behind their parent (v1 layout; both builders emit children at higher indices)
+    if (me.first == 0 || uint64_t(me.first) + 1 >= a.n_nodes) { atomicOr(&a.status[0], kErrChild); return; }
+    a.parent[me.first] = i;
+    a.parent[me.first + 1] = i;
+}
+
+__global__ __launch_bounds__(256) void lin_counts(LinArgs a)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.n_nodes) return;
+    const uint32_t pc = a.nodes[i].prim_count;
+    if (pc == 0) return;                                   // the leaves start the walks
+    st_agent(&a.cnt[i], 0);
+    st_agent(&a.tcount[i], pc);
+    uint32_t x = i;
+    for (int guard = 0; guard < kMaxWalk; ++guard) {
+        const uint32_t p = a.parent[x];
+        if (p == kNone) return;
+        __threadfence();                                   // my counts are visible before my arrival is
+        if (atomicAdd(&a.flag[p], 1u) == 0) return;        // first at this node: the sibling's walk will carry on
+        __threadfence();
+        const uint32_t L = a.nodes[p].first;
+        st_agent(&a.cnt[p], 1u + ld_agent(&a.cnt[L]) + ld_agent(&a.cnt[L + 1]));
+        st_agent(&a.tcount[p], ld_agent(&a.tcount[L]) + ld_agent(&a.tcount[L + 1]));
+        x = p;
+    }
+    atomicOr(&a.status[0], kErrDepth);
+}
+
+// Depth-first numbering without a walk from the root: node x below pair P (x = P's left or right child) comes behind
+//   P itself, P's leaf children (emitted when P is numbered), and -- if x is the right child -- the whole left subtree.
+__global__ __launch_bounds__(256) void lin_offsets(LinArgs a)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.n_nodes) return;
+    const bool leaf = a.nodes[i].prim_count != 0;
+    uint32_t x = i, ap = 0, at = 0, d = 0;
+    bool first = true;
+    for (;;) {
+        const uint32_t P = a.parent[x];
+        if (P == kNone) break;
+        const uint32_t L = a.nodes[P].first;
+        const bool right = x != L;
+        const uint32_t pcL = a.nodes[L].prim_count, pcR = a.nodes[L + 1].prim_count;
+        if (first && leaf) {
+            at += (right && pcL != 0) ? pcL : 0u;          // a leaf sits in its pair's own block: behind the left sibling leaf
+        } else {
+            ap += 1u + ((right && pcL == 0) ? a.cnt[L] : 0u);
+            at += pcL + pcR + ((right && pcL == 0) ? a.tcount[L] : 0u);   // pcX = 0 for an inner child: only leaf children count here
+        }
+        first = false;
+        x = P;
+        if (++d > uint32_t(kMaxWalk)) { atomicOr(&a.status[0], kErrDepth); return; }
+    }
+    a.tbase[i] = at;
+    if (!leaf) {
+        a.pidx[i] = ap;
+        a.depth[i] = d + 1;                                // the root's pair has depth 1 (linearise.cpp)
+        atomicMax(&a.status[1], d + 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void lin_emit(LinArgs a, vt_node_pair* pairs, vt_tri64* tris_out, uint32_t* prim_to_slot, uint32_t* keys,
+                                                uint32_t* vals, uint32_t max_depth)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.n_nodes) return;
+    const vt_bvh_node me = a.nodes[i];
+    if (me.prim_count == 0) {
+        const uint32_t p = a.pidx[i];
+        vt_node_pair rec;
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t c = me.first + uint32_t(side);
+            vt_bvh_node ch = a.nodes[c];
+            ch.first = ch.prim_count != 0 ? a.tbase[c] : a.pidx[c];
+            rec.child[side] = ch;
+        }
+        pairs[p] = rec;
+        keys[p] = max_depth - a.depth[i];                  // deepest level first
+        vals[p] = p;
+        return;
+    }
+    const uint32_t slot = a.tbase[i];
+    for (uint32_t q = 0; q < me.prim_count; ++q) {
+        const uint32_t idx = a.prim_indices[me.first + q];
+        if (idx >= a.ntris) { atomicOr(&a.status[0], kErrPrim); continue; }
+        vt_tri64 t = a.tris_in[idx];
+        t.prim = idx;
+        tris_out[slot + q] = t;
+        prim_to_slot[idx] = slot + q;
+    }
+}
+
+// where each level starts in the sorted keys (every level 0 .. max_depth-1 has at least one pair)
+__global__ __launch_bounds__(256) void level_starts(const uint32_t* sorted_keys, uint32_t n, uint32_t* begin)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= n) return;
+    if (j == 0 || sorted_keys[j] != sorted_keys[j - 1]) begin[sorted_keys[j]] = j;
+}
+
+// classic path (records linearised on the host): the two index tables from what is already on the device
+__global__ __launch_bounds__(256) void slots_from_records(const vt_tri64* tris, uint32_t n, uint32_t* prim_to_slot, uint32_t* status)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t prim = tris[i].prim;
+    if (prim >= n) { atomicOr(&status[0], kErrPrim); return; }
+    prim_to_slot[prim] = i;
+}
+
+__global__ __launch_bounds__(256) void keys_from_depth(const uint32_t* depth, uint32_t n, uint32_t max_depth, uint32_t* keys, uint32_t* vals)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    keys[p] = max_depth - depth[p];
+    vals[p] = p;
+}
+
+inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
+inline uint32_t blocks_for(uint64_t n) { return uint32_t((n + 255) / 256); }
+inline double ms_since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// pairs sorted by level (keys = max_depth - depth, vals = pair index: both in scratch) -> s->d_level_pairs, s->level_begin
+int build_level_lists(vt_scene* s, uint32_t* keys, uint32_t* vals, uint32_t* keys_out, uint32_t* begin, void* sort_tmp, size_t sort_tmp_bytes,
+                      uint32_t* h_begin /* pinned, max_depth entries */)
+{
+    vt_engine* e = s->engine;
+    const uint32_t np = s->npairs, md = s->max_depth;
+    size_t need = sort_tmp_bytes;
+    VT_HIP(rocprim::radix_sort_pairs(sort_tmp, need, keys, keys_out, vals, s->d_level_pairs, np, 0, 8, e->stream));
+    hipLaunchKernelGGL(level_starts, dim3(blocks_for(np)), dim3(256), 0, e->stream, keys_out, np, begin);
+    VT_HIP(hipGetLastError());
+    VT_HIP(hipMemcpyAsync(h_begin, begin, size_t(md) * 4, hipMemcpyDeviceToHost, e->stream));
+    return VT_OK;
+}
+
+size_t sort_tmp_bytes_for(uint32_t np)
+{
+    size_t need = 0;
+    uint32_t* nul = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, need, nul, nul, nul, nul, np, 0, 8, hipStream_t(nullptr));
+    return al256(need) + 256;
+}
+
+} // namespace
+
+namespace vt {
+
+// Shared by vt_scene_upload (host-linearised records already copied into s->d_records) : prim_to_slot and the level lists on the
+// device.  h_pair_depth: depth of every pair (HostScene::pair_depth).
+int scene_index_tables(vt_scene* s, const uint32_t* h_pair_depth)
+{
+    vt_engine* e = s->engine;
+    const uint32_t np = s->npairs, nt = s->ntris, md = s->max_depth;
+    if (md > 255) return fail(VT_ERR_UNSUPPORTED, "vt_scene_upload: the tree is deeper than 255 levels");
+    const size_t sort_b = np ? sort_tmp_bytes_for(np) : 0;
+    const size_t need = 5 * al256(size_t(np) * 4) + al256(size_t(md + 1) * 4) + sort_b + 512;
+    int rc = ensure_bytes(&e->d_build, &e->d_build_bytes, need);
+    if (rc != VT_OK) return rc;
+    if (!e->h_build) VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_build), 4096));
+    char* base = static_cast<char*>(e->d_build);
+    uint32_t* status = reinterpret_cast<uint32_t*>(base);
+    char* cur = base + 256;
+    auto take = [&](size_t bytes) { char* p = cur; cur += al256(bytes); return p; };
+    uint32_t* depth = reinterpret_cast<uint32_t*>(take(size_t(np) * 4));
+    uint32_t* keys = reinterpret_cast<uint32_t*>(take(size_t(np) * 4));
+    uint32_t* vals = reinterpret_cast<uint32_t*>(take(size_t(np) * 4));
+    uint32_t* keys_out = reinterpret_cast<uint32_t*>(take(size_t(np) * 4));
+    uint32_t* begin = reinterpret_cast<uint32_t*>(take(size_t(md + 1) * 4));
+    void* sort_tmp = take(sort_b);
+    VT_HIP(hipMemsetAsync(status, 0, 256, e->stream));
+    if (nt) {
+        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_prim_to_slot), size_t(nt) * 4));
+        s->bytes += size_t(nt) * 4;
+        hipLaunchKernelGGL(slots_from_records, dim3(blocks_for(nt)), dim3(256), 0, e->stream, s->d_tris, nt, s->d_prim_to_slot, status);
+        VT_HIP(hipGetLastError());
+    }
+    uint32_t* h = reinterpret_cast<uint32_t*>(e->h_build);
+    if (np) {
+        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_level_pairs), size_t(np) * 4));
+        s->bytes += size_t(np) * 4;
+        VT_HIP(hipMemcpyAsync(depth, h_pair_depth, size_t(np) * 4, hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(keys_from_depth, dim3(blocks_for(np)), dim3(256), 0, e->stream, depth, np, md, keys, vals);
+        VT_HIP(hipGetLastError());
+        rc = build_level_lists(s, keys, vals, keys_out, begin, sort_tmp, sort_b, h + 64);
+        if (rc != VT_OK) return rc;
+    }
+    VT_HIP(hipMemcpyAsync(h, status, 16, hipMemcpyDeviceToHost, e->stream));
+    VT_HIP(hipStreamSynchronize(e->stream));
+    if (h[0] & kErrPrim) return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: bad prim index");
+    s->level_begin.clear();
+    if (np) {
+        for (uint32_t k = 0; k < md; ++k) s->level_begin.push_back(h[64 + k]);
+        s->level_begin.push_back(np);
+    }
+    return VT_OK;
+}
+
+} // namespace vt
+
+extern "C" {
+
+int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris, uint32_t ntris, vt_scene** out)
+{
+    if (!e || !bvhw || !out) return fail(VT_ERR_INVALID_ARG, "vt_scene_upload_tree: NULL argument");
+    *out = nullptr;
+    const Bvh& bvh = bvhw->bvh;
+    const uint32_t N = uint32_t(bvh.nodes.size()), M = uint32_t(bvh.prim_indices.size());
+    if (M != ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_upload_tree: ntris differs from the tree's primitive count");
+    if (N != 0 && !tris) return fail(VT_ERR_INVALID_ARG, "vt_scene_upload_tree: tris is NULL");
+    // an empty tree and a tree whose root is a leaf have nothing to number: the host path serves them (a handful of records)
+    if (N == 0 || bvh.nodes[0].prim_count != 0) {
+        vt_host_scene* hs = nullptr;
+        int rc = vt_scene_linearise(bvhw, tris, &hs);
+        if (rc == VT_OK) rc = vt_scene_upload(e, hs, out);
+        if (rc == VT_OK && *out) { (*out)->host_stale.reset(); for (vt_scene* rep : (*out)->replicas) rep->host_stale.reset(); }
+        vt_host_scene_free(hs);
+        return rc;
+    }
+    if ((N & 1u) == 0) return fail(VT_ERR_INVALID_ARG, "vt_scene_upload_tree: malformed tree (even node count)");
+    const auto t_begin = std::chrono::steady_clock::now();
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_upload_tree: hipSetDevice failed");
+    std::lock_guard<std::mutex> host_lock(e->host_mu);
+    const uint32_t np = (N - 1) / 2;
+    uint64_t gap = 0;                                        // test hook, as vt_scene_upload (include/vistrace_hip.h, "Test hooks")
+    if (const char* env = test_hook("VT_TEST_RECORD_GAP")) gap = std::strtoull(env, nullptr, 10) & ~uint64_t(1);
+    if (uint64_t(np) + gap + 2 * uint64_t(ntris) + 4 >= 0xFFFFFFFFull) return fail(VT_ERR_INVALID_ARG, "vt_scene_upload_tree: scene too large");
+
+    // ---- staging block: the tree as the builder left it, per-node scratch, sort scratch ---------------------------------------
+    const size_t sort_b = sort_tmp_bytes_for(np);
+    const size_t need = 512 + al256(size_t(N) * 32) + al256(size_t(M) * 4) + al256(size_t(ntris) * 64) + 7 * al256(size_t(N) * 4) +
+                        3 * al256(size_t(np) * 4) + al256(1024) + sort_b;
+    int rc = ensure_bytes(&e->d_build, &e->d_build_bytes, need);
+    if (rc != VT_OK) return rc;
+    if (!e->h_build) VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_build), 4096));
+    char* base = static_cast<char*>(e->d_build);
+    char* cur = base + 512;
+    auto take = [&](size_t bytes) { char* p = cur; cur += al256(bytes); return p; };
+    LinArgs a{};
+    a.status = reinterpret_cast<uint32_t*>(base);
+    vt_bvh_node* d_nodes = reinterpret_cast<vt_bvh_node*>(take(size_t(N) * 32));
+    uint32_t* d_prims = reinterpret_cast<uint32_t*>(take(size_t(M) * 4));
+    vt_tri64* d_tris_in = reinterpret_cast<vt_tri64*>(take(size_t(ntris) * 64));
+    a.nodes = d_nodes; a.n_nodes = N; a.prim_indices = d_prims; a.n_prims = M; a.tris_in = d_tris_in; a.ntris = ntris;
+    uint32_t** per_node[] = {&a.parent, &a.cnt, &a.tcount, &a.flag, &a.pidx, &a.tbase, &a.depth};
+    for (uint32_t** pn : per_node) *pn = reinterpret_cast<uint32_t*>(take(size_t(N) * 4));
+    uint32_t* keys = reinterpret_cast<uint32_t*>(take(size_t(np) * 4));
+    uint32_t* vals = reinterpret_cast<uint32_t*>(take(size_t(np) * 4));
+    uint32_t* keys_out = reinterpret_cast<uint32_t*>(take(size_t(np) * 4));
+    uint32_t* begin = reinterpret_cast<uint32_t*>(take(1024));
+    void* sort_tmp = take(sort_b);
+    const double alloc_ms = ms_since(t_begin);
+
+    // ---- three plain copies, then the numbering ---------------------------------------------------------------------------------
+    const auto t_copy = std::chrono::steady_clock::now();
+    hipStream_t st = e->stream;
+    VT_HIP(hipMemsetAsync(a.status, 0, 512, st));
+    VT_HIP(hipMemsetAsync(a.flag, 0, size_t(N) * 4, st));
+    VT_HIP(hipMemcpyAsync(d_nodes, bvh.nodes.data(), size_t(N) * 32, hipMemcpyHostToDevice, st));
+    VT_HIP(hipMemcpyAsync(d_prims, bvh.prim_indices.data(), size_t(M) * 4, hipMemcpyHostToDevice, st));
+    VT_HIP(hipMemcpyAsync(d_tris_in, tris, size_t(ntris) * 64, hipMemcpyHostToDevice, st));
+    const double copy_issue_ms = ms_since(t_copy);
+    const auto t_kern = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(lin_alpha_flag, dim3(blocks_for(ntris)), dim3(256), 0, st, d_tris_in, ntris, a.status);
+    hipLaunchKernelGGL(lin_parents, dim3(blocks_for(N)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(lin_counts, dim3(blocks_for(N)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(lin_offsets, dim3(blocks_for(N)), dim3(256), 0, st, a);
+    VT_HIP(hipGetLastError());
+    uint32_t* h = reinterpret_cast<uint32_t*>(e->h_build);
+    VT_HIP(hipMemcpyAsync(h, a.status, 16, hipMemcpyDeviceToHost, st));
+    VT_HIP(hipMemcpyAsync(h + 4, a.cnt, 4, hipMemcpyDeviceToHost, st));         // inner nodes and triangles below the root
+    VT_HIP(hipMemcpyAsync(h + 5, a.tcount, 4, hipMemcpyDeviceToHost, st));
+    VT_HIP(hipStreamSynchronize(st));
+    const uint32_t err = h[0], max_depth = h[1];
+    const bool has_alpha = h[2] != 0;
+    if (err != 0 || h[4] != np || h[5] != ntris || max_depth == 0)
+        return fail(VT_ERR_INVALID_ARG, "vt_scene_upload_tree: malformed tree");
+    if (max_depth > 255) return fail(VT_ERR_UNSUPPORTED, "vt_scene_upload_tree: the tree is deeper than 255 levels");
+
+    // ---- the scene: records (pairs | triangles | room for AlphaRecs), index tables ---------------------------------------------
+    vt_scene* s = new vt_scene();
+    s->engine = e;
+    s->has_alpha = has_alpha;
+    s->npairs = np;
+    s->ntris = ntris;
+    s->max_depth = max_depth;
+    s->root_leaf_count = 0;
+    s->tri_base = ((np + 1u) & ~1u) + uint32_t(gap);
+    if (has_alpha) s->alpha_base = (s->tri_base + ntris + 1u) & ~1u;
+    s->record_capacity = std::max<size_t>(has_alpha ? size_t(s->alpha_base) + ntris : size_t(s->tri_base) + ntris, 2);
+    const size_t rec_bytes = s->record_capacity * 64;
+    hipError_t herr = hipMalloc(reinterpret_cast<void**>(&s->d_records), rec_bytes);
+    if (herr == hipSuccess) herr = hipMalloc(reinterpret_cast<void**>(&s->d_prim_to_slot), size_t(ntris) * 4);
+    if (herr == hipSuccess) herr = hipMalloc(reinterpret_cast<void**>(&s->d_level_pairs), size_t(np) * 4);
+    if (herr != hipSuccess) {
+        e->scenes.push_back(s);
+        vt_scene_free(s);
+        return fail(VT_ERR_HIP, std::string("vt_scene_upload_tree: ") + hipGetErrorString(herr));
+    }
+    e->scenes.push_back(s);
+    s->bytes = rec_bytes + size_t(ntris) * 4 + size_t(np) * 4;
+    s->d_tris = reinterpret_cast<vt_tri64*>(s->d_records + size_t(s->tri_base) * 64);
+    // only what the kernels do not write needs zeros: the padding record between pairs and triangles (+ the test gap), the AlphaRec room
+    const size_t pair_end = size_t(np) * 64, tri_off = size_t(s->tri_base) * 64, tri_end = tri_off + size_t(ntris) * 64;
+    herr = hipSuccess;
+    if (tri_off > pair_end) herr = hipMemsetAsync(s->d_records + pair_end, 0, tri_off - pair_end, st);
+    if (herr == hipSuccess && rec_bytes > tri_end) herr = hipMemsetAsync(s->d_records + tri_end, 0, rec_bytes - tri_end, st);
+    if (herr != hipSuccess) { vt_scene_free(s); return fail(VT_ERR_HIP, std::string("vt_scene_upload_tree: ") + hipGetErrorString(herr)); }
+    hipLaunchKernelGGL(lin_emit, dim3(blocks_for(N)), dim3(256), 0, st, a, reinterpret_cast<vt_node_pair*>(s->d_records), s->d_tris,
+                       s->d_prim_to_slot, keys, vals, max_depth);
+    rc = hipGetLastError() == hipSuccess ? VT_OK : fail(VT_ERR_HIP, "vt_scene_upload_tree: kernel launch failed");
+    if (rc == VT_OK) rc = build_level_lists(s, keys, vals, keys_out, begin, sort_tmp, sort_b, h + 64);
+    if (rc == VT_OK) {
+        herr = hipMemcpyAsync(h + 8, a.status, 4, hipMemcpyDeviceToHost, st);
+        if (herr == hipSuccess) herr = hipMemcpyAsync(h + 512, s->d_records, sizeof(vt_node_pair), hipMemcpyDeviceToHost, st);   // the root pair: packet radius
+        if (herr == hipSuccess) herr = hipStreamSynchronize(st);
+        if (herr != hipSuccess) rc = fail(VT_ERR_HIP, std::string("vt_scene_upload_tree: ") + hipGetErrorString(herr));
+    }
+    if (rc == VT_OK && h[8] != 0) rc = fail(VT_ERR_INVALID_ARG, "vt_scene_upload_tree: bad prim index");
+    if (rc != VT_OK) { vt_scene_free(s); return rc; }
+    for (uint32_t k = 0; k < max_depth; ++k) s->level_begin.push_back(h[64 + k]);
+    s->level_begin.push_back(np);
+    vt_node_pair root;
+    std::memcpy(&root, h + 512, sizeof(root));
+    s->coherent_radius2 = scene_packet_radius2(root);
+    s->upload_stats.alloc_ms = float(alloc_ms);
+    s->upload_stats.copy_ms = float(copy_issue_ms);
+    s->upload_stats.device_ms = float(ms_since(t_kern));
+    s->upload_stats.total_ms = float(ms_since(t_begin));
+    s->upload_stats.bytes_h2d = uint64_t(N) * 32 + uint64_t(M) * 4 + uint64_t(ntris) * 64;
+    s->upload_stats.linearised_on_device = 1;
+
+    // a group's scene lives on every device: each member numbers its own copy
+    for (vt_engine* p : e->peers) {
+        vt_scene* rep = nullptr;
+        rc = vt_scene_upload_tree(p, bvhw, tris, ntris, &rep);
+        if (rc != VT_OK) { vt_scene_free(s); return rc; }
+        s->replicas.push_back(rep);
+    }
+    s->upload_stats.total_ms = float(ms_since(t_begin));
+    *out = s;
+    return VT_OK;
+}
+
+int vt_scene_upload_stats(const vt_scene* s, vt_upload_stats* out)
+{
+    if (!s || !out) return fail(VT_ERR_INVALID_ARG, "vt_scene_upload_stats: NULL argument");
+    *out = s->upload_stats;
+    return VT_OK;
+}
+
+int vt_host_scene_download(vt_scene* s, vt_host_scene** out)
+{
+    if (!out) return fail(VT_ERR_INVALID_ARG, "vt_host_scene_download: out is NULL");
+    *out = nullptr;
+    if (!s) return fail(VT_ERR_INVALID_ARG, "vt_host_scene_download: scene is NULL");
+    if (!s->engine) return fail(VT_ERR_INVALID_ARG, "vt_host_scene_download: the scene\'s engine has been closed");
+    if (s->poisoned) return fail(VT_ERR_INVALID_ARG, "vt_host_scene_download: the last refit left non-finite triangles; refit with finite data first");
+    vt_host_scene* hsw = nullptr;
+    try {
+        hsw = new vt_host_scene();
+        hsw->hs.pairs.resize(s->npairs);
+        hsw->hs.tris.resize(s->ntris);
+        hsw->hs.pair_depth.resize(s->npairs);
+    } catch (const std::bad_alloc&) {
+        delete hsw;
+        return fail(VT_ERR_NOMEM, "vt_host_scene_download: out of host memory");
+    }
+    HostScene& hs = hsw->hs;
+    hs.max_depth = s->max_depth;
+    hs.root_leaf_count = s->root_leaf_count;
+    int rc = vt_scene_read_records(s, hs.pairs.data(), hs.tris.data());
+    if (rc == VT_OK && s->npairs) {
+        // depth of every pair from the level lists: level k (deepest first) holds pairs of depth max_depth - k
+        std::vector<uint32_t> order(s->npairs);
+        DeviceGuard guard(s->engine->device);
+        const hipError_t err = hipMemcpy(order.data(), s->d_level_pairs, size_t(s->npairs) * 4, hipMemcpyDeviceToHost);
+        if (err != hipSuccess) rc = fail(VT_ERR_HIP, std::string("vt_host_scene_download: ") + hipGetErrorString(err));
+        for (size_t k = 0; rc == VT_OK && k + 1 < s->level_begin.size(); ++k)
+            for (uint32_t j = s->level_begin[k]; j < s->level_begin[k + 1]; ++j) hs.pair_depth[order[j]] = s->max_depth - uint32_t(k);
+    }
+    if (rc != VT_OK) { delete hsw; return rc; }
+    bool alpha = false;
+    for (const vt_tri64& t : hs.tris) alpha |= (t.flags & VT_TRI_ALPHATEST) != 0;
+    hs.has_alpha = alpha;
+    // from now on a device-side refit marks this copy stale (vt_host_scene_sync refreshes it), on every member of a group
+    s->host_stale = hsw->stale;
+    for (vt_scene* rep : s->replicas) rep->host_stale = hsw->stale;
+    *out = hsw;
+    return VT_OK;
+}
+
+} // extern "C"
