@@ -30,15 +30,17 @@ int main(void)
     vt_scene* scene = NULL;
     CHECK(vt_tris_setup(verts, NULL, 2, recs));
     CHECK(vt_bvh_build(recs, 2, 0, &bvh));
-    CHECK(vt_scene_linearise(bvh, recs, &hs));
     int ndev = 0, devs[64];
     CHECK(vt_device_count(&ndev));
     if (ndev > 64) ndev = 64;
     for (int i = 0; i < ndev; ++i) devs[i] = i;
     if (ndev <= 0) { fprintf(stderr, "no HIP device (the library has no CPU fallback)\n"); return 2; }
     CHECK(vt_engine_open_multi(devs, ndev, &eng));
-    CHECK(vt_scene_upload(eng, hs, &scene));
+    /* Rebuild's upload step: the tree and the records go up as they are, the device re-packs them;
+     * the host copy that single rays are walked on comes back from the device */
+    CHECK(vt_scene_upload_tree(eng, bvh, recs, 2, &scene));
     vt_bvh_free(bvh);
+    CHECK(vt_host_scene_download(scene, &hs));
 
     const vt_ray rays[3] = {
         {{0.25f, 0.25f, 5.f}, {0, 0, -1}, 0.f, FLT_MAX}, /* hits the upper triangle at t = 4 */

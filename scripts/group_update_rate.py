@@ -23,8 +23,10 @@ for members in (1, 2, 8):
     for _ in range(5):
         scene.skin_refit(bones, binds)
     t0 = time.perf_counter()
+    enq, wait = [], []
     for _ in range(20):
         scene.skin_refit(bones, binds)
+        enq.append(eng.get_option("last_update_enqueue_us")); wait.append(eng.get_option("last_update_wait_us"))
     skin_ms = (time.perf_counter() - t0) / 20 * 1e3
     scene.refit(moved)
     t0 = time.perf_counter()
@@ -32,6 +34,7 @@ for members in (1, 2, 8):
         scene.refit(moved)
     refit_ms = (time.perf_counter() - t0) / 5 * 1e3
     print(f"members {members}: vt_scene_skin_refit {skin_ms:.3f} ms per frame ({skin_ms / members:.3f} per member), vt_scene_refit {refit_ms:.2f} ms "
-          f"({refit_ms / members:.2f} per member); early waits {eng.get_option('last_update_early_waits')} of {eng.get_option('last_update_members')} members", flush=True)
+          f"({refit_ms / members:.2f} per member); early waits {eng.get_option('last_update_early_waits')} of {eng.get_option('last_update_members')} members; "
+          f"skin refit host time: prepare + enqueue of all members {np.median(enq):.0f} us, waits {np.median(wait):.0f} us", flush=True)
     scene.free()
     eng.close()

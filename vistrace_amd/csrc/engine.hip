@@ -624,6 +624,10 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
     // were waited for before the last member's work had been enqueued (0 by construction; tests/fake_group_check.py)
     else if (k == "last_update_members") *value = e->last_update_members;
     else if (k == "last_update_early_waits") *value = e->last_update_early_waits;
+    // ... and its host time: prepare + enqueue of every member (the host is busy), then the waits (one member's device time when
+    // every member has a device of its own)
+    else if (k == "last_update_enqueue_us") *value = e->last_update_enqueue_us;
+    else if (k == "last_update_wait_us") *value = e->last_update_wait_us;
     else return fail(VT_ERR_INVALID_ARG, "vt_engine_get_option: unknown key: " + k);
     return VT_OK;
 }
@@ -1000,6 +1004,7 @@ static int update_every_member(vt_scene* root, const char* who, const std::funct
     if (root) for (vt_scene* rep : root->replicas) { UpdateJob j; j.s = rep; jobs.push_back(j); }
     { UpdateJob j; j.s = root; jobs.push_back(j); }
     t_update_log.clear();
+    const auto t_begin = std::chrono::steady_clock::now();
     for (UpdateJob& j : jobs) {                          // prepare: may block, may allocate
         const int rc = prepare(j.s);
         if (rc == VT_OK) j.active = true;
@@ -1013,6 +1018,7 @@ static int update_every_member(vt_scene* root, const char* who, const std::funct
         t_update_log.push_back('E');
         if (rc != VT_OK) job_fail(j, rc);
     }
+    const auto t_enqueued = std::chrono::steady_clock::now();
     for (UpdateJob& j : jobs) {                          // finish: the first host wait of the call
         if (!j.active) continue;
         int rc = finish_update(j.s, who);
@@ -1024,6 +1030,9 @@ static int update_every_member(vt_scene* root, const char* who, const std::funct
         const uint32_t early_waits = last_e == std::string::npos ? 0 : uint32_t(std::count(t_update_log.begin(), t_update_log.begin() + long(last_e), 'W'));
         root->engine->last_update_members = uint32_t(jobs.size());
         root->engine->last_update_early_waits = early_waits;
+        const auto t_end = std::chrono::steady_clock::now();
+        root->engine->last_update_enqueue_us = uint32_t(std::chrono::duration<double, std::micro>(t_enqueued - t_begin).count());
+        root->engine->last_update_wait_us = uint32_t(std::chrono::duration<double, std::micro>(t_end - t_enqueued).count());
     }
     for (UpdateJob& j : jobs)                            // a failed member that passed `prepare` left work on its stream: drain it
         if (j.rc != VT_OK && j.s && j.s->engine) { DeviceGuard guard(j.s->engine->device); (void)hipStreamSynchronize(j.s->engine->stream); }

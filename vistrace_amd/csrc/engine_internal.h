@@ -117,7 +117,7 @@ struct vt_engine {
     std::vector<std::pair<char*, size_t>> device_spare;   // device blocks of freed batches, for the next ones that fit (at most 32)
     std::vector<std::pair<void*, size_t>> pinned_spare;   // pinned host blocks of freed batches (their downloaded arrays)
 
-    uint32_t last_update_members = 0, last_update_early_waits = 0;   // the latest group-wide refit / skin refit (diagnostic)
+    uint32_t last_update_members = 0, last_update_early_waits = 0, last_update_enqueue_us = 0, last_update_wait_us = 0;   // the latest group-wide refit / skin refit (diagnostic)
 
     bool alpha_regs_checked = false;         // ALPHA kernels: hipFuncGetAttributes agreed with the build-time ISA check
 

@@ -515,8 +515,17 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             // quad-cooperative fetch through LDS: row k receives the records of every quad's lane k.
             // Addresses are base + 32-bit byte offset (the engine uses this kernel below 4 GiB).
             const uint32_t piece = (lane & 3u) * 16u;
+#ifdef VT_EXP_NEIGHBOUR_FETCH
+            // experiment (round 5): an idle lane asks for what the lane at its position in the previous quad of its row of 16 asks
+            // for (DPP row_ror:4), instead of record 0 -- the row's instruction then names 15 distinct lines instead of 16
+            const uint32_t nb_rec = uint32_t(__builtin_amdgcn_update_dpp(0, int(rec), 0x124, 0xF, 0xF, true));
+            const uint32_t frec = (do_tri || want_node || alpha1) ? rec : nb_rec;
+            const uint32_t r0 = quad_broadcast<0>(frec), r1 = quad_broadcast<1>(frec),
+                           r2 = quad_broadcast<2>(frec), r3 = quad_broadcast<3>(frec);
+#else
             const uint32_t r0 = quad_broadcast<0>(rec), r1 = quad_broadcast<1>(rec),
                            r2 = quad_broadcast<2>(rec), r3 = quad_broadcast<3>(rec);
+#endif
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r0 << 6) | piece)),
                                              (lds_ptr)(uintptr_t)(stage_lds + 0u * kStageRow), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r1 << 6) | piece)),
