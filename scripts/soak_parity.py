@@ -49,7 +49,15 @@ for seed in range(first, first + count):
         tris = va.tris_setup(verts, flags)
     bvh = va.HostBvh(tris, nthreads=int(rng.integers(1, 9)), builder=("sah", "ploc", "sah_refined")[seed % 3])
     host_scene = va.HostScene(bvh)
-    scene = va.Scene(eng, host_scene)
+    if seed % 2 == 0:                                         # round 5: the tree re-packed ON THE DEVICE (vt_scene_upload_tree) -- the records
+        scene = va.Scene.from_tree(eng, bvh)                  # must equal the host lineariser's byte for byte, and everything below runs on them
+        dp, dt = scene.read_records()                         # (fetches the host copy back: vt_host_scene_download)
+        if not (dp.tobytes() == host_scene.pairs().tobytes() and dt.tobytes() == host_scene.tris().tobytes()
+                and scene.host_scene.trace_closest_host(np.zeros(0, va.RAY)).shape == (0,)):
+            bad += 1
+            print(f"DEVICE RE-PACK MISMATCH seed {seed} n {n}", flush=True)
+    else:
+        scene = va.Scene(eng, host_scene)
     otris = O.tris_from_tri64(tris)
     if rig is not None:
         scene.set_tri_attribs(rig[1].view(va.TRI_ATTRIBS))

@@ -57,7 +57,8 @@ for ndev in (2, 3, 4, 8):
     eng = va.Engine([0] * ndev)
     assert eng.device_count == ndev
     eng.set_option("persistent", 1 if ndev in (3, 8) else 2)      # persistent waves on the small shards too
-    scene = va.Scene(eng, host_scene)         # replicated to every member
+    # replicated to every member: re-packed on each member's device (vt_scene_upload_tree) or uploaded from the host lineariser's output
+    scene = va.Scene.from_tree(eng, bvh) if ndev in (3, 8) else va.Scene(eng, host_scene)
     cap = va.shard_capacity(n, ndev)
     shards, ptrs = [], []
     for j in range(NB):

@@ -9,7 +9,7 @@
 //
 //   lin_parents   node i -> parent of its two children
 //   lin_counts    bottom-up: inner nodes and triangles below every node (each leaf walks up; the second arrival at a node
-//                 continues -- the classic atomic-counter refit pattern)
+//                 continues, and takes the first one's counts out of the 64-bit atomic they both add to: no fences)
 //   lin_offsets   every node walks up to the root and sums what precedes it in the depth-first order: its pair index, the
 //                 first triangle slot of its pair / of its leaf, its depth
 //   lin_emit      inner node -> its pair record (children's `first` re-targeted); leaf -> its triangle records + prim_to_slot
@@ -45,12 +45,10 @@ struct LinArgs {
     const vt_bvh_node* nodes;  uint32_t n_nodes;
     const uint32_t* prim_indices; uint32_t n_prims;
     const vt_tri64* tris_in;   uint32_t ntris;
-    uint32_t *parent, *cnt, *tcount, *flag, *pidx, *tbase, *depth;
+    uint32_t *parent, *cnt, *tcount, *pidx, *tbase, *depth;
+    unsigned long long* acc;   // per node: packed counts of the subtree walk(s) that have arrived (lin_counts)
     uint32_t* status;          // [0] error bits, [1] deepest pair, [2] a triangle carries VT_TRI_ALPHATEST
 };
-
-__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(256) void lin_alpha_flag(const vt_tri64* tris, uint32_t n, uint32_t* status)
 {
@@ -74,24 +72,27 @@ __global__ __launch_bounds__(256) void lin_parents(LinArgs a)
     a.parent[me.first + 1] = i;
 }
 
+// Bottom-up counts without fences: the two walks that meet at a node exchange their counts THROUGH the atomic itself.  A walk adds
+// its packed (inner nodes << 32 | triangles) to the node's 64-bit accumulator; the first to arrive sees 0 and ends, the second sees
+// the sibling subtree's counts in the returned value, stores the node's totals and carries them upwards.  (A first version wrote
+// the counts with plain stores and published them with __threadfence + a flag: an agent-scope release / acquire writes back and
+// invalidates the XCD's L2 on this part -- 4.3 ms for 1.15 M nodes, 49 ms for 11.7 M; this form: see profiles/r5/notes.md.)
 __global__ __launch_bounds__(256) void lin_counts(LinArgs a)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= a.n_nodes) return;
     const uint32_t pc = a.nodes[i].prim_count;
     if (pc == 0) return;                                   // the leaves start the walks
-    st_agent(&a.cnt[i], 0);
-    st_agent(&a.tcount[i], pc);
+    unsigned long long mine = pc;                          // a leaf: no inner nodes, pc triangles (never 0: a packed value marks an arrival)
     uint32_t x = i;
     for (int guard = 0; guard < kMaxWalk; ++guard) {
         const uint32_t p = a.parent[x];
         if (p == kNone) return;
-        __threadfence();                                   // my counts are visible before my arrival is
-        if (atomicAdd(&a.flag[p], 1u) == 0) return;        // first at this node: the sibling's walk will carry on
-        __threadfence();
-        const uint32_t L = a.nodes[p].first;
-        st_agent(&a.cnt[p], 1u + ld_agent(&a.cnt[L]) + ld_agent(&a.cnt[L + 1]));
-        st_agent(&a.tcount[p], ld_agent(&a.tcount[L]) + ld_agent(&a.tcount[L + 1]));
+        const unsigned long long other = atomicAdd(&a.acc[p], mine);
+        if (other == 0) return;                            // first at this node: the sibling's walk will carry on
+        mine += other + (1ull << 32);                      // both subtrees + this inner node
+        a.cnt[p] = uint32_t(mine >> 32);
+        a.tcount[p] = uint32_t(mine);
         x = p;
     }
     atomicOr(&a.status[0], kErrDepth);
@@ -303,7 +304,7 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
 
     // ---- staging block: the tree as the builder left it, per-node scratch, sort scratch ---------------------------------------
     const size_t sort_b = sort_tmp_bytes_for(np);
-    const size_t need = 512 + al256(size_t(N) * 32) + al256(size_t(M) * 4) + al256(size_t(ntris) * 64) + 7 * al256(size_t(N) * 4) +
+    const size_t need = 512 + al256(size_t(N) * 32) + al256(size_t(M) * 4) + al256(size_t(ntris) * 64) + 6 * al256(size_t(N) * 4) + al256(size_t(N) * 8) +
                         3 * al256(size_t(np) * 4) + al256(1024) + sort_b;
     int rc = ensure_bytes(&e->d_build, &e->d_build_bytes, need);
     if (rc != VT_OK) return rc;
@@ -317,8 +318,9 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
     uint32_t* d_prims = reinterpret_cast<uint32_t*>(take(size_t(M) * 4));
     vt_tri64* d_tris_in = reinterpret_cast<vt_tri64*>(take(size_t(ntris) * 64));
     a.nodes = d_nodes; a.n_nodes = N; a.prim_indices = d_prims; a.n_prims = M; a.tris_in = d_tris_in; a.ntris = ntris;
-    uint32_t** per_node[] = {&a.parent, &a.cnt, &a.tcount, &a.flag, &a.pidx, &a.tbase, &a.depth};
+    uint32_t** per_node[] = {&a.parent, &a.cnt, &a.tcount, &a.pidx, &a.tbase, &a.depth};
     for (uint32_t** pn : per_node) *pn = reinterpret_cast<uint32_t*>(take(size_t(N) * 4));
+    a.acc = reinterpret_cast<unsigned long long*>(take(size_t(N) * 8));
     uint32_t* keys = reinterpret_cast<uint32_t*>(take(size_t(np) * 4));
     uint32_t* vals = reinterpret_cast<uint32_t*>(take(size_t(np) * 4));
     uint32_t* keys_out = reinterpret_cast<uint32_t*>(take(size_t(np) * 4));
@@ -330,7 +332,7 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
     const auto t_copy = std::chrono::steady_clock::now();
     hipStream_t st = e->stream;
     VT_HIP(hipMemsetAsync(a.status, 0, 512, st));
-    VT_HIP(hipMemsetAsync(a.flag, 0, size_t(N) * 4, st));
+    VT_HIP(hipMemsetAsync(a.acc, 0, size_t(N) * 8, st));
     VT_HIP(hipMemcpyAsync(d_nodes, bvh.nodes.data(), size_t(N) * 32, hipMemcpyHostToDevice, st));
     VT_HIP(hipMemcpyAsync(d_prims, bvh.prim_indices.data(), size_t(M) * 4, hipMemcpyHostToDevice, st));
     VT_HIP(hipMemcpyAsync(d_tris_in, tris, size_t(ntris) * 64, hipMemcpyHostToDevice, st));

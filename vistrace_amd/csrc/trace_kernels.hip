@@ -494,7 +494,10 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
         const bool run_tri = tri_mask != 0 && (uint32_t(__popcll(tri_mask)) >= a.tri_threshold || __ballot(want_node) == 0);
         const bool do_tri = want_tri && run_tri;
         // idle lanes (no ray, or waiting for the TRI branch) fetch record 0 in the DMA form: an always-valid
-        // address keeps the four DMA loads branch-free; the direct form skips them instead
+        // address keeps the four DMA loads branch-free; the direct form skips them instead.  (11 % of the L1 accesses of the
+        // headline launch are such dummies.  Neither way of removing them pays: EXEC-masked rows +4 % (round 3); handing an idle
+        // lane the record of its neighbour quad's lane so that the row names 15 lines instead of 16 does not lower the access
+        // count at all -- every quad of a DMA instruction is its own L1 access -- and costs +2 % (round 5, profiles/r5/notes.md).)
         // (ALPHA: the AlphaRec of the triangle just tested sits at alpha_base + its slot; tri_cur is already past it)
         const uint32_t rec = do_tri ? a.tri_base + L.tri_cur
                                     : (want_node ? L.node : (alpha1 ? a.alpha_base + L.tri_cur - 1u : (FETCH_DMA ? 0u : kNoFetch)));
@@ -515,17 +518,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             // quad-cooperative fetch through LDS: row k receives the records of every quad's lane k.
             // Addresses are base + 32-bit byte offset (the engine uses this kernel below 4 GiB).
             const uint32_t piece = (lane & 3u) * 16u;
-#ifdef VT_EXP_NEIGHBOUR_FETCH
-            // experiment (round 5): an idle lane asks for what the lane at its position in the previous quad of its row of 16 asks
-            // for (DPP row_ror:4), instead of record 0 -- the row's instruction then names 15 distinct lines instead of 16
-            const uint32_t nb_rec = uint32_t(__builtin_amdgcn_update_dpp(0, int(rec), 0x124, 0xF, 0xF, true));
-            const uint32_t frec = (do_tri || want_node || alpha1) ? rec : nb_rec;
-            const uint32_t r0 = quad_broadcast<0>(frec), r1 = quad_broadcast<1>(frec),
-                           r2 = quad_broadcast<2>(frec), r3 = quad_broadcast<3>(frec);
-#else
             const uint32_t r0 = quad_broadcast<0>(rec), r1 = quad_broadcast<1>(rec),
                            r2 = quad_broadcast<2>(rec), r3 = quad_broadcast<3>(rec);
-#endif
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r0 << 6) | piece)),
                                              (lds_ptr)(uintptr_t)(stage_lds + 0u * kStageRow), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((global_cptr)(records + ((r1 << 6) | piece)),
