@@ -96,6 +96,9 @@ def build_scene(args, va, W, dev_index, world):
     engine = va.Engine(dev_index)
     if args.mode is not None:
         engine.set_option("persistent", 1 if args.mode == "persistent" else 0)
+    for kv in args.engine_opt:
+        k, v = kv.split("=")
+        engine.set_option(k, int(v))
     t2b = time.time()
     # Rebuild's upload step: the tree and the triangle records go up as they are, the device re-packs them (vt_scene_upload_tree)
     scene = va.Scene.from_tree(engine, bvh)
@@ -213,6 +216,8 @@ def child_workload_args(args) -> list:
          "--shadow-per-hit", str(args.shadow_per_hit)]
     if args.mode is not None:
         a += ["--mode", args.mode]
+    for kv in args.engine_opt:
+        a += ["--engine-opt", kv]
     return a
 
 
@@ -792,6 +797,8 @@ def main() -> None:
                          "the test hooks (VT_ENABLE_TEST_HOOKS=1 VT_TEST_ALLOW_DEVICE_ALIASES=1) and the RCCL test double (VT_RCCL_LIB): "
                          "the line is then labelled simulated")
     ap.add_argument("--mode", default=None, choices=[None, "persistent", "static"])
+    ap.add_argument("--engine-opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="dev: vt_engine_set_option on the workload's engine (e.g. alpha_threshold=4); recorded in config.launch_options")
     ap.add_argument("--image-hint", default="on", choices=["on", "off"],
                     help="camera-ray workloads (--kind primary, --scaling strong): pass the image's row length to the engine "
                          "(option ray_image_width); off = lanes take consecutive rays as for any other batch")
@@ -1121,7 +1128,7 @@ def main() -> None:
             "gather_verified": gather_verified,
             "dist_breakdown": dist_breakdown,
             "kernel_mode": ("persistent" + ("+lds-dma-fetch" if dma else "")) if persistent else "static",
-            "launch_options": {k: engine.get_option(k) for k in ("lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold", "reserved_cus", "reserved_limit", "ray_image_width")},
+            "launch_options": {k: engine.get_option(k) for k in ("lds_entries", "blocks_per_cu", "block_rays", "refill_threshold", "tri_threshold", "alpha_threshold", "reserved_cus", "reserved_limit", "ray_image_width")},
             "launch": engine.launch_info(),
         },
         "roofline": {

@@ -220,6 +220,7 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
     }
     a.refill_threshold = std::min(std::max(e->refill_threshold, 1u), 64u);
     a.tri_threshold = std::min(std::max(e->tri_threshold, 1u), 64u);
+    a.alpha_threshold = std::min(std::max(e->alpha_threshold, 1u), 64u);
     a.coherent_detect = e->coherent_detect;
     a.coherent_radius2 = s->coherent_radius2;
     a.alpha_base = s->alpha_base;
@@ -580,6 +581,7 @@ int vt_engine_set_option(vt_engine* e, const char* key, int64_t value)
     else if (k == "block_rays" && value >= 64 && value <= (1 << 24)) e->block_rays = uint32_t(value);
     else if (k == "refill_threshold" && value >= 1 && value <= 64) e->refill_threshold = uint32_t(value);
     else if (k == "tri_threshold" && value >= 1 && value <= 64) e->tri_threshold = uint32_t(value);
+    else if (k == "alpha_threshold" && value >= 1 && value <= 64) e->alpha_threshold = uint32_t(value);
     else if (k == "fetch_dma") e->fetch_dma = value != 0;
     else if (k == "spin_wait") e->spin_wait = value != 0;
     else if (k == "xcd_cursors") e->xcd_cursors = value != 0;
@@ -606,6 +608,7 @@ int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value)
     else if (k == "static_overflow_mb") *value = e->static_overflow_mb;
     else if (k == "coherent_detect") *value = e->coherent_detect;
     else if (k == "tri_threshold") *value = e->tri_threshold;
+    else if (k == "alpha_threshold") *value = e->alpha_threshold;
     else if (k == "fetch_dma") *value = e->fetch_dma;
     else if (k == "spin_wait") *value = e->spin_wait;
     else if (k == "xcd_cursors") *value = e->xcd_cursors;

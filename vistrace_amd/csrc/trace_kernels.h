@@ -56,6 +56,7 @@ struct TraceArgs {
     float               coherent_radius2; // ... only for rays whose origins lie within this squared distance of the first
     // alpha test (ALPHA variants only): record index of the AlphaRec of triangle slot 0, the alpha planes
     uint32_t                  alpha_base;
+    uint32_t                  alpha_threshold;   // run the AlphaRec -> texel-address block once this many lanes wait for it
     const uint8_t*            alpha_texels;
     uint32_t            xcd_cursors;      // persistent mode: 1 = one cursor per XCD (block_cursor[16 * xcd]), each over its own
                                           // eighth of the ray blocks, with stealing; 0 = one global cursor

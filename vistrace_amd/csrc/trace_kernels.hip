@@ -501,6 +501,16 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
         // (ALPHA: the AlphaRec of the triangle just tested sits at alpha_base + its slot; tri_cur is already past it)
         const uint32_t rec = do_tri ? a.tri_base + L.tri_cur
                                     : (want_node ? L.node : (alpha1 ? a.alpha_base + L.tri_cur - 1u : (FETCH_DMA ? 0u : kNoFetch)));
+        // ALPHA: the block that turns an AlphaRec into texel addresses is ~60 instructions for the WHOLE wave whenever one lane
+        // needs it; like the TRI branch it waits until `alpha_threshold` lanes have a candidate parked, or nobody else can make
+        // progress.  A waiting lane asks for its AlphaRec again next iteration (an L1 hit).  Scheduling only: the order of a ray's
+        // own steps and tests is untouched.
+        bool do_alpha1 = alpha1;
+        if constexpr (ALPHA) {
+            const uint64_t a1_mask = __ballot(alpha1);
+            const bool run_a1 = a1_mask != 0 && (uint32_t(__popcll(a1_mask)) >= a.alpha_threshold || __ballot(want_node || do_tri || alpha2) == 0);
+            do_alpha1 = alpha1 && run_a1;
+        }
 
         float4 q0, q1, q2, q3;   // the record
         bool fetched = false;
@@ -588,7 +598,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                 L.prim = tprim; L.u = u; L.v = v; L.tmax = t;
                 if constexpr (ANY_HIT) { L.tri_cur = L.tri_end; L.node = kDone; }
             }
-        } else if (ALPHA && (alpha1 || alpha2)) {
+        } else if (ALPHA && (do_alpha1 || alpha2)) {
             if constexpr (ALPHA) {
                 bool decided = false, pass = false;
                 if (!STATS && alpha2) {
@@ -601,7 +611,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                     const float alpha = alpha_from_texels(t0, t1, t2, t3, L.ax, L.ay);
                     decided = true; pass = !(alpha < L.aref);
                 }
-                if (alpha1) {
+                if (do_alpha1) {
                     // ---- ALPHA 1: the triangle's AlphaRec has arrived: texUV (:198), TransformTexcoord, texel addresses
                     const float w = 1.0f - L.cu - L.cv;
                     const float tx = (w * q0.x + L.cu * q0.z) + L.cv * q1.x;
