@@ -876,6 +876,27 @@ def test_alpha_test_in_kernel(va, engine, O):
     finally:
         for k, v in saved.items():
             engine.set_option(k, v)
+    # camera rays declared an image (ray_image_width): the one-ray-per-lane ALPHA kernel walks them as 4 x 16 tiles (round 5) and
+    # the engine's auto rule picks it -- and every alpha_threshold (how many parked candidates the AlphaRec block waits for) gives
+    # the same bytes and counters
+    cam = W.primary_rays(128, 96)
+    try:
+        O.set_alpha(otris, attribs["uv"].reshape(n, 6), attribs["material"], mats.view(O.ALPHA_MATERIAL), texels)
+        cam_ref, cam_st = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, cam, want_stats=True)[:2]
+    finally:
+        O.set_alpha()
+    saved = {k: engine.get_option(k) for k in ("ray_image_width", "alpha_threshold", "persistent")}
+    try:
+        for width, thr, mode in ((128, 4, saved["persistent"]), (128, 1, 2), (64, 16, 0), (128, 64, 1), (0, 2, 1)):
+            engine.set_option("ray_image_width", width); engine.set_option("alpha_threshold", thr); engine.set_option("persistent", mode)
+            assert_hits_equal(scene.trace_closest(cam), cam_ref)
+            got, st = stats_on_device(va, scene, cam)
+            assert_hits_equal(got, cam_ref)
+            assert (st["steps"] == cam_st[:, 0]).all() and (st["tests"] == cam_st[:, 1]).all()
+            assert_hits_equal(scene.trace_closest(rays), ref)
+    finally:
+        for k, v in saved.items():
+            engine.set_option(k, v)
     # materials beyond the table: the reference's test is skipped for them, the geometric hit stands
     attribs2 = attribs.copy()
     attribs2["material"][::3] = len(mats) + 5

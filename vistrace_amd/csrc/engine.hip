@@ -157,7 +157,7 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
         else all_tiled = false;
     }
     LaunchPlan p;
-    int rc = plan_launch(e, s, n, static_blocks, any_tiled && all_tiled && !s->has_alpha, any_hit, stats, p);
+    int rc = plan_launch(e, s, n, static_blocks, any_tiled && all_tiled, any_hit, stats, p);
     if (rc != VT_OK) return rc;
 
     // this launch's private scratch: the next slot of the ring (see vt_engine::LaunchSlot)

@@ -38,7 +38,7 @@ struct vt_engine {
     uint32_t block_rays       = 128;  // consecutive rays handed to a wave at a time (128: primary rays -4 %, bounce rays unchanged)
     uint32_t refill_threshold = 8;    // idle lanes that trigger a re-fill
     uint32_t tri_threshold    = 4;    // lanes with pending triangles that trigger the TRI branch
-    uint32_t alpha_threshold  = 1;    // ALPHA kernels: lanes with a parked candidate that trigger the AlphaRec -> texel-address block
+    uint32_t alpha_threshold  = 4;    // ALPHA kernels: lanes with a parked candidate that trigger the AlphaRec -> texel-address block
     int      fetch_dma        = 1;    // quad-cooperative global->LDS record fetch (persistent mode)
     uint32_t ray_image_width  = 0;    // rays per image row of the batches to come (0 = unknown): lanes take 4 x 16 pixel tiles
     uint32_t max_claim        = 0;    // persistent mode: ray blocks one cursor atomic may claim while plenty are left (0 = auto)

@@ -357,7 +357,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
     if constexpr (!PERSISTENT) {
         uint64_t idx = uint64_t(enter_batch(blockIdx.x)) * kBlockThreads + threadIdx.x;
         const uint32_t tile_w = cur->tile_w;
-        if (!ALPHA && tile_w != 0 && idx < cur->tiled_rays) { // this wave's 64 rays are one 4 x 16 pixel tile (see TraceSeg::tile_w)
+        // (the ALPHA variants too: the mapping is worked out once, in front of the loop, and costs the loop no register)
+        if (tile_w != 0 && idx < cur->tiled_rays) { // this wave's 64 rays are one 4 x 16 pixel tile (see TraceSeg::tile_w)
             const uint32_t j = uint32_t(idx), t = j >> 6, k = j & 63u, tpr = tile_w >> 2;
             const uint32_t ty = t / tpr, tx = t - ty * tpr;
             idx = uint64_t(ty * 16u + (k >> 2)) * tile_w + tx * 4u + (k & 3u);
@@ -419,7 +420,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                             blk_cur = uint64_t(b) * a.block_rays;
                             blk_end = blk_cur + a.block_rays < n ? blk_cur + a.block_rays : n;
                             // image-order batch: the block is one or two 4 x 16 pixel tiles side by side (see TraceSeg::tile_w)
-                            // (not in the ALPHA variants: their register budget has no room for the extra wave state)
+                            // (not in the persistent ALPHA variants: their register budget has no room for the extra wave state; the
+                            // one-ray-per-lane ALPHA variants do tile, and the engine picks them for hinted camera batches)
                             blk_tile_w = cur->tile_w;
                             blk_tiled = !ALPHA && blk_tile_w != 0 && blk_cur + a.block_rays <= cur->tiled_rays;
                             if (blk_tiled) {
