@@ -189,8 +189,9 @@ void vt_engine_close(vt_engine* e);
  * The reference has nothing like it (one ray per call on one thread); this is the seam its C++ module would use.
  *
  * vt_engine_open_multi: ONE process, ndev devices.  The returned engine is the group's root (devices[0]):
- *   - vt_scene_upload (and every later call that changes the scene: refit, skinning, attribs, alpha) applies to all
- *     devices; vt_engine_set_option / vt_engine_synchronize / vt_engine_close act on the whole group;
+ *   - vt_scene_upload / vt_scene_upload_tree (and every later call that changes the scene: refit, skinning, attribs, alpha)
+ *     apply to all devices -- refit and skin refit in three phases over the members (prepare, enqueue, finish: no member is
+ *     waited for before the last one's work has been enqueued); vt_engine_set_option / vt_engine_synchronize / vt_engine_close act on the whole group;
  *   - vt_trace_closest / vt_trace_any split a host ray array of >= 1 Mi rays into contiguous shards
  *     (vt_shard_bounds) and run one staging pipeline per device side by side; results land in the caller's array;
  *   - vt_trace_closest_gather_dev traces device-resident shards and gathers the hit records to the root device;
@@ -435,7 +436,12 @@ void     vt_batch_free(vt_batch* b);
  *   "gather_overlap"     multi-GPU: 0 = every trace waits for the previous batch's gather (diagnostic: step = trace + gather)
  *   "gather_chunks"      multi-GPU, single-process form: pieces a shard is traced and gathered in (1 .. 16, default 1; see
  *                        vt_gather_hits_part_dev)
- * Read-only: "cu_count", "device", "device_count", "last_persistent", "last_fetch_dma" (what the last launch used).
+ *   "alpha_threshold"    scenes with alpha-tested triangles: lanes with a parked candidate hit that trigger the block which
+ *                        turns their AlphaRecs into texel addresses (4; 1 = as soon as one lane has a candidate)
+ * Read-only: "cu_count", "device", "device_count", "last_persistent", "last_fetch_dma" (what the last launch used);
+ * "last_update_members", "last_update_early_waits", "last_update_enqueue_us", "last_update_wait_us" (the latest vt_scene_refit /
+ * vt_scene_skin_refit of a scene of this engine: members it reached, members waited for before the last member's work had been
+ * enqueued -- 0 by construction --, host time of the prepare + enqueue phases and of the waits).
  * Results never depend on these, only speed does. */
 int vt_engine_set_option(vt_engine* e, const char* key, int64_t value);
 int vt_engine_get_option(vt_engine* e, const char* key, int64_t* value);
