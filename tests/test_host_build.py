@@ -213,3 +213,21 @@ def test_host_refit_keeps_topology_and_bounds_the_moved_triangles(va):
     check_linearised(va.HostScene(bvh), bvh, mtris)
     bvh.refit(tris)                                  # moving back restores the original bounds exactly
     assert (bvh.nodes().view(np.uint8) == before.view(np.uint8)).all()
+
+
+def test_default_builder_tree_is_pinned(va):
+    """The binned-SAH tree (+ re-insertion) is pinned by hash: round 5 rewrote the builder's working set (triangle records permuted
+    in place, occupancy-masked bins, children's bounds accumulated by the partition: 2.3 x faster) and the tree had to stay
+    bit-identical to the one rounds 2-4 built -- the headline's steps per ray and every golden vector depend on it."""
+    import hashlib
+    from vistrace_amd import workloads as W
+    want = {("S10k", "sah"): "428727de4d34", ("S10k", "sah_refined"): "36bc20fdf2fc", ("S100k", "sah"): "45e26ff4d67d",
+            ("S100k", "sah_refined"): "f7a360558e64"}
+    for (name, builder), h in want.items():
+        tris = va.tris_setup(W.make_scene(name))
+        for nt in (1, 3, 8):
+            bvh = va.HostBvh(tris, nthreads=nt, builder=builder)
+            assert hashlib.sha1(bvh.nodes().tobytes() + bvh.prim_indices().tobytes()).hexdigest()[:12] == h, (name, builder, nt)
+    verts, flags = W.make_terrain()
+    bvh = va.HostBvh(va.tris_setup(verts, flags), nthreads=4)
+    assert hashlib.sha1(bvh.nodes().tobytes() + bvh.prim_indices().tobytes()).hexdigest()[:12] == "53135742de7e"

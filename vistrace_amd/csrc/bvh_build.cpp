@@ -25,6 +25,8 @@
 #include <omp.h>
 #endif
 
+#include <xmmintrin.h>
+
 namespace vt {
 
 namespace {
@@ -196,10 +198,18 @@ namespace {
 // kTaskPrims triangles becomes an OpenMP task that builds its subtree serially into a vector of its own; the subtrees
 // are appended in the order the tasks were created.  Bin sums are integer counts and min / max, and every range is
 // partitioned by one thread: the result does not depend on the number of threads or on scheduling.
+// Working set (round 5): one 40-B record per triangle -- box, centre, original index -- PERMUTED IN PLACE as ranges are partitioned,
+// so every pass over a node's range streams through contiguous memory (rounds 2-4 permuted 4-B indices and fetched boxes and
+// centres through them: two cache lines per triangle and pass, 2.8 s per million triangles on one core).  A node costs two passes:
+// binning (boxes into 3 x 16 bins, SSE min / max) and the partition, which also accumulates the bounds of both children, so only
+// the root (and the rare node split by index) is ever scanned for its bounds.  The partition is libstdc++'s bidirectional
+// std::partition written out (same swaps for the same predicate values), min / max are exact and order-free: the tree is
+// bit-identical to the one rounds 2-4 built (tests/test_host_build.py pins its hash).
+struct Prim { float lo[3], hi[3], c[3]; uint32_t idx; };
+static_assert(sizeof(Prim) == 40, "Prim layout: lo | hi | c | idx, read with two overlapping 16-B loads");
+
 struct SahCtx {
-    const Box* boxes;
-    const float* centers;            // 3 per triangle
-    uint32_t* idx;                   // permuted in place; becomes prim_indices
+    Prim* prims;                     // permuted in place; prims[i].idx becomes prim_indices[i]
     int nthreads;
 };
 constexpr int      kSahBins    = 16;
@@ -207,11 +217,38 @@ constexpr uint32_t kSahMaxLeaf = 4;
 constexpr uint32_t kTaskPrims  = 16384;
 
 struct SahSplit { int axis; int bin; float cost; };
+struct Bounds { Box nb, cb; };                      // of a range: its triangles' boxes, its centres
+const Box kEmptyBox{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
 
-// bins of all three axes in one pass over [begin, end); `par` = fill them with all threads
+// lanes 0..2 of two SSE registers = a Box; lane 3 carries whatever lies behind the three floats and is never read
+struct Box4 { __m128 lo, hi; };
+inline Box4 empty4() { return Box4{_mm_set1_ps(FLT_MAX), _mm_set1_ps(-FLT_MAX)}; }
+inline void grow4(Box4& b, const Prim& p)           // box_union(b, p's box): same operand order as the scalar form
+{
+    b.lo = _mm_min_ps(b.lo, _mm_loadu_ps(p.lo));
+    b.hi = _mm_max_ps(b.hi, _mm_loadu_ps(p.hi));
+}
+inline void grow4c(Box4& b, const Prim& p)          // ... with p's centre (a point)
+{
+    const __m128 c = _mm_loadu_ps(p.c);
+    b.lo = _mm_min_ps(b.lo, c);
+    b.hi = _mm_max_ps(b.hi, c);
+}
+inline void merge4(Box4& a, const Box4& b) { a.lo = _mm_min_ps(a.lo, b.lo); a.hi = _mm_max_ps(a.hi, b.hi); }
+inline Box to_box(const Box4& b)
+{
+    alignas(16) float l[4], h[4];
+    _mm_store_ps(l, b.lo); _mm_store_ps(h, b.hi);
+    return Box{{l[0], l[1], l[2]}, {h[0], h[1], h[2]}};
+}
+
+// bins of all three axes in one pass over [begin, end); `par` = fill them with all threads.
+// Only bins that received a triangle are initialised, converted and swept (an occupancy mask per axis): most nodes hold a handful
+// of triangles, and 3 x 16 bins of set-up and sweep per node were three quarters of the build.  Skipping an empty bin changes
+// nothing: the split candidate "behind an empty bin" has exactly the cost of the candidate behind the last occupied one (same
+// left set, same right set, same float operations) and `cost < best` is strict, so the first of the two wins either way.
 SahSplit sah_best_split(const SahCtx& c, uint32_t begin, uint32_t end, const Box& cb, bool par)
 {
-    const Box empty{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
     float scale[3], lo[3];
     bool live[3];
     for (int a = 0; a < 3; ++a) {
@@ -220,95 +257,107 @@ SahSplit sah_best_split(const SahCtx& c, uint32_t begin, uint32_t end, const Box
         scale[a] = live[a] ? float(kSahBins) / extent : 0.0f;
         lo[a] = cb.lo[a];
     }
-    Box bin_box[3][kSahBins];
+    Box4 bin_box[3][kSahBins];
     uint32_t bin_n[3][kSahBins];
-    for (int a = 0; a < 3; ++a) for (int b = 0; b < kSahBins; ++b) { bin_box[a][b] = empty; bin_n[a][b] = 0; }
-    auto fill = [&](Box (*bb)[kSahBins], uint32_t (*bn)[kSahBins], int64_t i0, int64_t i1) {
+    uint32_t occupied[3] = {0, 0, 0};
+    auto fill = [&](Box4 (*bb)[kSahBins], uint32_t (*bn)[kSahBins], uint32_t* occ, int64_t i0, int64_t i1) {
         for (int64_t i = i0; i < i1; ++i) {
-            const uint32_t p = c.idx[i];
+            const Prim& p = c.prims[i];
             for (int a = 0; a < 3; ++a) {
                 if (!live[a]) continue;
-                int b = int((c.centers[size_t(p) * 3 + a] - lo[a]) * scale[a]);
+                int b = int((p.c[a] - lo[a]) * scale[a]);
                 b = b < 0 ? 0 : (b >= kSahBins ? kSahBins - 1 : b);
-                bb[a][b] = box_union(bb[a][b], c.boxes[p]);
-                ++bn[a][b];
+                if (occ[a] >> b & 1u) {
+                    grow4(bb[a][b], p);
+                    ++bn[a][b];
+                } else {                                     // first triangle of this bin: union with the empty box = the box itself
+                    occ[a] |= 1u << b;
+                    bb[a][b] = Box4{_mm_loadu_ps(p.lo), _mm_loadu_ps(p.hi)};
+                    bn[a][b] = 1;
+                }
             }
         }
     };
     if (par && c.nthreads > 1) {
 #pragma omp parallel num_threads(c.nthreads)
         {
-            Box lb[3][kSahBins];
+            Box4 lb[3][kSahBins];
             uint32_t ln[3][kSahBins];
-            for (int a = 0; a < 3; ++a) for (int b = 0; b < kSahBins; ++b) { lb[a][b] = empty; ln[a][b] = 0; }
+            uint32_t locc[3] = {0, 0, 0};
             const int64_t total = int64_t(end) - begin, nt = omp_get_num_threads(), t = omp_get_thread_num();
-            fill(lb, ln, begin + total * t / nt, begin + total * (t + 1) / nt);
+            fill(lb, ln, locc, begin + total * t / nt, begin + total * (t + 1) / nt);
 #pragma omp critical(vt_sah_bins)
-            for (int a = 0; a < 3; ++a) for (int b = 0; b < kSahBins; ++b) { bin_box[a][b] = box_union(bin_box[a][b], lb[a][b]); bin_n[a][b] += ln[a][b]; }
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < kSahBins; ++b) {
+                    if (!(locc[a] >> b & 1u)) continue;
+                    if (occupied[a] >> b & 1u) { merge4(bin_box[a][b], lb[a][b]); bin_n[a][b] += ln[a][b]; }
+                    else { occupied[a] |= 1u << b; bin_box[a][b] = lb[a][b]; bin_n[a][b] = ln[a][b]; }
+                }
         }
     } else {
-        fill(bin_box, bin_n, begin, end);
+        fill(bin_box, bin_n, occupied, begin, end);
     }
     SahSplit best{-1, 0, FLT_MAX};
     for (int a = 0; a < 3; ++a) {
-        if (!live[a]) continue;
+        if (!live[a] || (occupied[a] & (occupied[a] - 1u)) == 0) continue;     // fewer than two occupied bins: nothing to split
+        int used[kSahBins], nused = 0;
+        Box bins[kSahBins];
+        for (int b = 0; b < kSahBins; ++b)
+            if (occupied[a] >> b & 1u) { used[nused] = b; bins[nused] = to_box(bin_box[a][b]); ++nused; }
+        // right_area[k] / right_n[k]: everything from occupied bin k on
         float right_area[kSahBins];
         uint32_t right_n[kSahBins];
-        Box acc = empty;
+        Box acc = kEmptyBox;
         uint32_t cnt = 0;
-        for (int b = kSahBins - 1; b > 0; --b) {
-            acc = box_union(acc, bin_box[a][b]);
-            cnt += bin_n[a][b];
-            right_area[b] = cnt ? half_area(acc) : 0.0f;
-            right_n[b] = cnt;
+        for (int k = nused - 1; k > 0; --k) {
+            acc = box_union(acc, bins[k]);
+            cnt += bin_n[a][used[k]];
+            right_area[k] = half_area(acc);
+            right_n[k] = cnt;
         }
-        acc = empty;
+        acc = kEmptyBox;
         cnt = 0;
-        for (int b = 0; b < kSahBins - 1; ++b) {
-            acc = box_union(acc, bin_box[a][b]);
-            cnt += bin_n[a][b];
-            if (cnt == 0 || right_n[b + 1] == 0) continue;
-            const float cost = half_area(acc) * float(cnt) + right_area[b + 1] * float(right_n[b + 1]);
-            if (cost < best.cost) best = SahSplit{a, b, cost};      // axis order, then bin order: deterministic ties
+        for (int k = 0; k < nused - 1; ++k) {
+            acc = box_union(acc, bins[k]);
+            cnt += bin_n[a][used[k]];
+            const float cost = half_area(acc) * float(cnt) + right_area[k + 1] * float(right_n[k + 1]);
+            if (cost < best.cost) best = SahSplit{a, used[k], cost};      // axis order, then bin order: deterministic ties
         }
     }
     return best;
 }
 
-// node bounds and centroid bounds of [begin, end)
-void sah_bounds(const SahCtx& c, uint32_t begin, uint32_t end, bool par, Box& nb, Box& cb)
+// node bounds and centroid bounds of [begin, end): the root, and nodes whose parent was split by index
+Bounds sah_bounds(const SahCtx& c, uint32_t begin, uint32_t end, bool par)
 {
-    const Box empty{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
-    nb = empty; cb = empty;
-    auto scan = [&](Box& n, Box& ce, int64_t i0, int64_t i1) {
-        for (int64_t i = i0; i < i1; ++i) {
-            const uint32_t p = c.idx[i];
-            n = box_union(n, c.boxes[p]);
-            const float* q = &c.centers[size_t(p) * 3];
-            for (int k = 0; k < 3; ++k) { ce.lo[k] = q[k] < ce.lo[k] ? q[k] : ce.lo[k]; ce.hi[k] = q[k] > ce.hi[k] ? q[k] : ce.hi[k]; }
-        }
+    Box4 nb = empty4(), cb = empty4();
+    auto scan = [&](Box4& n, Box4& ce, int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) { grow4(n, c.prims[i]); grow4c(ce, c.prims[i]); }
     };
     if (par && c.nthreads > 1) {
 #pragma omp parallel num_threads(c.nthreads)
         {
-            Box ln = empty, lc = empty;
+            Box4 ln = empty4(), lc = empty4();
             const int64_t total = int64_t(end) - begin, nt = omp_get_num_threads(), t = omp_get_thread_num();
             scan(ln, lc, begin + total * t / nt, begin + total * (t + 1) / nt);
 #pragma omp critical(vt_sah_bounds)
-            { nb = box_union(nb, ln); cb = box_union(cb, lc); }
+            { merge4(nb, ln); merge4(cb, lc); }
         }
     } else {
         scan(nb, cb, begin, end);
     }
+    return Bounds{to_box(nb), to_box(cb)};
 }
 
-// Decides node `self` over [begin, end): sets its box and returns 0 for a leaf, else the split position `mid`
-// (begin < mid < end) after partitioning idx in place.
-uint32_t sah_split_node(const SahCtx& c, vt_bvh_node& self, uint32_t begin, uint32_t end, bool par)
+// Decides node `self` over [begin, end) whose bounds are B: sets its box and returns 0 for a leaf, else the split position `mid`
+// (begin < mid < end) after partitioning the range in place.  kids_known: kids[0 / 1] hold the bounds of [begin, mid) / [mid, end).
+uint32_t sah_split_node(const SahCtx& c, vt_bvh_node& self, uint32_t begin, uint32_t end, bool par, const Bounds& B, Bounds kids[2],
+                        bool& kids_known)
 {
     const uint32_t count = end - begin;
-    Box nb, cb;
-    sah_bounds(c, begin, end, par, nb, cb);
+    const Box& nb = B.nb;
+    const Box& cb = B.cb;
+    kids_known = false;
     set_node_box(self, nb);
     if (count <= 1) { self.prim_count = count; self.first = begin; return 0; }
     const SahSplit best = sah_best_split(c, begin, end, cb, par);
@@ -320,15 +369,42 @@ uint32_t sah_split_node(const SahCtx& c, vt_bvh_node& self, uint32_t begin, uint
     } else {
         const float scale = float(kSahBins) / (cb.hi[best.axis] - cb.lo[best.axis]);
         const float lo = cb.lo[best.axis];
-        // std::partition works in place (stable_partition allocates a buffer per call); every range is partitioned by
-        // exactly one thread with this one algorithm, so the order it leaves is as deterministic as a stable one
-        uint32_t* m = std::partition(c.idx + begin, c.idx + end, [&](uint32_t p) {
-            int b = int((c.centers[size_t(p) * 3 + best.axis] - lo) * scale);
+        const int axis = best.axis, bin = best.bin;
+        Box4 knb[2] = {empty4(), empty4()}, kcb[2] = {empty4(), empty4()};
+        // evaluates a triangle ONCE: which side it goes to, and that side's bounds grow by it
+        auto goes_left = [&](const Prim& p) {
+            int b = int((p.c[axis] - lo) * scale);
             b = b < 0 ? 0 : (b >= kSahBins ? kSahBins - 1 : b);
-            return b <= best.bin;
-        });
-        mid = uint32_t(m - c.idx);
+            const int side = b <= bin ? 0 : 1;
+            grow4(knb[side], p); grow4c(kcb[side], p);
+            return side == 0;
+        };
+        // libstdc++'s std::partition for bidirectional iterators, written out (it applies the predicate exactly once per
+        // element): in place, and every range is partitioned by exactly one thread with this one algorithm, so the order it
+        // leaves is as deterministic as a stable one -- and the same as when 4-B indices were partitioned
+        Prim* first = c.prims + begin;
+        Prim* last = c.prims + end;
+        for (;;) {
+            for (;;) {
+                if (first == last) goto partitioned;
+                if (goes_left(*first)) ++first; else break;
+            }
+            --last;
+            for (;;) {
+                if (first == last) goto partitioned;
+                if (!goes_left(*last)) --last; else break;
+            }
+            std::swap(*first, *last);
+            ++first;
+        }
+    partitioned:
+        mid = uint32_t(first - c.prims);
         if (mid == begin || mid == end) mid = begin + count / 2;
+        else {
+            kids[0] = Bounds{to_box(knb[0]), to_box(kcb[0])};
+            kids[1] = Bounds{to_box(knb[1]), to_box(kcb[1])};
+            kids_known = true;
+        }
     }
     self.prim_count = 0;
     return mid;
@@ -342,25 +418,27 @@ void refine_nodes(std::vector<vt_bvh_node>& N, int nthreads, int passes, float f
 constexpr int   kLocalRefinePasses = 3;
 constexpr float kLocalRefineFraction = 0.02f;
 
-// serial build of the subtree over [begin, end) into `out` (out[0] = its root, children behind their parents)
-void sah_build_subtree(const SahCtx& c, uint32_t begin, uint32_t end, std::vector<vt_bvh_node>& out)
+// serial build of the subtree over [begin, end) (bounds B) into `out` (out[0] = its root, children behind their parents)
+void sah_build_subtree(const SahCtx& c, uint32_t begin, uint32_t end, const Bounds& B, std::vector<vt_bvh_node>& out)
 {
     out.clear();
     out.reserve(size_t(end - begin));
     out.emplace_back();
-    struct Task { uint32_t node, begin, end; };
-    std::vector<Task> stack{{0u, begin, end}};
+    struct Task { uint32_t node, begin, end; bool known; Bounds b; };
+    std::vector<Task> stack{{0u, begin, end, true, B}};
     while (!stack.empty()) {
         const Task t = stack.back();
         stack.pop_back();
         vt_bvh_node self{};
-        const uint32_t mid = sah_split_node(c, self, t.begin, t.end, false);
+        Bounds kids[2];
+        bool kids_known = false;
+        const uint32_t mid = sah_split_node(c, self, t.begin, t.end, false, t.known ? t.b : sah_bounds(c, t.begin, t.end, false), kids, kids_known);
         if (mid != 0) {
             self.first = uint32_t(out.size());
             out.emplace_back();
             out.emplace_back();
-            stack.push_back({self.first + 1, mid, t.end});
-            stack.push_back({self.first, t.begin, mid});
+            stack.push_back({self.first + 1, mid, t.end, kids_known, kids[1]});
+            stack.push_back({self.first, t.begin, mid, kids_known, kids[0]});
         }
         out[t.node] = self;
     }
@@ -390,28 +468,31 @@ constexpr float    kRegionRefineFraction = VT_REGION_REFINE_FRACTION;
 // parallel loop --, and stitches the result into `out` (v1 layout: out[0] = root, siblings adjacent, children behind their
 // parents; pieces appended in creation order, so the tree does not depend on scheduling or on the number of threads).
 template <class BuildPiece>
-void sah_build_split(const SahCtx& c, uint32_t begin, uint32_t end, uint32_t piece_prims, bool par_bins, bool tasks,
+void sah_build_split(const SahCtx& c, uint32_t begin, uint32_t end, const Bounds& B, uint32_t piece_prims, bool par_bins, bool tasks,
                      const BuildPiece& build_piece, std::vector<vt_bvh_node>& out)
 {
-    struct Piece { uint32_t slot, begin, end; std::vector<vt_bvh_node> nodes; };
+    struct Piece { uint32_t slot, begin, end; Bounds b; std::vector<vt_bvh_node> nodes; };
     std::vector<vt_bvh_node> top;
     top.emplace_back();
     std::vector<Piece> pieces;
     {
-        struct Task { uint32_t node, begin, end; };
-        std::vector<Task> stack{{0u, begin, end}};
+        struct Task { uint32_t node, begin, end; bool known; Bounds b; };
+        std::vector<Task> stack{{0u, begin, end, true, B}};
         while (!stack.empty()) {
             const Task t = stack.back();
             stack.pop_back();
-            if (t.end - t.begin <= piece_prims) { pieces.push_back(Piece{t.node, t.begin, t.end, {}}); continue; }
+            const Bounds tb = t.known ? t.b : sah_bounds(c, t.begin, t.end, par_bins);
+            if (t.end - t.begin <= piece_prims) { pieces.push_back(Piece{t.node, t.begin, t.end, tb, {}}); continue; }
             vt_bvh_node self{};
-            const uint32_t mid = sah_split_node(c, self, t.begin, t.end, par_bins);
+            Bounds kids[2];
+            bool kids_known = false;
+            const uint32_t mid = sah_split_node(c, self, t.begin, t.end, par_bins, tb, kids, kids_known);
             if (mid != 0) {
                 self.first = uint32_t(top.size());
                 top.emplace_back();
                 top.emplace_back();
-                stack.push_back({self.first + 1, mid, t.end});
-                stack.push_back({self.first, t.begin, mid});
+                stack.push_back({self.first + 1, mid, t.end, kids_known, kids[1]});
+                stack.push_back({self.first, t.begin, mid, kids_known, kids[0]});
             }
             top[t.node] = self;
         }
@@ -420,7 +501,7 @@ void sah_build_split(const SahCtx& c, uint32_t begin, uint32_t end, uint32_t pie
         for (size_t k = 0; k < pieces.size(); ++k) {
             Piece* p = &pieces[k];
 #pragma omp task firstprivate(p) shared(c, build_piece)
-            build_piece(p->begin, p->end, p->nodes);
+            build_piece(p->begin, p->end, p->b, p->nodes);
         }
 #pragma omp taskwait
     } else {
@@ -430,7 +511,7 @@ void sah_build_split(const SahCtx& c, uint32_t begin, uint32_t end, uint32_t pie
             for (size_t k = 0; k < pieces.size(); ++k) {
                 Piece* p = &pieces[k];
 #pragma omp task firstprivate(p) shared(c, build_piece)
-                build_piece(p->begin, p->end, p->nodes);
+                build_piece(p->begin, p->end, p->b, p->nodes);
             }
 #pragma omp taskwait
         }
@@ -452,36 +533,39 @@ void sah_build_split(const SahCtx& c, uint32_t begin, uint32_t end, uint32_t pie
 
 int build_binned_sah(const vt_tri64* tris, uint32_t n, int nthreads, Bvh& out)
 {
-    std::vector<Box> boxes(n);
-    std::vector<float> centers(size_t(n) * 3);
-    std::vector<uint32_t> idx(n);
+    std::vector<Prim> prims(n);
 #pragma omp parallel for schedule(static) num_threads(nthreads)
     for (int64_t i = 0; i < int64_t(n); ++i) {
-        tri_box_center(tris[i], boxes[i], &centers[size_t(i) * 3]);
+        Prim& p = prims[size_t(i)];
+        Box b;
+        tri_box_center(tris[i], b, p.c);
         // A triangle with a NaN / infinite vertex can never be hit (Primitives.h:173-189 yields NaN or -inf), but its box
         // would poison every box above it (NaN slab terms drop out of the reference's test, so rays would walk into it):
         // it gets the empty box (neutral in every union, fails every slab test) and a harmless centre.
         bool finite = true;
         for (int k = 0; k < 3; ++k)
-            finite = finite && std::fabs(boxes[i].lo[k]) <= FLT_MAX && std::fabs(boxes[i].hi[k]) <= FLT_MAX;
+            finite = finite && std::fabs(b.lo[k]) <= FLT_MAX && std::fabs(b.hi[k]) <= FLT_MAX;
         if (!finite) {
-            boxes[i] = Box{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
-            centers[size_t(i) * 3] = centers[size_t(i) * 3 + 1] = centers[size_t(i) * 3 + 2] = 0.0f;
+            b = kEmptyBox;
+            p.c[0] = p.c[1] = p.c[2] = 0.0f;
         }
-        idx[i] = uint32_t(i);
+        for (int k = 0; k < 3; ++k) { p.lo[k] = b.lo[k]; p.hi[k] = b.hi[k]; }
+        p.idx = uint32_t(i);
     }
-    const SahCtx ctx{boxes.data(), centers.data(), idx.data(), nthreads};
+    const SahCtx ctx{prims.data(), nthreads};
 
     // top of the tree on this thread (bins filled by all threads); regions of <= kRegionPrims triangles as tasks, each of
     // which splits itself into subtree tasks of <= kTaskPrims triangles and refines the stitched region afterwards
-    const auto build_subtree = [&ctx](uint32_t b, uint32_t e, std::vector<vt_bvh_node>& nodes) { sah_build_subtree(ctx, b, e, nodes); };
-    const auto build_region = [&ctx, &build_subtree](uint32_t b, uint32_t e, std::vector<vt_bvh_node>& nodes) {
-        if (e - b <= kTaskPrims) { sah_build_subtree(ctx, b, e, nodes); return; }
-        sah_build_split(ctx, b, e, kTaskPrims, false, true, build_subtree, nodes);
+    const auto build_subtree = [&ctx](uint32_t b, uint32_t e, const Bounds& B, std::vector<vt_bvh_node>& nodes) { sah_build_subtree(ctx, b, e, B, nodes); };
+    const auto build_region = [&ctx, &build_subtree](uint32_t b, uint32_t e, const Bounds& B, std::vector<vt_bvh_node>& nodes) {
+        if (e - b <= kTaskPrims) { sah_build_subtree(ctx, b, e, B, nodes); return; }
+        sah_build_split(ctx, b, e, B, kTaskPrims, false, true, build_subtree, nodes);
         refine_nodes(nodes, 1, kRegionRefinePasses, kRegionRefineFraction);
     };
-    sah_build_split(ctx, 0u, n, kRegionPrims, true, false, build_region, out.nodes);
-    out.prim_indices.swap(idx);
+    sah_build_split(ctx, 0u, n, sah_bounds(ctx, 0u, n, true), kRegionPrims, true, false, build_region, out.nodes);
+    out.prim_indices.resize(n);
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t i = 0; i < int64_t(n); ++i) out.prim_indices[size_t(i)] = prims[size_t(i)].idx;
     return VT_OK;
 }
 
@@ -639,6 +723,9 @@ int bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, int builder, Bvh& 
     // host (scripts/build_rate.py, 1 M triangles): 1 thread 0.60 s, 16 threads 0.20 s, 128 threads 0.52 s,
     // 256 threads 3.4 s -- more threads only add fork/join and cross-socket traffic.
     if (nthreads <= 0) nthreads = std::min(omp_get_max_threads(), 16);
+    // a small scene is built faster by few threads than it takes to wake many (10 k triangles: 30 ms on one thread, 50 on two,
+    // more on eight); the tree does not depend on the thread count
+    nthreads = std::max(1, std::min(nthreads, int(n / 8192u)));
 #else
     nthreads = 1;
 #endif
