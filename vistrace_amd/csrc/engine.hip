@@ -649,7 +649,7 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
 
     vt_scene* s = new vt_scene();
     s->engine = e;
-    s->host_stale = hsw->stale;
+    s->add_host_copy(hsw->stale);
     s->has_alpha = has_alpha;
     if (!hs.pairs.empty()) s->coherent_radius2 = packet_radius2(hs.pairs[0]);
     s->npairs = uint32_t(hs.pairs.size());
@@ -1076,7 +1076,7 @@ int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32
         RefitTrisArgs ta{static_cast<const float*>(e->d_rays), flags ? static_cast<const uint8_t*>(e->d_out) : nullptr,
                          m->d_prim_to_slot, m->d_tris, n, m->d_bad};
         VT_HIP(launch_refit_tris(ta, e->stream));
-        if (m->host_stale) m->host_stale->store(1, std::memory_order_release);   // the host copy (single-ray path) is now out of date
+        m->mark_host_copies_stale();             // the host copies (single-ray path) are now out of date
         return enqueue_levels_and_verdict(m);
     };
     auto after = [&](vt_scene* m) -> int {                 // the flags switched the alpha test on: its records are built now
@@ -1148,7 +1148,7 @@ int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uin
         SkinTrisArgs ta{m->d_bind_verts, m->d_skin, m->d_matrix_base, d_prod, m->d_prim_to_slot, m->d_tris, m->ntris, nmat, m->d_bad};
         VT_HIP(launch_skin_tris(ta, e->stream));
         VT_HIP(skin_frames(m, d_prod, nmat, e->stream));                     // normals / tangents, AccelStruct.cpp:82-92
-        if (m->host_stale) m->host_stale->store(1, std::memory_order_release);
+        m->mark_host_copies_stale();
         return enqueue_levels_and_verdict(m);
     };
     return update_every_member(s, "vt_scene_skin_refit", prepare, enqueue, nullptr);

@@ -189,7 +189,17 @@ struct vt_scene {
     uint32_t      npairs = 0, ntris = 0, max_depth = 0, root_leaf_count = 0;
     uint64_t      bytes = 0;
     vt_upload_stats upload_stats{};         // where the time of this scene's upload went (vt_scene_upload_stats)
-    std::shared_ptr<std::atomic<int>> host_stale;   // the vt_host_scene this scene was uploaded from: set by a device-side refit
+    // the host copies of this scene's records (the vt_host_scene it was uploaded from, and / or copies fetched with
+    // vt_host_scene_download): a device-side refit marks every one of them stale
+    std::vector<std::weak_ptr<std::atomic<int>>> host_copies;
+    void add_host_copy(const std::shared_ptr<std::atomic<int>>& flag) { host_copies.emplace_back(flag); }
+    void mark_host_copies_stale()
+    {
+        size_t live = 0;
+        for (size_t k = 0; k < host_copies.size(); ++k)
+            if (auto f = host_copies[k].lock()) { f->store(1, std::memory_order_release); host_copies[live++] = host_copies[k]; }
+        host_copies.resize(live);                // copies that have been freed drop out
+    }
     // multi-GPU group: the same scene on every peer device (replicas[g-1] lives on engine->peers[g-1]); owned by this scene
     std::vector<vt_scene*> replicas;
 };

@@ -288,7 +288,6 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
         vt_host_scene* hs = nullptr;
         int rc = vt_scene_linearise(bvhw, tris, &hs);
         if (rc == VT_OK) rc = vt_scene_upload(e, hs, out);
-        if (rc == VT_OK && *out) { (*out)->host_stale.reset(); for (vt_scene* rep : (*out)->replicas) rep->host_stale.reset(); }
         vt_host_scene_free(hs);
         return rc;
     }
@@ -461,8 +460,8 @@ int vt_host_scene_download(vt_scene* s, vt_host_scene** out)
     for (const vt_tri64& t : hs.tris) alpha |= (t.flags & VT_TRI_ALPHATEST) != 0;
     hs.has_alpha = alpha;
     // from now on a device-side refit marks this copy stale (vt_host_scene_sync refreshes it), on every member of a group
-    s->host_stale = hsw->stale;
-    for (vt_scene* rep : s->replicas) rep->host_stale = hsw->stale;
+    s->add_host_copy(hsw->stale);
+    for (vt_scene* rep : s->replicas) rep->add_host_copy(hsw->stale);
     *out = hsw;
     return VT_OK;
 }
