@@ -999,7 +999,7 @@ static int finish_update(vt_scene* s, const char* who)
 }
 
 // The three phases over every member (replicas first, the root last, as before); the caller sees the root's failure, else the
-// first replica's.  g_update_* : what tests/fake_group_check.py reads through engine option "last_update_early_waits".
+// first replica's.  The order log becomes engine option "last_update_early_waits" (tests/fake_group_check.py asserts 0).
 static int update_every_member(vt_scene* root, const char* who, const std::function<int(vt_scene*)>& prepare,
                                const std::function<int(vt_scene*)>& enqueue, const std::function<int(vt_scene*)>& after)
 {
