@@ -71,7 +71,8 @@ def test_host_binding_through_a_two_member_group():
 
 
 def test_parity_suites_through_the_root_of_a_group():
-    """tests/test_gpu_parity.py, test_gpu_shading_frame.py and test_gpu_multi_batch.py once more with the `engine` fixture opened
+    """tests/test_gpu_parity.py, test_gpu_shading_frame.py, test_gpu_multi_batch.py and test_gpu_rebuild.py (the device re-pack on
+    every member, refits in phases, host copies) once more with the `engine` fixture opened
     as a two-member group (VT_TEST_GROUP_MEMBERS=2, tests/conftest.py): every scene, refit, skin, alpha table and frame table is
     replicated, host batches of >= 1 Mi rays are sharded over the members, everything else runs on the root.  (This is how a
     refused refit was found to leave the members of a group with different geometry: vt_scene_refit / vt_scene_skin_refit now go
@@ -81,7 +82,8 @@ def test_parity_suites_through_the_root_of_a_group():
                VT_TEST_GROUP_MEMBERS="2")
     p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_shading_frame.py"),
-                        os.path.join(ROOT, "tests", "test_gpu_multi_batch.py")], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+                        os.path.join(ROOT, "tests", "test_gpu_multi_batch.py"), os.path.join(ROOT, "tests", "test_gpu_rebuild.py")],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     tail = [ln for ln in p.stdout.splitlines() if "passed" in ln or "failed" in ln]
     assert p.returncode == 0 and tail and "failed" not in tail[-1], (p.stdout[-12000:], p.stderr[-2000:])
 
