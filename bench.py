@@ -640,9 +640,20 @@ def run_group(args) -> None:
         scene.trace_closest_gather_dev(ptrs, n_total, outs[batch[0] % 2].data_ptr())
         batch[0] += 1
 
+    import threading
+
+    def fire():
+        print(f"[bench] FATAL: the group's warm-up (traces + gather) did not finish within {args.gather_timeout:.0f} s; no result line", file=sys.stderr, flush=True)
+        os._exit(6)
+    timer = threading.Timer(args.gather_timeout, fire) if args.gather_timeout > 0 else None
+    if timer:
+        timer.daemon = True
+        timer.start()
     for _ in range(max(args.warmup, 2)):
         step()
     engine.synchronize()
+    if timer:
+        timer.cancel()
     # the proof that the gather delivered every member's records to the root unchanged (64-bit word sums per shard)
     last = outs[(batch[0] - 1) % 2].view(torch.int64).view(ndev, -1).sum(dim=1).cpu().numpy()
     gather_verified = bool(all(int(last[g]) == ref_sums[g] for g in range(ndev)))
@@ -755,6 +766,9 @@ def main() -> None:
     ap.add_argument("--pmc-passes", default="fetch,write,sq,mix,tcp,l2")
     ap.add_argument("--pmc-timeout", type=float, default=240.0)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--gather-timeout", type=float, default=180.0,
+                    help="N > 1: seconds the warm-up (and, plus 0.25 s per step, the timed region) may take before the run is ended with a "
+                         "reason and exit code 6 instead of hanging in a collective; 0 = no watchdog")
     ap.add_argument("--pieces-timeout", type=float, default=60.0,
                     help="N > 1: seconds the closing measurement of one batch in 2 / 4 / 8 pieces may take before it is abandoned")
     ap.add_argument("--legs", default=None, choices=["all", "host", "off"],
@@ -946,11 +960,36 @@ def main() -> None:
         elif pipe is not None:
             pipe.drain()
 
+    # N > 1: a collective that never completes (RCCL's kernels and the links have only ever run against a test double here) must
+    # end the run with a reason, not with the launcher's timeout: a watchdog armed around the phases that contain a gather
+    class Watchdog:
+        def __init__(self):
+            self.t = None
+        def arm(self, seconds, what):
+            self.disarm()
+            if not dist_on or seconds <= 0:
+                return
+            import threading
+            def fire():
+                print(f"[bench] FATAL rank {rank}: {what} did not finish within {seconds:.0f} s (a gather that never completes?); "
+                      f"no result line", file=sys.stderr, flush=True)
+                os._exit(6)
+            self.t = threading.Timer(seconds, fire)
+            self.t.daemon = True
+            self.t.start()
+        def disarm(self):
+            if self.t is not None:
+                self.t.cancel()
+                self.t = None
+    watchdog = Watchdog()
+
     # warm-up; with N > 1 also the proof that the gather delivers every rank's records to rank 0 unchanged
+    watchdog.arm(args.gather_timeout, "the warm-up (trace + gather)")
     for _ in range(max(args.warmup, 2 if dist_on else 0)):
         step()
     drain()
     torch.cuda.synchronize(device)
+    watchdog.disarm()
     gather_verified = None
     if native is not None:
         b = (native.batch - 1) % 2
@@ -983,6 +1022,7 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize(device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    watchdog.arm(args.gather_timeout + 0.25 * args.steps, "the timed region")      # generous: a step is milliseconds
     start = time.perf_counter()
     ev0.record()                                       # on the launch stream (torch's current stream)
     for _ in range(args.steps):
@@ -994,6 +1034,7 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - start
+    watchdog.disarm()
     region_ms = ev0.elapsed_time(ev1)                  # launch-stream time of the K steps
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
