@@ -878,6 +878,13 @@ def main() -> None:
     if any_hit and (world > 1 or args.force_dist or args.scaling == "strong"):
         raise SystemExit("--kind shadow is a single-GPU workload (BASELINE configs[3])")
     dist_on = world > 1 or args.force_dist
+    result_fd = None
+    if dist_on:
+        # Everything a rank writes to stdout -- RCCL's version banner comes from C code -- goes to stderr from here on; the result
+        # line alone is written to the real stdout at the end, so that stdout carries ONE line whoever launched the ranks.
+        sys.stdout.flush()
+        result_fd = os.dup(1)
+        os.dup2(2, 1)
     if dist_on:
         if args.force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
@@ -1579,20 +1586,25 @@ def main() -> None:
             dist_breakdown["single_batch_note"] = f"the measurement in pieces did not finish within {args.pieces_timeout} s and was abandoned (K = 1 is the path of the timed steps)"
             log(f"[bench] rank {rank}: single batch in pieces timed out; leaving without collective teardown")
             if rank == 0:
-                print(json.dumps(result), flush=True)
+                line = (json.dumps(result) + "\n").encode()
+                os.write(result_fd if result_fd is not None else 1, line)
             sys.stdout.flush(); sys.stderr.flush()
             os._exit(0)
+    def emit_result():
+        line = (json.dumps(result) + "\n").encode()
+        if result_fd is not None:
+            os.write(result_fd, line)                      # the real stdout (everything else went to stderr)
+        else:
+            sys.stdout.write(line.decode()); sys.stdout.flush()
     if dist_on:
-        # RCCL writes a version banner to the C stdout of rank 0; when stdout is a pipe it sits in the stdio buffer until
-        # exit and would land BEHIND the result.  Push it out first so that the JSON line is the last line of the run.
         import ctypes
         try:
-            ctypes.CDLL(None).fflush(None)
+            ctypes.CDLL(None).fflush(None)                 # C stdio of RCCL (its banner), now headed for stderr
         except Exception:
             pass
         dist.barrier()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit_result()
     if dist_on:
         dist.destroy_process_group()
 

@@ -31,6 +31,8 @@ def _run(nranks, extra):
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "rank 0 prints ONE JSON line"
+    # ... and nothing else reaches stdout: the ranks send everything but the result (RCCL's banner comes from C code) to stderr
+    assert [ln for ln in p.stdout.splitlines() if ln.strip()] == lines, p.stdout[-2000:]
     return json.loads(lines[0])
 
 
