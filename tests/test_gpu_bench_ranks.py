@@ -72,3 +72,19 @@ def test_bare_command_reports_a_crashed_rank():
                         "--scene", "no_such_scene"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and p.stdout.strip() == ""
     assert [ln for ln in p.stderr.splitlines() if ln.strip()][-1].startswith("[bench] FATAL: the ranks exited with code")
+
+
+def test_one_rank_runs_the_native_rccl_control_flow():
+    """--force-dist: the N > 1 control flow of the per-rank form with REAL RCCL and one rank (communicator, vt_gather_hits_dev on the
+    communication stream, double-buffered pipeline, reserved CUs, the one-batch-in-pieces measurement behind its watchdog): stdout
+    carries the result line and nothing else (RCCL's banner goes to stderr), the gather is verified."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "5", "--warmup", "2", "--no-cpu", "--no-pmc",
+                        "--alt-builder", "none", "--side", "1024"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1 and out[0].startswith("{"), p.stdout[-2000:]
+    d = json.loads(out[0])
+    bd = d["config"]["dist_breakdown"]
+    assert d["config"]["gather_verified"] is True and "native ncclGather" in bd["gather_kind"]
+    assert set(bd["single_batch_ms"]) == {"1", "2", "4", "8"} and d["config"]["launch_options"]["reserved_cus"] == 32
