@@ -794,10 +794,13 @@ def main() -> None:
                     help="N > 1: off = every trace waits for the previous batch's gather (diagnostic: step = trace + gather)")
     ap.add_argument("--force-dist", action="store_true",
                     help="dev: run the N > 1 control flow (process group, gather pipeline, barriers) even with one rank")
-    ap.add_argument("--reserve-cus", type=int, default=32,
+    ap.add_argument("--reserve-cus", default="auto",
                     help="N > 1: CUs (one per shader engine of every XCD) on which the persistent trace grid leaves room "
                          "for the RCCL gather's kernels, so that the transfer of batch b overlaps the trace of batch b+1; "
-                         "0 = off (the gather then only starts when the resident grid drains)")
+                         "0 = off (the gather then only starts when the resident grid drains).  auto (default) = 32, and with more than one "
+                         "rank a short probe behind the warm-up times 64 / 32 / 16 / 0 with the gather in flight and keeps the fastest "
+                         "(what RCCL's kernels need beside the grid can only be measured on a multi-GPU node; results never depend on it); "
+                         "probe = run that probe with one rank too (test)")
     ap.add_argument("--chunks", type=int, default=1,
                     help="N > 1: pieces a rank's batch is traced and gathered in (piece c crosses the links while piece c + 1 is traced; "
                          "native: vt_gather_hits_part_dev, 1 .. 16).  1 = one trace + one ncclGather per step: in a stream of steps the gather "
@@ -817,6 +820,9 @@ def main() -> None:
                     help="camera-ray workloads (--kind primary, --scaling strong): pass the image's row length to the engine "
                          "(option ray_image_width); off = lanes take consecutive rays as for any other batch")
     args = ap.parse_args()
+    args.reserve_probe = args.reserve_cus in ("auto", "probe")
+    args.reserve_probe_always = args.reserve_cus == "probe"
+    args.reserve_cus = 32 if args.reserve_probe else int(args.reserve_cus)
     if args.legs is None:   # the S10M leg only beside the default (headline) workload: the other configs are lines of their own
         args.legs = "all" if (args.scene == "S1M" and args.kind == "bounce" and args.side == 4096 and args.scaling == "weak" and args.alpha_frac == 0) else "host"
 
@@ -1015,6 +1021,45 @@ def main() -> None:
         gather_verified = verify_gather(dist, rank, world, n_send, pipe.hits[b], recv, device, args.backend)
         del recv
 
+    # ---- N > 1: how many CUs to leave to the gather's kernels (auto): measured with the gather in flight, the fastest stays ------
+    reserve_probe = None
+    if args.reserve_probe and native is not None and n > 0 and (world > 1 or args.reserve_probe_always):
+        try:
+            watchdog.arm(args.gather_timeout, "the reserved-CU probe")
+            times = {}
+            for cand in (64, 32, 16, 0):
+                if cand > engine.get_option("cu_count") // 2:
+                    continue
+                engine.set_option("reserved_cus", cand)
+                for _ in range(3):
+                    step()
+                drain()
+                torch.cuda.synchronize(device)
+                dist.barrier()
+                tq = time.perf_counter()
+                for _ in range(20):
+                    step()
+                drain()
+                torch.cuda.synchronize(device)
+                tt = torch.tensor([(time.perf_counter() - tq) / 20 * 1e3], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)               # every rank sees the same table and takes the same decision
+                times[cand] = round(float(tt.item()), 4)
+            watchdog.disarm()
+            best = min(times, key=lambda c: (times[c], -c))
+            if 32 in times and times[32] <= times[best] * 1.01:         # within 1 %: stay with the calibrated default
+                best = 32
+            engine.set_option("reserved_cus", best)
+            reserve_probe = {"ms_per_step": {str(k): v for k, v in times.items()}, "chosen": best,
+                             "how": "20 steps each (trace + gather, double-buffered) behind 3 warm-up steps, max over ranks; scheduling only: results do not depend on it"}
+            log(f"[bench] reserved-CU probe: {times} -> {best}")
+        except Exception as exc:   # never lose the run over an optimisation
+            watchdog.disarm()
+            log(f"[bench] reserved-CU probe failed ({exc}); staying with {args.reserve_cus}")
+            try:
+                engine.set_option("reserved_cus", args.reserve_cus)
+            except Exception:
+                pass
+
     # single-launch durations (HIP events on the launch stream around one launch each)
     single_ms = []
     if n > 0:
@@ -1110,6 +1155,7 @@ def main() -> None:
             "overlap_note": "(trace + gather - step) / min(trace, gather): 1 = the shorter of the two is fully hidden, 0 = they run back to back",
             "gather_kind": gather_kind,
             "bytes_into_root_per_step": int((world - 1) * n_send * 16),
+            "reserved_cus_probe": reserve_probe,
         }
     engine.set_timing(False)
 

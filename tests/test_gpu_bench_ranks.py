@@ -88,3 +88,19 @@ def test_one_rank_runs_the_native_rccl_control_flow():
     bd = d["config"]["dist_breakdown"]
     assert d["config"]["gather_verified"] is True and "native ncclGather" in bd["gather_kind"]
     assert set(bd["single_batch_ms"]) == {"1", "2", "4", "8"} and d["config"]["launch_options"]["reserved_cus"] == 32
+
+
+def test_reserved_cu_probe_runs_with_one_rank():
+    """--reserve-cus probe: the auto-tuning step of an N > 1 run (64 / 32 / 16 / 0 reserved CUs timed with the gather in flight, the
+    fastest kept) executed with one rank -- there is no transfer to hide here, so it must settle on a small reservation, and the
+    line must say what it measured."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--reserve-cus", "probe", "--steps", "5", "--warmup", "2", "--no-cpu",
+                        "--no-pmc", "--alt-builder", "none", "--side", "2048"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    probe = d["config"]["dist_breakdown"]["reserved_cus_probe"]
+    assert set(probe["ms_per_step"]) == {"64", "32", "16", "0"} and all(v > 0 for v in probe["ms_per_step"].values())
+    assert probe["chosen"] in (0, 16, 32) and d["config"]["launch_options"]["reserved_cus"] == probe["chosen"]
+    assert probe["ms_per_step"]["64"] >= probe["ms_per_step"]["0"] * 0.98        # reserving CUs never makes the lone trace faster
+    assert d["config"]["gather_verified"] is True
