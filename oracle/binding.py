@@ -143,6 +143,9 @@ def lib() -> C.CDLL:
         L.vto_skin_verts.argtypes = [vp, vp, vp, u32, vp, vp]
         L.vto_hit_tbn.argtypes = [vp, vp, C.c_float, C.c_float, C.c_float, vp, vp, vp, C.c_float, C.c_float, vp]
         L.vto_skin_frames.argtypes = [vp, vp, vp, u32, vp, vp]
+        L.vto_alt_mask.restype = C.c_uint32
+        if L.vto_alt_mask() != 0:
+            raise RuntimeError("oracle/_build/libvt_oracle.so was built with a VTO_ALT switch: not the oracle proper")
         _lib = L
     return _lib
 
@@ -184,9 +187,33 @@ def min_t_set(tris: np.ndarray, ray: np.ndarray, max_ids: int = 16):
     return t.value, ids[:min(n, max_ids)].copy(), n
 
 
+ALT_NAMES = ("PLAIN_INVERSE", "SWAP_GE", "FMA", "RETEST_RIGHT", "LEAF_DESC", "ACCEPT_LT", "PUSH_NODE_CULL", "FMINMAX")
+_alts = {}
+
+
+def alt_lib(name: str) -> C.CDLL:
+    """A recall-sensitivity VARIANT of the oracle (vt_oracle.c built with -DVTO_ALT_<name>, `make -C oracle alts`): one
+    recalled bvh-v1 detail read the other way.  For scripts/recall_sensitivity.py and its test only -- never the checker."""
+    if name not in ALT_NAMES:
+        raise ValueError(name)
+    if name not in _alts:
+        path = os.path.join(_HERE, "_build", "alt", f"libvt_oracle_{name}.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", _HERE, "alts"], stdout=subprocess.DEVNULL)
+        L = C.CDLL(path)
+        vp, u64 = C.c_void_p, C.c_uint64
+        L.vto_traverse_batch.argtypes = [vp, vp, vp, vp, u64, C.c_int, vp, vp, vp, C.c_int]
+        L.vto_traverse_batch.restype = C.c_int
+        L.vto_alt_mask.restype = C.c_uint32
+        assert L.vto_alt_mask() == 1 << ALT_NAMES.index(name), name
+        _alts[name] = L
+    return _alts[name]
+
+
 def traverse_batch(nodes: np.ndarray, prim_indices: np.ndarray, tris: np.ndarray, rays: np.ndarray,
-                   any_hit: bool = False, want_stats: bool = False, nthreads: int = 0):
-    """Returns (hits, per_ray_stats or None, total_steps, total_tests, threads_used)."""
+                   any_hit: bool = False, want_stats: bool = False, nthreads: int = 0, L=None):
+    """Returns (hits, per_ray_stats or None, total_steps, total_tests, threads_used).  `L`: an alt_lib() variant
+    (recall-sensitivity counts only); the default is the oracle proper."""
     assert nodes.dtype == NODE and tris.dtype == TRI
     nodes = np.ascontiguousarray(nodes)
     prim_indices = np.ascontiguousarray(prim_indices, np.uint32)
@@ -194,7 +221,7 @@ def traverse_batch(nodes: np.ndarray, prim_indices: np.ndarray, tris: np.ndarray
     hits = np.zeros(len(rays), HIT)
     st = np.zeros((len(rays), 2), np.uint32) if want_stats else None
     tot = _Stats()
-    used = lib().vto_traverse_batch(nodes.ctypes.data, prim_indices.ctypes.data, tris.ctypes.data, rays.ctypes.data,
+    used = (L or lib()).vto_traverse_batch(nodes.ctypes.data, prim_indices.ctypes.data, tris.ctypes.data, rays.ctypes.data,
                                     len(rays), int(any_hit), hits.ctypes.data,
                                     st.ctypes.data if st is not None else None, C.addressof(tot), nthreads)
     return hits, st, int(tot.steps), int(tot.tests), used

@@ -9,6 +9,23 @@
  *
  * PARITY STATUS: parity unpinned (no reference tests/vectors exist; libs/bvh
  * is absent).  See the header.
+ *
+ * RECALL-SENSITIVITY SWITCHES (scripts/recall_sensitivity.py, `make -C oracle alts`): each -DVTO_ALT_<X> builds a
+ * VARIANT of this oracle in which ONE detail of the walk recalled from madmann91/bvh v1 (SURVEY.md section 3.2's
+ * confidence table; libs/bvh is absent, reference call sites source/objects/AccelStruct.h:23-31) is read the OTHER
+ * plausible way.  The variants exist to count how many rays would change if upstream differs from the shipped reading;
+ * nothing but that script and tests/test_recall_sensitivity.py loads them, and the default build defines none of them
+ * (vto_alt_mask() == 0 is asserted).
+ *   VTO_ALT_PLAIN_INVERSE  inv_dir = 1/x (early v1: +-inf for zero components) instead of safe_inverse
+ *   VTO_ALT_SWAP_GE        near/far swap on dL.first >= dR.first instead of >
+ *   VTO_ALT_FMA            fast_multiply_add fused (FP_FAST_FMAF builds) instead of a*b then +c
+ *   VTO_ALT_RETEST_RIGHT   right child's slab test AFTER the left leaf was intersected (sees the shrunk tmax)
+ *   VTO_ALT_LEAF_DESC      leaf slots visited in descending instead of ascending order
+ *   VTO_ALT_ACCEPT_LT      node accepted on first < second instead of <=
+ *   VTO_ALT_PUSH_NODE_CULL stack holds the far NODE with its entry distance and a pop discards it when that
+ *                          distance exceeds the current tmax (storing the node instead of its first child without
+ *                          that test is the same walk by construction)
+ *   VTO_ALT_FMINMAX        fmaxf/fminf (NaN-ignoring) instead of robust_max/robust_min (a > b ? a : b)
  */
 #include "vt_oracle.h"
 
@@ -198,10 +215,59 @@ uint32_t vto_min_t_set(const vto_tri* tris, uint32_t ntris, const vto_ray* ray,
  * fast_multiply_add(a,b,c) = a*b + c  (unfused; FP_FAST_FMAF not defined)     */
 static inline float safe_inverse(float x)
 {
+#ifdef VTO_ALT_PLAIN_INVERSE
+    return 1.0f / x;
+#else
     return fabsf(x) <= FLT_EPSILON ? copysignf(1.0f / FLT_EPSILON, x) : 1.0f / x;
+#endif
 }
+#ifdef VTO_ALT_FMINMAX
+static inline float robust_max(float a, float b) { return fmaxf(a, b); }
+static inline float robust_min(float a, float b) { return fminf(a, b); }
+#else
 static inline float robust_max(float a, float b) { return a > b ? a : b; }
 static inline float robust_min(float a, float b) { return a < b ? a : b; }
+#endif
+#ifdef VTO_ALT_FMA
+static inline float fast_multiply_add(float a, float b, float c) { return fmaf(a, b, c); }
+#else
+static inline float fast_multiply_add(float a, float b, float c) { return a * b + c; }
+#endif
+#ifdef VTO_ALT_ACCEPT_LT
+#define VTO_NODE_ACCEPT(first, second) ((first) < (second))
+#else
+#define VTO_NODE_ACCEPT(first, second) ((first) <= (second))
+#endif
+
+uint32_t vto_alt_mask(void)
+{
+    uint32_t m = 0;
+#ifdef VTO_ALT_PLAIN_INVERSE
+    m |= 1u;
+#endif
+#ifdef VTO_ALT_SWAP_GE
+    m |= 2u;
+#endif
+#ifdef VTO_ALT_FMA
+    m |= 4u;
+#endif
+#ifdef VTO_ALT_RETEST_RIGHT
+    m |= 8u;
+#endif
+#ifdef VTO_ALT_LEAF_DESC
+    m |= 16u;
+#endif
+#ifdef VTO_ALT_ACCEPT_LT
+    m |= 32u;
+#endif
+#ifdef VTO_ALT_PUSH_NODE_CULL
+    m |= 64u;
+#endif
+#ifdef VTO_ALT_FMINMAX
+    m |= 128u;
+#endif
+    return m;
+}
 
 /* FastNodeIntersector [UPSTREAM-RECALL bvh/node_intersectors.hpp] */
 typedef struct {
@@ -224,8 +290,8 @@ static inline void node_slab(const node_isect* ni, const vto_node* node,
 {
     float entry[3], exit_[3];
     for (int a = 0; a < 3; ++a) {
-        entry[a] = node->bounds[2 * a + ni->oct[a]]     * ni->inv_dir[a] + ni->scaled_org[a];
-        exit_[a] = node->bounds[2 * a + 1 - ni->oct[a]] * ni->inv_dir[a] + ni->scaled_org[a];
+        entry[a] = fast_multiply_add(node->bounds[2 * a + ni->oct[a]],     ni->inv_dir[a], ni->scaled_org[a]);
+        exit_[a] = fast_multiply_add(node->bounds[2 * a + 1 - ni->oct[a]], ni->inv_dir[a], ni->scaled_org[a]);
     }
     *first  = robust_max(entry[0], robust_max(entry[1], robust_max(entry[2], tmin)));
     *second = robust_min(exit_[0], robust_min(exit_[1], robust_min(exit_[2], tmax)));
@@ -241,7 +307,12 @@ static inline int leaf_isect(const vto_node* leaf, const uint32_t* prim_indices,
                              int any_hit, vto_hit* best, int* found, uint64_t* tests)
 {
     uint32_t begin = leaf->first, end = begin + leaf->prim_count;
-    for (uint32_t i = begin; i < end; ++i) {
+    for (uint32_t k = begin; k < end; ++k) {
+#ifdef VTO_ALT_LEAF_DESC
+        const uint32_t i = end - 1 - (k - begin);
+#else
+        const uint32_t i = k;
+#endif
         uint32_t idx = prim_indices[i];            /* ClosestPrimitiveIntersector, PreShuffled=false */
         float t, u, v;
         ++*tests;
@@ -278,6 +349,9 @@ int vto_traverse(const vto_node* nodes, const uint32_t* prim_indices,
         node_isect ni;
         node_isect_init(&ni, ray);
         uint32_t stack[VTO_STACK_CAP];
+#ifdef VTO_ALT_PUSH_NODE_CULL
+        float stack_first[VTO_STACK_CAP];
+#endif
         int sp = 0;
         const vto_node* left = &nodes[nodes[0].first];
         for (;;) {
@@ -286,9 +360,11 @@ int vto_traverse(const vto_node* nodes, const uint32_t* prim_indices,
             float fl, sl, fr, sr;
             /* both children are slab-tested BEFORE either leaf is intersected */
             node_slab(&ni, left,  ray->tmin, tmax, &fl, &sl);
+#ifndef VTO_ALT_RETEST_RIGHT
             node_slab(&ni, right, ray->tmin, tmax, &fr, &sr);
+#endif
 
-            if (fl <= sl) {
+            if (VTO_NODE_ACCEPT(fl, sl)) {
                 if (left->prim_count != 0) {
                     if (leaf_isect(left, prim_indices, tris, ray, &tmax, any_hit, best, &found, &tests))
                         goto done;
@@ -296,7 +372,10 @@ int vto_traverse(const vto_node* nodes, const uint32_t* prim_indices,
                 }
             } else left = NULL;
 
-            if (fr <= sr) {
+#ifdef VTO_ALT_RETEST_RIGHT
+            node_slab(&ni, right, ray->tmin, tmax, &fr, &sr);
+#endif
+            if (VTO_NODE_ACCEPT(fr, sr)) {
                 if (right->prim_count != 0) {
                     if (leaf_isect(right, prim_indices, tris, ray, &tmax, any_hit, best, &found, &tests))
                         goto done;
@@ -306,8 +385,20 @@ int vto_traverse(const vto_node* nodes, const uint32_t* prim_indices,
 
             if (left) {
                 if (right) {
-                    if (fl > fr) { const vto_node* tmp = left; left = right; right = tmp; }
+#ifdef VTO_ALT_SWAP_GE
+                    if (fl >= fr) {
+#else
+                    if (fl > fr) {
+#endif
+                        const vto_node* tmp = left; left = right; right = tmp;
+#ifdef VTO_ALT_PUSH_NODE_CULL
+                        float tf = fl; fl = fr; fr = tf;
+#endif
+                    }
                     if (sp >= VTO_STACK_CAP) { fprintf(stderr, "vt_oracle: stack overflow\n"); abort(); }
+#ifdef VTO_ALT_PUSH_NODE_CULL
+                    stack_first[sp] = fr;
+#endif
                     stack[sp++] = right->first;     /* far inner node's first-child index */
                     ++g_last_pushes;
                     if ((uint32_t)sp > g_last_max_sp) g_last_max_sp = (uint32_t)sp;
@@ -316,6 +407,9 @@ int vto_traverse(const vto_node* nodes, const uint32_t* prim_indices,
             } else if (right) {
                 left = &nodes[right->first];
             } else {
+#ifdef VTO_ALT_PUSH_NODE_CULL
+                while (sp > 0 && stack_first[sp - 1] > tmax) --sp;   /* the stored node no longer reaches below tmax */
+#endif
                 if (sp == 0) break;
                 left = &nodes[stack[--sp]];
             }

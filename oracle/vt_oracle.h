@@ -97,6 +97,10 @@ int vto_traverse(const vto_node* nodes, const uint32_t* prim_indices,
                  const vto_tri* tris, const vto_ray* ray, int any_hit,
                  vto_hit* hit, vto_stats* stats);
 
+/* Bit mask of the -DVTO_ALT_<X> recall-sensitivity switches this library was built with (vt_oracle.c's header lists
+ * them); 0 for the oracle proper -- the only build tests, smoke() and bench.py use as the checker. */
+uint32_t vto_alt_mask(void);
+
 /* Stack use of the calling thread's last vto_traverse (diagnostic for stack sizing). */
 void vto_last_stack_use(uint32_t* max_sp, uint32_t* pushes);
 

@@ -476,25 +476,11 @@ def test_random_triangle_soups(va, engine, O, seed):
     """Seeded random soups: mixed scales, degenerate (zero-area / collinear / duplicate) triangles,
     random cull flags, rays from inside/outside with random windows -- device == oracle, bit for bit,
     and oracle == brute force on t (index inside the min-t set)."""
-    rng = np.random.default_rng(seed)
-    n = int(rng.integers(50, 3000))
-    centre = rng.uniform(-50, 50, (n, 1, 3))
-    scale = 10.0 ** rng.uniform(-3, 1.5, (n, 1, 1))
-    verts = (centre + rng.normal(size=(n, 3, 3)) * scale).astype(np.float32)
-    verts[::17, 1] = verts[::17, 0]                                  # zero-area: two equal vertices
-    verts[5::23, 2] = (verts[5::23, 0] + verts[5::23, 1]) / 2        # collinear
-    verts[3::29] = verts[2::29][: len(verts[3::29])]                 # exact duplicates (ties)
-    flags = (rng.random(n) < 0.4).astype(np.uint8)
+    from vistrace_amd import workloads as W
+    verts, flags, org, d, tmin, tmax = W.random_soup(seed)
     tris = va.tris_setup(verts, flags)
     bvh = va.HostBvh(tris)
     scene = va.Scene(engine, va.HostScene(bvh))
-    m = 6000
-    org = rng.uniform(-80, 80, (m, 3)).astype(np.float32)
-    d = rng.normal(size=(m, 3)).astype(np.float32)
-    d[: m // 4] = (centre[rng.integers(0, n, m // 4), 0] - org[: m // 4]).astype(np.float32)   # aimed at geometry
-    d[::50, rng.integers(0, 3)] = 0.0
-    tmin = np.where(rng.random(m) < 0.3, rng.uniform(0, 20, m), 0.0).astype(np.float32)
-    tmax = np.where(rng.random(m) < 0.3, tmin + rng.uniform(0.1, 100, m), np.finfo(np.float32).max).astype(np.float32)
     rays = va.make_rays(org, d, tmin, tmax)
     otris = O.tris_from_tri64(tris)
     ref, ref_st, _, _, _ = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays, want_stats=True)

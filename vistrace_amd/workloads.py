@@ -414,3 +414,27 @@ def alpha_test_rig(ntris: int, nmats: int = 6, alpha_fraction: float = 0.4, seed
         off += w * h
     texels = np.concatenate(planes) if off else np.zeros(0, np.uint8)
     return flags, attribs, mats, texels
+
+
+def random_soup(seed: int):
+    """Seeded random triangle soup + rays (tests/test_gpu_parity.py::test_random_triangle_soups, scripts/recall_sensitivity.py):
+    mixed scales, degenerate (zero-area / collinear) and exactly duplicated triangles, random cull flags, rays from inside and
+    outside with random [tmin, tmax] windows and some zero direction components.
+    Returns (verts (n,3,3) f32, flags (n,) u8, org (m,3), dir (m,3), tmin (m,), tmax (m,))."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(50, 3000))
+    centre = rng.uniform(-50, 50, (n, 1, 3))
+    scale = 10.0 ** rng.uniform(-3, 1.5, (n, 1, 1))
+    verts = (centre + rng.normal(size=(n, 3, 3)) * scale).astype(np.float32)
+    verts[::17, 1] = verts[::17, 0]                                  # zero-area: two equal vertices
+    verts[5::23, 2] = (verts[5::23, 0] + verts[5::23, 1]) / 2        # collinear
+    verts[3::29] = verts[2::29][: len(verts[3::29])]                 # exact duplicates (ties)
+    flags = (rng.random(n) < 0.4).astype(np.uint8)
+    m = 6000
+    org = rng.uniform(-80, 80, (m, 3)).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32)
+    d[: m // 4] = (centre[rng.integers(0, n, m // 4), 0] - org[: m // 4]).astype(np.float32)   # aimed at geometry
+    d[::50, rng.integers(0, 3)] = 0.0
+    tmin = np.where(rng.random(m) < 0.3, rng.uniform(0, 20, m), 0.0).astype(np.float32)
+    tmax = np.where(rng.random(m) < 0.3, tmin + rng.uniform(0.1, 100, m), np.finfo(np.float32).max).astype(np.float32)
+    return verts, flags, org, d, tmin, tmax
