@@ -1,0 +1,54 @@
+#!/bin/bash
+# Mutation testing of the GPU parity suite (run on the GPU box; writes profiles/r6/mutants.txt via gpurun_out/):
+#   bash scripts/mutants.sh [out.txt] [mutant numbers...]
+# Every library vistrace_amd/lib/variants/libvistrace_hip_mut_<k>.so (built here on the CPU box by
+# `make -C vistrace_amd/csrc mutant K=<k>`, i.e. trace_kernels.hip with ONE deliberate deviation, see its VT_MUT list)
+# is put in front of the `-m gpu` tests through VISTRACE_HIP_LIB.  A mutant is KILLED by the first test that goes red
+# (parity files first, then everything else); a mutant that passes every test SURVIVED and names a missing test.
+# The unmutated product library runs first as the control and must be green.
+OUT=${1:-gpurun_out/mutants.txt}; shift
+KS=${@:-1 2 3 4 5 6 7 8 9 10 11 12}
+declare -A WHAT=(
+ [1]="near/far swap on fl >= fr instead of >"
+ [2]="hit accepted on t < tmax instead of <="
+ [3]="fp contraction on (fused multiply-add)"
+ [4]="pending leaf range drained from the back"
+ [5]="plain 1/x instead of safe_inverse"
+ [6]="slab entry without the tmin term"
+ [7]="node accepted on first < second instead of <="
+ [8]="hit needs u > 0 instead of >= 0"
+ [9]="back face culled on n.d >= 0 instead of > 0"
+ [10]="stack entries beyond the LDS part hold the near child"
+ [11]="hit accepted on t > tmin instead of >="
+ [12]="w = 1 - (u + v) instead of (1 - u) - v"
+)
+FIRST="tests/test_gpu_parity.py tests/test_gpu_configs.py"
+REST="tests/test_gpu_multi_batch.py tests/test_gpu_rebuild.py tests/test_gpu_shading_frame.py tests/test_gpu_fake_group.py tests/test_gpu_bench_ranks.py"
+mkdir -p "$(dirname "$OUT")"
+{
+echo "# mutation testing of the -m gpu parity suite, $(date -u +%Y-%m-%dT%H:%MZ), $(python3 -c 'import subprocess;print(subprocess.run(["git","rev-parse","--short","HEAD"],capture_output=True,text=True).stdout.strip() or "snapshot")')"
+echo "# control: the product library"
+} > "$OUT"
+t0=$(date +%s)
+if timeout 900 python -m pytest $FIRST -m gpu -x -q -p no:cacheprovider > /tmp/mut_ctl.log 2>&1; then
+  echo "control   product library                                          GREEN  ($(grep -E ' passed' /tmp/mut_ctl.log | tail -1)) $(( $(date +%s) - t0 )) s" >> "$OUT"
+else
+  echo "control   product library                                          RED -- the run below means nothing" >> "$OUT"; tail -20 /tmp/mut_ctl.log >> "$OUT"
+fi
+for k in $KS; do
+  L=$PWD/vistrace_amd/lib/variants/libvistrace_hip_mut_$k.so
+  [ -f "$L" ] || { echo "mutant $k: $L not built" >> "$OUT"; continue; }
+  t0=$(date +%s)
+  verdict=SURVIVED; by=""
+  for files in "$FIRST" "$REST"; do
+    VISTRACE_HIP_LIB=$L timeout 900 python -m pytest $files -m gpu -x -q -p no:cacheprovider > /tmp/mut_$k.log 2>&1
+    rc=$?
+    if [ $rc -ne 0 ]; then
+      by=$(grep -m1 -E "^(FAILED|ERROR) " /tmp/mut_$k.log | sed -E 's/ - .*//')
+      [ -z "$by" ] && by="rc=$rc: $(tail -1 /tmp/mut_$k.log | cut -c1-120)"
+      verdict=KILLED; break
+    fi
+  done
+  printf "mutant %-2s %-58s %-8s %s (%s s)\n" "$k" "${WHAT[$k]}" "$verdict" "$by" "$(( $(date +%s) - t0 ))" >> "$OUT"
+done
+cat "$OUT"

@@ -25,6 +25,19 @@ def test_every_declared_symbol_is_exported(va):
     assert set(va._lib.SYMBOLS) == set(syms), "python binding table and header disagree"
 
 
+def test_product_library_is_no_mutant():
+    """Mutation testing (scripts/mutants.sh) builds deliberately wrong kernels from trace_kernels.hip's VT_MUT sites; those
+    libraries export vt_mutant().  The product library must not: nothing of a mutant is compiled into it, and the build never
+    passes -DVT_MUTANT (the Makefile's `mutant` / `variant` targets write to lib/variants/ only)."""
+    lib = C.CDLL(os.path.join(ROOT, "vistrace_amd", "lib", "libvistrace_hip.so"))
+    assert not hasattr(lib, "vt_mutant")
+    mk = open(os.path.join(ROOT, "vistrace_amd", "csrc", "Makefile")).read()
+    flags = [ln for ln in mk.splitlines() if ln.startswith(("CXXFLAGS", "HIPFLAGS", " ", "\t")) and "VT_MUTANT" in ln]
+    assert all("variants" in ln or "_build_mut_" in ln or "-DVT_MUTANT=$(K)" in ln for ln in flags), flags
+    src = open(os.path.join(ROOT, "vistrace_amd", "csrc", "trace_kernels.hip")).read()
+    assert "#define VT_MUT(k, wrong, right) (right)" in src         # without -DVT_MUTANT every site is its shipped token
+
+
 def test_pod_sizes(va):
     L = va._lib
     assert (L.RAY.itemsize, L.HIT.itemsize, L.BVH_NODE.itemsize, L.NODE_PAIR.itemsize, L.TRI64.itemsize,

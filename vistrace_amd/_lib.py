@@ -197,6 +197,10 @@ def _load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    if hasattr(lib, "vt_mutant"):       # a deliberately wrong kernel (mutation testing, scripts/mutants.sh): never silently
+        import sys
+        print(f"[vistrace_amd] {LIB_PATH} is MUTANT {lib.vt_mutant()} of the traversal kernel: results are wrong on purpose",
+              file=sys.stderr)
     return lib
 
 

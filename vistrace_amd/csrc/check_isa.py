@@ -126,10 +126,19 @@ def check(obj):
     return errors, seen, alpha_checked
 
 
+def is_mutant(obj):
+    """a trace_kernels object compiled with -DVT_MUTANT=<k> (mutation testing, scripts/mutants.sh) defines vt_mutant"""
+    syms = subprocess.run([f"{LLVM}/llvm-readelf", "--symbols", "--wide", obj], check=True, capture_output=True, text=True).stdout
+    return any(f[-1] == "vt_mutant" and f[-2] != "UND" for f in (line.split() for line in syms.splitlines()) if len(f) >= 8)
+
+
 def main():
     if len(sys.argv) != 2:
         raise SystemExit(__doc__)
     errors, seen, alpha_checked = check(sys.argv[1])
+    # a deliberately wrong kernel may only ever be written to a variant directory, never to the product's _build/
+    if is_mutant(sys.argv[1]) and os.path.basename(os.path.dirname(os.path.abspath(sys.argv[1]))) == "_build":
+        errors.append("this object was compiled with -DVT_MUTANT: a mutant must not be built into the product library")
     for e in errors:
         print("check_isa: " + e, file=sys.stderr)
     if errors:

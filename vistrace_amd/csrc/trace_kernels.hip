@@ -44,7 +44,30 @@
 
 #include "trace_kernels.h"
 
+// ---- mutation testing of the parity suite (scripts/mutants.sh -> profiles/r6/mutants.txt) ---------------------------------
+// `make variant NAME=mut_<k> HIPDEFS=-DVT_MUTANT=<k>` builds a deliberately WRONG traversal kernel: ONE deviation from the walk
+// of SURVEY.md 3.2 / the triangle test of source/objects/Primitives.h:168-215, each of the kind a slip of the pen (or a wrong
+// recall of bvh v1) would produce.  Every such library must turn at least one `-m gpu` test red; a mutant that survives is a
+// missing test.  The product build never defines VT_MUTANT: VT_MUT(k, wrong, right) is then the token `right` after
+// preprocessing, nothing of a mutant is compiled in, and the library does not export vt_mutant (tests/test_abi_symbols.py,
+// check_isa.py).
+//   1 near/far swap on fl >= fr            2 hit accepted on t < tmax            3 fp contraction on (fused multiply-add)
+//   4 pending leaf range drained from the back (right leaf before left, descending slots)
+//   5 plain 1/x instead of safe_inverse    6 slab entry without the tmin term    7 node accepted on first < second
+//   8 hit needs u > 0                      9 back face culled on n.d >= 0       10 stack entries beyond the LDS part hold the near child
+//  11 hit accepted on t > tmin            12 w = 1 - (u + v)
+#ifdef VT_MUTANT
+#define VT_MUT(k, wrong, right) ((VT_MUTANT == (k)) ? (wrong) : (right))
+extern "C" __attribute__((visibility("default"))) int vt_mutant(void) { return VT_MUTANT; }
+#else
+#define VT_MUT(k, wrong, right) (right)
+#endif
+
+#if defined(VT_MUTANT) && VT_MUTANT == 3
+#pragma clang fp contract(fast)
+#else
 #pragma clang fp contract(off)
+#endif
 
 namespace vt {
 
@@ -74,7 +97,7 @@ __device__ __forceinline__ uint32_t quad_broadcast(uint32_t v)
 // bvh v1 safe_inverse
 __device__ __forceinline__ float safe_inverse(float x)
 {
-    return fabsf(x) <= FLT_EPSILON ? copysignf(1.0f / FLT_EPSILON, x) : 1.0f / x;
+    return VT_MUT(5, 1.0f / x, fabsf(x) <= FLT_EPSILON ? copysignf(1.0f / FLT_EPSILON, x) : 1.0f / x);
 }
 
 // bvh v1 robust_max(a,b) = a > b ? a : b and robust_min(a,b) = a < b ? a : b, nested as
@@ -89,7 +112,7 @@ __device__ __forceinline__ float safe_inverse(float x)
 __device__ __forceinline__ float slab_first(float e0, float e1, float e2, float tmin)
 {
     float m, r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(e2), "v"(tmin));
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(e2), "v"(VT_MUT(6, e2, tmin)));
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(e0), "v"(e1), "v"(m));
     return r;
 }
@@ -501,8 +524,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
         // lane the record of its neighbour quad's lane so that the row names 15 lines instead of 16 does not lower the access
         // count at all -- every quad of a DMA instruction is its own L1 access -- and costs +2 % (round 5, profiles/r5/notes.md).)
         // (ALPHA: the AlphaRec of the triangle just tested sits at alpha_base + its slot; tri_cur is already past it)
-        const uint32_t rec = do_tri ? a.tri_base + L.tri_cur
-                                    : (want_node ? L.node : (alpha1 ? a.alpha_base + L.tri_cur - 1u : (FETCH_DMA ? 0u : kNoFetch)));
+        const uint32_t rec = do_tri ? a.tri_base + VT_MUT(4, L.tri_end - 1u, L.tri_cur)
+                                    : (want_node ? L.node : (alpha1 ? a.alpha_base + VT_MUT(4, L.tri_end, L.tri_cur - 1u) : (FETCH_DMA ? 0u : kNoFetch)));
         // ALPHA: the block that turns an AlphaRec into texel addresses is ~60 instructions for the WHOLE wave whenever one lane
         // needs it; like the TRI branch it waits until `alpha_threshold` lanes have a candidate parked, or nobody else can make
         // progress.  A waiting lane asks for its AlphaRec again next iteration (an L1 hit).  Scheduling only: the order of a ray's
@@ -569,7 +592,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
 
         if (do_tri) {
             // ---- TRI: TriangleBackfaceCull::intersect, Primitives.h:168-215 --------------
-            ++L.tri_cur;
+            VT_MUT(4, --L.tri_end, ++L.tri_cur);
             if constexpr (STATS) ++L.tests;
             const float p0x = q0.x, p0y = q0.y, p0z = q0.z;
             const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
@@ -578,7 +601,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             const uint32_t tprim = __float_as_uint(q3.x), tflags = __float_as_uint(q3.y);
 
             const float nDotDir = (nx * L.dx + ny * L.dy) + nz * L.dz;                 // :173
-            const bool culled = (tflags & VT_TRI_CULL_BACKFACE) && nDotDir > 0.0f;     // :174
+            const bool culled = (tflags & VT_TRI_CULL_BACKFACE) && VT_MUT(9, nDotDir >= 0.0f, nDotDir > 0.0f);   // :174
             const float cx = p0x - L.ox, cy = p0y - L.oy, cz = p0z - L.oz;             // :176
             const float rx = L.dy * cz - L.dz * cy;                                    // :177
             const float ry = L.dz * cx - L.dx * cz;
@@ -586,10 +609,10 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             const float inv_det = 1.0f / nDotDir;                                      // :178
             const float u = ((rx * e2x + ry * e2y) + rz * e2z) * inv_det;              // :180
             const float v = ((rx * e1x + ry * e1y) + rz * e1z) * inv_det;              // :181
-            const float w = 1.0f - u - v;                                              // :182
+            const float w = VT_MUT(12, 1.0f - (u + v), 1.0f - u - v);                  // :182
             const float t = ((nx * cx + ny * cy) + nz * cz) * inv_det;                 // :188
-            bool hit = !culled && u >= 0.0f && v >= 0.0f && w >= 0.0f &&               // :187
-                       t >= L.tmin && t <= L.tmax;                                     // :189
+            bool hit = !culled && VT_MUT(8, u > 0.0f, u >= 0.0f) && v >= 0.0f && w >= 0.0f &&        // :187
+                       VT_MUT(11, t > L.tmin, t >= L.tmin) && VT_MUT(2, t < L.tmax, t <= L.tmax);    // :189
             if constexpr (ALPHA) {                                                     // :196-208
                 if (hit && (tflags & VT_TRI_ALPHATEST)) {        // the candidate is parked until its alpha is known
                     L.astate = 1; L.cprim = tprim; L.cu = u; L.cv = v; L.ct = t;
@@ -699,7 +722,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             const float fr = slab_first(rnx * L.ix + L.sx, rny * L.iy + L.sy, rnz * L.iz + L.sz, L.tmin);
             const float sr = slab_second(rfx * L.ix + L.sx, rfy * L.iy + L.sy, rfz * L.iz + L.sz, L.tmax);
 
-            const bool hit_l = fl <= sl, hit_r = fr <= sr;
+            const bool hit_l = VT_MUT(7, fl < sl, fl <= sl), hit_r = VT_MUT(7, fr < sr, fr <= sr);
             const bool leaf_l = lcount != 0, leaf_r = rcount != 0;
 
             // leaves that were hit become the pending triangle range, left before right;
@@ -713,11 +736,11 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             uint32_t next;
             if (go_l && go_r) {
                 // near child first (ties keep left first); push the far child's pair
-                const bool swap = fl > fr;
+                const bool swap = VT_MUT(1, fl >= fr, fl > fr);
                 next = swap ? rfirst : lfirst;
                 uint32_t far = swap ? lfirst : rfirst;
                 if (L.sp < a.lds_entries) st_lds[L.sp * 64] = far;
-                else st_ovf[size_t(L.sp - a.lds_entries) * gstride] = far;
+                else st_ovf[size_t(L.sp - a.lds_entries) * gstride] = VT_MUT(10, next, far);
                 ++L.sp;
             } else if (go_l) {
                 next = lfirst;
