@@ -576,8 +576,20 @@ int vt_engine_launch_info(vt_engine* e, uint32_t* blocks, uint32_t* threads, uin
  *   VT_TEST_RECORD_GAP=<records>     vt_scene_upload leaves that many unused 64-B records between the pairs and the
  *                                    triangles (a multi-GiB allocation): the 64-bit record addressing of scenes with more than
  *                                    67 M records on a 10 k-triangle scene (tests/test_gpu_parity.py::test_records_beyond_4_gib).
+ *   VT_TEST_FAIL_ALLOC=<k>           fault injection: the k-th device / pinned-host allocation the library makes in this process
+ *                                    fails as if memory had run out (every hipMalloc / hipHostMalloc of the library goes through
+ *                                    one counted wrapper).  vt_test_fail_alloc(k) re-arms it at run time.  What the reference
+ *                                    does on such paths: delete-before-throw (source/VisTrace.cpp:782-785,
+ *                                    source/objects/AccelStruct.cpp:186-203, :780); here: a non-zero status, vt_last_error set,
+ *                                    nothing leaked, the engine still usable (tests/test_gpu_fault_injection.py).
  * Not hooks but configuration, always honoured: VT_RCCL_LIB (path of the RCCL library to dlopen instead of librccl.so),
  * VT_BUILDER (default builder of vt_bvh_build), VT_BATCH_UPLOAD (staged | direct), VT_COPY_THREADS (staging-copy threads). */
+
+/* Re-arms the fault injection above: the k-th allocation FROM NOW ON fails (once); k = 0 disarms.  The count restarts either
+ * way.  VT_ERR_UNSUPPORTED unless VT_ENABLE_TEST_HOOKS=1. */
+int vt_test_fail_alloc(uint64_t k);
+/* Allocations the library has attempted since the last vt_test_fail_alloc (or since it was loaded); 0 with the hooks off. */
+uint64_t vt_test_alloc_count(void);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,15 @@ bones, binds = W.rig_pose(nmat, 0)
 moved = (verts + np.float32(0.25)).astype(np.float32)
 for members in (1, 2, 8):
     eng = va.Engine([0] * members) if members > 1 else va.Engine(0)
+    va.Scene.from_tree(eng, bvh).free()                      # first upload of an engine: staging allocations
+    up = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        sc = va.Scene.from_tree(eng, bvh)                    # Rebuild's upload step: vt_scene_upload_tree on the root, replicas by device-to-device copies
+        up.append((time.perf_counter() - t0) * 1e3)
+        rep_us = (eng.get_option("last_update_enqueue_us"), eng.get_option("last_update_wait_us")) if members > 1 else (0, 0)
+        sc.free()
+    print(f"members {members}: vt_scene_upload_tree {np.median(up):.2f} ms (replicas: prepare + enqueue {rep_us[0]} us, waits {rep_us[1]} us)", flush=True)
     scene = va.Scene(eng, hs)
     scene.set_skin(verts, skin, base)
     for _ in range(5):

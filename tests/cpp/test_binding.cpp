@@ -765,8 +765,107 @@ static void bench_batch_forms()
     SetWorld(nullptr);
 }
 
+// ---- fault injection through the Lua surface (needs VT_ENABLE_TEST_HOOKS=1; tests/test_gpu_fault_injection.py) ---------------
+// Every device / pinned allocation behind vistrace.CreateAccel, accel:Rebuild and accel:TraverseBatch is made to fail in turn
+// (vt_test_fail_alloc).  The reference's convention on such paths is delete-before-throw (source/VisTrace.cpp:782-785,
+// source/objects/AccelStruct.cpp:186-203, :780): the script sees a Lua error, never an abort, and the module stays usable.
+static void test_fail_alloc_side()
+{
+    State L;
+    RegisterTracingApi(&L);
+    install_entity_global(L);
+    FakeMeshSource src;
+    AccelStruct::SetEntityMeshSource(&src);
+    World world;
+    world.materials.push_back(Material{"brush/floor", MATFLAG_NONE});
+    world.entities.push_back(Entity{nullptr, 0});
+    world.triangles.push_back(make_tri({0, 0, 0}, {10, 0, 0}, {0, 10, 0}, true, 0));
+    world.triangles.push_back(make_tri({20, 0, 0}, {30, 0, 0}, {20, 10, 0}, true, 0));
+    SetWorld(&world);
+    int dummyEntity = 0;
+    g_entityByIndex[42] = &dummyEntity;
+    if (vt_test_fail_alloc(0) != VT_OK) { ++g_fail; std::printf("FAIL: --fail-alloc needs VT_ENABLE_TEST_HOOKS=1\n"); return; }
+
+    auto create = [&]() -> fakelua::Value {
+        L.Pop(L.Top());
+        L.PushValue(State::Array({State::User(&dummyEntity, LT::Entity)}));
+        L.PushBool(true);
+        if (L.find_global("vistrace", "CreateAccel")->fn(&L) != 1) return State::Nil();
+        return L.stack.back();
+    };
+    auto works = [&](const fakelua::Value& accelValue) {       // the entity quad from above, through the single-ray path
+        AccelStruct* accel = static_cast<AccelStruct*>(*accelValue.ud);
+        if (call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1)}) != 1 || L.GetType(1) != TraceResult::id) return false;
+        return L.GetUserType<TraceResult>(1, TraceResult::id)->distance == 3.0f;
+    };
+    // 400 rays: above AccelStruct::kDeviceBatchMin, so the batch goes to the device (staging pipeline, batch block, launch scratch)
+    std::vector<fakelua::Value> many;
+    for (int i = 0; i < 400; ++i)
+        many.push_back(State::Array({State::Vec(float((i * 37) % 320) * 0.1f - 1.f, float((i * 53) % 120) * 0.1f - 1.f, 9.f), State::Vec(0.01f * float(i % 7), 0.02f, -1.f)}));
+    auto batch_hits = [&](const fakelua::Value& accelValue) -> int {
+        if (call_method(L, accelValue, "TraverseBatch", {State::Array(many)}) != 1) return -1;
+        int nhit = 0;
+        for (auto& kv : L.stack.back().tab->kv)
+            if (kv.second.type == TraceResult::id) { ++nhit; delete static_cast<TraceResult*>(*kv.second.ud); }
+        return nhit;
+    };
+
+    // a clean run counts the allocations of each call (the first CreateAccel also opens the engine)
+    fakelua::Value ref = create();
+    const uint64_t n_create = vt_test_alloc_count();
+    CHECK(ref.type == AccelStruct_id && works(ref) && n_create >= 4);
+    (void)vt_test_fail_alloc(0);
+    const int ref_hits = batch_hits(ref);
+    const uint64_t n_batch = vt_test_alloc_count();
+    CHECK(ref_hits > 0 && n_batch >= 1);
+    int failed_create = 0, failed_rebuild = 0, failed_batch = 0;
+    for (uint64_t k = 1; k <= n_create; ++k) {               // vistrace.CreateAccel with its k-th allocation failing
+        (void)vt_test_fail_alloc(k);
+        fakelua::Value got;
+        const std::string e = error_of([&] { got = create(); });
+        (void)vt_test_fail_alloc(0);
+        if (!e.empty()) { ++failed_create; CHECK(contains(e.c_str(), "VisTrace:")); }
+        else { CHECK(got.type == AccelStruct_id && works(got)); CHECK(call_method(L, got, "__gc") == 0); }
+        CHECK(works(ref) && batch_hits(ref) == ref_hits);    // the module is still usable, the older accel untouched
+    }
+    for (uint64_t k = 1; k <= n_create; ++k) {               // accel:Rebuild: a failure leaves the accel invalid, the next Rebuild heals it
+        fakelua::Value a = create();
+        (void)vt_test_fail_alloc(k);
+        const std::string e = error_of([&] { call_method(L, a, "Rebuild", {State::Array({State::User(&dummyEntity, LT::Entity)}), State::Bool(true)}); });
+        (void)vt_test_fail_alloc(0);
+        if (!e.empty()) {
+            ++failed_rebuild;
+            AccelStruct* accel = static_cast<AccelStruct*>(*a.ud);
+            const std::string t = error_of([&] { call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1)}); });
+            CHECK(contains(t.c_str(), "acceleration structure invalid"));
+            CHECK(error_of([&] { call_method(L, a, "Rebuild", {State::Array({State::User(&dummyEntity, LT::Entity)}), State::Bool(true)}); }).empty());
+        }
+        CHECK(works(a));
+        CHECK(call_method(L, a, "__gc") == 0);
+    }
+    for (uint64_t k = 1; k <= n_batch + 2; ++k) {            // accel:TraverseBatch above the device crossover
+        (void)vt_test_fail_alloc(k);
+        int got = -2;
+        const std::string e = error_of([&] { got = batch_hits(ref); });
+        (void)vt_test_fail_alloc(0);
+        if (!e.empty()) { ++failed_batch; CHECK(contains(e.c_str(), "VisTrace: traversal failed")); }
+        else CHECK(got == ref_hits);
+        CHECK(batch_hits(ref) == ref_hits);
+    }
+    std::printf("fail-alloc through Lua: CreateAccel %d of %llu, Rebuild %d, TraverseBatch %d of %llu injected failures surfaced as Lua errors\n",
+                failed_create, (unsigned long long)n_create, failed_rebuild, failed_batch, (unsigned long long)n_batch);
+    CHECK(failed_create >= 3 && failed_rebuild >= 3);
+    CHECK(call_method(L, ref, "__gc") == 0);
+    SetWorld(nullptr);
+}
+
 int main(int argc, char** argv)
 {
+    if (argc > 1 && std::strcmp(argv[1], "--fail-alloc") == 0) {
+        test_fail_alloc_side();
+        std::printf("binding (fail-alloc): %d checks, %d failed\n", g_run, g_fail);
+        return g_fail ? 1 : 0;
+    }
     if (argc > 1 && std::strcmp(argv[1], "--bench") == 0) {
         bench_single_calls();
         bench_batch_forms();

@@ -59,6 +59,9 @@ for ndev in (2, 3, 4, 8):
     eng.set_option("persistent", 1 if ndev in (3, 8) else 2)      # persistent waves on the small shards too
     # replicated to every member: re-packed on each member's device (vt_scene_upload_tree) or uploaded from the host lineariser's output
     scene = va.Scene.from_tree(eng, bvh) if ndev in (3, 8) else va.Scene(eng, host_scene)
+    # ... by device-to-device copies of the root's finished records, in phases: every member's copies were enqueued before the
+    # first member was waited for (engine.hip: scene_replicate)
+    assert eng.get_option("last_update_members") == ndev and eng.get_option("last_update_early_waits") == 0
     cap = va.shard_capacity(n, ndev)
     shards, ptrs = [], []
     for j in range(NB):

@@ -150,6 +150,8 @@ SYMBOLS = {
     "vt_engine_set_timing": (C.c_int, [_vp, C.c_int]),
     "vt_engine_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "vt_engine_launch_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "vt_test_fail_alloc": (C.c_int, [_u64]),
+    "vt_test_alloc_count": (_u64, []),
 }
 
 

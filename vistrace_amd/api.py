@@ -503,6 +503,9 @@ class Scene:
 
     def sync_host_scene(self) -> None:
         """After refit / skin_refit: read the device records back into the host scene the single-ray path walks."""
+        if self.host_scene is None:                 # from_tree: no host copy yet -- fetching one IS the sync
+            self.download_host_scene()
+            return
         check(lib.vt_host_scene_sync(self.host_scene._h, self._h))
 
     def read_records(self):
@@ -530,6 +533,8 @@ class Scene:
         check(lib.vt_scene_set_tri_frames(self._h, ptr(frames) if len(frames) else None, len(frames)))
 
     def read_tri_frames(self) -> np.ndarray:
+        if self.host_scene is None:
+            self.download_host_scene()
         frames = np.zeros(self.host_scene.tri_count, dtype=TRI_FRAME)
         check(lib.vt_scene_read_tri_frames(self._h, ptr(frames) if len(frames) else None))
         return frames

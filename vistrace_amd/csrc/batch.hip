@@ -37,24 +37,26 @@ int take_pinned(vt_engine* e, size_t need, vt_batch::HostArray& h)
                 return VT_OK;
             }
     }
-    VT_HIP(hipHostMalloc(&h.p, need));
+    VT_HIP(pinned_malloc(&h.p, need));
     h.bytes = need;
     return VT_OK;
 }
 
 int ensure_host_pipeline(vt_engine* e)
 {
-    if (e->s_in) return VT_OK;
+    if (e->pipeline_ready) return VT_OK;
+    // every piece is created once; a call that failed half-way (out of pinned memory) is resumed by the next one
     const uint64_t C = vt_engine::kHostChunk;
-    VT_HIP(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
-    VT_HIP(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
+    if (!e->s_in) VT_HIP(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
+    if (!e->s_out) VT_HIP(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
     for (int k = 0; k < vt_engine::kStageBufs; ++k) {
-        VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage_in[k]), C * sizeof(vt_ray)));
-        VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage_out[k]), C * sizeof(vt_hit)));
-        VT_HIP(hipEventCreateWithFlags(&e->ev_in[k], hipEventDisableTiming));
-        VT_HIP(hipEventCreateWithFlags(&e->ev_k[k], hipEventDisableTiming));
-        VT_HIP(hipEventCreateWithFlags(&e->ev_out[k], hipEventDisableTiming));
+        if (!e->h_stage_in[k]) VT_HIP(pinned_malloc(reinterpret_cast<void**>(&e->h_stage_in[k]), C * sizeof(vt_ray)));
+        if (!e->h_stage_out[k]) VT_HIP(pinned_malloc(reinterpret_cast<void**>(&e->h_stage_out[k]), C * sizeof(vt_hit)));
+        if (!e->ev_in[k]) VT_HIP(hipEventCreateWithFlags(&e->ev_in[k], hipEventDisableTiming));
+        if (!e->ev_k[k]) VT_HIP(hipEventCreateWithFlags(&e->ev_k[k], hipEventDisableTiming));
+        if (!e->ev_out[k]) VT_HIP(hipEventCreateWithFlags(&e->ev_out[k], hipEventDisableTiming));
     }
+    e->pipeline_ready = true;
     return VT_OK;
 }
 
@@ -87,7 +89,7 @@ bool pageable_copies_are_fast(vt_engine* e)
     k = 0;
     void* d = nullptr;
     char* pageable = static_cast<char*>(std::malloc(bytes));
-    if (pageable && hipMalloc(&d, bytes) == hipSuccess) {
+    if (pageable && dev_malloc(&d, bytes) == hipSuccess) {
         std::memset(pageable, 1, bytes);
         auto timed = [&](const void* src) {
             double best = 1e30;
@@ -141,7 +143,7 @@ int batch_pipeline(vt_scene* s, vt_batch* b, const void* rays, uint64_t n, uint3
     const bool direct = pageable_copies_are_fast(e);
     unsigned long long* const d_first_bad = reinterpret_cast<unsigned long long*>(b->d_mem + b->d_mem_bytes - kBatchTail);
     if (direct && check) {
-        if (!e->h_live) VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_live), 64));
+        if (!e->h_live) VT_HIP(pinned_malloc(reinterpret_cast<void**>(&e->h_live), 64));
         VT_HIP(hipMemsetAsync(d_first_bad, 0xFF, sizeof(unsigned long long), e->s_in));
     }
     // (the pinned staging buffers are free: every host-pointer call leaves them so, and e->host_mu is held; the kernels an earlier
@@ -219,7 +221,7 @@ int batch_new(vt_scene* s, uint64_t n, vt_batch** out)
                 break;
             }
     }
-    if (!b->d_mem) { err = hipMalloc(reinterpret_cast<void**>(&b->d_mem), need); b->d_mem_bytes = need; }
+    if (!b->d_mem) { err = dev_malloc(reinterpret_cast<void**>(&b->d_mem), need); b->d_mem_bytes = need; }
     if (err == hipSuccess) err = hipEventCreateWithFlags(&b->done, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&b->hits_down, hipEventDisableTiming);
     if (err != hipSuccess) {

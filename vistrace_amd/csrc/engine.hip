@@ -32,7 +32,7 @@ int ensure_bytes(void** ptr, size_t* have, size_t need)
     if (*have >= need) return VT_OK;
     if (*ptr) { VT_HIP(hipFree(*ptr)); *ptr = nullptr; *have = 0; }
     size_t cap = std::max(need, size_t(1) << 20);
-    VT_HIP(hipMalloc(ptr, cap));
+    VT_HIP(dev_malloc(ptr, cap));
     *have = cap;
     return VT_OK;
 }
@@ -176,10 +176,10 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
             if (&other != &slot && other.overflow_words < ovf_words && (!other.used || hipEventQuery(other.done) == hipSuccess)) takers.push_back(&other);
         (void)hipGetLastError();                             // hipEventQuery of a launch in flight reports hipErrorNotReady
         void* block = nullptr;
-        if (hipMalloc(&block, takers.size() * ovf_words * sizeof(uint32_t)) != hipSuccess) {   // not enough room for all: this slot alone
+        if (dev_malloc(&block, takers.size() * ovf_words * sizeof(uint32_t)) != hipSuccess) {   // not enough room for all: this slot alone
             (void)hipGetLastError();
             takers.resize(1);
-            VT_HIP(hipMalloc(&block, ovf_words * sizeof(uint32_t)));
+            VT_HIP(dev_malloc(&block, ovf_words * sizeof(uint32_t)));
         }
         std::shared_ptr<void> owner(block, [](void* p) { (void)hipFree(p); });
         for (size_t k = 0; k < takers.size(); ++k) {
@@ -261,8 +261,8 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
             // first merged launch of the engine: tables of kSlotSegs batches for ALL slots from one allocation each -- otherwise every
             // slot would allocate its own on its first merged launch (16 launches of ~0.2 ms extra: profiles/r4/notes.md section 1)
             const size_t per = vt_engine::kSlotSegs * sizeof(TraceSeg), all = vt_engine::kLaunchSlots * per;
-            VT_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_segs_all), all));
-            if (hipHostMalloc(reinterpret_cast<void**>(&e->h_segs_all), all) != hipSuccess) {
+            VT_HIP(dev_malloc(reinterpret_cast<void**>(&e->d_segs_all), all));
+            if (pinned_malloc(reinterpret_cast<void**>(&e->h_segs_all), all) != hipSuccess) {
                 (void)hipGetLastError(); (void)hipFree(e->d_segs_all); e->d_segs_all = nullptr;
                 return fail(VT_ERR_HIP, "trace launch: no pinned memory for the batch tables");
             }
@@ -282,8 +282,8 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
             slot.d_segs = nullptr; slot.h_segs = nullptr; slot.segs_shared = false;
             slot.segs_cap = 0;
             const size_t cap = std::max<size_t>(64, size_t(nreq) * 2);
-            VT_HIP(hipMalloc(reinterpret_cast<void**>(&slot.d_segs), cap * sizeof(TraceSeg)));
-            VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&slot.h_segs), cap * sizeof(TraceSeg)));
+            VT_HIP(dev_malloc(reinterpret_cast<void**>(&slot.d_segs), cap * sizeof(TraceSeg)));
+            VT_HIP(pinned_malloc(reinterpret_cast<void**>(&slot.h_segs), cap * sizeof(TraceSeg)));
             slot.segs_cap = cap;
         } else if (slot.segs_copied_valid) {
             VT_HIP(hipEventSynchronize(slot.segs_copied));   // the table copy of the merged launch that last used this slot (long over)
@@ -354,7 +354,7 @@ int reserve_cus(vt_engine* e, uint32_t want)
     VT_HIP(hipDeviceSynchronize());                       // no launch may be reading the set while it changes
     e->reserved_cus = 0;
     if (want == 0) return VT_OK;
-    if (!e->d_reserved) VT_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_reserved), 128 + 4096));
+    if (!e->d_reserved) VT_HIP(dev_malloc(reinterpret_cast<void**>(&e->d_reserved), 128 + 4096));
     uint32_t seen[32] = {};
     for (int round = 0; round < 4; ++round) {             // 2 probe blocks fit a CU: a few rounds reach all of them
         VT_HIP(hipMemsetAsync(e->d_reserved, 0, 128, e->stream));
@@ -406,16 +406,16 @@ float packet_radius2(const vt_node_pair& root)
 // The AlphaRecs of a scene with alpha-tested triangles (trace_kernels.h): room for them behind the triangles (the record
 // array is re-allocated once if the scene was uploaded without any flagged triangle), then one kernel over the slots.
 // The engine's device is current and idle (the callers synchronise first).
-int build_alpha_records(vt_scene* s)
+// ensure_alpha_room: one AlphaRec per triangle slot behind the triangles; when it fails nothing has changed.
+int ensure_alpha_room(vt_scene* s)
 {
-    s->alpha_ready = false;
-    if (!s->has_alpha || !s->d_attribs || !s->d_alpha_mats || s->ntris == 0) return VT_OK;
+    if (!s->has_alpha || s->ntris == 0 || s->alpha_base != 0) return VT_OK;
     vt_engine* e = s->engine;
-    if (s->alpha_base == 0) {
+    {
         const uint32_t base = (s->tri_base + s->ntris + 1u) & ~1u;
         const size_t cap = size_t(base) + s->ntris;
         char* grown = nullptr;
-        VT_HIP(hipMalloc(reinterpret_cast<void**>(&grown), cap * 64));
+        VT_HIP(dev_malloc(reinterpret_cast<void**>(&grown), cap * 64));
         hipError_t err = hipMemset(grown, 0, cap * 64);
         if (err == hipSuccess) err = hipMemcpy(grown, s->d_records, s->record_capacity * 64, hipMemcpyDeviceToDevice);
         if (err != hipSuccess) { (void)hipFree(grown); return fail(VT_ERR_HIP, std::string("alpha records: ") + hipGetErrorString(err)); }
@@ -430,6 +430,16 @@ int build_alpha_records(vt_scene* s)
         }
         if (s->refit_graph) { (void)hipGraphExecDestroy(s->refit_graph); s->refit_graph = nullptr; }   // it captured the old pointers
     }
+    return VT_OK;
+}
+
+int build_alpha_records(vt_scene* s)
+{
+    if (!s->has_alpha || !s->d_attribs || !s->d_alpha_mats || s->ntris == 0) { s->alpha_ready = false; return VT_OK; }
+    vt_engine* e = s->engine;
+    const int room = ensure_alpha_room(s);       // (a scene without room has no AlphaRecs yet: alpha_ready is false already)
+    if (room != VT_OK) return room;
+    s->alpha_ready = false;
     AlphaRecArgs a{s->d_tris, s->d_attribs, s->d_alpha_mats, s->n_alpha_mats,
                    reinterpret_cast<AlphaRec*>(s->d_records + size_t(s->alpha_base) * 64), s->ntris};
     VT_HIP(launch_alpha_records(a, e->stream));
@@ -484,15 +494,15 @@ int vt_engine_open(int device, vt_engine** out)
     e->tri_threshold = uint32_t(env_long("VT_TRI_THRESHOLD", e->tri_threshold));
     e->fetch_dma = int(env_long("VT_FETCH_DMA", e->fetch_dma));
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->d_slot_ctl), vt_engine::kLaunchSlots * vt_engine::kSlotCtlBytes);
+    if (err == hipSuccess) err = dev_malloc(reinterpret_cast<void**>(&e->d_slot_ctl), vt_engine::kLaunchSlots * vt_engine::kSlotCtlBytes);
     if (err == hipSuccess) err = hipMemset(e->d_slot_ctl, 0, vt_engine::kLaunchSlots * vt_engine::kSlotCtlBytes);
     for (uint32_t k = 0; k < vt_engine::kLaunchSlots && err == hipSuccess; ++k) {
         e->slots[k].d_ctl = reinterpret_cast<uint32_t*>(e->d_slot_ctl + k * vt_engine::kSlotCtlBytes);
         err = hipEventCreateWithFlags(&e->slots[k].done, hipEventDisableTiming);
     }
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_loop, hipEventDisableTiming);
-    if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&e->h_tiny_rays), vt_engine::kTinyRays * sizeof(vt_ray), hipHostMallocMapped);
-    if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&e->h_tiny_out), vt_engine::kTinyRays * sizeof(vt_hit), hipHostMallocMapped);
+    if (err == hipSuccess) err = pinned_malloc(reinterpret_cast<void**>(&e->h_tiny_rays), vt_engine::kTinyRays * sizeof(vt_ray), hipHostMallocMapped);
+    if (err == hipSuccess) err = pinned_malloc(reinterpret_cast<void**>(&e->h_tiny_out), vt_engine::kTinyRays * sizeof(vt_hit), hipHostMallocMapped);
     if (err == hipSuccess) err = hipHostGetDevicePointer(&e->d_tiny_rays, e->h_tiny_rays, 0);
     if (err == hipSuccess) err = hipHostGetDevicePointer(&e->d_tiny_out, e->h_tiny_out, 0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_start);
@@ -543,6 +553,7 @@ void vt_engine_close(vt_engine* e)
     if (e->h_segs_all) (void)hipHostFree(e->h_segs_all);
     if (e->d_slot_ctl) (void)hipFree(e->d_slot_ctl);
     if (e->ev_loop) (void)hipEventDestroy(e->ev_loop);
+    if (e->ev_staged) (void)hipEventDestroy(e->ev_staged);
     if (e->d_rays) (void)hipFree(e->d_rays);
     if (e->d_out) (void)hipFree(e->d_out);
     if (e->d_loop) (void)hipFree(e->d_loop);
@@ -676,7 +687,7 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
         s->record_capacity = std::max<size_t>(has_alpha ? size_t(s->alpha_base) + s->ntris : size_t(s->tri_base) + s->ntris, 2);
         // never empty: idle lanes of the DMA-fetch kernel read record 0, so it must exist (zeros for an empty scene)
         const size_t rec_bytes = s->record_capacity * 64;
-        err = hipMalloc(reinterpret_cast<void**>(&s->d_records), rec_bytes);
+        err = dev_malloc(reinterpret_cast<void**>(&s->d_records), rec_bytes);
         // zeros only where no copy lands: the padding between pairs and triangles (+ the test gap), the AlphaRec room
         if (err == hipSuccess && tri_off > pair_bytes) err = hipMemsetAsync(s->d_records + pair_bytes, 0, tri_off - pair_bytes, e->stream);
         if (err == hipSuccess && rec_bytes > tri_off + tri_bytes) err = hipMemsetAsync(s->d_records + tri_off + tri_bytes, 0, rec_bytes - tri_off - tri_bytes, e->stream);
@@ -703,11 +714,9 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
     s->upload_stats.total_ms = float(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     s->upload_stats.device_ms = s->upload_stats.total_ms - s->upload_stats.copy_ms;
     // a group's scene lives on every device: the BVH is replicated, rays are what is sharded
-    for (vt_engine* p : e->peers) {
-        vt_scene* rep = nullptr;
-        const int rc = vt_scene_upload(p, hsw, &rep);
+    {
+        const int rc = scene_replicate(s, [&](vt_engine* p, vt_scene** rep) { return vt_scene_upload(p, hsw, rep); });
         if (rc != VT_OK) { vt_scene_free(s); return rc; }
-        s->replicas.push_back(rep);
     }
     *out = s;
     return VT_OK;
@@ -857,7 +866,7 @@ int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t dep
     }
     int rc = ensure_bytes(&e->d_loop, &e->d_loop_bytes, loop_need);
     if (rc != VT_OK) return rc;
-    if (!e->h_live) VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_live), 64));
+    if (!e->h_live) VT_HIP(pinned_malloc(reinterpret_cast<void**>(&e->h_live), 64));
     char* base = static_cast<char*>(e->d_loop);
     vt_ray* R[2] = {reinterpret_cast<vt_ray*>(base), reinterpret_cast<vt_ray*>(base + ray_b)};
     uint32_t* I[2] = {reinterpret_cast<uint32_t*>(base + 2 * ray_b), reinterpret_cast<uint32_t*>(base + 2 * ray_b + id_b)};
@@ -927,8 +936,8 @@ static int job_fail(UpdateJob& j, int rc)
 // pinned read-back block of a scene: the finite check's counter and the root pair behind a refit
 static int ensure_verdict_block(vt_scene* s)
 {
-    if (!s->d_bad) VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_bad), 64));
-    if (!s->h_verdict) VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_verdict), 128));
+    if (!s->d_bad) VT_HIP(dev_malloc(reinterpret_cast<void**>(&s->d_bad), 64));
+    if (!s->h_verdict) VT_HIP(pinned_malloc(reinterpret_cast<void**>(&s->h_verdict), 128));
     return VT_OK;
 }
 
@@ -1000,18 +1009,29 @@ static int finish_update(vt_scene* s, const char* who)
 
 // The three phases over every member (replicas first, the root last, as before); the caller sees the root's failure, else the
 // first replica's.  The order log becomes engine option "last_update_early_waits" (tests/fake_group_check.py asserts 0).
+// `stage` (optional) runs once between the two first phases, on the root: input that every member needs goes to the root's device
+// there, the other members fetch it device to device in their enqueue step.
 static int update_every_member(vt_scene* root, const char* who, const std::function<int(vt_scene*)>& prepare,
-                               const std::function<int(vt_scene*)>& enqueue, const std::function<int(vt_scene*)>& after)
+                               const std::function<int(vt_scene*)>& enqueue, const std::function<int(vt_scene*)>& after,
+                               const std::function<int(vt_scene*)>& stage = nullptr)
 {
     std::vector<UpdateJob> jobs;
     if (root) for (vt_scene* rep : root->replicas) { UpdateJob j; j.s = rep; jobs.push_back(j); }
     { UpdateJob j; j.s = root; jobs.push_back(j); }
     t_update_log.clear();
     const auto t_begin = std::chrono::steady_clock::now();
-    for (UpdateJob& j : jobs) {                          // prepare: may block, may allocate
+    bool prepared = true;
+    for (UpdateJob& j : jobs) {                          // prepare: may block, may allocate -- and changes nothing a trace can see
         const int rc = prepare(j.s);
         if (rc == VT_OK) j.active = true;
-        else if (rc > 0) job_fail(j, rc);                // rc < 0: nothing to do for this member (empty scene), not a failure
+        else if (rc > 0) { job_fail(j, rc); prepared = false; }   // rc < 0: nothing to do for this member (empty scene), not a failure
+    }
+    // a member that cannot even prepare (bad arguments, out of memory) stops the call for ALL of them before anything is
+    // rewritten: the members of a group never end up with different geometry because one of them could not allocate
+    if (!prepared) for (UpdateJob& j : jobs) j.active = false;
+    if (stage && jobs.back().active) {
+        const int rc = stage(root);
+        if (rc != VT_OK) { job_fail(jobs.back(), rc); for (UpdateJob& j : jobs) j.active = false; }   // nothing has been rewritten yet
     }
     for (UpdateJob& j : jobs) {                          // enqueue: asynchronous calls only
         if (!j.active) continue;
@@ -1056,7 +1076,6 @@ int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32
         if (n != m->ntris) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: n differs from the scene's triangle count");
         if (n == 0) return -1;
         if (!verts) return fail(VT_ERR_INVALID_ARG, "vt_scene_refit: verts is NULL");
-        if (flags) m->has_alpha = alpha_from_flags;        // new flags replace the old ones: so does the scene's alpha-test state
         vt_engine* e = m->engine;
         DeviceGuard guard(e->device);
         if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_refit: hipSetDevice failed");
@@ -1068,10 +1087,30 @@ int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32
         if (rc == VT_OK && flags) rc = ensure_bytes(&e->d_out, &e->d_out_bytes, n);
         return rc != VT_OK ? rc : ensure_verdict_block(m);
     };
+    // The vertices (36 B per triangle, pageable caller memory: the copy holds the host for its whole length) go up ONCE, to the
+    // root's staging area; the other members of a group fetch them from there, device to device, behind an event -- round 5
+    // uploaded them per member (0.7 ms of host time each for a million triangles, profiles/r5/notes.md section 3).
+    const size_t vert_b = size_t(n) * 9 * sizeof(float);
+    auto stage = [&](vt_scene* root) -> int {
+        vt_engine* e = root->engine;
+        DeviceGuard guard(e->device);
+        if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_refit: hipSetDevice failed");
+        VT_HIP(hipMemcpyAsync(e->d_rays, verts, vert_b, hipMemcpyHostToDevice, e->stream));
+        if (flags) VT_HIP(hipMemcpyAsync(e->d_out, flags, n, hipMemcpyHostToDevice, e->stream));
+        if (!root->replicas.empty()) {
+            if (!e->ev_staged) VT_HIP(hipEventCreateWithFlags(&e->ev_staged, hipEventDisableTiming));
+            VT_HIP(hipEventRecord(e->ev_staged, e->stream));
+        }
+        return VT_OK;
+    };
     auto enqueue = [&](vt_scene* m) -> int {
         vt_engine* e = m->engine;
-        VT_HIP(hipMemcpyAsync(e->d_rays, verts, size_t(n) * 9 * sizeof(float), hipMemcpyHostToDevice, e->stream));
-        if (flags) VT_HIP(hipMemcpyAsync(e->d_out, flags, n, hipMemcpyHostToDevice, e->stream));
+        if (flags) m->has_alpha = alpha_from_flags;        // new flags replace the old ones: so does the scene's alpha-test state
+        if (vt_engine* re = e->root) {                     // a replica: the staged input comes from the root's device
+            VT_HIP(hipStreamWaitEvent(e->stream, re->ev_staged, 0));
+            VT_HIP(hipMemcpyPeerAsync(e->d_rays, e->device, re->d_rays, re->device, vert_b, e->stream));
+            if (flags) VT_HIP(hipMemcpyPeerAsync(e->d_out, e->device, re->d_out, re->device, n, e->stream));
+        }
         VT_HIP(hipMemsetAsync(m->d_bad, 0, 4, e->stream));
         RefitTrisArgs ta{static_cast<const float*>(e->d_rays), flags ? static_cast<const uint8_t*>(e->d_out) : nullptr,
                          m->d_prim_to_slot, m->d_tris, n, m->d_bad};
@@ -1082,7 +1121,7 @@ int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32
     auto after = [&](vt_scene* m) -> int {                 // the flags switched the alpha test on: its records are built now
         return flags && m->has_alpha && !m->alpha_ready ? build_alpha_records(m) : VT_OK;
     };
-    return update_every_member(s, "vt_scene_refit", prepare, enqueue, after);
+    return update_every_member(s, "vt_scene_refit", prepare, enqueue, after, stage);
 }
 
 int vt_scene_set_skin(vt_scene* s, const float* bind_verts, const vt_skin_vertex* skin, const uint32_t* matrix_base, uint32_t n)
@@ -1103,9 +1142,18 @@ int vt_scene_set_skin(vt_scene* s, const float* bind_verts, const vt_skin_vertex
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_set_skin: hipSetDevice failed");
     const size_t vb = size_t(n) * 9 * sizeof(float), sb = size_t(n) * 3 * sizeof(vt_skin_vertex), mb = size_t(n) * sizeof(uint32_t);
     if (!s->d_bind_verts) {
-        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_bind_verts), vb));
-        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_skin), sb));
-        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_matrix_base), mb));
+        // all three or none: d_bind_verts != NULL is what "the scene has skin data" means everywhere else
+        void *v = nullptr, *k = nullptr, *m = nullptr;
+        hipError_t err = dev_malloc(&v, vb);
+        if (err == hipSuccess) err = dev_malloc(&k, sb);
+        if (err == hipSuccess) err = dev_malloc(&m, mb);
+        if (err != hipSuccess) {
+            (void)hipGetLastError();
+            if (v) (void)hipFree(v);
+            if (k) (void)hipFree(k);
+            return fail(VT_ERR_HIP, std::string("vt_scene_set_skin: ") + hipGetErrorString(err));
+        }
+        s->d_bind_verts = static_cast<float*>(v); s->d_skin = static_cast<vt_skin_vertex*>(k); s->d_matrix_base = static_cast<uint32_t*>(m);
         s->bytes += vb + sb + mb;
     }
     VT_HIP(hipMemcpyAsync(s->d_bind_verts, bind_verts, vb, hipMemcpyHostToDevice, e->stream));
@@ -1131,7 +1179,7 @@ int vt_scene_skin_refit(vt_scene* s, const float* bones, const float* binds, uin
         VT_HIP(hipDeviceSynchronize());          // in-flight traces of this scene read the records that are about to change
         if (nmat > m->mats_cap) {
             if (m->d_skin_mats) { VT_HIP(hipFree(m->d_skin_mats)); m->d_skin_mats = nullptr; m->mats_cap = 0; }
-            VT_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_skin_mats), size_t(nmat) * 3 * 64));
+            VT_HIP(dev_malloc(reinterpret_cast<void**>(&m->d_skin_mats), size_t(nmat) * 3 * 64));
             m->mats_cap = nmat;
         }
         return ensure_verdict_block(m);
@@ -1195,7 +1243,7 @@ int vt_scene_set_tri_attribs(vt_scene* s, const vt_tri_attribs* attribs, uint32_
     const size_t bytes = size_t(n) * sizeof(vt_tri_attribs);
     std::lock_guard<std::mutex> host_lock(s->engine->host_mu);   // as vt_scene_refit: one call that rewrites the scene at a time
     if (!s->d_attribs) {
-        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_attribs), bytes));
+        VT_HIP(dev_malloc(reinterpret_cast<void**>(&s->d_attribs), bytes));
         s->bytes += bytes;
     }
     VT_HIP(hipDeviceSynchronize());                  // traces in flight may read the AlphaRecs derived from the old table
@@ -1225,14 +1273,28 @@ int vt_scene_set_alpha(vt_scene* s, const vt_alpha_material* mats, uint32_t nmat
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_set_alpha: hipSetDevice failed");
     std::lock_guard<std::mutex> host_lock(e->host_mu);           // as vt_scene_refit: one call that rewrites the scene at a time
     VT_HIP(hipDeviceSynchronize());                              // no launch may still read the old tables
-    if (s->d_alpha_mats) { VT_HIP(hipFree(s->d_alpha_mats)); s->d_alpha_mats = nullptr; }
-    if (s->d_alpha_texels) { VT_HIP(hipFree(s->d_alpha_texels)); s->d_alpha_texels = nullptr; }
-    VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_alpha_mats), size_t(nmats) * sizeof(vt_alpha_material)));
-    VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_alpha_texels), std::max<uint64_t>(ntexels, 16)));
-    VT_HIP(hipMemcpy(s->d_alpha_mats, mats, size_t(nmats) * sizeof(vt_alpha_material), hipMemcpyHostToDevice));
-    if (ntexels) VT_HIP(hipMemcpy(s->d_alpha_texels, texels, ntexels, hipMemcpyHostToDevice));
+    // room for the AlphaRecs and the new tables first, then the swap: a call that runs out of memory leaves the scene as it was
+    // (old tables, old AlphaRecs)
+    if (const int room = ensure_alpha_room(s); room != VT_OK) return room;
+    const size_t mats_b = size_t(nmats) * sizeof(vt_alpha_material), tex_b = std::max<uint64_t>(ntexels, 16);
+    void *d_mats = nullptr, *d_tex = nullptr;
+    hipError_t err = dev_malloc(&d_mats, mats_b);
+    if (err == hipSuccess) err = dev_malloc(&d_tex, tex_b);
+    if (err == hipSuccess) err = hipMemcpy(d_mats, mats, mats_b, hipMemcpyHostToDevice);
+    if (err == hipSuccess && ntexels) err = hipMemcpy(d_tex, texels, ntexels, hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        if (d_mats) (void)hipFree(d_mats);
+        if (d_tex) (void)hipFree(d_tex);
+        return fail(VT_ERR_HIP, std::string("vt_scene_set_alpha: ") + hipGetErrorString(err));
+    }
+    if (s->d_alpha_mats) { (void)hipFree(s->d_alpha_mats); s->bytes -= s->alpha_table_bytes; }
+    if (s->d_alpha_texels) (void)hipFree(s->d_alpha_texels);
+    s->d_alpha_mats = static_cast<vt_alpha_material*>(d_mats);
+    s->d_alpha_texels = static_cast<uint8_t*>(d_tex);
     s->n_alpha_mats = nmats;
-    s->bytes += size_t(nmats) * sizeof(vt_alpha_material) + ntexels;
+    s->alpha_table_bytes = mats_b + ntexels;
+    s->bytes += s->alpha_table_bytes;
     return build_alpha_records(s);
 }
 
@@ -1320,6 +1382,81 @@ int vt_engine_launch_info(vt_engine* e, uint32_t* blocks, uint32_t* threads, uin
 namespace vt {
 
 float scene_packet_radius2(const vt_node_pair& root) { return packet_radius2(root); }
+
+// Rebuild on a group (reference: one tree per AccelStruct, source/objects/AccelStruct.cpp:762-775; here one copy per GPU).  The
+// root's scene is complete on its device; every other member gets the same bytes -- records, triangle -> slot table, level lists --
+// by device-to-device copies on its own stream (xGMI between the GPUs of a node), in the three phases of the group-wide refits:
+// prepare (allocations on every member), enqueue (asynchronous copies only), finish (the waits).  The host uploads the tree ONCE;
+// round 5 uploaded and re-numbered it per member, one member after the other.
+int scene_replicate(vt_scene* s, const std::function<int(vt_engine*, vt_scene**)>& rebuild)
+{
+    vt_engine* e = s->engine;
+    if (e->peers.empty()) return VT_OK;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const size_t rec_b = s->record_capacity * 64, slot_b = size_t(s->ntris) * 4, lvl_b = size_t(s->npairs) * 4;
+    std::vector<vt_scene*> reps;
+    int rc = VT_OK;
+    for (vt_engine* p : e->peers) {                       // prepare: the shells and their device arrays
+        DeviceGuard guard(p->device);
+        if (!guard.ok) { rc = fail(VT_ERR_HIP, "scene replica: hipSetDevice failed"); break; }
+        vt_scene* r = new vt_scene();
+        r->engine = p;
+        r->has_alpha = s->has_alpha; r->npairs = s->npairs; r->ntris = s->ntris; r->max_depth = s->max_depth;
+        r->root_leaf_count = s->root_leaf_count; r->tri_base = s->tri_base; r->alpha_base = s->alpha_base;
+        r->record_capacity = s->record_capacity; r->coherent_radius2 = s->coherent_radius2; r->level_begin = s->level_begin;
+        r->upload_stats = s->upload_stats;
+        r->host_copies = s->host_copies;                  // the host copies the root was uploaded from go stale with this member's refits too
+        p->scenes.push_back(r);
+        reps.push_back(r);
+        hipError_t err = dev_malloc(reinterpret_cast<void**>(&r->d_records), rec_b);
+        if (err == hipSuccess && slot_b) err = dev_malloc(reinterpret_cast<void**>(&r->d_prim_to_slot), slot_b);
+        if (err == hipSuccess && lvl_b) err = dev_malloc(reinterpret_cast<void**>(&r->d_level_pairs), lvl_b);
+        if (err != hipSuccess) { (void)hipGetLastError(); rc = fail(VT_ERR_HIP, std::string("scene replica: ") + hipGetErrorString(err)); break; }
+        r->d_tris = reinterpret_cast<vt_tri64*>(r->d_records + size_t(r->tri_base) * 64);
+        r->bytes = rec_b + slot_b + lvl_b;
+    }
+    std::string log;                                      // 'E' a member's copies are enqueued, 'W' a member is waited for
+    bool copy_refused = false;
+    if (rc == VT_OK) {
+        for (vt_scene* r : reps) {                        // enqueue: asynchronous copies only (the root's stream is idle: its upload ended with a wait)
+            vt_engine* p = r->engine;
+            DeviceGuard guard(p->device);
+            hipError_t err = guard.ok ? hipSuccess : hipErrorInvalidDevice;
+            if (err == hipSuccess) err = hipMemcpyPeerAsync(r->d_records, p->device, s->d_records, e->device, rec_b, p->stream);
+            if (err == hipSuccess && slot_b) err = hipMemcpyPeerAsync(r->d_prim_to_slot, p->device, s->d_prim_to_slot, e->device, slot_b, p->stream);
+            if (err == hipSuccess && lvl_b) err = hipMemcpyPeerAsync(r->d_level_pairs, p->device, s->d_level_pairs, e->device, lvl_b, p->stream);
+            log.push_back('E');
+            if (err != hipSuccess) { (void)hipGetLastError(); copy_refused = true; rc = fail(VT_ERR_HIP, std::string("scene replica: ") + hipGetErrorString(err)); break; }
+        }
+    }
+    const auto t_enqueued = std::chrono::steady_clock::now();
+    for (vt_scene* r : reps) {                            // finish: the first host waits of the call (also behind a failure: nothing may be in flight when the shells go)
+        DeviceGuard guard(r->engine->device);
+        if (log.find('E') != std::string::npos) log.push_back('W');
+        const hipError_t err = hipStreamSynchronize(r->engine->stream);
+        if (err != hipSuccess && rc == VT_OK) { copy_refused = true; rc = fail(VT_ERR_HIP, std::string("scene replica: ") + hipGetErrorString(err)); }
+    }
+    const size_t last_e = log.rfind('E');
+    e->last_update_members = uint32_t(reps.size()) + 1;
+    e->last_update_early_waits = last_e == std::string::npos ? 0 : uint32_t(std::count(log.begin(), log.begin() + long(last_e), 'W'));
+    e->last_update_enqueue_us = uint32_t(std::chrono::duration<double, std::micro>(t_enqueued - t_begin).count());
+    e->last_update_wait_us = uint32_t(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enqueued).count());
+    if (rc != VT_OK) {
+        const std::string msg = vt_last_error();
+        for (vt_scene* r : reps) vt_scene_free(r);
+        reps.clear();
+        if (!copy_refused || !rebuild) return fail(rc, msg);
+        // a runtime that refuses copies between these two devices: every member is uploaded from the host instead (round 5's way)
+        for (vt_engine* p : e->peers) {
+            vt_scene* rep = nullptr;
+            rc = rebuild(p, &rep);
+            if (rc != VT_OK) { const std::string m2 = vt_last_error(); for (vt_scene* r : reps) vt_scene_free(r); return fail(rc, m2); }
+            reps.push_back(rep);
+        }
+    }
+    s->replicas = reps;
+    return VT_OK;
+}
 
 int engine_launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, void* d_occ, void* d_stats, bool any_hit, bool stats,
                   hipStream_t stream)

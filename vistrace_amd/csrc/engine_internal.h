@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -80,6 +81,7 @@ struct vt_engine {
     std::mutex host_mu;                      // the host-pointer entry points share the staging buffers
     hipEvent_t ev_loop = nullptr;            // behind the last vt_bounce_loop_dev (its queues are engine-wide)
     bool       loop_used = false;
+    hipEvent_t ev_staged = nullptr;          // root of a group: behind the upload of a refit's vertices into d_rays (the replicas copy from there)
 
     // staging for the host-pointer entry points
     void*  d_rays = nullptr;  size_t d_rays_bytes = 0;
@@ -94,10 +96,11 @@ struct vt_engine {
     char* h_stage_in[kStageBufs]  = {};
     char* h_stage_out[kStageBufs] = {};
     hipStream_t s_in = nullptr, s_out = nullptr;
+    bool pipeline_ready = false;             // streams, staging buffers and events above all exist (batch.hip: ensure_host_pipeline)
     hipEvent_t ev_in[kStageBufs] = {}, ev_k[kStageBufs] = {}, ev_out[kStageBufs] = {};
     // Rebuild (scene_build.hip): staging block of the device lineariser / index tables, kept across Rebuilds; pinned read-back
     void*  d_build = nullptr;  size_t d_build_bytes = 0;
-    char*  h_build = nullptr;
+    char*  h_build = nullptr;  size_t h_build_bytes = 0;
     // bounce loop: two ray queues, two path-id queues, the queue's hit records, block offsets, live counter
     void*  d_loop = nullptr;  size_t d_loop_bytes = 0;
     uint32_t* h_live = nullptr;           // pinned read-back of the live-path count
@@ -174,6 +177,7 @@ struct vt_scene {
     vt_alpha_material* d_alpha_mats = nullptr;
     uint8_t*           d_alpha_texels = nullptr;
     uint32_t           n_alpha_mats = 0;
+    uint64_t           alpha_table_bytes = 0; // what the two tables add to `bytes`
     // ... and what the kernels read: one 64-B AlphaRec per triangle slot behind the triangles in d_records (built from
     // the two side tables by alpha_records_kernel whenever either changes; trace_kernels.h)
     uint32_t           alpha_base = 0;        // record index of slot 0's AlphaRec; 0 = no room reserved yet
@@ -235,6 +239,19 @@ struct DeviceGuard {
 
 namespace vt {
 
+// EVERY device / pinned-host allocation of the library goes through these two (tests/test_abi_symbols.py greps for strays): one
+// place for the fault injection of include/vistrace_hip.h's "Test hooks" (VT_TEST_FAIL_ALLOC); a plain call otherwise.
+inline hipError_t dev_malloc(void** p, size_t bytes)
+{
+    if (test_alloc_fails()) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipMalloc(p, bytes);
+}
+inline hipError_t pinned_malloc(void** p, size_t bytes, unsigned flags = hipHostMallocDefault)
+{
+    if (test_alloc_fails()) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipHostMalloc(p, bytes, flags);
+}
+
 int ensure_bytes(void** ptr, size_t* have, size_t need);
 // one batch of a launch: d_out = its vt_hit array (closest hit) or its byte array (any hit); image_width as vt_batch_desc
 struct BatchReq { const void* d_rays; void* d_out; uint64_t n; uint32_t image_width; };
@@ -247,6 +264,9 @@ int engine_launch(vt_scene* s, const void* d_rays, uint64_t n, void* d_hits, voi
 float scene_packet_radius2(const vt_node_pair& root);
 // scene_build.hip: prim_to_slot and the level lists of a scene whose records are on the device (h_pair_depth: depth of every pair)
 int scene_index_tables(vt_scene* s, const uint32_t* h_pair_depth);
+// engine.hip: the scene of a group's root, complete on its device, is copied device to device to every other member
+// (s->replicas); `rebuild` uploads it to one member from the host instead -- only used if a peer copy is refused
+int scene_replicate(vt_scene* s, const std::function<int(vt_engine*, vt_scene**)>& rebuild);
 // batch.hip: the open batch sets of a scene that is being freed lose their scene (their later calls fail, abort still frees them)
 void batch_sets_detach(vt_scene* s);
 // the host-pointer path of ONE device: staging copies + launch(es) + copy-out, synchronous

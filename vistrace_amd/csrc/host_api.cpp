@@ -45,6 +45,36 @@ const char* test_hook(const char* name)
     return v;
 }
 
+// ---- fault injection on the allocation paths (include/vistrace_hip.h, "Test hooks") ------------------------------------------
+namespace {
+std::atomic<int>      g_alloc_hooks{-1};       // -1 unknown, 0 off, 1 on (VT_ENABLE_TEST_HOOKS=1, read once)
+std::atomic<uint64_t> g_alloc_count{0};        // attempts since the hook was last armed
+std::atomic<uint64_t> g_alloc_fail_at{0};      // 0 = none
+
+bool alloc_hooks_on()
+{
+    int on = g_alloc_hooks.load(std::memory_order_acquire);
+    if (on < 0) {
+        const char* en = std::getenv("VT_ENABLE_TEST_HOOKS");
+        on = en && en[0] == '1' && en[1] == '\0' ? 1 : 0;
+        if (on) if (const char* v = test_hook("VT_TEST_FAIL_ALLOC")) g_alloc_fail_at.store(std::strtoull(v, nullptr, 10), std::memory_order_release);
+        g_alloc_hooks.store(on, std::memory_order_release);
+    }
+    return on == 1;
+}
+} // namespace
+
+bool test_alloc_fails()
+{
+    if (!alloc_hooks_on()) return false;
+    const uint64_t mine = g_alloc_count.fetch_add(1, std::memory_order_acq_rel) + 1;
+    uint64_t at = g_alloc_fail_at.load(std::memory_order_acquire);
+    if (at == 0 || mine != at) return false;
+    g_alloc_fail_at.store(0, std::memory_order_release);          // once: what cleans up or retries afterwards allocates normally
+    std::fprintf(stderr, "[vistrace_hip] TEST HOOK: allocation %llu fails on purpose\n", static_cast<unsigned long long>(mine));
+    return true;
+}
+
 void parallel_copy(void* dst, const void* src, size_t bytes)
 {
     const long long piece = 1 << 20;
@@ -190,5 +220,19 @@ const vt_tri64* vt_host_scene_tris(const vt_host_scene* hs)
 {
     return hs && !hs->hs.tris.empty() ? hs->hs.tris.data() : nullptr;
 }
+
+} // extern "C"
+
+extern "C" {
+
+int vt_test_fail_alloc(uint64_t k)
+{
+    if (!vt::alloc_hooks_on()) return vt::fail(VT_ERR_UNSUPPORTED, "vt_test_fail_alloc: test hooks are off (VT_ENABLE_TEST_HOOKS=1)");
+    vt::g_alloc_count.store(0, std::memory_order_release);
+    vt::g_alloc_fail_at.store(k, std::memory_order_release);
+    return VT_OK;
+}
+
+uint64_t vt_test_alloc_count(void) { return vt::alloc_hooks_on() ? vt::g_alloc_count.load(std::memory_order_acquire) : 0; }
 
 } // extern "C"

@@ -56,20 +56,22 @@ __global__ __launch_bounds__(256) void lin_alpha_flag(const vt_tri64* tris, uint
     if (i < n && (tris[i].flags & VT_TRI_ALPHATEST)) status[2] = 1;
 }
 
+// parent[] arrives filled with kNone (a node no inner node points to stays a root of its own walk and the totals below the real
+// root come out short: "malformed tree").  A child index that does not lie behind its parent, lies outside the array or is claimed
+// by two parents is an error; the kernels behind this one do nothing once an error bit is up, so no walk ever follows a bad index.
 __global__ __launch_bounds__(256) void lin_parents(LinArgs a)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= a.n_nodes) return;
-    if (i == 0) a.parent[0] = kNone;
     const vt_bvh_node me = a.nodes[i];
     if (me.prim_count != 0) {
         if (uint64_t(me.first) + me.prim_count > a.n_prims) atomicOr(&a.status[0], kErrPrim);
         return;
     }
     // children sit side by side behind their parent (v1 layout; both builders emit children at higher indices)
-    if (me.first == 0 || uint64_t(me.first) + 1 >= a.n_nodes) { atomicOr(&a.status[0], kErrChild); return; }
-    a.parent[me.first] = i;
-    a.parent[me.first + 1] = i;
+    if (me.first <= i || uint64_t(me.first) + 1 >= a.n_nodes) { atomicOr(&a.status[0], kErrChild); return; }
+    if (atomicCAS(&a.parent[me.first], kNone, i) != kNone || atomicCAS(&a.parent[me.first + 1], kNone, i) != kNone)
+        atomicOr(&a.status[0], kErrChild);
 }
 
 // Bottom-up counts without fences: the two walks that meet at a node exchange their counts THROUGH the atomic itself.  A walk adds
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void lin_parents(LinArgs a)
 __global__ __launch_bounds__(256) void lin_counts(LinArgs a)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= a.n_nodes) return;
+    if (i >= a.n_nodes || a.status[0] != 0) return;        // (an error bit of lin_parents: the parent links are not to be trusted)
     const uint32_t pc = a.nodes[i].prim_count;
     if (pc == 0) return;                                   // the leaves start the walks
     unsigned long long mine = pc;                          // a leaf: no inner nodes, pc triangles (never 0: a packed value marks an arrival)
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void lin_counts(LinArgs a)
 __global__ __launch_bounds__(256) void lin_offsets(LinArgs a)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= a.n_nodes) return;
+    if (i >= a.n_nodes || a.status[0] != 0) return;
     const bool leaf = a.nodes[i].prim_count != 0;
     uint32_t x = i, ap = 0, at = 0, d = 0;
     bool first = true;
@@ -188,6 +190,14 @@ __global__ __launch_bounds__(256) void keys_from_depth(const uint32_t* depth, ui
     vals[p] = p;
 }
 
+constexpr uint32_t kLevelWord = 64, kRootWord = 16;   // words of the pinned read-back block: level starts from 64 on, the root pair at 16
+constexpr unsigned kMaxDepthBits = 17;                // kMaxWalk + 1 levels at most
+inline unsigned key_bits(uint32_t max_depth)          // radix-sort bits that cover the keys 0 .. max_depth - 1
+{
+    unsigned b = 1;
+    while (b < 32 && (uint64_t(1) << b) < max_depth) ++b;
+    return std::max(b, 8u);
+}
 inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
 inline uint32_t blocks_for(uint64_t n) { return uint32_t((n + 255) / 256); }
 inline double ms_since(std::chrono::steady_clock::time_point t0)
@@ -202,19 +212,33 @@ int build_level_lists(vt_scene* s, uint32_t* keys, uint32_t* vals, uint32_t* key
     vt_engine* e = s->engine;
     const uint32_t np = s->npairs, md = s->max_depth;
     size_t need = sort_tmp_bytes;
-    VT_HIP(rocprim::radix_sort_pairs(sort_tmp, need, keys, keys_out, vals, s->d_level_pairs, np, 0, 8, e->stream));
+    VT_HIP(rocprim::radix_sort_pairs(sort_tmp, need, keys, keys_out, vals, s->d_level_pairs, np, 0, key_bits(md), e->stream));
     hipLaunchKernelGGL(level_starts, dim3(blocks_for(np)), dim3(256), 0, e->stream, keys_out, np, begin);
     VT_HIP(hipGetLastError());
     VT_HIP(hipMemcpyAsync(h_begin, begin, size_t(md) * 4, hipMemcpyDeviceToHost, e->stream));
     return VT_OK;
 }
 
+// sort scratch for np pairs, whatever the tree's depth turns out to be (8 key bits cover 255 levels, kMaxDepthBits the deepest
+// tree the walks accept)
 size_t sort_tmp_bytes_for(uint32_t np)
 {
-    size_t need = 0;
+    size_t need = 0, need_deep = 0;
     uint32_t* nul = nullptr;
     (void)rocprim::radix_sort_pairs(nullptr, need, nul, nul, nul, nul, np, 0, 8, hipStream_t(nullptr));
-    return al256(need) + 256;
+    (void)rocprim::radix_sort_pairs(nullptr, need_deep, nul, nul, nul, nul, np, 0, kMaxDepthBits, hipStream_t(nullptr));
+    return al256(std::max(need, need_deep)) + 256;
+}
+
+// pinned read-back block of the engine: 64 words of status / counts / the root pair, then one word per tree level
+int ensure_readback(vt_engine* e, uint32_t levels)
+{
+    const size_t need = std::max<size_t>(4096, (size_t(kLevelWord) + levels + 1) * 4);
+    if (e->h_build && e->h_build_bytes >= need) return VT_OK;
+    if (e->h_build) { (void)hipHostFree(e->h_build); e->h_build = nullptr; e->h_build_bytes = 0; }
+    VT_HIP(pinned_malloc(reinterpret_cast<void**>(&e->h_build), need));
+    e->h_build_bytes = need;
+    return VT_OK;
 }
 
 } // namespace
@@ -227,12 +251,12 @@ int scene_index_tables(vt_scene* s, const uint32_t* h_pair_depth)
 {
     vt_engine* e = s->engine;
     const uint32_t np = s->npairs, nt = s->ntris, md = s->max_depth;
-    if (md > 255) return fail(VT_ERR_UNSUPPORTED, "vt_scene_upload: the tree is deeper than 255 levels");
+    if (md > uint32_t(kMaxWalk)) return fail(VT_ERR_UNSUPPORTED, "vt_scene_upload: the tree is deeper than 65536 levels");
     const size_t sort_b = np ? sort_tmp_bytes_for(np) : 0;
     const size_t need = 5 * al256(size_t(np) * 4) + al256(size_t(md + 1) * 4) + sort_b + 512;
     int rc = ensure_bytes(&e->d_build, &e->d_build_bytes, need);
+    if (rc == VT_OK) rc = ensure_readback(e, md);
     if (rc != VT_OK) return rc;
-    if (!e->h_build) VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_build), 4096));
     char* base = static_cast<char*>(e->d_build);
     uint32_t* status = reinterpret_cast<uint32_t*>(base);
     char* cur = base + 256;
@@ -245,19 +269,19 @@ int scene_index_tables(vt_scene* s, const uint32_t* h_pair_depth)
     void* sort_tmp = take(sort_b);
     VT_HIP(hipMemsetAsync(status, 0, 256, e->stream));
     if (nt) {
-        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_prim_to_slot), size_t(nt) * 4));
+        VT_HIP(dev_malloc(reinterpret_cast<void**>(&s->d_prim_to_slot), size_t(nt) * 4));
         s->bytes += size_t(nt) * 4;
         hipLaunchKernelGGL(slots_from_records, dim3(blocks_for(nt)), dim3(256), 0, e->stream, s->d_tris, nt, s->d_prim_to_slot, status);
         VT_HIP(hipGetLastError());
     }
     uint32_t* h = reinterpret_cast<uint32_t*>(e->h_build);
     if (np) {
-        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_level_pairs), size_t(np) * 4));
+        VT_HIP(dev_malloc(reinterpret_cast<void**>(&s->d_level_pairs), size_t(np) * 4));
         s->bytes += size_t(np) * 4;
         VT_HIP(hipMemcpyAsync(depth, h_pair_depth, size_t(np) * 4, hipMemcpyHostToDevice, e->stream));
         hipLaunchKernelGGL(keys_from_depth, dim3(blocks_for(np)), dim3(256), 0, e->stream, depth, np, md, keys, vals);
         VT_HIP(hipGetLastError());
-        rc = build_level_lists(s, keys, vals, keys_out, begin, sort_tmp, sort_b, h + 64);
+        rc = build_level_lists(s, keys, vals, keys_out, begin, sort_tmp, sort_b, h + kLevelWord);
         if (rc != VT_OK) return rc;
     }
     VT_HIP(hipMemcpyAsync(h, status, 16, hipMemcpyDeviceToHost, e->stream));
@@ -265,7 +289,7 @@ int scene_index_tables(vt_scene* s, const uint32_t* h_pair_depth)
     if (h[0] & kErrPrim) return fail(VT_ERR_INVALID_ARG, "vt_scene_upload: bad prim index");
     s->level_begin.clear();
     if (np) {
-        for (uint32_t k = 0; k < md; ++k) s->level_begin.push_back(h[64 + k]);
+        for (uint32_t k = 0; k < md; ++k) s->level_begin.push_back(h[kLevelWord + k]);
         s->level_begin.push_back(np);
     }
     return VT_OK;
@@ -295,7 +319,9 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
     const auto t_begin = std::chrono::steady_clock::now();
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(VT_ERR_HIP, "vt_scene_upload_tree: hipSetDevice failed");
-    std::lock_guard<std::mutex> host_lock(e->host_mu);
+    // (released before the scene goes to the group's other members: a call holds ONE member's lock at a time, or all of them
+    // in the fixed order of update_every_member -- never a root's while it asks for a replica's)
+    std::unique_lock<std::mutex> host_lock(e->host_mu);
     const uint32_t np = (N - 1) / 2;
     uint64_t gap = 0;                                        // test hook, as vt_scene_upload (include/vistrace_hip.h, "Test hooks")
     if (const char* env = test_hook("VT_TEST_RECORD_GAP")) gap = std::strtoull(env, nullptr, 10) & ~uint64_t(1);
@@ -303,11 +329,12 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
 
     // ---- staging block: the tree as the builder left it, per-node scratch, sort scratch ---------------------------------------
     const size_t sort_b = sort_tmp_bytes_for(np);
+    const size_t begin_b = (size_t(std::min<uint32_t>(np, uint32_t(kMaxWalk) + 1u)) + 1) * 4;      // one word per tree level, whatever the depth
     const size_t need = 512 + al256(size_t(N) * 32) + al256(size_t(M) * 4) + al256(size_t(ntris) * 64) + 6 * al256(size_t(N) * 4) + al256(size_t(N) * 8) +
-                        3 * al256(size_t(np) * 4) + al256(1024) + sort_b;
+                        3 * al256(size_t(np) * 4) + al256(begin_b) + sort_b;
     int rc = ensure_bytes(&e->d_build, &e->d_build_bytes, need);
+    if (rc == VT_OK) rc = ensure_readback(e, 0);
     if (rc != VT_OK) return rc;
-    if (!e->h_build) VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_build), 4096));
     char* base = static_cast<char*>(e->d_build);
     char* cur = base + 512;
     auto take = [&](size_t bytes) { char* p = cur; cur += al256(bytes); return p; };
@@ -323,7 +350,7 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
     uint32_t* keys = reinterpret_cast<uint32_t*>(take(size_t(np) * 4));
     uint32_t* vals = reinterpret_cast<uint32_t*>(take(size_t(np) * 4));
     uint32_t* keys_out = reinterpret_cast<uint32_t*>(take(size_t(np) * 4));
-    uint32_t* begin = reinterpret_cast<uint32_t*>(take(1024));
+    uint32_t* begin = reinterpret_cast<uint32_t*>(take(begin_b));
     void* sort_tmp = take(sort_b);
     const double alloc_ms = ms_since(t_begin);
 
@@ -332,6 +359,7 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
     hipStream_t st = e->stream;
     VT_HIP(hipMemsetAsync(a.status, 0, 512, st));
     VT_HIP(hipMemsetAsync(a.acc, 0, size_t(N) * 8, st));
+    VT_HIP(hipMemsetAsync(a.parent, 0xFF, size_t(N) * 4, st));                  // kNone: lin_parents claims children with a CAS
     VT_HIP(hipMemcpyAsync(d_nodes, bvh.nodes.data(), size_t(N) * 32, hipMemcpyHostToDevice, st));
     VT_HIP(hipMemcpyAsync(d_prims, bvh.prim_indices.data(), size_t(M) * 4, hipMemcpyHostToDevice, st));
     VT_HIP(hipMemcpyAsync(d_tris_in, tris, size_t(ntris) * 64, hipMemcpyHostToDevice, st));
@@ -351,7 +379,9 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
     const bool has_alpha = h[2] != 0;
     if (err != 0 || h[4] != np || h[5] != ntris || max_depth == 0)
         return fail(VT_ERR_INVALID_ARG, "vt_scene_upload_tree: malformed tree");
-    if (max_depth > 255) return fail(VT_ERR_UNSUPPORTED, "vt_scene_upload_tree: the tree is deeper than 255 levels");
+    rc = ensure_readback(e, max_depth);          // (h is not read again before the level starts have come back)
+    if (rc != VT_OK) return rc;
+    h = reinterpret_cast<uint32_t*>(e->h_build);
 
     // ---- the scene: records (pairs | triangles | room for AlphaRecs), index tables ---------------------------------------------
     vt_scene* s = new vt_scene();
@@ -365,9 +395,9 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
     if (has_alpha) s->alpha_base = (s->tri_base + ntris + 1u) & ~1u;
     s->record_capacity = std::max<size_t>(has_alpha ? size_t(s->alpha_base) + ntris : size_t(s->tri_base) + ntris, 2);
     const size_t rec_bytes = s->record_capacity * 64;
-    hipError_t herr = hipMalloc(reinterpret_cast<void**>(&s->d_records), rec_bytes);
-    if (herr == hipSuccess) herr = hipMalloc(reinterpret_cast<void**>(&s->d_prim_to_slot), size_t(ntris) * 4);
-    if (herr == hipSuccess) herr = hipMalloc(reinterpret_cast<void**>(&s->d_level_pairs), size_t(np) * 4);
+    hipError_t herr = dev_malloc(reinterpret_cast<void**>(&s->d_records), rec_bytes);
+    if (herr == hipSuccess) herr = dev_malloc(reinterpret_cast<void**>(&s->d_prim_to_slot), size_t(ntris) * 4);
+    if (herr == hipSuccess) herr = dev_malloc(reinterpret_cast<void**>(&s->d_level_pairs), size_t(np) * 4);
     if (herr != hipSuccess) {
         e->scenes.push_back(s);
         vt_scene_free(s);
@@ -385,19 +415,19 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
     hipLaunchKernelGGL(lin_emit, dim3(blocks_for(N)), dim3(256), 0, st, a, reinterpret_cast<vt_node_pair*>(s->d_records), s->d_tris,
                        s->d_prim_to_slot, keys, vals, max_depth);
     rc = hipGetLastError() == hipSuccess ? VT_OK : fail(VT_ERR_HIP, "vt_scene_upload_tree: kernel launch failed");
-    if (rc == VT_OK) rc = build_level_lists(s, keys, vals, keys_out, begin, sort_tmp, sort_b, h + 64);
+    if (rc == VT_OK) rc = build_level_lists(s, keys, vals, keys_out, begin, sort_tmp, sort_b, h + kLevelWord);
     if (rc == VT_OK) {
         herr = hipMemcpyAsync(h + 8, a.status, 4, hipMemcpyDeviceToHost, st);
-        if (herr == hipSuccess) herr = hipMemcpyAsync(h + 512, s->d_records, sizeof(vt_node_pair), hipMemcpyDeviceToHost, st);   // the root pair: packet radius
+        if (herr == hipSuccess) herr = hipMemcpyAsync(h + kRootWord, s->d_records, sizeof(vt_node_pair), hipMemcpyDeviceToHost, st);   // the root pair: packet radius
         if (herr == hipSuccess) herr = hipStreamSynchronize(st);
         if (herr != hipSuccess) rc = fail(VT_ERR_HIP, std::string("vt_scene_upload_tree: ") + hipGetErrorString(herr));
     }
     if (rc == VT_OK && h[8] != 0) rc = fail(VT_ERR_INVALID_ARG, "vt_scene_upload_tree: bad prim index");
     if (rc != VT_OK) { vt_scene_free(s); return rc; }
-    for (uint32_t k = 0; k < max_depth; ++k) s->level_begin.push_back(h[64 + k]);
+    for (uint32_t k = 0; k < max_depth; ++k) s->level_begin.push_back(h[kLevelWord + k]);
     s->level_begin.push_back(np);
     vt_node_pair root;
-    std::memcpy(&root, h + 512, sizeof(root));
+    std::memcpy(&root, h + kRootWord, sizeof(root));
     s->coherent_radius2 = scene_packet_radius2(root);
     s->upload_stats.alloc_ms = float(alloc_ms);
     s->upload_stats.copy_ms = float(copy_issue_ms);
@@ -406,13 +436,11 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
     s->upload_stats.bytes_h2d = uint64_t(N) * 32 + uint64_t(M) * 4 + uint64_t(ntris) * 64;
     s->upload_stats.linearised_on_device = 1;
 
-    // a group's scene lives on every device: each member numbers its own copy
-    for (vt_engine* p : e->peers) {
-        vt_scene* rep = nullptr;
-        rc = vt_scene_upload_tree(p, bvhw, tris, ntris, &rep);
-        if (rc != VT_OK) { vt_scene_free(s); return rc; }
-        s->replicas.push_back(rep);
-    }
+    host_lock.unlock();
+    // a group's scene lives on every device: the finished records and index tables go from this device to the
+    // others as device-to-device copies (engine.hip: scene_replicate) -- the host uploads the tree once
+    rc = scene_replicate(s, [&](vt_engine* p, vt_scene** rep) { return vt_scene_upload_tree(p, bvhw, tris, ntris, rep); });
+    if (rc != VT_OK) { vt_scene_free(s); return rc; }
     s->upload_stats.total_ms = float(ms_since(t_begin));
     *out = s;
     return VT_OK;

@@ -163,7 +163,7 @@ int vt_scene_set_tri_frames(vt_scene* s, const vt_tri_frame* frames, uint32_t n)
     std::lock_guard<std::mutex> host_lock(s->engine->host_mu);   // as the other calls that rewrite a scene's tables
     if (!s->d_frames_bind) {
         // bind-pose and current frames in one block: the current ones are rewritten by every vt_scene_skin_refit
-        VT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_frames_bind), 2 * bytes));
+        VT_HIP(dev_malloc(reinterpret_cast<void**>(&s->d_frames_bind), 2 * bytes));
         s->d_frames = s->d_frames_bind + n;
         s->bytes += 2 * bytes;
     }

@@ -55,7 +55,10 @@
 //   4 pending leaf range drained from the back (right leaf before left, descending slots)
 //   5 plain 1/x instead of safe_inverse    6 slab entry without the tmin term    7 node accepted on first < second
 //   8 hit needs u > 0                      9 back face culled on n.d >= 0       10 stack entries beyond the LDS part hold the near child
-//  11 hit accepted on t > tmin            12 w = 1 - (u + v)
+//  11 hit accepted on t > tmin            12 w = 1 - (u + v)                   13 FRONT faces culled (n.d < 0)
+//  14 hit needs v > 0                     15 hit needs w > 0                   16 stack entry `lds_entries` still written to LDS
+// (9 is an EQUIVALENT mutant, kept as the record of why: with n.d == +-0 the test goes on to inv_det = +-inf, and then u, v are
+//  NaN or infinite -- if both are +inf, w = 1 - u - v is -inf -- so the triangle is rejected either way: no input tells 9 apart.)
 #ifdef VT_MUTANT
 #define VT_MUT(k, wrong, right) ((VT_MUTANT == (k)) ? (wrong) : (right))
 extern "C" __attribute__((visibility("default"))) int vt_mutant(void) { return VT_MUTANT; }
@@ -601,7 +604,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             const uint32_t tprim = __float_as_uint(q3.x), tflags = __float_as_uint(q3.y);
 
             const float nDotDir = (nx * L.dx + ny * L.dy) + nz * L.dz;                 // :173
-            const bool culled = (tflags & VT_TRI_CULL_BACKFACE) && VT_MUT(9, nDotDir >= 0.0f, nDotDir > 0.0f);   // :174
+            const bool culled = (tflags & VT_TRI_CULL_BACKFACE) && VT_MUT(13, nDotDir < 0.0f, VT_MUT(9, nDotDir >= 0.0f, nDotDir > 0.0f));   // :174
             const float cx = p0x - L.ox, cy = p0y - L.oy, cz = p0z - L.oz;             // :176
             const float rx = L.dy * cz - L.dz * cy;                                    // :177
             const float ry = L.dz * cx - L.dx * cz;
@@ -611,7 +614,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             const float v = ((rx * e1x + ry * e1y) + rz * e1z) * inv_det;              // :181
             const float w = VT_MUT(12, 1.0f - (u + v), 1.0f - u - v);                  // :182
             const float t = ((nx * cx + ny * cy) + nz * cz) * inv_det;                 // :188
-            bool hit = !culled && VT_MUT(8, u > 0.0f, u >= 0.0f) && v >= 0.0f && w >= 0.0f &&        // :187
+            bool hit = !culled && VT_MUT(8, u > 0.0f, u >= 0.0f) && VT_MUT(14, v > 0.0f, v >= 0.0f) && VT_MUT(15, w > 0.0f, w >= 0.0f) &&        // :187
                        VT_MUT(11, t > L.tmin, t >= L.tmin) && VT_MUT(2, t < L.tmax, t <= L.tmax);    // :189
             if constexpr (ALPHA) {                                                     // :196-208
                 if (hit && (tflags & VT_TRI_ALPHATEST)) {        // the candidate is parked until its alpha is known
@@ -739,7 +742,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                 const bool swap = VT_MUT(1, fl >= fr, fl > fr);
                 next = swap ? rfirst : lfirst;
                 uint32_t far = swap ? lfirst : rfirst;
-                if (L.sp < a.lds_entries) st_lds[L.sp * 64] = far;
+                if (VT_MUT(16, L.sp <= a.lds_entries, L.sp < a.lds_entries)) st_lds[L.sp * 64] = far;
                 else st_ovf[size_t(L.sp - a.lds_entries) * gstride] = VT_MUT(10, next, far);
                 ++L.sp;
             } else if (go_l) {

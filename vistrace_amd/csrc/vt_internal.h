@@ -54,6 +54,10 @@ uint64_t parallel_copy_checked(vt_ray* dst, const void* src, uint64_t n);
 // value of a test-hook environment variable, NULL unless VT_ENABLE_TEST_HOOKS=1 (announced on stderr once per hook)
 const char* test_hook(const char* name);
 
+// fault injection (VT_TEST_FAIL_ALLOC / vt_test_fail_alloc, dead without VT_ENABLE_TEST_HOOKS=1): counts one allocation attempt of
+// the library; true = this is the one that must fail.  Called by dev_malloc / pinned_malloc (engine_internal.h) only.
+bool test_alloc_fails();
+
 void set_error(const std::string& msg);
 int  fail(int code, const std::string& msg);
 
