@@ -31,6 +31,7 @@ Data is synthetic (seeded generator, vistrace_amd/workloads.py); nothing reads /
 from __future__ import annotations
 
 import argparse
+from types import SimpleNamespace
 import csv
 import glob
 import hashlib
@@ -192,6 +193,10 @@ PMC_PASSES = {
     # the vector L1 (TCP) and the L2 (TCC): what the record gather costs (profiles/r3/notes.md)
     "tcp": ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCC_READ_REQ_LATENCY_sum"],
     "l2": ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "GRBM_GUI_ACTIVE"],
+    # round 6: how busy the vector ALUs are, COUNTED (SQ_ACTIVE_INST_VALU: quad-cycles waves spend executing vector instructions;
+    # rocprofiler-sdk's VALUBusy = that / CUs / GRBM_GUI_ACTIVE) -- with the cycle count of the same pass beside it
+    "busy": ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_MISC",
+             "SQ_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"],
 }
 
 
@@ -280,28 +285,49 @@ def committed_pmc(workload: str, builder: str, sha: str) -> dict:
     return dict(tj.get("counters", {}), _source=os.path.relpath(path, ROOT))
 
 
-def bound_actual(pmc: dict, kernel_ms: float) -> dict | None:
+def kernel_cycles(pmc: dict, kernel_ms: float):
+    """(shader cycles of the launch, clock in GHz, where the clock comes from): ONE figure for everything that is a share of the
+    launch's cycles.  GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back); taken in a profiled pass,
+    like every counter it is compared with."""
+    if pmc.get("GRBM_GUI_ACTIVE"):
+        cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0
+        return cyc, cyc / (kernel_ms * 1e-3) / 1e9, "effective: GRBM_GUI_ACTIVE / 8 XCDs of the profiled launch (its duration taken as the un-profiled kernel_ms)"
+    return kernel_ms * 1e-3 * CLOCK_GHZ * 1e9, CLOCK_GHZ, CLOCK_SOURCE
+
+
+def bound_actual(pmc: dict, kernel_ms: float, cus: int = 0) -> dict | None:
     if "SQ_INSTS_VALU" not in pmc:
         return None
     valu = pmc["SQ_INSTS_VALU"]
+    cyc, ghz, clock_src = kernel_cycles(pmc, kernel_ms)
     out = {"kind": "valu_issue", "sq_insts_valu": valu, "sq_insts_salu": pmc.get("SQ_INSTS_SALU"),
-           "lane_utilisation": round(pmc["SQ_THREAD_CYCLES_VALU"] / (valu * 64.0), 4) if pmc.get("SQ_THREAD_CYCLES_VALU") else None}
+           "lane_utilisation": round(pmc["SQ_THREAD_CYCLES_VALU"] / (valu * 64.0), 4) if pmc.get("SQ_THREAD_CYCLES_VALU") else None,
+           "kernel_cycles": round(cyc), "clock_ghz": round(ghz, 3), "clock_source": clock_src}
     if "SQ_WAVE_CYCLES" in pmc and pmc["SQ_WAVE_CYCLES"]:
         wc = pmc["SQ_WAVE_CYCLES"]
         out["wave_time_split"] = {k: round(pmc.get(c, 0.0) / wc, 3) for k, c in
                                   (("executing", "SQ_ACTIVE_INST_ANY"), ("waiting_memory_or_barrier", "SQ_WAIT_ANY"), ("waiting_to_issue", "SQ_WAIT_INST_ANY"))}
+    if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("GRBM_GUI_ACTIVE") and cus:
+        # COUNTED: quad-cycles the waves spent executing vector instructions, over CUs x cycles of the same pass = the share of
+        # SIMD cycles with a vector instruction in execution (rocprofiler-sdk's VALUBusy formula for gfx9)
+        out["valu_busy_counter"] = round(pmc["SQ_ACTIVE_INST_VALU"] / cus / cyc, 3)
+        out["valu_busy_counter_how"] = "SQ_ACTIVE_INST_VALU / CUs / (GRBM_GUI_ACTIVE / 8), one rocprofv3 --pmc pass"
+        out["inst_busy_counters"] = {k: round(pmc[f"SQ_ACTIVE_INST_{k}"] / cus / cyc, 3) for k in ("SCA", "LDS", "VMEM", "MISC") if pmc.get(f"SQ_ACTIVE_INST_{k}")}
+        if pmc.get("SQ_BUSY_CU_CYCLES"):
+            out["cu_busy_frac"] = round(pmc["SQ_BUSY_CU_CYCLES"] / cus / cyc, 3)
     if "SQ_INSTS_VALU_MUL_F32" in pmc:
         named = {k: pmc.get(f"SQ_INSTS_VALU_{k}", 0.0) for k in ("MUL_F32", "ADD_F32", "FMA_F32", "TRANS_F32", "INT32")}
         other = max(0.0, valu - sum(named.values()))
         cycles = sum(named[k] * ISSUE_COST[k] for k in named) + other * ISSUE_COST["OTHER"]
         per_simd = cycles / SIMDS
         out["valu_issue_cycles_per_simd"] = round(per_simd)
-        out["kernel_cycles"] = round(kernel_ms * 1e-3 * CLOCK_GHZ * 1e9)
-        out["valu_busy_frac"] = round(per_simd / (kernel_ms * 1e-3 * CLOCK_GHZ * 1e9), 3)
-        out["clock_ghz"] = round(CLOCK_GHZ, 3)
-        out["clock_source"] = CLOCK_SOURCE
-        out["issue_cost_source"] = "scripts/ubench_valu.hip (cycles per wave-instruction and SIMD: mul/add 2.4, int 3.2, fma/select/minmax 4.2, rcp 8.2)"
+        out["valu_busy_model"] = round(per_simd / cyc, 3)
+        out["valu_busy_model_how"] = "instruction-class counts x issue costs of scripts/ubench_valu.hip (cycles per wave-instruction and SIMD: mul/add 2.4, int 3.2, fma/select/minmax 4.2, rcp 8.2) / kernel_cycles"
+        out["valu_class_share_of_issue_cycles"] = {k: round(named[k] * ISSUE_COST[k] / cycles, 3) for k in named} | {"OTHER(select/minmax/cmp/mov/dpp)": round(other * ISSUE_COST["OTHER"] / cycles, 3)}
         out["branches"] = pmc.get("SQ_INSTS_BRANCH")
+    # the figure the "VALU-bound" sentence of DESIGN.md section 5 rests on: the counter when the pass delivered it, else the model
+    out["valu_busy_frac"] = out.get("valu_busy_counter", out.get("valu_busy_model"))
+    out["valu_busy_frac_is"] = "counter" if "valu_busy_counter" in out else ("model" if "valu_busy_model" in out else None)
     return out
 
 
@@ -321,9 +347,8 @@ def gather_path(pmc: dict, kernel_ms: float, cus: int) -> dict | None:
     if pmc.get("TCP_TCC_READ_REQ_LATENCY_sum") and req:
         out["avg_l2_read_latency_cycles"] = round(pmc["TCP_TCC_READ_REQ_LATENCY_sum"] / req, 1)
     if "GRBM_GUI_ACTIVE" in pmc:
-        cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0                                    # summed over the 8 XCDs
-        out["kernel_cycles"] = round(cyc)
-        out["effective_clock_ghz"] = round(cyc / (kernel_ms * 1e-3) / 1e9, 3)
+        cyc, ghz, _ = kernel_cycles(pmc, kernel_ms)                           # the one cycle count (roofline.bound_actual.kernel_cycles)
+        out["effective_clock_ghz"] = round(ghz, 3)
         out["tcp_accesses_per_cycle_per_cu"] = round(acc / cus / cyc, 3)
         if "TCP_PENDING_STALL_CYCLES_sum" in pmc:
             out["tcp_pending_stall_frac"] = round(pmc["TCP_PENDING_STALL_CYCLES_sum"] / cus / cyc, 3)
@@ -763,7 +788,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the live rocprofv3 PMC passes (traffic then comes from profiles/ or is null)")
-    ap.add_argument("--pmc-passes", default="fetch,write,sq,mix,tcp,l2")
+    ap.add_argument("--pmc-passes", default="fetch,write,sq,mix,tcp,l2,busy")
     ap.add_argument("--pmc-timeout", type=float, default=240.0)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gather-timeout", type=float, default=180.0,
@@ -1024,41 +1049,57 @@ def main() -> None:
     # ---- N > 1: how many CUs to leave to the gather's kernels (auto): measured with the gather in flight, the fastest stays ------
     reserve_probe = None
     if args.reserve_probe and native is not None and n > 0 and (world > 1 or args.reserve_probe_always):
-        try:
-            watchdog.arm(args.gather_timeout, "the reserved-CU probe")
-            times = {}
-            for cand in (64, 32, 16, 0):
-                if cand > engine.get_option("cu_count") // 2:
-                    continue
+        # Every rank takes the same decisions at the same points: the candidate list comes from an all-reduced limit, and behind
+        # every step that can fail locally (an option the engine refuses) the ranks exchange a status word, so that one rank's
+        # exception ends the probe on ALL ranks together instead of leaving the others in the next collective.
+        cdev = device if args.backend == "nccl" else "cpu"
+
+        def all_ok(ok: bool) -> bool:
+            t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item() > 0.5)
+
+        watchdog.arm(args.gather_timeout, "the reserved-CU probe")
+        lim = torch.tensor([float(engine.get_option("cu_count") // 2)], dtype=torch.float64, device=cdev)
+        dist.all_reduce(lim, op=dist.ReduceOp.MIN)
+        times, why = {}, None
+        for cand in [c for c in (64, 32, 16, 0) if c <= int(lim.item())]:
+            try:
                 engine.set_option("reserved_cus", cand)
-                for _ in range(3):
-                    step()
-                drain()
-                torch.cuda.synchronize(device)
-                dist.barrier()
-                tq = time.perf_counter()
-                for _ in range(20):
-                    step()
-                drain()
-                torch.cuda.synchronize(device)
-                tt = torch.tensor([(time.perf_counter() - tq) / 20 * 1e3], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)               # every rank sees the same table and takes the same decision
-                times[cand] = round(float(tt.item()), 4)
-            watchdog.disarm()
+                ok = True
+            except Exception as exc:
+                ok, why = False, f"reserved_cus={cand}: {exc}"
+            if not all_ok(ok):
+                why = why or f"another rank could not set reserved_cus={cand}"
+                break
+            for _ in range(3):
+                step()
+            drain()
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            tq = time.perf_counter()
+            for _ in range(20):
+                step()
+            drain()
+            torch.cuda.synchronize(device)
+            tt = torch.tensor([(time.perf_counter() - tq) / 20 * 1e3], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)               # every rank sees the same table and takes the same decision
+            times[cand] = round(float(tt.item()), 4)
+        watchdog.disarm()
+        best = args.reserve_cus
+        if why is None and times:
             best = min(times, key=lambda c: (times[c], -c))
             if 32 in times and times[32] <= times[best] * 1.01:         # within 1 %: stay with the calibrated default
                 best = 32
-            engine.set_option("reserved_cus", best)
             reserve_probe = {"ms_per_step": {str(k): v for k, v in times.items()}, "chosen": best,
                              "how": "20 steps each (trace + gather, double-buffered) behind 3 warm-up steps, max over ranks; scheduling only: results do not depend on it"}
             log(f"[bench] reserved-CU probe: {times} -> {best}")
+        else:
+            log(f"[bench] reserved-CU probe abandoned on every rank ({why or 'no candidate'}); staying with {args.reserve_cus}")
+        try:                                                            # (the same value on every rank, whatever happened above)
+            engine.set_option("reserved_cus", best)
         except Exception as exc:   # never lose the run over an optimisation
-            watchdog.disarm()
-            log(f"[bench] reserved-CU probe failed ({exc}); staying with {args.reserve_cus}")
-            try:
-                engine.set_option("reserved_cus", args.reserve_cus)
-            except Exception:
-                pass
+            log(f"[bench] reserved_cus={best} refused: {exc}")
 
     # single-launch durations (HIP events on the launch stream around one launch each)
     single_ms = []
@@ -1247,7 +1288,7 @@ def main() -> None:
             "alg_bytes_per_ray": round(alg_bytes / max(n, 1), 1),
             "steps_per_ray": round(tot_steps / max(n, 1), 2),
             "tests_per_ray": round(tot_tests / max(n, 1), 2),
-            "bound_actual": bound_actual(pmc, k_ms),
+            "bound_actual": bound_actual(pmc, k_ms, engine.get_option("cu_count")),
             "gather_path": gather_path(pmc, k_ms, engine.get_option("cu_count")),
             "kernel_sources_sha": sha,
         },
@@ -1275,242 +1316,12 @@ def main() -> None:
         "lane_utilisation": ba.get("lane_utilisation"),
     })
 
-    # ---- the same workload on the other builder's tree (N = 1): what the tree is worth ------------------------------------
-    if rank == 0 and world == 1 and not dist_on and args.alt_builder not in ("none", args.builder) and n > 0 and not any_hit and args.alpha_frac == 0:
-        try:
-            alt_args = argparse.Namespace(**vars(args))
-            alt_args.builder = args.alt_builder
-            a_tris, a_bvh, a_hs, a_engine, a_scene, _ = build_scene(alt_args, va, W, dev_index, world)
-            a_rays, a_n, _, _, _ = make_rays(alt_args, rank, world, va, W, tp, a_engine, a_scene, device)
-            apply_image_hint(alt_args, a_engine)
-            a_hits = tp.empty_records(a_n, HIT, device)
-            _, a_stats = tp.trace_stats(a_scene, a_rays, a_n)
-            a_st = a_stats.view(torch.int32).view(a_n, 2).sum(dim=0, dtype=torch.int64).cpu().numpy() / a_n
-            del a_stats
-            for _ in range(3):
-                tp.trace_closest(a_scene, a_rays, a_n, a_hits)
-            torch.cuda.synchronize(device)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            alt_steps = max(10, min(args.steps, 50))
-            e0.record()
-            for _ in range(alt_steps):
-                tp.trace_closest(a_scene, a_rays, a_n, a_hits)
-            e1.record()
-            torch.cuda.synchronize(device)
-            a_ms = e0.elapsed_time(e1) / alt_steps
-            result["alt_builder"] = {
-                "bvh_builder": BUILDER_NAMES[args.alt_builder],
-                "value": round(a_n / (a_ms * 1e-3) / 1e6, 2), "unit": "Mrays/s", "kernel_ms": round(a_ms, 4),
-                "steps_per_ray": round(float(a_st[0]), 2), "tests_per_ray": round(float(a_st[1]), 2),
-                "note": "same rays procedure, same kernel; kernel time is proportional to steps per ray (profiles/r2/notes.md)",
-            }
-            del a_rays, a_hits, a_scene, a_engine
-        except Exception as exc:   # a secondary figure must never cost the headline line
-            log(f"[bench] alt_builder leg failed: {exc}")
-
-    # ---- independent batches on two streams (rank 0, N = 1): an extra figure, never `value` ---------------------------------
-    # A launch ends with ~0.3 ms of drain (profiles/r3/notes.md section 6); a caller whose batches are independent can hide it by
-    # alternating between two streams -- the next grid's blocks move in as this one's leave.  Reported beside the serial figure.
-    if rank == 0 and world == 1 and not dist_on and n > 0 and not under_profiler():
-        try:
-            two = [torch.cuda.Stream(device=device) for _ in range(2)]
-            buf2 = [d_hits, torch.empty_like(d_hits)]
-
-            def launch_on(k):
-                if any_hit:
-                    scene.trace_any_dev(d_rays.data_ptr(), n, buf2[k % 2].data_ptr(), two[k % 2].cuda_stream)
-                else:
-                    scene.trace_closest_dev(d_rays.data_ptr(), n, buf2[k % 2].data_ptr(), two[k % 2].cuda_stream)
-            k2 = max(10, min(args.steps, 200))
-            for k in range(4):
-                launch_on(k)
-            torch.cuda.synchronize(device)
-            t0 = time.perf_counter()
-            for k in range(k2):
-                launch_on(k)
-            torch.cuda.synchronize(device)
-            ms2 = (time.perf_counter() - t0) / k2 * 1e3
-            same = bool((buf2[0].view(torch.uint8) == buf2[1].view(torch.uint8)).all())
-            result["two_streams"] = {
-                "value": round(n / ms2 / 1e3, 2), "unit": result["unit"], "ms_per_step": round(ms2, 4), "steps": k2,
-                "results_equal": same,
-                "note": "the same step alternating between two HIP streams (two result buffers): the start of one launch hides the drain of "
-                        "the other.  Only for callers whose consecutive batches are independent; `value` above is the one-stream figure",
-            }
-            del buf2
-        except Exception as exc:   # a secondary figure must never cost the headline line
-            log(f"[bench] two-stream leg failed: {exc}")
-
-    # ---- many small batches (rank 0, N = 1): the same rays as 16 sets, 16 launches against ONE merged launch ----------------------
-    # What a caller with many small ray sets per frame pays: a launch costs ~0.3 ms beyond its rays (grid start + drain), 16 sets pay
-    # it 16 times unless they share a launch (vt_trace_closest_multi_dev: one cursor over all sets, one drain).  Never `value`.
-    if rank == 0 and world == 1 and not dist_on and n >= 16 * 4096 and not under_profiler() and args.legs != "off":
-        try:
-            sets = 16
-            per = (n // sets) // (16 * image_width) * (16 * image_width) if image_width else (n // sets) // 64 * 64
-            if per > 0:
-                esz = 1 if any_hit else HIT.itemsize
-                out_a, out_b = torch.zeros_like(d_hits), torch.zeros_like(d_hits)
-                descs = [(d_rays.data_ptr() + k * per * RAY.itemsize, out_b.data_ptr() + k * per * esz, per, image_width) for k in range(sets)]
-
-                def separate():
-                    for k in range(sets):
-                        if any_hit:
-                            scene.trace_any_dev(d_rays.data_ptr() + k * per * RAY.itemsize, per, out_a.data_ptr() + k * per * esz, stream)
-                        else:
-                            scene.trace_closest_dev(d_rays.data_ptr() + k * per * RAY.itemsize, per, out_a.data_ptr() + k * per * esz, stream)
-
-                def merged():
-                    scene.trace_multi_dev(descs, stream, any_hit=any_hit)
-
-                times = {}
-                for name, fn in (("separate", separate), ("merged", merged)):
-                    for _ in range(3):
-                        fn()
-                    torch.cuda.synchronize(device)
-                    reps = max(3, min(50, int(0.25 / max(ms_per_step * 1e-3, 1e-5))))
-                    t0 = time.perf_counter()
-                    for _ in range(reps):
-                        fn()
-                    torch.cuda.synchronize(device)
-                    times[name] = (time.perf_counter() - t0) / reps * 1e3
-                same = bool(torch.equal(out_a[: sets * per * esz], out_b[: sets * per * esz]))
-                result["merged_launch"] = {
-                    "sets": sets, "rays_per_set": per,
-                    "separate_launches_ms": round(times["separate"], 4), "separate_launches_value": round(sets * per / times["separate"] / 1e3, 2),
-                    "one_merged_launch_ms": round(times["merged"], 4), "one_merged_launch_value": round(sets * per / times["merged"] / 1e3, 2),
-                    "unit": result["unit"], "results_equal": same,
-                    "note": "the workload's rays cut into 16 equal sets (whole bands of 16 image rows for camera rays): 16 launches on one stream "
-                            "against vt_trace_*_multi_dev (one grid start, one drain); the results must be byte-equal",
-                }
-                del out_a, out_b
-        except Exception as exc:   # a secondary figure must never cost the headline line
-            log(f"[bench] merged-launch leg failed: {exc}")
-
-    # ---- the transfer-inclusive figure of SURVEY 8(d) (rank 0, N = 1): never `value` ------------------------------------------
-    # vt_trace_closest on HOST buffers: the same rays from pageable caller memory, every copy inside the call (the engine's chunked
-    # pinned pipeline: upload of chunk c + 1, trace of chunk c and download of chunk c - 1 overlap)
-    if rank == 0 and world == 1 and not dist_on and n > 0 and not under_profiler() and args.legs != "off":
-        try:
-            h_rays = rays_host if rays_host is not None else tp.to_host(d_rays, RAY)
-            rays_host = h_rays
-            nh = len(h_rays)
-            h_out = np.empty(nh, dtype=np.uint8) if any_hit else np.empty(nh, dtype=HIT)
-            fn = (lambda: va._lib.check(va._lib.lib.vt_trace_any(scene._h, va._lib.ptr(h_rays), nh, va._lib.ptr(h_out)))) if any_hit else \
-                 (lambda: scene.trace_closest(h_rays, h_out))
-            engine.set_option("ray_image_width", 0)
-            fn()
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                fn()
-                ts.append(time.perf_counter() - t0)
-            apply_image_hint(args, engine)
-            ref_dev = d_hits[:nh].cpu().numpy() if any_hit else tp.to_host(d_hits[: nh * HIT.itemsize], HIT)
-            same_p = bool((h_out.view(np.uint8) == ref_dev.view(np.uint8)).all())
-            # the same call on arrays the caller has page-locked once (vt_host_register): no staging copies, copy engines only
-            locked, ts_l, same_l = None, [], None
-            try:
-                va.host_register(h_rays); va.host_register(h_out)
-                locked = True
-                h_out[...] = 0 if any_hit else np.zeros(1, HIT)[0]
-                fn()
-                for _ in range(3):
-                    t0 = time.perf_counter()
-                    fn()
-                    ts_l.append(time.perf_counter() - t0)
-                same_l = bool((h_out.view(np.uint8) == ref_dev.view(np.uint8)).all())
-            except Exception as exc:
-                log(f"[bench] host-inclusive leg, page-locked arrays: {exc}")
-            finally:
-                if locked:
-                    va.host_unregister(h_rays); va.host_unregister(h_out)
-            result["host_inclusive"] = {
-                "value": round(nh / min(ts) / 1e6, 2), "unit": result["unit"], "ms_per_call": round(min(ts) * 1e3, 3), "rays": nh,
-                "bytes_over_pcie_per_ray": 32 + out_bytes,
-                "results_equal_device_resident": same_p,
-                "page_locked_arrays": {"value": round(nh / min(ts_l) / 1e6, 2), "ms_per_call": round(min(ts_l) * 1e3, 3), "results_equal_device_resident": same_l,
-                                       "note": "the caller's arrays page-locked once with vt_host_register (not timed: ~70 us per MB): the copy engines "
-                                               "read and write them in place, no staging copies"} if ts_l else None,
-                "note": "vt_trace_closest / vt_trace_any on pageable host arrays, best of 3 calls: staging copies, H2D, trace, D2H and copy-out "
-                        "all inside the call.  The transfer-inclusive second figure of SURVEY 8(d); `value` above has rays and hits resident in HBM",
-            }
-            del h_out
-        except Exception as exc:   # a secondary figure must never cost the headline line
-            log(f"[bench] host-inclusive leg failed: {exc}")
-
-    # ---- beyond every cache (rank 0, N = 1): the same ray kind into S10M, where HBM CAN bind ------------------------------------
-    # The headline scene (104 MB of records) lives in L2 / Infinity Cache, so its HBM fraction says little about the kernel.  S10M is
-    # 1.04 GB of records -- beyond the 256 MiB Infinity Cache: this leg reports its rate, its algorithmic bytes and, from the FETCH /
-    # WRITE counters (live with --beyond-cache-pmc, else the committed pass of exactly these kernel sources), its HBM fraction.
-    if rank == 0 and world == 1 and not dist_on and n > 0 and not under_profiler() and args.legs == "all" and args.scene != "S10M" \
-            and not any_hit and args.alpha_frac == 0 and args.scaling == "weak":
-        try:
-            b_args = argparse.Namespace(**vars(args))
-            b_args.scene, b_args.kind = "S10M", "bounce"
-            _, _, _, b_engine, b_scene, _ = build_scene(b_args, va, W, dev_index, world)
-            b_rays, b_n, _, b_workload, _ = make_rays(b_args, rank, world, va, W, tp, b_engine, b_scene, device)
-            b_engine.set_option("ray_image_width", 0)
-            b_hits = tp.empty_records(b_n, HIT, device)
-            _, b_stats = tp.trace_stats(b_scene, b_rays, b_n)
-            b_st = b_stats.view(torch.int32).view(b_n, 2).sum(dim=0, dtype=torch.int64).cpu().numpy()
-            del b_stats
-            for _ in range(3):
-                tp.trace_closest(b_scene, b_rays, b_n, b_hits)
-            torch.cuda.synchronize(device)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            b_steps = 20
-            e0.record()
-            for _ in range(b_steps):
-                tp.trace_closest(b_scene, b_rays, b_n, b_hits)
-            e1.record()
-            torch.cuda.synchronize(device)
-            b_ms = e0.elapsed_time(e1) / b_steps
-            b_alg = float(b_n) * 48.0 + 64.0 * float(b_st[0] + b_st[1])
-            b_pmc, b_src = {}, None
-            if args.beyond_cache_pmc:
-                b_pmc = collect_pmc_live(b_args, ["FETCH_SIZE", "WRITE_SIZE"])
-                b_src = "live rocprofv3 --pmc passes of this launch (child processes of this run)" if "FETCH_SIZE" in b_pmc else None
-            if "FETCH_SIZE" not in b_pmc:
-                b_pmc = committed_pmc(b_workload, args.builder, sha)
-                b_src = b_pmc.pop("_source") + " (kernel sources unchanged since that pass)" if "FETCH_SIZE" in b_pmc else None
-            b_traffic = int(b_pmc["FETCH_SIZE"] * 1024 + b_pmc.get("WRITE_SIZE", 0.0) * 1024) if "FETCH_SIZE" in b_pmc else None
-            result["beyond_cache"] = {
-                "workload": b_workload, "scene_record_bytes": int(b_scene.device_bytes),
-                "value": round(b_n / (b_ms * 1e-3) / 1e6, 2), "unit": "Mrays/s", "kernel_ms": round(b_ms, 4), "steps": b_steps,
-                "steps_per_ray": round(float(b_st[0]) / b_n, 2), "tests_per_ray": round(float(b_st[1]) / b_n, 2),
-                "alg_achieved_gb_s": round(b_alg / (b_ms * 1e-3) / 1e9, 1), "alg_over_peak": round(b_alg / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "traffic": b_traffic, "traffic_source": b_src,
-                "achieved_gb_s": round(b_traffic / (b_ms * 1e-3) / 1e9, 1) if b_traffic else None,
-                "frac": round(b_traffic / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b_traffic else None,
-                "note": "16 Mi bounce rays into 10 M triangles (1.04 GB of records: beyond L2 and the Infinity Cache); frac = (FETCH_SIZE + "
-                        "WRITE_SIZE) x 1024 B / kernel time / 8 TB/s, as roofline.frac",
-            }
-            del b_rays, b_hits, b_scene, b_engine
-        except Exception as exc:   # a secondary figure must never cost the headline line
-            log(f"[bench] beyond-cache leg failed: {exc}")
-
-    # ---- what a Rebuild costs (rank 0, N = 1): never `value` -------------------------------------------------------------------
-    if rank == 0 and world == 1 and not dist_on and not under_profiler() and (args.rebuild_leg == "on" or (args.rebuild_leg == "auto" and args.legs == "all")):
-        try:
-            result["rebuild"] = rebuild_leg(args, va, W, engine, host_threads)
-        except Exception as exc:   # a secondary figure must never cost the headline line
-            log(f"[bench] rebuild leg failed: {exc}")
-
-    # the legs' figures flat in `roofline` as well (scalars only: what a parser that drops nested objects still keeps)
-    if rank == 0:
-        hi_, bc_, ts_ = result.get("host_inclusive") or {}, result.get("beyond_cache") or {}, result.get("two_streams") or {}
-        result["roofline"].update({
-            "l1_gather_reference_loop_lo": 66, "l1_gather_reference_loop_hi": 73,
-            "host_inclusive_mrays_s": hi_.get("value"), "host_inclusive_ms": hi_.get("ms_per_call"),
-            "host_inclusive_page_locked_mrays_s": (hi_.get("page_locked_arrays") or {}).get("value"),
-            "host_inclusive_page_locked_ms": (hi_.get("page_locked_arrays") or {}).get("ms_per_call"),
-            "beyond_cache_workload": bc_.get("workload"), "beyond_cache_mrays_s": bc_.get("value"), "beyond_cache_kernel_ms": bc_.get("kernel_ms"),
-            "beyond_cache_frac": bc_.get("frac"), "beyond_cache_alg_over_peak": bc_.get("alg_over_peak"),
-            "two_streams_mrays_s": ts_.get("value"),
-            "sets16_separate_launches_mrays_s": (result.get("merged_launch") or {}).get("separate_launches_value"),
-            "sets16_one_merged_launch_mrays_s": (result.get("merged_launch") or {}).get("one_merged_launch_value"),
-        })
+    # ---- secondary figures (never `value`): bench_legs.py -- the other builder's tree, two streams, merged launches, the
+    # transfer-inclusive rate, the scene beyond every cache, what a Rebuild costs; selected by --legs / --alt-builder / --rebuild-leg
+    import bench_legs
+    ctx = SimpleNamespace(**{**globals(), **locals()})
+    bench_legs.run(ctx)
+    rays_host = ctx.rays_host
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) -------------------
     if rank == 0 and world == 1 and not args.no_cpu and n > 0:

@@ -125,16 +125,26 @@ typedef struct vt_host_scene vt_host_scene; /* host: linearised pairs + tri reco
 typedef struct vt_engine     vt_engine;     /* one HIP device + stream              */
 typedef struct vt_scene      vt_scene;      /* device-resident scene                */
 
+
+/* ==== CORE: the twelve calls a VisTrace patch needs =============================================================================
+ * INTEGRATION.md sections 1-3 use exactly these, in this order: module open, Rebuild (AccelStruct.cpp:762-775), Traverse
+ * (:810-831), teardown (:525-542).  Everything behind this block is an EXTENSION: additive, and none of it is needed to replace
+ * the reference's path (tests/test_abi_symbols.py checks this list against INTEGRATION.md). */
+
+/*  1 */
 /* Thread-local description of the last error on this thread ("" if none). */
 const char* vt_last_error(void);
-int         vt_abi_version(void);
 
-/* ---- host side: Rebuild (CPU, as in the reference) --------------------------------- */
+/*  2, 3: GMOD_MODULE_OPEN / GMOD_MODULE_CLOSE -- one engine = one HIP device + its stream and staging. */
+int  vt_engine_open(int device, vt_engine** out);
+void vt_engine_close(vt_engine* e);
 
+/*  4 */
 /* Triangle constructor + ComputeNormalAndLoD: source/objects/Primitives.h:75-102.
  * verts = n x {p0,p1,p2} (9 floats); flags may be NULL (all 0); out[i].prim = i. */
 int vt_tris_setup(const float* verts, const uint8_t* flags, uint32_t n, vt_tri64* out);
 
+/*  5, 6 */
 /* BVH build tail of AccelStruct::PopulateAccel, source/objects/AccelStruct.cpp:763-770 (bounding boxes + centres,
  * Primitives.h:107-118; build; leaves of several triangles).  tris in ORIGINAL order.  n == 0 gives an empty tree (every
  * trace misses).  nthreads <= 0: min(OpenMP default, 16).  Two builders, same v1 node layout, same traversal, identical
@@ -143,7 +153,7 @@ int vt_tris_setup(const float* verts, const uint8_t* flags, uint32_t n, vt_tri64
  *                          refining its subtree by re-insertion (below) -- the DEFAULT of
  *                          vt_bvh_build: kernel time is proportional to the node steps per ray, and this tree needs 14 %
  *                          (incoherent rays) to 39 % (camera rays) fewer of them than the PLOC tree at the same Rebuild
- *                          time (1 M triangles, 8 threads: 0.42 s against 0.39 s; 10 M: 5.3 s against 6.4 s);
+ *                          time (1 M triangles, 8 threads: 0.27 s against 0.37 s; 10 M: 5.0 s against 6.3 s; README.md has the table by thread count);
  *   VT_BUILDER_BINNED_SAH_REFINED  the same followed by two passes of insertion-based optimisation over the WHOLE tree (Bittner
  *                          et al. 2013: the worst 1 % of the inner nodes are taken out and their subtrees re-inserted where they
  *                          enlarge the tree least).  Opt-in (VT_BUILDER=sah_refined) for scenes that are built once and traced
@@ -151,10 +161,44 @@ int vt_tris_setup(const float* verts, const uint8_t* flags, uint32_t n, vt_tri64
  *   VT_BUILDER_PLOC        the reference's algorithm: Morton-32 sort, PLOC (search radius 14), SAH leaf collapse
  *                          (bvh v1 LocallyOrderedClusteringBuilder + LeafCollapser).  VT_BUILDER=ploc in the environment
  *                          makes vt_bvh_build use it. */
-int             vt_bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, vt_bvh** out);
+int  vt_bvh_build(const vt_tri64* tris, uint32_t n, int nthreads, vt_bvh** out);
+void vt_bvh_free(vt_bvh* bvh);
+
+/*  7, 8: replaces `new Intersector(...)` / `new Traverser(...)`, source/objects/AccelStruct.cpp:772-773, and their deletes */
+/* Upload once per Rebuild, the re-packing done ON THE DEVICE: the tree as vt_bvh_build left it and the triangle records in
+ * original order go up as three plain copies; kernels number the pairs depth-first, shuffle the triangles into leaf order and
+ * derive the index tables.  Result byte-equal to the extension pair vt_scene_linearise + vt_scene_upload (records, level lists, triangle -> slot),
+ * without the host walk (85-100 ms per million triangles on one core) -- stands where the reference constructs its intersector
+ * and traverser over the finished tree (source/objects/AccelStruct.cpp:772-773).  tris = the vt_tris_setup output the tree
+ * was built from, ntris = its length.  On a group's root the scene is built on every member. */
+int  vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvh, const vt_tri64* tris, uint32_t ntris, vt_scene** out);
+void vt_scene_free(vt_scene* s);
+
+/*  9, 10: single rays are walked on the host copy of the records (call 11) */
+/* The host-side copy of a device scene (pairs, leaf-ordered triangles, depths): what vt_host_scene_trace_* and the accessors
+ * need when the scene came from vt_scene_upload_tree.  From then on a device-side refit marks the copy stale and
+ * vt_host_scene_sync refreshes it, exactly as for a host scene the device scene was uploaded from. */
+int  vt_host_scene_download(vt_scene* s, vt_host_scene** out);
+void vt_host_scene_free(vt_host_scene* hs);
+
+/* 11: what ONE accel:Traverse(origin, dir) does, source/objects/AccelStruct.cpp:818 (see "the single-ray latency path" below) */
+int vt_host_scene_trace_closest(const vt_host_scene* hs, const vt_ray* rays, uint64_t n, vt_hit* hits);
+
+/* 12: batches */
+/* The call at source/objects/AccelStruct.cpp:818, batched: closest hit per ray. */
+/* Rays with a NaN or infinite origin / direction component miss, as in the reference -- but without the walk the
+ * reference performs for them (its slab test ignores NaN terms, so such a ray can visit the whole tree before
+ * missing); vt_trace_stats_dev alone still walks, to report the reference's counters. */
+int vt_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_hit* hits);
+
+/* ==== EXTENSIONS ================================================================================================================ */
+int vt_abi_version(void);
+
+/* ---- host side: Rebuild (CPU, as in the reference) --------------------------------- */
+
+/* vt_bvh_build with the builder named explicitly (the three builders: at vt_bvh_build above), and the tree's arrays */
 enum vt_builder { VT_BUILDER_PLOC = 0, VT_BUILDER_BINNED_SAH = 1, VT_BUILDER_BINNED_SAH_REFINED = 2 };
 int             vt_bvh_build_ex(const vt_tri64* tris, uint32_t n, int nthreads, int builder, vt_bvh** out);
-void            vt_bvh_free(vt_bvh* bvh);
 uint32_t        vt_bvh_node_count(const vt_bvh* bvh);
 uint32_t        vt_bvh_prim_count(const vt_bvh* bvh);
 const vt_bvh_node* vt_bvh_nodes(const vt_bvh* bvh);
@@ -169,7 +213,6 @@ int             vt_bvh_refit(vt_bvh* bvh, const vt_tri64* tris);
  * `new Traverser(mAccel)`, source/objects/AccelStruct.cpp:772-773): sibling pairs
  * in depth-first order, triangles pre-shuffled into leaf order. */
 int                 vt_scene_linearise(const vt_bvh* bvh, const vt_tri64* tris, vt_host_scene** out);
-void                vt_host_scene_free(vt_host_scene* hs);
 uint32_t            vt_host_scene_pair_count(const vt_host_scene* hs);
 uint32_t            vt_host_scene_tri_count(const vt_host_scene* hs);
 uint32_t            vt_host_scene_max_depth(const vt_host_scene* hs);
@@ -180,8 +223,6 @@ const vt_tri64*     vt_host_scene_tris(const vt_host_scene* hs);
 /* ---- device side ---------------------------------------------------------------------- */
 
 int  vt_device_count(int* count);
-int  vt_engine_open(int device, vt_engine** out);
-void vt_engine_close(vt_engine* e);
 
 /* ---- multi-GPU: BVH replicated in every device's HBM, rays sharded, ONE RCCL gather of hits ----
  * Rays never interact and the scene is read-only, so the path shards by independent units; the only exchange is the
@@ -263,29 +304,12 @@ int vt_engine_last_gather_ms(vt_engine* e, float* ms);
 
 /* Upload once per Rebuild (north star: "uploaded once per Rebuild"). */
 int  vt_scene_upload(vt_engine* e, const vt_host_scene* hs, vt_scene** out);
-/* The same step with the re-packing done ON THE DEVICE (round 5): the tree as vt_bvh_build left it and the triangle records in
- * original order go up as three plain copies; kernels number the pairs depth-first, shuffle the triangles into leaf order and
- * derive the index tables.  Result byte-equal to vt_scene_linearise + vt_scene_upload (records, level lists, triangle -> slot),
- * without the host walk (85-100 ms per million triangles on one core) -- stands where the reference constructs its intersector
- * and traverser over the finished tree (source/objects/AccelStruct.cpp:772-773).  tris = the vt_tris_setup output the tree
- * was built from, ntris = its length.  On a group's root the scene is built on every member. */
-int  vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvh, const vt_tri64* tris, uint32_t ntris, vt_scene** out);
 /* Where the time of a scene's upload went (host clock, ms): alloc = staging block, copy = issuing the host -> device copies,
  * device = kernels + read-backs + waiting for them, total = the whole call (for a group's root: all members). */
 typedef struct vt_upload_stats { float alloc_ms, copy_ms, device_ms, total_ms; uint64_t bytes_h2d; uint32_t linearised_on_device; uint32_t pad; } vt_upload_stats;
 int  vt_scene_upload_stats(const vt_scene* s, vt_upload_stats* out);
-/* The host-side copy of a device scene (pairs, leaf-ordered triangles, depths): what vt_host_scene_trace_* and the accessors
- * need when the scene came from vt_scene_upload_tree.  From then on a device-side refit marks the copy stale and
- * vt_host_scene_sync refreshes it, exactly as for a host scene the device scene was uploaded from. */
-int  vt_host_scene_download(vt_scene* s, vt_host_scene** out);
-void vt_scene_free(vt_scene* s);
 uint64_t vt_scene_device_bytes(const vt_scene* s);
 
-/* The call at source/objects/AccelStruct.cpp:818, batched: closest hit per ray. */
-/* Rays with a NaN or infinite origin / direction component miss, as in the reference -- but without the walk the
- * reference performs for them (its slab test ignores NaN terms, so such a ray can visit the whole tree before
- * missing); vt_trace_stats_dev alone still walks, to report the reference's counters. */
-int vt_trace_closest(vt_scene* s, const vt_ray* rays, uint64_t n, vt_hit* hits);
 /* bvh v1 AnyPrimitiveIntersector semantics (any_hit early-out): occluded[i] = 0/1. */
 int vt_trace_any(vt_scene* s, const vt_ray* rays, uint64_t n, uint8_t* occluded);
 
@@ -517,7 +541,6 @@ int vt_scene_set_alpha(vt_scene* s, const vt_alpha_material* mats, uint32_t nmat
  * a fallback: vt_trace_* and the *_dev entries never run on the CPU, and without a HIP device no vt_scene exists.
  * Serial; callable from any thread (the scene is read-only).  Non-finite rays miss without the reference's walk,
  * as on the device.  Scenes with VT_TRI_ALPHATEST triangles need vt_host_scene_set_alpha first (VT_ERR_UNSUPPORTED). */
-int vt_host_scene_trace_closest(const vt_host_scene* hs, const vt_ray* rays, uint64_t n, vt_hit* hits);
 int vt_host_scene_trace_any(const vt_host_scene* hs, const vt_ray* rays, uint64_t n, uint8_t* occluded);
 /* The alpha-test side data for the host walk: the same tables vt_scene_set_tri_attribs + vt_scene_set_alpha take. */
 int vt_host_scene_set_alpha(vt_host_scene* hs, const vt_tri_attribs* attribs, uint32_t ntris, const vt_alpha_material* mats,
@@ -553,9 +576,12 @@ int vt_gen_bounce_dev(vt_engine* e, const void* d_attrs, uint64_t n, uint64_t se
  * ended reads VT_MISS/0/0/0), and give every path that hit something its next ray -- exactly
  * vt_gen_bounce_dev(vt_hit_attrs_dev(...), seed + d) with the path index as the sample counter.  Paths that miss
  * leave the queue, which is compacted in path order, so the result does not depend on scheduling and equals the
- * uncompacted composition of the three calls.  live_out (host, depth entries, may be NULL): paths traced at each
- * depth.  Only the live-path count crosses the bus (4 B per depth); the call returns with the last depth's work
- * still in flight on `stream`. */
+ * uncompacted composition of the three calls.  The whole loop is ENQUEUED: no host wait per depth -- the live-path
+ * count stays on the device, the launches behind depth 0 are sized for n and read it from there.  live_out (host,
+ * depth entries, may be NULL): paths traced at each depth; entry 0 is written at once, the others by a host function
+ * in stream order -- they are valid once `stream` has passed the call (synchronise it, or an event recorded behind
+ * the call, before reading them), and the array must stay alive until then.  (A scene with alpha-tested triangles
+ * waits for the count once per depth, as round 5 did: live_out is then complete on return.) */
 int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t depth, uint64_t seed, void* d_hits,
                        uint64_t* live_out, void* stream);
 

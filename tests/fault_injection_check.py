@@ -387,7 +387,7 @@ for case in cases:
         assert abs(now - level) <= (2 << 20), f"{case.name} k={k}: device memory not back at its level ({(level - now) / 1e6:.1f} MB missing)"
     total_k += count
     total_failed += failed
-    assert failed >= 1 or count == 0, f"{case.name}: no injected failure surfaced"
+    assert failed + survived == count and (case.may_absorb or failed == count), f"{case.name}: {failed} of {count} injected failures surfaced"
     print(f"{case.name}: {count} allocations, {failed} injected failures reported as errors, {survived} absorbed by a designed retry; memory level kept", flush=True)
 
 print(f"fault injection: ok, {total_k} injected failures over {len(cases)} operations, {total_failed} surfaced as a status + message")

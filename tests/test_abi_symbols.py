@@ -38,6 +38,21 @@ def test_product_library_is_no_mutant():
     assert "#define VT_MUT(k, wrong, right) (right)" in src         # without -DVT_MUTANT every site is its shipped token
 
 
+def test_core_block_matches_integration_md():
+    """The header's CORE block = the twelve calls INTEGRATION.md's patch uses, one to one and in the same order."""
+    text = open(os.path.join(ROOT, "include", "vistrace_hip.h")).read()
+    core = text[text.index("/* ==== CORE:"):text.index("/* ==== EXTENSIONS")]
+    core = re.sub(r"/\*.*?\*/", "", core, flags=re.S)
+    in_header = re.findall(r"\b(vt_[a-z0-9_]+)\s*\(", core)
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    para = md[md.index("**The twelve core calls**"):md.index("## 1. Members")]
+    in_md = re.findall(r"`(vt_[a-z0-9_]+)`", para)
+    assert len(in_header) == 12 and in_header == in_md, (in_header, in_md)
+    patch = md[md.index("## 1. Members"):md.index("## 4.")] if "## 4." in md else md
+    for name in in_md:                                   # ... and each of them really appears in sections 1-3
+        assert name in patch or name == "vt_engine_close", name
+
+
 def test_pod_sizes(va):
     L = va._lib
     assert (L.RAY.itemsize, L.HIT.itemsize, L.BVH_NODE.itemsize, L.NODE_PAIR.itemsize, L.TRI64.itemsize,

@@ -716,6 +716,95 @@ def test_bounce_loop_matches_composition_and_oracle(va, engine, make_bundle, nam
     assert scene.bounce_loop_dev(d_start.data_ptr(), 0, 3, seed, d_rows.data_ptr()) == [0, 0, 0]
 
 
+def test_bounce_loop_kernel_forms_and_alpha_scene(va, O):
+    """The loop's traces behind depth 0 read their ray count from device memory (trace_kernel_devn): persistent with and without
+    the DMA fetch, one ray per lane, and a batch far smaller than the grid give the same rows as the call-by-call composition.
+    A scene with alpha-tested triangles takes the older form (count read back per depth): same contract."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    dev = torch.device("cuda", 0)
+    verts, tflags = W.make_terrain()                     # open scene: paths leave the queue
+    n_tri = len(verts)
+    flags, attribs, mats, texels = W.alpha_test_rig(n_tri)
+
+    def composition(eng, scene, d_start, n, depth, seed):
+        rows, d_rays = [], d_start
+        for d in range(depth):
+            d_hits = tp.trace_closest(scene, d_rays, n)
+            rows.append(tp.to_host(d_hits, va.HIT).copy())
+            d_attrs = tp.hit_attrs(scene, d_rays, d_hits, n)
+            d_next = tp.empty_records(n, va.RAY, dev)
+            eng.gen_bounce_dev(d_attrs.data_ptr(), n, seed + d, d_next.data_ptr(), stream=tp.current_stream_handle(dev))
+            d_rays = d_next
+        return rows
+
+    for alpha in (False, True):
+        eng = va.Engine(0)
+        tris = va.tris_setup(verts, (tflags | (flags & 2)) if alpha else tflags)
+        scene = va.Scene.from_tree(eng, va.HostBvh(tris))
+        if alpha:
+            scene.set_tri_attribs(attribs.view(va.TRI_ATTRIBS))
+            scene.set_alpha(mats.view(va.ALPHA_MATERIAL), texels)
+        for n in (70001, 300):
+            start = W.sphere_rays(n, 5, origin=(3.0, -4.0, 60.0))
+            d_start = tp.to_device(start, dev)
+            ref = None
+            for cfg in (dict(persistent=1, fetch_dma=1), dict(persistent=1, fetch_dma=0), dict(persistent=0), dict(persistent=2)):
+                for k, v in cfg.items():
+                    eng.set_option(k, v)
+                d_rows, live = tp.bounce_loop(scene, d_start, n, 4, 99)
+                torch.cuda.synchronize()
+                rows = tp.to_host(d_rows, va.HIT).reshape(4, n)
+                if ref is None:
+                    ref = composition(eng, scene, d_start, n, 4, 99)
+                    assert live[0] == n and live[1] < n and live[3] <= live[2] <= live[1]
+                for d in range(4):
+                    assert_hits_equal(rows[d], ref[d])
+                    if d:
+                        assert live[d] == int((ref[d - 1]["prim"] != O_MISS).sum())
+        scene.free()
+        eng.close()
+
+
+def test_bounce_loop_only_enqueues(va, make_bundle):
+    """vt_bounce_loop_dev returns with its work in flight: behind a long-running kernel on the same stream the call comes back at
+    once (round 5 waited for the live-path count once per depth), and the live counts arrive in stream order."""
+    import ctypes as C
+    import time
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S10k")
+    eng = va.Engine(0)
+    scene = va.Scene.from_tree(eng, b.bvh)
+    dev = torch.device("cuda", 0)
+    n, depth = 200_000, 6
+    d_start = tp.to_device(W.sphere_rays(n, 8, origin=(1.0, 2.0, 3.0)), dev)
+    d_rows = tp.empty_records(n * depth, va.HIT, dev)
+    sh = tp.current_stream_handle(dev)
+    live = (C.c_uint64 * depth)()
+    L = va._lib
+    L.check(L.lib.vt_bounce_loop_dev(scene._h, d_start.data_ptr(), n, depth, 7, d_rows.data_ptr(), live, sh or None))   # warm-up: allocations
+    torch.cuda.synchronize()
+    ref = list(live)
+    big = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    for _ in range(40):                                        # ~1 GiB fills: tens of milliseconds of work queued ahead of the loop
+        big.fill_(1.0)
+    live2 = (C.c_uint64 * depth)()
+    t0 = time.perf_counter()
+    L.check(L.lib.vt_bounce_loop_dev(scene._h, d_start.data_ptr(), n, depth, 7, d_rows.data_ptr(), live2, sh or None))
+    t_call = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t_drain = time.perf_counter() - t1
+    assert t_drain > 5 * t_call and t_call < 0.01, (t_call, t_drain)      # the call did not wait for the stream
+    assert list(live2) == ref and ref[0] == n and ref[1] <= n
+    scene.free()
+    eng.close()
+
+
 def test_reserved_cus_do_not_change_results(va, make_bundle):
     """Engine option reserved_cus (persistent grid leaves room on some CUs for a concurrent collective):
     blocks that leave take no rays with them -- results, any-hit flags and counters stay exact."""

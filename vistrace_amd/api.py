@@ -423,6 +423,8 @@ class Scene:
         Returns the number of live paths traced at each depth."""
         live = (C.c_uint64 * max(depth, 1))()
         check(lib.vt_bounce_loop_dev(self._h, d_rays, n, depth, seed & 0xFFFFFFFFFFFFFFFF, d_hits, live, stream or None))
+        # the call only enqueues; the counts arrive in stream order (a host function behind the last depth)
+        _lib.hip_stream_synchronize(stream)
         return [int(x) for x in live[:depth]]
 
     def trace_any_dev(self, d_rays: int, n: int, d_occ: int, stream: int = 0) -> None:

@@ -143,7 +143,7 @@ int batch_pipeline(vt_scene* s, vt_batch* b, const void* rays, uint64_t n, uint3
     const bool direct = pageable_copies_are_fast(e);
     unsigned long long* const d_first_bad = reinterpret_cast<unsigned long long*>(b->d_mem + b->d_mem_bytes - kBatchTail);
     if (direct && check) {
-        if (!e->h_live) VT_HIP(pinned_malloc(reinterpret_cast<void**>(&e->h_live), 64));
+        if (!e->h_bad) VT_HIP(pinned_malloc(reinterpret_cast<void**>(&e->h_bad), 64));
         VT_HIP(hipMemsetAsync(d_first_bad, 0xFF, sizeof(unsigned long long), e->s_in));
     }
     // (the pinned staging buffers are free: every host-pointer call leaves them so, and e->host_mu is held; the kernels an earlier
@@ -185,10 +185,10 @@ int batch_pipeline(vt_scene* s, vt_batch* b, const void* rays, uint64_t n, uint3
         }
     }
     if (direct && check) {                                   // the verdict of the device-side checks: behind the last upload, not behind a trace
-        VT_HIP(hipMemcpyAsync(e->h_live, d_first_bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->s_in));
+        VT_HIP(hipMemcpyAsync(e->h_bad, d_first_bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->s_in));
         VT_HIP(hipStreamSynchronize(e->s_in));
         unsigned long long first_bad;
-        std::memcpy(&first_bad, e->h_live, sizeof(first_bad));
+        std::memcpy(&first_bad, e->h_bad, sizeof(first_bad));
         if (first_bad < n) *bad_ray = first_bad;
     }
     if (!trace_chunks) return VT_OK;                         // the set's caller traces, downloads and waits for the uploads

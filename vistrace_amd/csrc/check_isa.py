@@ -29,6 +29,7 @@ PLAIN_VGPR_CAP = 72
 
 PLAIN_RE = re.compile(r"^_ZN2vt12trace_kernelILb(\d)ELb(\d)ELb(\d)ELb(\d)ELb0EEEvNS_9TraceArgsE$")
 ALPHA_RE = re.compile(r"^_ZN2vt18trace_kernel_alphaILb(\d)ELb(\d)ELb(\d)ELb(\d)EEEvNS_9TraceArgsE$")
+DEVN_RE = re.compile(r"^_ZN2vt17trace_kernel_devnILb(\d)ELb(\d)EEEvNS_9TraceArgsE$")    # ray count in device memory (bounce loop)
 
 
 def device_code_object(obj, tmp):
@@ -87,6 +88,10 @@ def check(obj):
     seen = alpha_checked = 0
     for name, m in meta.items():
         plain, alpha = PLAIN_RE.match(name), ALPHA_RE.match(name)
+        if DEVN_RE.match(name):              # same budget as the plain variants; not counted among the 20
+            if int(m["vgpr_count"]) > PLAIN_VGPR_CAP or int(m.get("vgpr_spill_count", 0)) or int(m.get("sgpr_spill_count", 0)) or int(m.get("private_segment_fixed_size", 0)):
+                errors.append(f"{name}: over budget or spilling ({m})")
+            continue
         if not plain and not alpha:
             continue
         seen += 1

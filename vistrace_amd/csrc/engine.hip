@@ -133,6 +133,8 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
     }
     if (n == 0) return VT_OK;
     if (stats && nreq != 1) return fail(VT_ERR_INVALID_ARG, "the counters kernels take one batch per launch");
+    if (first->d_count && (nreq != 1 || any_hit || stats || s->has_alpha))
+        return fail(VT_ERR_UNSUPPORTED, "a device-side ray count needs a one-batch closest-hit launch on a scene without alpha test");
     if (s->poisoned)
         return fail(VT_ERR_INVALID_ARG, "the scene was last refitted with non-finite vertex positions; refit it with finite data");
     if (s->has_alpha && (!s->d_attribs || !s->d_alpha_mats || !s->alpha_ready))
@@ -228,6 +230,7 @@ int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_sta
     a.reserved_cus = p.persistent && e->reserved_cus ? e->d_reserved : nullptr;
     a.cu_slots = d_cu_slots;
     a.reserved_limit = e->reserved_limit;
+    a.live_n = first->d_count;
 
     // the first block of every wave is static (block w -> wave w); the cursor hands out the rest
     if (a.reserved_cus) VT_HIP(hipMemsetAsync(a.cu_slots, 0, 4096, stream));
@@ -561,6 +564,7 @@ void vt_engine_close(vt_engine* e)
     if (e->h_build) (void)hipHostFree(e->h_build);
     if (e->d_reserved) (void)hipFree(e->d_reserved);
     if (e->h_live) (void)hipHostFree(e->h_live);
+    if (e->h_bad) (void)hipHostFree(e->h_bad);
     for (int k = 0; k < vt_engine::kStageBufs; ++k) {
         if (e->h_stage_in[k]) (void)hipHostFree(e->h_stage_in[k]);
         if (e->h_stage_out[k]) (void)hipHostFree(e->h_stage_out[k]);
@@ -842,6 +846,23 @@ int vt_hit_attrs_dev(vt_scene* s, const void* d_rays, const void* d_hits, uint64
     return VT_OK;
 }
 
+// The reference's bounce loop is the script's: trace, shade, vistrace.CalcRayOrigin + a cosine-hemisphere direction, trace again
+// (source/VisTrace.cpp:1478-1519, source/libraries/BSDF.cpp:69-77), one Lua call per ray.  Here every depth is a trace over the
+// queue of live paths and a queue step (scatter the hits to their paths, emit the next queue in path order), all of it enqueued
+// WITHOUT a host round trip: the number of live paths stays on the device -- the traces and queue steps behind depth 0 are sized for
+// n and read the real count from the word the previous queue step wrote (trace_kernel_devn, QueueArgs::m_dev).  Round 5 read the
+// count back and waited for it once per depth.  live_out is written by a host function in stream order: valid once the stream has
+// passed this call.  (Scenes with alpha-tested triangles take the older form below: their kernels have no device-count variant.)
+namespace {
+struct LiveCopy { const uint32_t* src; uint64_t* dst; uint32_t count; };
+void copy_live_counts(void* p)
+{
+    LiveCopy* c = static_cast<LiveCopy*>(p);
+    for (uint32_t k = 0; k < c->count; ++k) c->dst[k] = c->src[k];
+    delete c;
+}
+} // namespace
+
 int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t depth, uint64_t seed, void* d_hits,
                        uint64_t* live_out, void* stream_)
 {
@@ -857,48 +878,83 @@ int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t dep
     const uint64_t nblocks = (n + kBlockThreads - 1) / kBlockThreads;
     auto al = [](uint64_t b) { return (b + 255) & ~uint64_t(255); };
     const uint64_t ray_b = al(n * sizeof(vt_ray)), id_b = al(n * 4), hit_b = al(n * sizeof(vt_hit)), off_b = al(nblocks * 4);
+    const uint64_t live_b = al((uint64_t(depth) + 1) * 4);
     // the queues are engine-wide scratch: a loop on another stream may still be using them
     std::lock_guard<std::mutex> loop_lock(e->host_mu);
-    const size_t loop_need = 2 * ray_b + 2 * id_b + hit_b + off_b + 256;
+    const size_t loop_need = 2 * ray_b + 2 * id_b + hit_b + off_b + live_b;
     if (e->loop_used) {
-        if (loop_need > e->d_loop_bytes) VT_HIP(hipEventSynchronize(e->ev_loop));     // about to be freed and re-allocated
+        if (loop_need > e->d_loop_bytes || live_b > e->h_live_bytes) VT_HIP(hipEventSynchronize(e->ev_loop));     // about to be freed and re-allocated
         else VT_HIP(hipStreamWaitEvent(stream, e->ev_loop, 0));
     }
     int rc = ensure_bytes(&e->d_loop, &e->d_loop_bytes, loop_need);
     if (rc != VT_OK) return rc;
-    if (!e->h_live) VT_HIP(pinned_malloc(reinterpret_cast<void**>(&e->h_live), 64));
+    if (e->h_live_bytes < live_b) {
+        if (e->h_live) { (void)hipHostFree(e->h_live); e->h_live = nullptr; e->h_live_bytes = 0; }
+        VT_HIP(pinned_malloc(reinterpret_cast<void**>(&e->h_live), live_b));
+        e->h_live_bytes = live_b;
+    }
     char* base = static_cast<char*>(e->d_loop);
     vt_ray* R[2] = {reinterpret_cast<vt_ray*>(base), reinterpret_cast<vt_ray*>(base + ray_b)};
     uint32_t* I[2] = {reinterpret_cast<uint32_t*>(base + 2 * ray_b), reinterpret_cast<uint32_t*>(base + 2 * ray_b + id_b)};
     vt_hit* hits_scratch = reinterpret_cast<vt_hit*>(base + 2 * ray_b + 2 * id_b);
     uint32_t* offsets = reinterpret_cast<uint32_t*>(base + 2 * ray_b + 2 * id_b + hit_b);
-    uint32_t* d_live = reinterpret_cast<uint32_t*>(base + 2 * ray_b + 2 * id_b + hit_b + off_b);
+    uint32_t* d_live = reinterpret_cast<uint32_t*>(base + 2 * ray_b + 2 * id_b + hit_b + off_b);   // [d] = paths alive at depth d (d >= 1)
     vt_hit* H = static_cast<vt_hit*>(d_hits);
 
-    uint64_t m = n;
     const vt_ray* rays_q = static_cast<const vt_ray*>(d_rays);
     const uint32_t* ids_q = nullptr;
-    if (live_out) live_out[0] = n;
+    if (s->has_alpha) {
+        // ---- older form: the live count comes back to the host once per depth (alpha-test kernels take their ray count from the host)
+        uint64_t m = n;
+        if (live_out) live_out[0] = n;
+        for (uint32_t d = 0; d < depth; ++d) {
+            vt_hit* row = H + uint64_t(d) * n;
+            if (m < n) VT_HIP(launch_fill_miss(row, n, nullptr, stream));   // paths that ended earlier read as misses
+            const bool last = d + 1 == depth;
+            if (m != 0) {
+                vt_hit* hits_q = d == 0 ? row : hits_scratch;               // depth 0: queue order = path order
+                rc = launch(s, rays_q, m, hits_q, nullptr, nullptr, false, false, stream);
+                if (rc != VT_OK) return rc;
+                QueueArgs qa{s->d_tris, s->d_prim_to_slot, rays_q, hits_q, ids_q, m, nullptr, d == 0 ? nullptr : row,
+                             last ? nullptr : R[d & 1], last ? nullptr : I[d & 1], offsets, seed + d};
+                VT_HIP(launch_queue_step(qa, d_live, stream));
+                if (!last) {
+                    VT_HIP(hipMemcpyAsync(e->h_live, d_live, 4, hipMemcpyDeviceToHost, stream));
+                    VT_HIP(hipStreamSynchronize(stream));
+                    m = *e->h_live;
+                    rays_q = R[d & 1];
+                    ids_q = I[d & 1];
+                }
+            }
+            if (live_out && !last) live_out[d + 1] = m;
+        }
+        VT_HIP(hipEventRecord(e->ev_loop, stream));
+        e->loop_used = true;
+        return VT_OK;
+    }
     for (uint32_t d = 0; d < depth; ++d) {
         vt_hit* row = H + uint64_t(d) * n;
-        if (m < n) VT_HIP(launch_fill_miss(row, n, stream));            // paths that ended earlier read as misses
+        const uint32_t* count = d == 0 ? nullptr : d_live + d;          // depth 0: all n paths, known here
+        if (d != 0) VT_HIP(launch_fill_miss(row, n, count, stream));    // paths that ended earlier read as misses
         const bool last = d + 1 == depth;
-        if (m != 0) {
-            vt_hit* hits_q = d == 0 ? row : hits_scratch;               // depth 0: queue order = path order
-            rc = launch(s, rays_q, m, hits_q, nullptr, nullptr, false, false, stream);
-            if (rc != VT_OK) return rc;
-            QueueArgs qa{s->d_tris, s->d_prim_to_slot, rays_q, hits_q, ids_q, m, d == 0 ? nullptr : row,
-                         last ? nullptr : R[d & 1], last ? nullptr : I[d & 1], offsets, seed + d};
-            VT_HIP(launch_queue_step(qa, d_live, stream));
-            if (!last) {
-                VT_HIP(hipMemcpyAsync(e->h_live, d_live, 4, hipMemcpyDeviceToHost, stream));
-                VT_HIP(hipStreamSynchronize(stream));
-                m = *e->h_live;
-                rays_q = R[d & 1];
-                ids_q = I[d & 1];
-            }
+        vt_hit* hits_q = d == 0 ? row : hits_scratch;                   // depth 0: queue order = path order
+        const BatchReq req{rays_q, hits_q, n, 0, count};
+        rc = launch_batches(s, &req, 1, nullptr, false, false, stream);
+        if (rc != VT_OK) return rc;
+        QueueArgs qa{s->d_tris, s->d_prim_to_slot, rays_q, hits_q, ids_q, n, count, d == 0 ? nullptr : row,
+                     last ? nullptr : R[d & 1], last ? nullptr : I[d & 1], offsets, seed + d};
+        VT_HIP(launch_queue_step(qa, d_live + d + 1, stream));
+        rays_q = R[d & 1];
+        ids_q = I[d & 1];
+    }
+    if (live_out) {
+        live_out[0] = n;
+        if (depth > 1) {
+            VT_HIP(hipMemcpyAsync(e->h_live, d_live + 1, size_t(depth - 1) * 4, hipMemcpyDeviceToHost, stream));
+            LiveCopy* job = new LiveCopy{e->h_live, live_out + 1, depth - 1};
+            const hipError_t herr = hipLaunchHostFunc(stream, copy_live_counts, job);
+            if (herr != hipSuccess) { delete job; return fail(VT_ERR_HIP, std::string("vt_bounce_loop_dev: ") + hipGetErrorString(herr)); }
         }
-        if (live_out && !last) live_out[d + 1] = m;
     }
     VT_HIP(hipEventRecord(e->ev_loop, stream));
     e->loop_used = true;

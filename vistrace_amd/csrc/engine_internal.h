@@ -103,7 +103,9 @@ struct vt_engine {
     char*  h_build = nullptr;  size_t h_build_bytes = 0;
     // bounce loop: two ray queues, two path-id queues, the queue's hit records, block offsets, live counter
     void*  d_loop = nullptr;  size_t d_loop_bytes = 0;
-    uint32_t* h_live = nullptr;           // pinned read-back of the live-path count
+    uint32_t* h_live = nullptr;           // pinned read-back of the live-path counts
+    size_t    h_live_bytes = 0;
+    char*     h_bad = nullptr;            // pinned read-back of a batch upload's first-bad-ray word (batch.hip)
     // single-ray / tiny-batch path: pinned, device-mapped host memory the kernel reads and writes in
     // place (no copy calls: one launch + one stream sync per Traverse)
     static constexpr uint32_t kTinyRays = 256;
@@ -254,7 +256,9 @@ inline hipError_t pinned_malloc(void** p, size_t bytes, unsigned flags = hipHost
 
 int ensure_bytes(void** ptr, size_t* have, size_t need);
 // one batch of a launch: d_out = its vt_hit array (closest hit) or its byte array (any hit); image_width as vt_batch_desc
-struct BatchReq { const void* d_rays; void* d_out; uint64_t n; uint32_t image_width; };
+// d_count (optional, one-batch closest-hit launches on scenes without alpha test): a device word holding how many of the n rays
+// really exist -- the launch is sized for n, the kernel reads the word (vt_bounce_loop_dev: no host round trip per depth)
+struct BatchReq { const void* d_rays; void* d_out; uint64_t n; uint32_t image_width; const uint32_t* d_count = nullptr; };
 // ONE launch over nreq batches on `stream` (per-launch scratch from the engine's slot ring); d_stats: counters kernels, one batch
 int launch_batches(vt_scene* s, const BatchReq* reqs, uint32_t nreq, void* d_stats, bool any_hit, bool stats, hipStream_t stream);
 // enqueue one trace of n device-resident rays on `stream` (per-launch scratch from the engine's slot ring)

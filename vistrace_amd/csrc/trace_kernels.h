@@ -65,6 +65,7 @@ struct TraceArgs {
     const uint32_t*     reserved_cus;     // persistent mode: 1024-bit set of __smid() values of the reserved CUs, or NULL
     uint32_t*           cu_slots;         // 1024 counters (zeroed per launch): blocks that asked to stay on a reserved CU
     uint32_t            reserved_limit;   // blocks a reserved CU keeps (0 = none)
+    const uint32_t*     live_n;           // trace_kernel_devn only: rays the launch's one batch really holds (<= seg0.n, which sized the launch)
 };
 
 // One per triangle slot of a scene with alpha-tested triangles, in the scene's record array behind the triangles (so
@@ -107,13 +108,16 @@ hipError_t launch_gen_bounce(const GenBounceArgs& a, hipStream_t stream);
 struct QueueArgs {
     const vt_tri64* tris; const uint32_t* prim_to_slot;
     const vt_ray* rays_q; const vt_hit* hits_q; const uint32_t* ids_q; uint64_t m;
+    const uint32_t* m_dev;     // NULL, or: the queue really holds *m_dev <= m entries (m sized the launch)
     vt_hit* hits_out;          // this depth's row of the result (indexed by path), or NULL when hits_q already is it
     vt_ray* rays_next; uint32_t* ids_next;   // next queue, or NULL at the last depth
     uint32_t* block_offsets;   // scratch: one entry per 256 queue entries
     uint64_t seed;
 };
 hipError_t launch_queue_step(const QueueArgs& a, uint32_t* live_out, hipStream_t stream);
-hipError_t launch_fill_miss(vt_hit* hits, uint64_t n, hipStream_t stream);
+// every record of a result row becomes a miss -- unless (count != NULL) *count == n: then every path is still in the queue and the
+// queue step is about to write the whole row
+hipError_t launch_fill_miss(vt_hit* hits, uint64_t n, const uint32_t* count, hipStream_t stream);
 
 struct RefitTrisArgs { const float* verts; const uint8_t* flags; const uint32_t* prim_to_slot; vt_tri64* tris; uint32_t n;
                        uint32_t* bad; /* counts triangles with a non-finite vertex */ };

@@ -66,6 +66,10 @@ extern "C" __attribute__((visibility("default"))) int vt_mutant(void) { return V
 #define VT_MUT(k, wrong, right) (right)
 #endif
 
+// Source anchors for scripts/isa_audit.py: where a body of the traversal loop starts.  The script compiles this file with line
+// tables and attributes every generated instruction to the body its source line lies in.  Expands to nothing.
+#define VT_ISA_MARK(name)
+
 #if defined(VT_MUTANT) && VT_MUTANT == 3
 #pragma clang fp contract(fast)
 #else
@@ -237,7 +241,9 @@ __device__ __forceinline__ void leave_grid(const TraceArgs& a, uint32_t waves_le
     }
 }
 
-template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA>
+// DEVN (vt_bounce_loop_dev, depth >= 1): the launch was sized on the host for an upper bound of its ONE batch; how many rays the
+// batch really holds is a device word (the live-path count the previous depth's queue step left there), read once per wave.
+template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA, bool ALPHA, bool DEVN = false>
 __device__ __forceinline__ void trace_body(const TraceArgs& a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
@@ -282,7 +288,21 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
     Lane L;
     if constexpr (ALPHA) { L.astate = 0; L.ax = L.ay = L.aref = 0.f; L.cprim = 0; L.cu = L.cv = L.ct = 0.f; }
     uint64_t ray_idx = 0;
-    bool has_ray = false;
+    // which lanes hold a ray: ONE wave-uniform 64-bit mask in scalar registers (round 6).  A per-lane `bool has_ray` carried around
+    // the loop lived in a VGPR as 0 / 1 and was turned back into a lane mask every iteration (v_and + v_cmp, and a masked v_mov
+    // wherever it changed); the mask form costs scalar instructions only -- inverse_ballot hands it to the compiler as the
+    // per-lane predicate it was.  start_ray / finish_ray run under divergent control flow and cannot update a uniform value:
+    // their callers do, with the ballot of the lanes that started / finished.
+    uint64_t live = 0;
+#define has_ray __builtin_amdgcn_inverse_ballot_w64(live)
+    // rays and ray blocks of the launch: kernel arguments, or (DEVN) derived from the device word
+    uint32_t dev_n = 0, dev_nblocks = 0;
+    if constexpr (DEVN) {
+        dev_n = __builtin_amdgcn_readfirstlane(*a.live_n);
+        const uint32_t unit = PERSISTENT ? a.block_rays : kBlockThreads;
+        dev_nblocks = dev_n / unit + (dev_n % unit != 0 ? 1u : 0u);
+    }
+    auto launch_nblocks = [&]() -> uint32_t { if constexpr (DEVN) return dev_nblocks; else return a.nblocks; };
 
     // wave-uniform block cursor (PERSISTENT)
     uint64_t blk_cur = 0, blk_end = 0;
@@ -361,7 +381,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             L.node = kDone; L.tri_cur = 0; L.tri_end = 0;
         }
         ray_idx = uint64_t(cur->out_off) + idx;    // where the result goes: all that a lane keeps of its batch
-        has_ray = true;
     };
 
     auto finish_ray = [&]() {
@@ -377,7 +396,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
         if constexpr (STATS) {
             a.ray_stats[ray_idx] = vt_ray_stats{L.steps, L.tests};
         }
-        has_ray = false;
     };
 
     if constexpr (!PERSISTENT) {
@@ -389,8 +407,11 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             const uint32_t ty = t / tpr, tx = t - ty * tpr;
             idx = uint64_t(ty * 16u + (k >> 2)) * tile_w + tx * 4u + (k & 3u);
         }
-        if (idx < cur->n) start_ray(idx);
-        if (has_ray && L.node == kDone && L.tri_cur >= L.tri_end) finish_ray();
+        const bool mine = DEVN ? idx < dev_n : idx < cur->n;
+        if (mine) start_ray(idx);
+        const bool at_once = mine && L.node == kDone && L.tri_cur >= L.tri_end;      // empty scene / NaN range
+        if (at_once) finish_ray();
+        live = __ballot(mine && !at_once);
     }
 
     for (;;) {
@@ -400,8 +421,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
         // rays 2.14 -> 2.08 ms, S10M 5.98 -> 5.87 ms (profiles/r2/notes.md; the opposite assignment is 1 % slower
         // than none).  Scheduling only: results are unaffected.
         __builtin_amdgcn_s_setprio(3);
+        VT_ISA_MARK("refill");
         if constexpr (PERSISTENT) {
-            const uint64_t idle = __ballot(!has_ray);
+            const uint64_t idle = ~live;
             if (idle != 0 && !exhausted) {
                 const uint32_t nidle = __popcll(idle);
                 // a coherent wave (see below) is only re-filled as a whole, so it stays coherent
@@ -415,18 +437,18 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                             b = 0xFFFFFFFFu;
                             while (xcd_off < 8u) {
                                 const uint32_t x = (my_xcd + xcd_off) & 7u;
-                                const uint32_t lo = uint32_t((uint64_t(x) * a.nblocks) >> 3);
-                                const uint32_t hi = uint32_t((uint64_t(x + 1) * a.nblocks) >> 3);
+                                const uint32_t lo = uint32_t((uint64_t(x) * launch_nblocks()) >> 3);
+                                const uint32_t hi = uint32_t((uint64_t(x + 1) * launch_nblocks()) >> 3);
                                 uint32_t t = 0xFFFFFFFFu;
                                 if (lane == 0 && lo < hi) t = atomicAdd(a.block_cursor + 16u * x, 1u);
                                 t = __builtin_amdgcn_readfirstlane(t);
                                 if (lo < hi && t < hi - lo) { b = lo + t; break; }
                                 ++xcd_off;
                             }
-                            if (b == 0xFFFFFFFFu) b = a.nblocks;          // everything handed out
+                            if (b == 0xFFFFFFFFu) b = launch_nblocks();          // everything handed out
                         } else {
                             if (claim_cur == claim_end) {
-                                const uint32_t left = a.nblocks > claim_end ? a.nblocks - claim_end : 0u;   // stale, fine
+                                const uint32_t left = launch_nblocks() > claim_end ? launch_nblocks() - claim_end : 0u;   // stale, fine
                                 const uint32_t waves = gridDim.x * (kBlockThreads / 64);
                                 uint32_t k = left / (2u * waves);
                                 k = k < 1u ? 1u : (k > a.max_claim ? a.max_claim : k);
@@ -438,11 +460,11 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                             b = claim_cur++;
                         }
                         b = __builtin_amdgcn_readfirstlane(b);
-                        if (b >= a.nblocks) {
+                        if (b >= launch_nblocks()) {
                             exhausted = true; blk_cur = blk_end = 0;
                         } else {
                             b = enter_batch(b);                  // now the block's index within its batch
-                            const uint64_t n = cur->n;
+                            const uint64_t n = DEVN ? uint64_t(dev_n) : cur->n;
                             blk_cur = uint64_t(b) * a.block_rays;
                             blk_end = blk_cur + a.block_rays < n ? blk_cur + a.block_rays : n;
                             // image-order batch: the block is one or two 4 x 16 pixel tiles side by side (see TraceSeg::tile_w)
@@ -461,15 +483,18 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                     if (!exhausted) {
                         const uint64_t avail = blk_end - blk_cur;
                         const uint32_t mine = prefix_count(idle);
-                        if (!has_ray && mine < avail) {
+                        const bool take = !has_ray && mine < avail;
+                        bool started = take;
+                        if (take) {
                             uint64_t idx = blk_cur + mine;
                             if (blk_tiled) {
                                 const uint32_t k = uint32_t(idx) - blk_first;
                                 idx = blk_base + ((k >> 6) << 2) + (k & 3u) + uint64_t((k >> 2) & 15u) * blk_tile_w;
                             }
                             start_ray(idx);
-                            if (L.node == kDone && L.tri_cur >= L.tri_end) finish_ray(); // empty scene / NaN range
+                            if (L.node == kDone && L.tri_cur >= L.tri_end) { finish_ray(); started = false; }   // empty scene / NaN range
                         }
+                        live |= __ballot(started);
                         blk_cur += nidle < avail ? nidle : avail;
                         if constexpr (FETCH_DMA) {
                             // Coherence probe when a wave starts from empty: if all of its rays share one
@@ -477,7 +502,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                             // fetch records directly (neighbouring lanes hit the same L1 lines) and never
                             // mix new rays into the wave until it has drained.
                             if (idle == ~0ull) {
-                                const uint64_t act = __ballot(has_ray);
+                                const uint64_t act = live;
                                 const uint64_t ax = __ballot(has_ray && (__float_as_uint(L.dx) >> 31)),
                                                ay = __ballot(has_ray && (__float_as_uint(L.dy) >> 31)),
                                                az = __ballot(has_ray && (__float_as_uint(L.dz) >> 31));
@@ -507,12 +532,13 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                     }
                 }
             }
-            if (exhausted && __ballot(has_ray) == 0) break;
+            if (exhausted && live == 0) break;
         } else {
-            if (__ballot(has_ray) == 0) break;
+            if (live == 0) break;
         }
 
         // ---- which record does this lane need? ----------------------------------------------
+        VT_ISA_MARK("select");
         bool alpha1 = false, alpha2 = false;                // ALPHA: the lane's parked candidate waits for its AlphaRec / its texels
         if constexpr (ALPHA) { alpha1 = has_ray && L.astate == 1; alpha2 = has_ray && L.astate == 2; }
         const bool want_tri  = has_ray && !alpha1 && !alpha2 && L.tri_cur < L.tri_end;
@@ -540,6 +566,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             do_alpha1 = alpha1 && run_a1;
         }
 
+        VT_ISA_MARK("fetch");
         float4 q0, q1, q2, q3;   // the record
         bool fetched = false;
         if constexpr (FETCH_DMA) {
@@ -593,6 +620,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             __builtin_amdgcn_s_setprio(0);
         }
 
+        VT_ISA_MARK("tri");
         if (do_tri) {
             // ---- TRI: TriangleBackfaceCull::intersect, Primitives.h:168-215 --------------
             VT_MUT(4, --L.tri_end, ++L.tri_cur);
@@ -699,6 +727,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             }
         } else if (want_node) {
             // ---- NODE: one iteration of SingleRayTraverser::traverse -------------------
+            VT_ISA_MARK("node");
             if constexpr (STATS) ++L.steps;
             // bounds[2a + octant[a]] (entry side) and bounds[2a + 1 - octant[a]] (exit side) of
             // the left and the right child; counts and first indices
@@ -759,8 +788,15 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             }
             L.node = next;
         }
-        if (has_ray && L.node == kDone && L.tri_cur >= L.tri_end && (!ALPHA || L.astate == 0)) finish_ray();
+        VT_ISA_MARK("finish");
+        {
+            const bool done = has_ray && L.node == kDone && L.tri_cur >= L.tri_end && (!ALPHA || L.astate == 0);
+            if (done) finish_ray();
+            live &= ~__ballot(done);
+        }
     }
+#undef has_ray
+    VT_ISA_MARK("exit");
     if constexpr (PERSISTENT) {
         if (lane == 0) leave_grid(a, 1);
     }
@@ -780,6 +816,13 @@ template <bool ANY_HIT, bool STATS, bool PERSISTENT, bool FETCH_DMA>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_vgpr(kCompilerVgprs))) void trace_kernel_alpha(TraceArgs a)
 {
     trace_body<ANY_HIT, STATS, PERSISTENT, FETCH_DMA, true>(a);
+}
+
+// closest hit with the ray count in device memory (TraceArgs::live_n): the traces of vt_bounce_loop_dev behind its first depth
+template <bool PERSISTENT, bool FETCH_DMA>
+__global__ __launch_bounds__(kBlockThreads) void trace_kernel_devn(TraceArgs a)
+{
+    trace_body<false, false, PERSISTENT, FETCH_DMA, false, true>(a);
 }
 
 // ---- TraceResult batch core: TraceResult.cpp:45-86, 255-262 -----------------------------
@@ -928,7 +971,8 @@ __global__ __launch_bounds__(kBlockThreads) void queue_count_kernel(QueueArgs a)
 {
     __shared__ uint32_t wave_count[kBlockThreads / 64];
     const uint64_t j = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
-    const bool live = j < a.m && a.hits_q[j].prim != VT_MISS;
+    const uint64_t m = a.m_dev ? uint64_t(*a.m_dev) : a.m;
+    const bool live = j < m && a.hits_q[j].prim != VT_MISS;
     const uint64_t mask = __ballot(live);
     if ((threadIdx.x & 63u) == 0) wave_count[threadIdx.x >> 6] = uint32_t(__popcll(mask));
     __syncthreads();
@@ -961,7 +1005,7 @@ __global__ __launch_bounds__(kBlockThreads) void queue_emit_kernel(QueueArgs a)
 {
     __shared__ uint32_t wave_count[kBlockThreads / 64];
     const uint64_t j = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
-    const bool valid = j < a.m;
+    const bool valid = j < (a.m_dev ? uint64_t(*a.m_dev) : a.m);
     vt_hit h{VT_MISS, 0.f, 0.f, 0.f};
     if (valid) h = a.hits_q[j];
     const uint32_t path = valid ? (a.ids_q ? a.ids_q[j] : uint32_t(j)) : 0u;
@@ -979,8 +1023,9 @@ __global__ __launch_bounds__(kBlockThreads) void queue_emit_kernel(QueueArgs a)
     a.ids_next[dst] = path;
 }
 
-__global__ __launch_bounds__(kBlockThreads) void fill_miss_kernel(vt_hit* hits, uint64_t n)
+__global__ __launch_bounds__(kBlockThreads) void fill_miss_kernel(vt_hit* hits, uint64_t n, const uint32_t* count)
 {
+    if (count && uint64_t(*count) == n) return;        // every path is still alive: the queue step writes the whole row
     const uint64_t i = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
     if (i < n) hits[i] = vt_hit{VT_MISS, 0.f, 0.f, 0.f};
 }
@@ -1174,6 +1219,14 @@ hipError_t dispatch(const TraceArgs* a, bool any_hit, bool stats, bool persisten
 hipError_t launch_trace(const TraceArgs& a, bool any_hit, bool stats, bool persistent, bool fetch_dma, bool alpha,
                         uint32_t grid_blocks, size_t lds_bytes, hipStream_t stream)
 {
+    if (a.live_n) {                        // the ray count lives on the device: closest hit, plain scenes (engine.hip checks)
+        if (any_hit || stats || alpha || a.nseg != 0) return hipErrorInvalidValue;
+        const dim3 grid(grid_blocks), block(kBlockThreads);
+        if (persistent && fetch_dma) hipLaunchKernelGGL((trace_kernel_devn<true, true>), grid, block, lds_bytes, stream, a);
+        else if (persistent) hipLaunchKernelGGL((trace_kernel_devn<true, false>), grid, block, lds_bytes, stream, a);
+        else hipLaunchKernelGGL((trace_kernel_devn<false, false>), grid, block, lds_bytes, stream, a);
+        return hipGetLastError();
+    }
     return alpha ? dispatch<true>(&a, any_hit, stats, persistent, fetch_dma, dim3(grid_blocks), lds_bytes, stream, nullptr)
                  : dispatch<false>(&a, any_hit, stats, persistent, fetch_dma, dim3(grid_blocks), lds_bytes, stream, nullptr);
 }
@@ -1267,11 +1320,11 @@ hipError_t launch_queue_step(const QueueArgs& a, uint32_t* live_out, hipStream_t
     return hipGetLastError();
 }
 
-hipError_t launch_fill_miss(vt_hit* hits, uint64_t n, hipStream_t stream)
+hipError_t launch_fill_miss(vt_hit* hits, uint64_t n, const uint32_t* count, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(fill_miss_kernel, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
-                       hits, n);
+                       hits, n, count);
     return hipGetLastError();
 }
 
