@@ -57,7 +57,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured streaming copy)
-ROUND = "r5"
+ROUND = "r6"
 KERNEL_SOURCES = ("vistrace_amd/csrc/trace_kernels.hip", "vistrace_amd/csrc/trace_kernels.h", "vistrace_amd/csrc/engine.hip",
                   "vistrace_amd/csrc/engine_internal.h", "vistrace_amd/csrc/Makefile")
 # issue cost per wave-instruction and SIMD in cycles, measured on this part (scripts/ubench_valu.hip, profiles/r1/notes.md)

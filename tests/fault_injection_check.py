@@ -306,7 +306,7 @@ def gather_run(e, c):
 cases.append(Case("vt_trace_closest_gather_dev (3 members)", members=3, setup=gather_setup, run=gather_run,
                   check=trace_check_factory(lambda: REF_SMALL), may_absorb=True))
 
-cases.append(Case("vt_engine_set_option reserved_cus", setup=trace_setup, run=lambda e, c: (e.set_option("reserved_cus", 16), True)[1],
+cases.append(Case("vt_engine_set_option reserved_cus", setup=trace_setup, run=lambda e, c: (e.set_option("reserved_cus", 16), None)[1],
                   check=trace_check_factory(lambda: REF_SMALL)))
 
 # ---- references (no injection) ------------------------------------------------------------------------------------------------------

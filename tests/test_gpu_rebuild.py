@@ -128,3 +128,98 @@ def test_every_host_copy_learns_of_a_device_refit(va, engine):
     L.check(L.lib.vt_host_scene_sync(first._h, scene._h))
     assert first.trace_closest_host(rays).tobytes() == fresh.tobytes()
     scene.free()
+
+
+def _nested_triangles(n=600, ratio=1.03):
+    """n triangles around one centroid, each 3 % larger than the one before: the reference's builder algorithm (PLOC: the two
+    smallest clusters are the only mutual nearest neighbours of a round) chains them into a tree ~n levels deep."""
+    s = ratio ** np.arange(n)
+    verts = np.zeros((n, 3, 3), np.float32)
+    verts[:, 0] = np.stack([-s, -s * 0.5, np.zeros(n)], 1)
+    verts[:, 1] = np.stack([s, -s * 0.5, np.zeros(n)], 1)
+    verts[:, 2] = np.stack([np.zeros(n), s, np.zeros(n)], 1)
+    return verts
+
+
+def test_trees_deeper_than_255_levels(va, O, engine):
+    """Round 5's device-side index tables refused trees deeper than 255 levels (an 8-bit radix sort over the depth, fixed read-back
+    offsets) although the host lineariser, the host walk and the launch planner take any depth.  A 582-level PLOC chain: both upload
+    paths, byte-equal records, refit through the level lists, hits and counters equal the oracle's (stack: 10 entries in LDS, the
+    rest in the per-lane overflow area)."""
+    from vistrace_amd import workloads as W
+    verts = _nested_triangles()
+    tris = va.tris_setup(verts)
+    bvh = va.HostBvh(tris, builder="ploc")
+    hs = va.HostScene(bvh)
+    assert hs.max_depth > 500
+    host = va.Scene(engine, hs)
+    dev = va.Scene.from_tree(engine, bvh)
+    hp, ht = host.read_records()
+    dp, dt = dev.read_records()
+    assert hp.tobytes() == dp.tobytes() and ht.tobytes() == dt.tobytes()
+    assert dev.host_scene.max_depth == hs.max_depth
+    rng = np.random.default_rng(5)
+    org = rng.uniform(-3, 3, (6000, 3)).astype(np.float32)
+    org[:, 2] = np.where(rng.random(6000) < 0.5, 5.0, -5.0)
+    d = np.zeros((6000, 3), np.float32)
+    d[:, 2] = -np.sign(org[:, 2])
+    d[:, :2] = rng.normal(scale=0.2, size=(6000, 2))
+    rays = va.make_rays(org, d)
+    ref, ref_st = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris), rays, want_stats=True)[:2]
+    assert int((ref["prim"] != 0xFFFFFFFF).sum()) > 3000 and int(ref_st[:, 0].max()) > 300          # rays that walk the chain
+    for sc in (host, dev):
+        assert sc.trace_closest(rays).tobytes() == ref.tobytes()
+        assert (sc.trace_any(rays) == (ref["prim"] != 0xFFFFFFFF)).all()
+    moved = (verts * np.float32(1.25)).astype(np.float32)
+    host.refit(moved)
+    dev.refit(moved)
+    hp, ht = host.read_records()
+    dp, dt = dev.read_records()
+    assert hp.tobytes() == dp.tobytes() and ht.tobytes() == dt.tobytes()
+    bvh.refit(va.tris_setup(moved))
+    ref2 = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(va.tris_setup(moved)), rays)[0]
+    assert dev.trace_closest(rays).tobytes() == ref2.tobytes()
+    host.free(); dev.free()
+
+
+def test_malformed_trees_are_refused_without_touching_memory_out_of_bounds(va, engine):
+    """vt_scene_upload_tree numbers the tree on the device from parent links it derives itself.  A tree whose child indices point
+    backwards, outside the array, or at a node another parent already claims must be refused ("malformed tree") BEFORE any kernel
+    follows such a link -- and the engine must go on working.  The tree is corrupted in place through the accessor's pointer."""
+    import ctypes as C
+    from vistrace_amd import workloads as W
+    L = va._lib
+    verts = np.ascontiguousarray(W.make_scene("S1k"), np.float32)
+    tris = va.tris_setup(verts)
+    rays = W.sphere_rays(2000, 3)
+    good = va.Scene.from_tree(engine, va.HostBvh(tris))
+    ref = good.trace_closest(rays)
+    good.free()
+
+    def corrupt(mutate):
+        bvh = va.HostBvh(tris)
+        n = L.lib.vt_bvh_node_count(bvh._h)
+        nodes = np.ctypeslib.as_array(C.cast(L.lib.vt_bvh_nodes(bvh._h), C.POINTER(C.c_uint8)), shape=(n * 32,)).view(L.BVH_NODE)
+        inner = [i for i in range(n) if nodes["prim_count"][i] == 0]
+        mutate(nodes, inner, n)
+        with pytest.raises(L.VisTraceError, match="malformed tree|bad prim index"):
+            va.Scene.from_tree(engine, bvh)
+
+    def backwards(nodes, inner, n):             # an inner node deep in the tree points back at the root's children: a cycle
+        nodes["first"][inner[-1]] = 1
+
+    def outside(nodes, inner, n):
+        nodes["first"][inner[len(inner) // 2]] = n + 1000
+
+    def claimed_twice(nodes, inner, n):         # two parents for one pair of children
+        nodes["first"][inner[1]] = nodes["first"][inner[2]]
+
+    def leaf_range_outside(nodes, inner, n):
+        leaf = next(i for i in range(n) if nodes["prim_count"][i] != 0)
+        nodes["first"][leaf] = 0xFFFFFF00
+
+    for mutate in (backwards, outside, claimed_twice, leaf_range_outside):
+        corrupt(mutate)
+        again = va.Scene.from_tree(engine, va.HostBvh(tris))          # the engine (and its staging block) are still sound
+        assert again.trace_closest(rays).tobytes() == ref.tobytes(), mutate.__name__
+        again.free()

@@ -38,6 +38,7 @@
 // v_min3, branch-free DMA): scripts/ubench_valu.hip, profiles/r1/notes.md.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cstddef>
 #include <cstdint>
@@ -288,13 +289,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
     Lane L;
     if constexpr (ALPHA) { L.astate = 0; L.ax = L.ay = L.aref = 0.f; L.cprim = 0; L.cu = L.cv = L.ct = 0.f; }
     uint64_t ray_idx = 0;
-    // which lanes hold a ray: ONE wave-uniform 64-bit mask in scalar registers (round 6).  A per-lane `bool has_ray` carried around
-    // the loop lived in a VGPR as 0 / 1 and was turned back into a lane mask every iteration (v_and + v_cmp, and a masked v_mov
-    // wherever it changed); the mask form costs scalar instructions only -- inverse_ballot hands it to the compiler as the
-    // per-lane predicate it was.  start_ray / finish_ray run under divergent control flow and cannot update a uniform value:
-    // their callers do, with the ballot of the lanes that started / finished.
-    uint64_t live = 0;
-#define has_ray __builtin_amdgcn_inverse_ballot_w64(live)
+    bool has_ray = false;
     // rays and ray blocks of the launch: kernel arguments, or (DEVN) derived from the device word
     uint32_t dev_n = 0, dev_nblocks = 0;
     if constexpr (DEVN) {
@@ -381,6 +376,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             L.node = kDone; L.tri_cur = 0; L.tri_end = 0;
         }
         ray_idx = uint64_t(cur->out_off) + idx;    // where the result goes: all that a lane keeps of its batch
+        has_ray = true;
     };
 
     auto finish_ray = [&]() {
@@ -396,6 +392,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
         if constexpr (STATS) {
             a.ray_stats[ray_idx] = vt_ray_stats{L.steps, L.tests};
         }
+        has_ray = false;
     };
 
     if constexpr (!PERSISTENT) {
@@ -407,11 +404,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             const uint32_t ty = t / tpr, tx = t - ty * tpr;
             idx = uint64_t(ty * 16u + (k >> 2)) * tile_w + tx * 4u + (k & 3u);
         }
-        const bool mine = DEVN ? idx < dev_n : idx < cur->n;
-        if (mine) start_ray(idx);
-        const bool at_once = mine && L.node == kDone && L.tri_cur >= L.tri_end;      // empty scene / NaN range
-        if (at_once) finish_ray();
-        live = __ballot(mine && !at_once);
+        if (DEVN ? idx < dev_n : idx < cur->n) start_ray(idx);
+        if (has_ray && L.node == kDone && L.tri_cur >= L.tri_end) finish_ray();
     }
 
     for (;;) {
@@ -423,7 +417,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
         __builtin_amdgcn_s_setprio(3);
         VT_ISA_MARK("refill");
         if constexpr (PERSISTENT) {
-            const uint64_t idle = ~live;
+            const uint64_t idle = __ballot(!has_ray);
             if (idle != 0 && !exhausted) {
                 const uint32_t nidle = __popcll(idle);
                 // a coherent wave (see below) is only re-filled as a whole, so it stays coherent
@@ -483,18 +477,15 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                     if (!exhausted) {
                         const uint64_t avail = blk_end - blk_cur;
                         const uint32_t mine = prefix_count(idle);
-                        const bool take = !has_ray && mine < avail;
-                        bool started = take;
-                        if (take) {
+                        if (!has_ray && mine < avail) {
                             uint64_t idx = blk_cur + mine;
                             if (blk_tiled) {
                                 const uint32_t k = uint32_t(idx) - blk_first;
                                 idx = blk_base + ((k >> 6) << 2) + (k & 3u) + uint64_t((k >> 2) & 15u) * blk_tile_w;
                             }
                             start_ray(idx);
-                            if (L.node == kDone && L.tri_cur >= L.tri_end) { finish_ray(); started = false; }   // empty scene / NaN range
+                            if (L.node == kDone && L.tri_cur >= L.tri_end) finish_ray(); // empty scene / NaN range
                         }
-                        live |= __ballot(started);
                         blk_cur += nidle < avail ? nidle : avail;
                         if constexpr (FETCH_DMA) {
                             // Coherence probe when a wave starts from empty: if all of its rays share one
@@ -502,7 +493,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                             // fetch records directly (neighbouring lanes hit the same L1 lines) and never
                             // mix new rays into the wave until it has drained.
                             if (idle == ~0ull) {
-                                const uint64_t act = live;
+                                const uint64_t act = __ballot(has_ray);
                                 const uint64_t ax = __ballot(has_ray && (__float_as_uint(L.dx) >> 31)),
                                                ay = __ballot(has_ray && (__float_as_uint(L.dy) >> 31)),
                                                az = __ballot(has_ray && (__float_as_uint(L.dz) >> 31));
@@ -532,9 +523,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                     }
                 }
             }
-            if (exhausted && live == 0) break;
+            if (exhausted && __ballot(has_ray) == 0) break;
         } else {
-            if (live == 0) break;
+            if (__ballot(has_ray) == 0) break;
         }
 
         // ---- which record does this lane need? ----------------------------------------------
@@ -789,13 +780,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             L.node = next;
         }
         VT_ISA_MARK("finish");
-        {
-            const bool done = has_ray && L.node == kDone && L.tri_cur >= L.tri_end && (!ALPHA || L.astate == 0);
-            if (done) finish_ray();
-            live &= ~__ballot(done);
-        }
+        if (has_ray && L.node == kDone && L.tri_cur >= L.tri_end && (!ALPHA || L.astate == 0)) finish_ray();
     }
-#undef has_ray
     VT_ISA_MARK("exit");
     if constexpr (PERSISTENT) {
         if (lane == 0) leave_grid(a, 1);
@@ -966,23 +952,35 @@ __global__ __launch_bounds__(kBlockThreads) void gen_bounce_kernel(GenBounceArgs
 }
 
 // ---- device-resident bounce loop: queue of live paths, compacted in path order ----
-// step 1: hits per 256-entry block of the queue
+// The queue holds m entries; with QueueArgs::m_dev the host only knows an upper bound (a.m) and the real count is a device word.
+// The kernels therefore run over 256-entry CHUNKS in a grid-stride loop bounded by the real count: a launch sized for 16 Mi
+// entries whose queue holds half of them does not start 32 Ki blocks that find nothing to do (first form of round 6: one block
+// per chunk of the upper bound, 0.12 ms per depth slower than the host-synchronised loop on an open scene).
+__device__ __forceinline__ uint64_t queue_size(const QueueArgs& a) { return a.m_dev ? uint64_t(*a.m_dev) : a.m; }
+
+// step 1: hits per 256-entry chunk of the queue
 __global__ __launch_bounds__(kBlockThreads) void queue_count_kernel(QueueArgs a)
 {
     __shared__ uint32_t wave_count[kBlockThreads / 64];
-    const uint64_t j = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
-    const uint64_t m = a.m_dev ? uint64_t(*a.m_dev) : a.m;
-    const bool live = j < m && a.hits_q[j].prim != VT_MISS;
-    const uint64_t mask = __ballot(live);
-    if ((threadIdx.x & 63u) == 0) wave_count[threadIdx.x >> 6] = uint32_t(__popcll(mask));
-    __syncthreads();
-    if (threadIdx.x == 0) a.block_offsets[blockIdx.x] = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+    const uint64_t m = queue_size(a);
+    const uint32_t chunks = uint32_t((m + kBlockThreads - 1) / kBlockThreads);
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        const uint64_t j = uint64_t(chunk) * kBlockThreads + threadIdx.x;
+        const bool live = j < m && a.hits_q[j].prim != VT_MISS;
+        const uint64_t mask = __ballot(live);
+        if ((threadIdx.x & 63u) == 0) wave_count[threadIdx.x >> 6] = uint32_t(__popcll(mask));
+        __syncthreads();
+        if (threadIdx.x == 0) a.block_offsets[chunk] = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        __syncthreads();
+    }
 }
 
-// step 2: exclusive scan of the block counts in place (one block; nblocks <= 2^24), total -> *live_out
-__global__ __launch_bounds__(1024) void queue_scan_kernel(uint32_t* counts, uint32_t nblocks, uint32_t* live_out)
+// step 2: exclusive scan of the chunk counts in place (one block; <= 2^24 chunks), total -> *live_out
+__global__ __launch_bounds__(1024) void queue_scan_kernel(QueueArgs a, uint32_t* live_out)
 {
     __shared__ uint32_t part[1024];
+    uint32_t* const counts = a.block_offsets;
+    const uint32_t nblocks = uint32_t((queue_size(a) + kBlockThreads - 1) / kBlockThreads);
     const uint32_t per = (nblocks + 1023u) / 1024u;
     const uint32_t lo = min(threadIdx.x * per, nblocks), hi = min(lo + per, nblocks);
     uint32_t sum = 0;
@@ -1004,30 +1002,37 @@ __global__ __launch_bounds__(1024) void queue_scan_kernel(uint32_t* counts, uint
 __global__ __launch_bounds__(kBlockThreads) void queue_emit_kernel(QueueArgs a)
 {
     __shared__ uint32_t wave_count[kBlockThreads / 64];
-    const uint64_t j = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
-    const bool valid = j < (a.m_dev ? uint64_t(*a.m_dev) : a.m);
-    vt_hit h{VT_MISS, 0.f, 0.f, 0.f};
-    if (valid) h = a.hits_q[j];
-    const uint32_t path = valid ? (a.ids_q ? a.ids_q[j] : uint32_t(j)) : 0u;
-    if (valid && a.hits_out) a.hits_out[path] = h;
-    const bool live = valid && h.prim != VT_MISS;
-    const uint64_t mask = __ballot(live);
+    const uint64_t m = queue_size(a);
+    const uint32_t chunks = uint32_t((m + kBlockThreads - 1) / kBlockThreads);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (lane == 0) wave_count[wave] = uint32_t(__popcll(mask));
-    __syncthreads();
-    if (!a.rays_next || !live) return;
-    uint32_t dst = a.block_offsets[blockIdx.x] + uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1)));
-    for (uint32_t w = 0; w < wave; ++w) dst += wave_count[w];
-    const vt_hit_attrs A = make_hit_attrs(a.tris[a.prim_to_slot[h.prim]], a.rays_q[j], h);
-    a.rays_next[dst] = make_bounce_ray(A, a.seed, path);
-    a.ids_next[dst] = path;
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        const uint64_t j = uint64_t(chunk) * kBlockThreads + threadIdx.x;
+        const bool valid = j < m;
+        vt_hit h{VT_MISS, 0.f, 0.f, 0.f};
+        if (valid) h = a.hits_q[j];
+        const uint32_t path = valid ? (a.ids_q ? a.ids_q[j] : uint32_t(j)) : 0u;
+        if (valid && a.hits_out) a.hits_out[path] = h;
+        if (!a.rays_next) continue;                                // last depth: nothing to emit (wave-uniform)
+        const bool live = valid && h.prim != VT_MISS;
+        const uint64_t mask = __ballot(live);
+        if (lane == 0) wave_count[wave] = uint32_t(__popcll(mask));
+        __syncthreads();
+        if (live) {
+            uint32_t dst = a.block_offsets[chunk] + uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1)));
+            for (uint32_t w = 0; w < wave; ++w) dst += wave_count[w];
+            const vt_hit_attrs A = make_hit_attrs(a.tris[a.prim_to_slot[h.prim]], a.rays_q[j], h);
+            a.rays_next[dst] = make_bounce_ray(A, a.seed, path);
+            a.ids_next[dst] = path;
+        }
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(kBlockThreads) void fill_miss_kernel(vt_hit* hits, uint64_t n, const uint32_t* count)
 {
     if (count && uint64_t(*count) == n) return;        // every path is still alive: the queue step writes the whole row
-    const uint64_t i = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x;
-    if (i < n) hits[i] = vt_hit{VT_MISS, 0.f, 0.f, 0.f};
+    for (uint64_t i = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlockThreads)
+        hits[i] = vt_hit{VT_MISS, 0.f, 0.f, 0.f};
 }
 
 // ---- refit: triangle records and pair bounds recomputed in place ----------
@@ -1308,13 +1313,16 @@ hipError_t launch_gen_bounce(const GenBounceArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
+// grid of the streaming helper kernels of the bounce loop: one block per 256 entries up to a few blocks per CU, a loop beyond
+constexpr uint32_t kQueueGridCap = 8192;
+
 hipError_t launch_queue_step(const QueueArgs& a, uint32_t* live_out, hipStream_t stream)
 {
     if (a.m == 0) return hipSuccess;
-    const uint32_t blocks = uint32_t((a.m + kBlockThreads - 1) / kBlockThreads);
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((a.m + kBlockThreads - 1) / kBlockThreads, kQueueGridCap));
     if (a.rays_next) {
         hipLaunchKernelGGL(queue_count_kernel, dim3(blocks), dim3(kBlockThreads), 0, stream, a);
-        hipLaunchKernelGGL(queue_scan_kernel, dim3(1), dim3(1024), 0, stream, a.block_offsets, blocks, live_out);
+        hipLaunchKernelGGL(queue_scan_kernel, dim3(1), dim3(1024), 0, stream, a, live_out);
     }
     hipLaunchKernelGGL(queue_emit_kernel, dim3(blocks), dim3(kBlockThreads), 0, stream, a);
     return hipGetLastError();
@@ -1323,7 +1331,7 @@ hipError_t launch_queue_step(const QueueArgs& a, uint32_t* live_out, hipStream_t
 hipError_t launch_fill_miss(vt_hit* hits, uint64_t n, const uint32_t* count, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(fill_miss_kernel, dim3(uint32_t((n + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, stream,
+    hipLaunchKernelGGL(fill_miss_kernel, dim3(uint32_t(std::min<uint64_t>((n + kBlockThreads - 1) / kBlockThreads, kQueueGridCap))), dim3(kBlockThreads), 0, stream,
                        hits, n, count);
     return hipGetLastError();
 }
