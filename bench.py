@@ -307,12 +307,20 @@ def bound_actual(pmc: dict, kernel_ms: float, cus: int = 0) -> dict | None:
         wc = pmc["SQ_WAVE_CYCLES"]
         out["wave_time_split"] = {k: round(pmc.get(c, 0.0) / wc, 3) for k, c in
                                   (("executing", "SQ_ACTIVE_INST_ANY"), ("waiting_memory_or_barrier", "SQ_WAIT_ANY"), ("waiting_to_issue", "SQ_WAIT_INST_ANY"))}
+        if cus:
+            out["resident_waves_per_simd"] = round(wc / cus / cyc, 2)      # SQ_WAVE_CYCLES (quad-cycles of wave residency) / CUs / cycles
     if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("GRBM_GUI_ACTIVE") and cus:
-        # COUNTED: quad-cycles the waves spent executing vector instructions, over CUs x cycles of the same pass = the share of
-        # SIMD cycles with a vector instruction in execution (rocprofiler-sdk's VALUBusy formula for gfx9)
-        out["valu_busy_counter"] = round(pmc["SQ_ACTIVE_INST_VALU"] / cus / cyc, 3)
-        out["valu_busy_counter_how"] = "SQ_ACTIVE_INST_VALU / CUs / (GRBM_GUI_ACTIVE / 8), one rocprofv3 --pmc pass"
-        out["inst_busy_counters"] = {k: round(pmc[f"SQ_ACTIVE_INST_{k}"] / cus / cyc, 3) for k in ("SCA", "LDS", "VMEM", "MISC") if pmc.get(f"SQ_ACTIVE_INST_{k}")}
+        # COUNTED: quad-cycles the waves spent executing vector instructions, over CUs x cycles of the same pass (rocprofiler-sdk's
+        # VALUBusy formula for gfx9).  On gfx950 this is NOT a busy fraction of the vector pipe: the counter charges one quad-cycle
+        # per instruction whatever the instruction costs the pipe (valu_active_per_inst below: ~1.0), and a SIMD retires a wave64
+        # mul / add in 2.4 cycles while the issuing wave holds it for 4 (MI355X_MICROARCH.md: "2 cyc (SIMD-32); one wave alone: 4") --
+        # the figure is the mean number of waves per SIMD that have a vector instruction in flight, between 1 x and 2 x the pipe's
+        # busy fraction.  What the counters alone say about the pipe: busy >= (instructions x 2 cycles) / SIMD cycles.
+        out["valu_active_waves_per_simd"] = round(pmc["SQ_ACTIVE_INST_VALU"] / cus / cyc, 3)
+        out["valu_active_how"] = "SQ_ACTIVE_INST_VALU / CUs / (GRBM_GUI_ACTIVE / 8), one rocprofv3 --pmc pass"
+        out["valu_active_quad_cycles_per_inst"] = round(pmc["SQ_ACTIVE_INST_VALU"] / valu, 3)
+        out["valu_busy_bounds_from_counters"] = [round(valu * 2.0 / SIMDS / cyc, 3), round(min(1.0, valu * 4.0 / SIMDS / cyc), 3)]
+        out["inst_active_waves_per_simd"] = {k: round(pmc[f"SQ_ACTIVE_INST_{k}"] / cus / cyc, 3) for k in ("SCA", "LDS", "VMEM", "MISC") if pmc.get(f"SQ_ACTIVE_INST_{k}")}
         if pmc.get("SQ_BUSY_CU_CYCLES"):
             out["cu_busy_frac"] = round(pmc["SQ_BUSY_CU_CYCLES"] / cus / cyc, 3)
     if "SQ_INSTS_VALU_MUL_F32" in pmc:
@@ -325,9 +333,10 @@ def bound_actual(pmc: dict, kernel_ms: float, cus: int = 0) -> dict | None:
         out["valu_busy_model_how"] = "instruction-class counts x issue costs of scripts/ubench_valu.hip (cycles per wave-instruction and SIMD: mul/add 2.4, int 3.2, fma/select/minmax 4.2, rcp 8.2) / kernel_cycles"
         out["valu_class_share_of_issue_cycles"] = {k: round(named[k] * ISSUE_COST[k] / cycles, 3) for k in named} | {"OTHER(select/minmax/cmp/mov/dpp)": round(other * ISSUE_COST["OTHER"] / cycles, 3)}
         out["branches"] = pmc.get("SQ_INSTS_BRANCH")
-    # the figure the "VALU-bound" sentence of DESIGN.md section 5 rests on: the counter when the pass delivered it, else the model
-    out["valu_busy_frac"] = out.get("valu_busy_counter", out.get("valu_busy_model"))
-    out["valu_busy_frac_is"] = "counter" if "valu_busy_counter" in out else ("model" if "valu_busy_model" in out else None)
+    # the figure DESIGN.md section 5 quotes: the MODEL (counted instructions x measured issue costs) -- gfx950 exposes no counter of
+    # the vector pipe's busy cycles (SQ_INST_CYCLES_VALU is gfx12's); the counters bracket it (valu_busy_bounds_from_counters)
+    out["valu_busy_frac"] = out.get("valu_busy_model")
+    out["valu_busy_frac_is"] = "model, bracketed by counters" if "valu_busy_bounds_from_counters" in out and "valu_busy_model" in out else ("model" if "valu_busy_model" in out else None)
     return out
 
 

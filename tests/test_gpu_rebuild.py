@@ -131,13 +131,17 @@ def test_every_host_copy_learns_of_a_device_refit(va, engine):
 
 
 def _nested_triangles(n=600, ratio=1.03):
-    """n triangles around one centroid, each 3 % larger than the one before: the reference's builder algorithm (PLOC: the two
-    smallest clusters are the only mutual nearest neighbours of a round) chains them into a tree ~n levels deep."""
-    s = ratio ** np.arange(n)
+    """n triangles around one axis, each 3 % larger than the one before: the reference's builder algorithm (PLOC: the two
+    smallest clusters are the only mutual nearest neighbours of a round) chains them into a tree ~n levels deep.  Every triangle
+    lies in a slightly tilted plane of its own (z = c_k y + k / 1000), so a ray down the axis enters nearly every box of the chain
+    before its closest hit: the walk really is hundreds of levels deep."""
+    k = np.arange(n)
+    s = ratio ** k
+    c, h = 0.001 * (k % 7 + 1), 1e-3 * k
     verts = np.zeros((n, 3, 3), np.float32)
-    verts[:, 0] = np.stack([-s, -s * 0.5, np.zeros(n)], 1)
-    verts[:, 1] = np.stack([s, -s * 0.5, np.zeros(n)], 1)
-    verts[:, 2] = np.stack([np.zeros(n), s, np.zeros(n)], 1)
+    verts[:, 0] = np.stack([-s, -s * 0.5, c * (-s * 0.5) + h], 1)
+    verts[:, 1] = np.stack([s, -s * 0.5, c * (-s * 0.5) + h], 1)
+    verts[:, 2] = np.stack([np.zeros(n), s, c * s + h], 1)
     return verts
 
 
@@ -160,13 +164,13 @@ def test_trees_deeper_than_255_levels(va, O, engine):
     assert dev.host_scene.max_depth == hs.max_depth
     rng = np.random.default_rng(5)
     org = rng.uniform(-3, 3, (6000, 3)).astype(np.float32)
-    org[:, 2] = np.where(rng.random(6000) < 0.5, 5.0, -5.0)
+    org[:, 2] = np.where(rng.random(6000) < 0.5, 50.0, -50.0)
     d = np.zeros((6000, 3), np.float32)
     d[:, 2] = -np.sign(org[:, 2])
     d[:, :2] = rng.normal(scale=0.2, size=(6000, 2))
     rays = va.make_rays(org, d)
     ref, ref_st = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris), rays, want_stats=True)[:2]
-    assert int((ref["prim"] != 0xFFFFFFFF).sum()) > 3000 and int(ref_st[:, 0].max()) > 300          # rays that walk the chain
+    assert int((ref["prim"] != 0xFFFFFFFF).sum()) > 3000 and int(ref_st[:, 0].max()) > 500 and len(np.unique(ref["prim"])) > 50   # rays that walk the chain
     for sc in (host, dev):
         assert sc.trace_closest(rays).tobytes() == ref.tobytes()
         assert (sc.trace_any(rays) == (ref["prim"] != 0xFFFFFFFF)).all()
