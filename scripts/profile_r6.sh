@@ -19,7 +19,7 @@ line ploc --builder ploc --alt-builder none --no-cpu --legs off
 line forcedist_1rank --force-dist --no-cpu --no-pmc --alt-builder none --steps 200
 # per-workload kernel statistics: a kernel TRACE of a run that launches the headline batch and nothing else on that kernel
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-pmc --alt-builder none --legs off > $OUT/trace.log 2>&1
-python3 scripts/kernel_stats_headline.py $OUT/trace $OUT/kernel_stats_headline.csv
+python3 scripts/kernel_stats_headline.py $OUT/trace $OUT/kernel_stats_headline.csv --warmup 5 --steps 20
 # ... and rocprofv3's own roll-up of the same command, for comparison (round 5's file: averages the camera pass in)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-pmc --alt-builder none --legs off > $OUT/stats.log 2>&1
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
