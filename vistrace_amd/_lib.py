@@ -209,18 +209,14 @@ def _load() -> C.CDLL:
 lib = _load()
 
 
-_hip = None
-
-
 def hip_stream_synchronize(stream: int) -> None:
-    """hipStreamSynchronize on a raw stream handle (0 = the null stream), through the HIP runtime the library itself is linked to:
-    for the few `_dev` calls whose host-side outputs arrive in stream order (Scene.bounce_loop_dev's live counts)."""
-    global _hip
-    if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")
-        _hip.hipStreamSynchronize.argtypes = [C.c_void_p]
-        _hip.hipStreamSynchronize.restype = C.c_int
-    rc = _hip.hipStreamSynchronize(stream or None)
+    """hipStreamSynchronize on a raw stream handle (0 = the null stream): for the few `_dev` calls whose host-side outputs arrive in
+    stream order (Scene.bounce_loop_dev's live counts).  The symbol is looked up THROUGH libvistrace_hip.so (dlsym on its handle
+    searches its dependencies), so it is the HIP runtime the library itself is bound to -- never a second copy of libamdhip64."""
+    fn = lib.hipStreamSynchronize
+    fn.argtypes = [C.c_void_p]
+    fn.restype = C.c_int
+    rc = fn(stream or None)
     if rc != 0:
         raise VisTraceError(VT_ERR_HIP, f"hipStreamSynchronize failed ({rc})")
 

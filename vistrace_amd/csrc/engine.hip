@@ -1162,7 +1162,7 @@ int vt_scene_refit(vt_scene* s, const float* verts, const uint8_t* flags, uint32
     auto enqueue = [&](vt_scene* m) -> int {
         vt_engine* e = m->engine;
         if (flags) m->has_alpha = alpha_from_flags;        // new flags replace the old ones: so does the scene's alpha-test state
-        if (vt_engine* re = e->root) {                     // a replica: the staged input comes from the root's device
+        if (vt_engine* re = m != s ? e->root : nullptr) {  // a replica of s: the staged input comes from the root's device
             VT_HIP(hipStreamWaitEvent(e->stream, re->ev_staged, 0));
             VT_HIP(hipMemcpyPeerAsync(e->d_rays, e->device, re->d_rays, re->device, vert_b, e->stream));
             if (flags) VT_HIP(hipMemcpyPeerAsync(e->d_out, e->device, re->d_out, re->device, n, e->stream));

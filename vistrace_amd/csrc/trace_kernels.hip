@@ -975,16 +975,20 @@ __global__ __launch_bounds__(kBlockThreads) void queue_count_kernel(QueueArgs a)
     }
 }
 
-// step 2: exclusive scan of the chunk counts in place (one block; <= 2^24 chunks), total -> *live_out
+// step 2: exclusive scan of the chunk counts in place (one block; <= 2^24 chunks), total -> *live_out.  Every thread owns a
+// contiguous run of counts, a multiple of four long, and moves it as 16-B words (the runs of neighbouring lanes lie 256 B apart:
+// with 4-B loads this one block took 0.1 ms for the 65 536 chunks of a 16 Mi-entry queue, 2 % of a depth).
 __global__ __launch_bounds__(1024) void queue_scan_kernel(QueueArgs a, uint32_t* live_out)
 {
     __shared__ uint32_t part[1024];
     uint32_t* const counts = a.block_offsets;
     const uint32_t nblocks = uint32_t((queue_size(a) + kBlockThreads - 1) / kBlockThreads);
-    const uint32_t per = (nblocks + 1023u) / 1024u;
+    const uint32_t per = ((nblocks + 1023u) / 1024u + 3u) & ~3u;        // (block_offsets is 256-B aligned: every run starts on 16 B)
     const uint32_t lo = min(threadIdx.x * per, nblocks), hi = min(lo + per, nblocks);
+    const uint32_t hi4 = lo + ((hi - lo) & ~3u);
     uint32_t sum = 0;
-    for (uint32_t k = lo; k < hi; ++k) sum += counts[k];
+    for (uint32_t k = lo; k < hi4; k += 4) { const uint4 c = *reinterpret_cast<const uint4*>(counts + k); sum += (c.x + c.y) + (c.z + c.w); }
+    for (uint32_t k = hi4; k < hi; ++k) sum += counts[k];
     part[threadIdx.x] = sum;
     __syncthreads();
     for (uint32_t d = 1; d < 1024u; d <<= 1) {                    // Hillis-Steele inclusive scan of the partials
@@ -994,7 +998,14 @@ __global__ __launch_bounds__(1024) void queue_scan_kernel(QueueArgs a, uint32_t*
         __syncthreads();
     }
     uint32_t run = part[threadIdx.x] - sum;
-    for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = counts[k]; counts[k] = run; run += c; }
+    for (uint32_t k = lo; k < hi4; k += 4) {
+        const uint4 c = *reinterpret_cast<const uint4*>(counts + k);
+        uint4 o;
+        o.x = run; o.y = o.x + c.x; o.z = o.y + c.y; o.w = o.z + c.z;
+        run = o.w + c.w;
+        *reinterpret_cast<uint4*>(counts + k) = o;
+    }
+    for (uint32_t k = hi4; k < hi; ++k) { const uint32_t c = counts[k]; counts[k] = run; run += c; }
     if (threadIdx.x == 1023u) *live_out = part[1023];
 }
 
