@@ -262,6 +262,24 @@ def test_hit_attrs_vs_oracle(va, engine, make_bundle, O):
         err = np.abs(attrs[k][hit] - ref[k][hit])
         scale = np.maximum(np.abs(ref[k][hit]).max(axis=1, keepdims=True), 1e-30)
         assert (err / scale).max() <= REL_TOL, k
+    # ... and, stronger than the 1e-5 the task asks for: the device evaluates the same unfused fp32 expression trees with correctly
+    # rounded divides and square roots, so every field is BIT-identical (round 6: the tolerance alone let `w = 1 - (u + v)` for
+    # `1 - u - v` through -- mutant 21 of scripts/mutants.sh)
+    for k in ("pos", "uvw", "ngeo", "wo"):
+        assert (attrs[k][hit].view(np.uint32) == ref[k][hit].view(np.uint32)).all(), k
+    # A record that no trace produces but the entry point accepts: a ray PARALLEL to its triangle.  dot(wo, n) is exactly 0 and
+    # TraceResult.cpp:85 says frontFacing = dot >= 0 (mutant 22: > 0).
+    flat = va.make_rays([[0.0, 0.0, 1.0]] * 4, [[1.0, 0.0, 0.0], [0.0, -2.0, 0.0], [3.0, 4.0, 0.0], [-1.0, 1.0, 0.0]])
+    tri = va.tris_setup(np.array([[[-5, -5, 0], [5, -5, 0], [0, 5, 0]]], np.float32))
+    fscene = va.Scene.from_tree(engine, va.HostBvh(tri))
+    fhits = np.zeros(4, va.HIT)
+    fhits["prim"], fhits["t"], fhits["u"], fhits["v"] = 0, 1.0, 0.25, 0.25
+    d_fr, d_fh = tp.to_device(flat, dev), tp.to_device(fhits, dev)
+    fat = tp.to_host(tp.hit_attrs(fscene, d_fr, d_fh, 4), va.HIT_ATTRS)
+    fref = O.hit_attrs(O.tris_from_tri64(tri), flat, fhits)
+    assert (fref["front"] == 1).all() and (fat["front"] == 1).all()
+    assert (fat["pos"].view(np.uint32) == fref["pos"].view(np.uint32)).all()
+    fscene.free()
 
 
 # ---- BASELINE sizes ----------------------------------------------------------------------------------
@@ -496,7 +514,7 @@ def test_random_triangle_soups(va, engine, O, seed):
         assert ref["prim"][i] in ids[:cnt]
 
 
-def test_device_ray_generation_matches_host(va, engine, make_bundle):
+def test_device_ray_generation_matches_host(va, engine, make_bundle, O):
     """vt_gen_primary_dev / vt_gen_bounce_dev against the numpy generators (workloads.py): origins and
     RNG samples exact, directions within 1e-6 (device vs host cos/sin/double rounding), and the traced
     results of both ray sets agree wherever the rays are bit-identical."""
@@ -533,6 +551,21 @@ def test_device_ray_generation_matches_host(va, engine, make_bundle):
     assert (got_b["org"].view(np.uint32) == ref_b["org"].view(np.uint32)).all()      # CalcRayOrigin: integer exact
     assert np.abs(got_b["dir"] - ref_b["dir"]).max() <= 2e-6
     assert np.allclose(np.linalg.norm(got_b["dir"], axis=1), 1.0, atol=1e-5)
+    # vistrace.CalcRayOrigin at its branch point, source/VisTrace.cpp:1495-1517: abs(pos) < 1/32 takes the float offset, anything else
+    # -- exactly 1/32 included -- the integer one (mutant 27 of scripts/mutants.sh: <=).  Records no trace would produce by chance.
+    edge = attrs[:64].copy()
+    vals = np.array([1 / 32, -1 / 32, np.nextafter(np.float32(1 / 32), np.float32(0)), np.nextafter(np.float32(1 / 32), np.float32(1)), 0.0, -0.0, 1e-30, 7.5], np.float32)
+    for j in range(64):
+        edge["pos"][j] = (vals[j % 8], vals[(j // 8) % 8], vals[(j * 3 + 1) % 8])
+        nrm = np.array([(-1) ** j * 0.6, 0.0, 0.8], np.float32)
+        edge["ngeo"][j], edge["wo"][j], edge["front"][j], edge["hit"][j] = nrm, nrm, 1, 1
+    d_e = tp.to_device(edge, dev)
+    d_eb = tp.empty_records(64, va.RAY, dev)
+    engine.gen_bounce_dev(d_e.data_ptr(), 64, 5, d_eb.data_ptr(), stream=tp.current_stream_handle(dev))
+    got_e, ref_e = tp.to_host(d_eb, va.RAY), W.bounce_rays(edge, 5)
+    assert (got_e["org"].view(np.uint32) == ref_e["org"].view(np.uint32)).all()
+    for j in range(64):                                                     # ... and the oracle's restatement says the same
+        assert (O.calc_ray_origin(edge["pos"][j], edge["ngeo"][j]).view(np.uint32) == got_e["org"][j].view(np.uint32)).all()
     # a missed record becomes a null ray
     attrs2 = attrs.copy(); attrs2["hit"][::7] = 0
     d_a2 = tp.to_device(attrs2, dev)

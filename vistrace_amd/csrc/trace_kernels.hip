@@ -58,6 +58,10 @@
 //   8 hit needs u > 0                      9 back face culled on n.d >= 0       10 stack entries beyond the LDS part hold the near child
 //  11 hit accepted on t > tmin            12 w = 1 - (u + v)                   13 FRONT faces culled (n.d < 0)
 //  14 hit needs v > 0                     15 hit needs w > 0                   16 stack entry `lds_entries` still written to LDS
+// Either side of the walk (the rows of SURVEY.md 8(f); killed by test_hit_attrs_vs_oracle, the refit / skin / bounce-loop tests):
+//  21 GetPos with w = 1 - (u + v)          22 frontFacing on dot(wo, n) > 0      23 texUV weights u and v swapped
+//  24 refit: e1 = p1 - p0                  25 refit: a leaf's box misses vertex 2  26 skinning: weight of bone 0 for every bone
+//  27 CalcRayOrigin: |pos| <= 1/32         28 bounce direction: sin and cos of phi swapped
 // (9 is an EQUIVALENT mutant, kept as the record of why: with n.d == +-0 the test goes on to inv_det = +-inf, and then u, v are
 //  NaN or infinite -- if both are +inf, w = 1 - u - v is -inf -- so the triangle is rejected either way: no input tells 9 apart.)
 #ifdef VT_MUTANT
@@ -819,7 +823,7 @@ __device__ __forceinline__ vt_hit_attrs make_hit_attrs(const vt_tri64& T, const 
     const float d2 = (r.dir[0] * r.dir[0] + r.dir[1] * r.dir[1]) + r.dir[2] * r.dir[2];
     const float inv = 1.0f / sqrtf(d2);
     o.wo[0] = -(r.dir[0] * inv); o.wo[1] = -(r.dir[1] * inv); o.wo[2] = -(r.dir[2] * inv);
-    const float w = 1.0f - h.u - h.v;                               // TraceResult.cpp:70
+    const float w = VT_MUT(21, 1.0f - (h.u + h.v), 1.0f - h.u - h.v);  // TraceResult.cpp:70
     o.uvw[0] = h.u; o.uvw[1] = h.v; o.uvw[2] = w;
     const float len = sqrtf((T.n[0] * T.n[0] + T.n[1] * T.n[1]) + T.n[2] * T.n[2]);
     for (int k = 0; k < 3; ++k) {
@@ -829,7 +833,8 @@ __device__ __forceinline__ vt_hit_attrs make_hit_attrs(const vt_tri64& T, const 
     }
     o.t = h.t;
     o.prim = h.prim;
-    o.front = ((o.wo[0] * o.ngeo[0] + o.wo[1] * o.ngeo[1]) + o.wo[2] * o.ngeo[2]) >= 0.0f ? 1u : 0u; // :85
+    const float facing = (o.wo[0] * o.ngeo[0] + o.wo[1] * o.ngeo[1]) + o.wo[2] * o.ngeo[2];
+    o.front = VT_MUT(22, facing > 0.0f, facing >= 0.0f) ? 1u : 0u; // :85
     o.hit = 1;
     return o;
 }
@@ -858,7 +863,7 @@ __global__ __launch_bounds__(kBlockThreads) void hit_shade_kernel(HitShadeArgs a
         const vt_tri_attribs A = a.attribs[h.prim];
         const float w = 1.0f - h.u - h.v;                                               // uvw = (u, v, 1-u-v) :70
         o.blend = (w * A.alpha[0] + h.u * A.alpha[1]) + h.v * A.alpha[2];               // :73
-        o.tex_uv[0] = (w * A.uv[0][0] + h.u * A.uv[1][0]) + h.v * A.uv[2][0];           // :74
+        o.tex_uv[0] = (w * A.uv[0][0] + VT_MUT(23, h.v, h.u) * A.uv[1][0]) + VT_MUT(23, h.u, h.v) * A.uv[2][0];   // :74
         o.tex_uv[1] = (w * A.uv[0][1] + h.u * A.uv[1][1]) + h.v * A.uv[2][1];
         o.ent_id = A.ent_id;                                                            // :76
         o.material = A.material;                                                        // :78
@@ -919,13 +924,13 @@ __device__ __forceinline__ vt_ray make_bounce_ray(const vt_hit_attrs& A, uint64_
         const int32_t iOff = int32_t(n[k] * iScale);
         const int32_t bits = int32_t(__float_as_uint(A.pos[k])) + (A.pos[k] < 0.f ? -iOff : iOff);
         const float iPos = __uint_as_float(uint32_t(bits));
-        ray.org[k] = fabsf(A.pos[k]) < origin ? A.pos[k] + n[k] * fScale : iPos;
+        ray.org[k] = VT_MUT(27, fabsf(A.pos[k]) <= origin, fabsf(A.pos[k]) < origin) ? A.pos[k] + n[k] * fScale : iPos;
     }
     // hemisphere_cos, BSDF.cpp:69-77, samples = top 24 bits of splitmix64 outputs 2i and 2i+1
     const float r1 = float(splitmix64_at(seed, 2 * i) >> 40) * (1.0f / 16777216.0f);
     const float r2 = float(splitmix64_at(seed, 2 * i + 1) >> 40) * (1.0f / 16777216.0f);
     const float z = sqrtf(r1), sinTheta = sqrtf(1.f - r1), phi = 2.f * 3.14159265358979323846f * r2;
-    const float lx = sinTheta * cosf(phi), ly = sinTheta * sinf(phi);
+    const float lx = sinTheta * VT_MUT(28, sinf(phi), cosf(phi)), ly = sinTheta * VT_MUT(28, cosf(phi), sinf(phi));
     // orthonormal basis around n (Duff et al. 2017), as vistrace_amd/workloads.py::_onb
     const float sign = n[2] >= 0.f ? 1.f : -1.f;
     const float aa = -1.f / (sign + n[2]);
@@ -1056,7 +1061,7 @@ __device__ __forceinline__ void store_tri_record(const float* v, uint32_t prim, 
     vt_tri64 t;
     for (int k = 0; k < 3; ++k) {
         t.p0[k] = v[k];
-        t.e1[k] = v[k] - v[3 + k];
+        t.e1[k] = VT_MUT(24, v[3 + k] - v[k], v[k] - v[3 + k]);
         t.e2[k] = v[6 + k] - v[k];
     }
     t.n[0] = t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1];
@@ -1122,7 +1127,7 @@ __global__ __launch_bounds__(kBlockThreads) void skin_tris_kernel(SkinTrisArgs a
             for (int r = 0; r < 3; ++r) {
                 const float a0 = m0[r] * pos[vi * 3] + m1[r] * pos[vi * 3 + 1];
                 const float a1 = m2[r] * pos[vi * 3 + 2] + m3[r] * 1.f;
-                fin[r] = fin[r] + (a0 + a1) * sv.weight[q];
+                fin[r] = fin[r] + (a0 + a1) * sv.weight[VT_MUT(26, 0u, q)];
             }
         }
         v[vi * 3] = fin[0]; v[vi * 3 + 1] = fin[1]; v[vi * 3 + 2] = fin[2];
@@ -1142,7 +1147,7 @@ __device__ __forceinline__ void box_of_child(const vt_node_pair* pairs, const vt
                 const float p0 = t.p0[k], p1 = t.p0[k] - t.e1[k], p2 = t.p0[k] + t.e2[k];
                 float l = p0, h = p0;
                 l = p1 < l ? p1 : l; h = p1 > h ? p1 : h;
-                l = p2 < l ? p2 : l; h = p2 > h ? p2 : h;
+                l = VT_MUT(25, l, p2 < l ? p2 : l); h = VT_MUT(25, h, p2 > h ? p2 : h);
                 lo[k] = l < lo[k] ? l : lo[k]; hi[k] = h > hi[k] ? h : hi[k];
             }
         }
