@@ -1,0 +1,30 @@
+#!/bin/bash
+# Mutation testing of the CPU tests of the single-ray host walk (vistrace_amd/csrc/host_walk.cpp: what ONE accel:Traverse runs,
+# BASELINE configs[0]).  No GPU: builds each mutant here and runs the host-walk and binding tests against it.
+#   bash scripts/mutants_host.sh [out.txt] [mutant numbers...]
+main() {
+OUT=${1:-profiles/r6/mutants_host.txt}; shift
+KS=${@:-1 2 4 5 6 7 8 11 12 13 14 15}
+declare -A WHAT=([1]="near/far swap on >=" [2]="hit accepted on t < tmax" [4]="leaf slots from the back" [5]="plain 1/x instead of safe_inverse"
+ [6]="slab entry without the tmin term" [7]="node accepted on first < second" [8]="hit needs u > 0" [11]="hit accepted on t > tmin"
+ [12]="w = 1 - (u + v)" [13]="FRONT faces culled" [14]="hit needs v > 0" [15]="hit needs w > 0")
+cd "$(dirname "$0")/.."
+TESTS="tests/test_host_walk.py tests/test_oracle_golden.py tests/test_host_binding.py"
+{ echo "# mutation testing of the CPU tests of the host walk (host_walk.cpp), $(date -u +%Y-%m-%dT%H:%MZ)"
+  echo "# a mutant library = the product's objects with host_walk.cpp compiled -DVT_MUTANT=<k>; tests: $TESTS -m 'not gpu'"; } > "$OUT"
+if timeout 600 python -m pytest $TESTS -m "not gpu" -x -q -p no:cacheprovider > /tmp/hm_ctl.log 2>&1; then
+  echo "control   product library                              GREEN  ($(grep -E ' passed' /tmp/hm_ctl.log | tail -1))" >> "$OUT"
+else echo "control   product library                              RED" >> "$OUT"; fi
+for k in $KS; do
+  make -C vistrace_amd/csrc host_mutant K=$k > /tmp/hm_build_$k.log 2>&1 || { echo "mutant $k: build failed" >> "$OUT"; continue; }
+  L=$PWD/vistrace_amd/lib/variants/libvistrace_hip_hostmut_$k.so
+  verdict=SURVIVED; by=""
+  if ! VISTRACE_HIP_LIB=$L timeout 600 python -m pytest $TESTS -m "not gpu" -x -q -p no:cacheprovider > /tmp/hm_$k.log 2>&1; then
+    by=$(grep -m1 -E "^(FAILED|ERROR) " /tmp/hm_$k.log | sed -E 's/ - .*//'); verdict=KILLED
+  fi
+  printf "host mutant %-2s %-40s %-8s %s\n" "$k" "${WHAT[$k]}" "$verdict" "$by" >> "$OUT"
+  rm -rf vistrace_amd/csrc/_build_hostmut_$k "$L"
+done
+cat "$OUT"
+}
+main "$@"; exit

@@ -115,3 +115,73 @@ def test_host_walk_alpha_test(va, O):
     assert int((plain["prim"] != ref["prim"]).sum()) > 50
     assert_hits_equal(hs.trace_closest_host(rays), ref)
     assert (hs.trace_any_host(rays) == (any_ref["prim"] != O_MISS)).all()
+
+
+TRI = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32)
+
+
+def test_host_walk_known_answers(va, O):
+    """The analytic cases of tests/test_oracle_kat.py / test_gpu_parity.py::test_single_triangle_kats through the HOST walk: a hit
+    exactly on each edge and corner (u, v, w == 0 count: Primitives.h:187), t == tMin and t == tMax both inside (:189), a ray in
+    the triangle's plane, the cull flag.  Once as a leaf root (no slab test) and once inside a small tree.  Round 6: the CPU tests
+    of the host walk let `t > tmin` and `w > 0` through (scripts/mutants_host.sh) -- the device had these cases, the host walk not."""
+    far = np.array([[[40, 40, 40], [41, 40, 40], [40, 41, 40]], [[-40, 3, 3], [-41, 3, 3], [-40, 4, 3]], [[7, -30, 1], [8, -30, 1], [7, -29, 1]]], np.float32)
+    for verts in (TRI, np.concatenate([TRI, far])):
+        for flags in (None, np.array([1] + [0] * (len(verts) - 1), np.uint8)):
+            tris = va.tris_setup(verts, flags)
+            bvh = va.HostBvh(tris)
+            hs = va.HostScene(bvh)
+            otris = O.tris_from_tri64(tris)
+
+            def both(org, d, tmin=0.0, tmax=np.finfo(np.float32).max):
+                r = va.make_rays([org], [d], tmin, tmax)
+                got = hs.trace_closest_host(r)
+                ref = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, r)[0]
+                assert_hits_equal(got, ref)
+                assert hs.trace_any_host(r)[0] == (ref["prim"][0] != O_MISS)
+                return got[0]
+
+            up = flags is None                          # the one-sided triangle is culled from above (n = (0,0,-1), n.d > 0)
+            h = both([0.25, 0.5, 1], [0, 0, -1])
+            assert (h["prim"] == 0 and h["t"] == 1.0 and h["u"] == 0.25 and h["v"] == 0.5) if up else h["prim"] == O_MISS
+            for x, y, hit in [(0, 0, 1), (1, 0, 1), (0, 1, 1), (0.5, 0.5, 1), (0.25, 0, 1), (0, 0.25, 1), (-0.001, 0.5, 0), (0.51, 0.51, 0)]:
+                got_above = both([x, y, 1], [0, 0, -1])["prim"] != O_MISS
+                if len(verts) == 1:                                        # a leaf root: the analytic answer (inside a tree an axis-parallel ray
+                    assert got_above == (bool(hit) and up), (x, y)         #   ON a box face is culled by the reference's clamped inverse: oracle only)
+                both([x, y, -1], [0, 0, 1])                                # from below the corners are a matter of rounding: oracle only
+            assert both([0.2, 0.2, 0], [1, 0, 0])["prim"] == O_MISS                                 # in the plane: 0 / 0
+            for tmin, tmax, hit in [(0, 1.0, 1), (1.0, 2.0, 1), (1.0, 1.0 + 1e-6, 1), (0, 0.999, 0), (1.001, 5, 0)]:
+                assert (both([0.25, 0.25, -1], [0, 0, 1], tmin, tmax)["prim"] != O_MISS) == bool(hit), (tmin, tmax)
+
+
+def test_host_walk_tie_break_follows_the_walk_order(va, O):
+    """64 coincident triangles: every inner pair of the tree has two identical boxes, so the near / far decision is a tie at every
+    level (ties keep the left child first) and the index reported is the LAST one visited.  Any other order names another triangle
+    (mutant 1: swap on >=)."""
+    verts = np.concatenate([TRI + np.float32(0)] * 64)
+    for builder in ("sah", "ploc"):
+        tris = va.tris_setup(verts)
+        bvh = va.HostBvh(tris, builder=builder)
+        hs = va.HostScene(bvh)
+        rays = va.make_rays([[0.25, 0.25, 1], [0.3, 0.1, -2], [0.1, 0.6, 5]], [[0, 0, -1], [0, 0, 1], [0.01, -0.02, -1]])
+        ref = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), O.tris_from_tri64(tris), rays)[0]
+        assert (ref["prim"] != O_MISS).all()
+        assert_hits_equal(hs.trace_closest_host(rays), ref)
+
+
+def test_host_walk_rays_aimed_at_edges(va, O, make_bundle):
+    """200 000 rays aimed at points ON triangle edges (shared by two triangles of the icospheres): u, v or w is zero up to rounding, so
+    the exact association of `w = 1 - u - v` and every `>= 0` decides which of the two neighbours reports the hit (mutant 12:
+    w = 1 - (u + v))."""
+    b = make_bundle("S10k")
+    rng = np.random.default_rng(12)
+    v = b.verts
+    k = rng.integers(0, len(v), 200_000)
+    e = rng.integers(0, 3, len(k))
+    a, c = v[k, e], v[k, (e + 1) % 3]
+    s = rng.random((len(k), 1)).astype(np.float32)
+    target = (a * (np.float32(1) - s) + c * s).astype(np.float32)
+    org = (target + rng.normal(size=target.shape).astype(np.float32) * np.float32(40)).astype(np.float32)
+    rays = va.make_rays(org, (target - org).astype(np.float32))
+    ref = b.oracle(rays)
+    assert_hits_equal(b.host_scene.trace_closest_host(rays), ref)

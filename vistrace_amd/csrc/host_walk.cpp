@@ -11,6 +11,9 @@
 // TriangleBackfaceCull::intersect (source/objects/Primitives.h:168-215) per leaf triangle, in the same order as the
 // device kernel (vistrace_amd/csrc/trace_kernels.hip) -- results are bit-identical to it (tests/test_gpu_parity.py).
 // Built with -ffp-contract=off: no FMA contraction, IEEE divide.
+// VT_MUT(k, wrong, right): mutation sites with the numbers of trace_kernels.hip's list (1 swap on >=, 2 t < tmax, 4 leaf slots from
+// the back, 5 plain 1/x, 6 no tmin term, 7 first < second, 8 / 14 / 15 u, v, w > 0, 11 t > tmin, 12 w = 1 - (u + v), 13 front faces
+// culled); compiled out of the product.  scripts/mutants_host.sh runs the CPU tests against each -- no GPU needed.
 #include "vt_internal.h"
 
 #include <string>
@@ -26,7 +29,7 @@ namespace {
 
 inline float safe_inverse(float x)            // bvh v1 utilities.hpp
 {
-    return std::fabs(x) <= FLT_EPSILON ? std::copysign(1.0f / FLT_EPSILON, x) : 1.0f / x;
+    return VT_MUT(5, 1.0f / x, std::fabs(x) <= FLT_EPSILON ? std::copysign(1.0f / FLT_EPSILON, x) : 1.0f / x);
 }
 inline float robust_max(float a, float b) { return a > b ? a : b; }
 inline float robust_min(float a, float b) { return a < b ? a : b; }
@@ -84,10 +87,11 @@ struct Walk {
     // intersect_leaf: ascending slot order, best = hit, tmax = t (any_hit: stop at the first)
     template <bool ANY_HIT> bool leaf(uint32_t first, uint32_t count)
     {
-        for (uint32_t q = first; q < first + count; ++q) {
+        for (uint32_t k = first; k < first + count; ++k) {
+            const uint32_t q = VT_MUT(4, first + count - 1 - (k - first), k);
             const vt_tri64& T = hs.tris[q];
             const float nDotDir = (T.n[0] * dx + T.n[1] * dy) + T.n[2] * dz;                      // :173
-            const bool culled = (T.flags & VT_TRI_CULL_BACKFACE) && nDotDir > 0.0f;               // :174
+            const bool culled = (T.flags & VT_TRI_CULL_BACKFACE) && VT_MUT(13, nDotDir < 0.0f, nDotDir > 0.0f);   // :174
             const float cx = T.p0[0] - ox, cy = T.p0[1] - oy, cz = T.p0[2] - oz;                  // :176
             const float rx = dy * cz - dz * cy;                                                   // :177
             const float ry = dz * cx - dx * cz;
@@ -95,9 +99,10 @@ struct Walk {
             const float inv_det = 1.0f / nDotDir;                                                 // :178
             const float uu = ((rx * T.e2[0] + ry * T.e2[1]) + rz * T.e2[2]) * inv_det;            // :180
             const float vv = ((rx * T.e1[0] + ry * T.e1[1]) + rz * T.e1[2]) * inv_det;            // :181
-            const float w = 1.0f - uu - vv;                                                       // :182
+            const float w = VT_MUT(12, 1.0f - (uu + vv), 1.0f - uu - vv);                           // :182
             const float t = ((T.n[0] * cx + T.n[1] * cy) + T.n[2] * cz) * inv_det;                // :188
-            bool hit = !culled && uu >= 0.0f && vv >= 0.0f && w >= 0.0f && t >= tmin && t <= tmax; // :187-189
+            bool hit = !culled && VT_MUT(8, uu > 0.0f, uu >= 0.0f) && VT_MUT(14, vv > 0.0f, vv >= 0.0f) && VT_MUT(15, w > 0.0f, w >= 0.0f) &&
+                       VT_MUT(11, t > tmin, t >= tmin) && VT_MUT(2, t < tmax, t <= tmax);           // :187-189
             if (hit && alpha && (T.flags & VT_TRI_ALPHATEST)) hit = alpha_pass(hs, T.prim, uu, vv); // :196-208
             if (hit) {
                 prim = T.prim; u = uu; v = vv; tmax = t;
@@ -122,13 +127,13 @@ struct Walk {
                 const float* b = P.child[c].bounds;
                 const float e0 = b[0 + ox_] * ix + sx, e1 = b[2 + oy_] * iy + sy, e2 = b[4 + oz_] * iz + sz;
                 const float x0 = b[1 - ox_] * ix + sx, x1 = b[3 - oy_] * iy + sy, x2 = b[5 - oz_] * iz + sz;
-                first[c] = robust_max(e0, robust_max(e1, robust_max(e2, tmin)));
+                first[c] = robust_max(e0, robust_max(e1, robust_max(e2, VT_MUT(6, e2, tmin))));
                 second[c] = robust_min(x0, robust_min(x1, robust_min(x2, tmax)));
             }
             bool go[2];
             for (int c = 0; c < 2; ++c) {
                 go[c] = false;
-                if (first[c] <= second[c]) {
+                if (VT_MUT(7, first[c] < second[c], first[c] <= second[c])) {
                     if (P.child[c].prim_count != 0) {
                         if (leaf<ANY_HIT>(P.child[c].first, P.child[c].prim_count)) return;
                     } else {
@@ -137,7 +142,7 @@ struct Walk {
                 }
             }
             if (go[0] && go[1]) {
-                const bool swap = first[0] > first[1];                   // near child first, ties keep left
+                const bool swap = VT_MUT(1, first[0] >= first[1], first[0] > first[1]);   // near child first, ties keep left
                 stack[sp++] = P.child[swap ? 0 : 1].first;
                 node = P.child[swap ? 1 : 0].first;
             } else if (go[0]) {

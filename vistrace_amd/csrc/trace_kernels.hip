@@ -69,7 +69,7 @@
 extern "C" __attribute__((visibility("default"))) int vt_mutant(void) { return VT_MUTANT; }
 #else
 #define VT_MUT(k, wrong, right) (right)
-#endif
+#endif     // (vt_internal.h has the same definition for the host walk; this file does not include it)
 
 // Source anchors for scripts/isa_audit.py: where a body of the traversal loop starts.  The script compiles this file with line
 // tables and attributes every generated instruction to the body its source line lies in.  Expands to nothing.

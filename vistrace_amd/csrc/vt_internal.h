@@ -18,6 +18,16 @@ static_assert(sizeof(vt_hit_attrs) == 64, "vt_hit_attrs must be 64 bytes");
 static_assert(sizeof(vt_tri_attribs) == 48, "vt_tri_attribs must be 48 bytes");
 static_assert(sizeof(vt_hit_shade) == 32, "vt_hit_shade must be 32 bytes");
 
+// Mutation testing (scripts/mutants.sh for the device kernels, scripts/mutants_host.sh for the host walk): with -DVT_MUTANT=<k> ONE
+// site answers `wrong`; the product build never defines VT_MUTANT, and every site is then the token `right` after preprocessing.
+#ifndef VT_MUT
+#ifdef VT_MUTANT
+#define VT_MUT(k, wrong, right) ((VT_MUTANT == (k)) ? (wrong) : (right))
+#else
+#define VT_MUT(k, wrong, right) (right)
+#endif
+#endif
+
 namespace vt {
 
 // v1-layout tree (what bvh::Bvh<float> holds in the reference: source/objects/AccelStruct.h:67)
