@@ -10,7 +10,7 @@
 # offset cannot make bash re-read lines -- round 6's first run listed three mutants twice)
 main() {
 OUT=${1:-gpurun_out/mutants.txt}; shift
-KS=${@:-1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 21 22 23 24 25 26 27 28}        # 16 only on request: it hangs the kernel (killed by the timeout)
+KS=${@:-1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 21 22 23 24 25 26 27 28 31 32 43 44 45}        # 16 only on request: it hangs the kernel (killed by the timeout)
 declare -A WHAT=(
  [1]="near/far swap on fl >= fr instead of >"
  [2]="hit accepted on t < tmax instead of <="
@@ -36,10 +36,15 @@ declare -A WHAT=(
  [26]="skinning: weight of bone 0 for every bone"
  [27]="CalcRayOrigin: |pos| <= 1/32 instead of <"
  [28]="bounce direction: sin and cos of phi swapped"
+ [31]="device lineariser: left subtree counted for left children too"
+ [32]="level lists: a level starts one pair late"
+ [43]="CalcTBN correction on cosTheta < 0.1 instead of <="
+ [44]="footprint off on coneAngle < 0 instead of <= 0"
+ [45]="corrected binormal = cross(normal, tangent)"
 )
 # mutant 9 is EQUIVALENT (trace_kernels.hip's VT_MUT list says why): it must survive; every other one must be killed
-FIRST="tests/test_gpu_parity.py tests/test_gpu_shading_frame.py tests/test_gpu_configs.py"
-REST="tests/test_gpu_multi_batch.py tests/test_gpu_rebuild.py tests/test_gpu_fake_group.py tests/test_gpu_bench_ranks.py"
+FIRST="tests/test_gpu_parity.py tests/test_gpu_shading_frame.py tests/test_gpu_rebuild.py tests/test_gpu_configs.py"
+REST="tests/test_gpu_multi_batch.py tests/test_gpu_fake_group.py tests/test_gpu_bench_ranks.py"
 mkdir -p "$(dirname "$OUT")"
 {
 echo "# mutation testing of the -m gpu parity suite, $(date -u +%Y-%m-%dT%H:%MZ), $(python3 -c 'import subprocess;print(subprocess.run(["git","rev-parse","--short","HEAD"],capture_output=True,text=True).stdout.strip() or "snapshot")')"

@@ -25,6 +25,19 @@ for k in $KS; do
   printf "host mutant %-2s %-40s %-8s %s\n" "$k" "${WHAT[$k]}" "$verdict" "$by" >> "$OUT"
   rm -rf vistrace_amd/csrc/_build_hostmut_$k "$L"
 done
+# the host TraceResult class (vistrace_amd/csrc/host/TraceResult.cpp: the fields one accel:Traverse hands to Lua) against the oracle:
+# tests/cpp/test_trace_result.cpp rebuilt with the class compiled -DVT_MUTANT=<k>
+make -C tests/cpp trace_result > /dev/null 2>&1
+echo "# host TraceResult class: tests/cpp/test_trace_result (class vs oracle, bit for bit) with TraceResult.cpp compiled -DVT_MUTANT=<k>" >> "$OUT"
+echo "control   product class                                $(tests/cpp/_build/test_trace_result | tail -1)" >> "$OUT"
+declare -A TWHAT=([41]="uvw.z = 1 - (u + v)" [42]="frontFacing on dot > 0" [43]="CalcTBN correction on cosTheta < 0.1" [44]="mipOverride on coneAngle < 0"
+ [45]="corrected binormal = cross(normal, tangent)" [46]="texUV weights u and v swapped" [48]="lerp weights both the geometric normal's")
+for k in 41 42 43 44 45 46 48; do
+  g++ -O1 -g -std=c++17 -ffp-contract=off -DVT_MUTANT=$k -Ivistrace_amd/csrc/host -Iinclude -Ioracle -o /tmp/ttr_$k tests/cpp/test_trace_result.cpp \
+      vistrace_amd/csrc/host/TraceResult.cpp tests/cpp/_build/vt_oracle_for_tests.o -fopenmp -lm 2> /dev/null || { echo "class mutant $k: build failed" >> "$OUT"; continue; }
+  if /tmp/ttr_$k > /tmp/ttr_$k.log 2>&1; then v=SURVIVED; else v=KILLED; fi
+  printf "class mutant %-2s %-48s %-8s %s\n" "$k" "${TWHAT[$k]}" "$v" "$(tail -1 /tmp/ttr_$k.log)" >> "$OUT"
+done
 cat "$OUT"
 }
 main "$@"; exit

@@ -85,6 +85,71 @@ int main()
         grazing += std::fabs((oa.wo[0] * n[0] * inv + oa.wo[1] * n[1] * inv) + oa.wo[2] * n[2] * inv) <= 0.1f;
     }
     CHECK(grazing > 500 && cone_on > 10000);
+
+    // ---- the branch points themselves (round 6: scripts/mutants_host.sh showed the random cases never sit ON one) ---------------
+    {
+        Triangle tri;
+        tri.p0 = Vec3{0, 0, 0}; tri.p1 = Vec3{1, 0, 0}; tri.p2 = Vec3{0, 1, 0};          // n = cross(p0 - p1, p2 - p0) = (0, 0, -1)
+        float normals[9], tangents[9], uvs[6] = {0, 0, 1, 0, 0, 1};
+        for (int k = 0; k < 3; ++k) {
+            tri.normals[k] = Vec3{0, 0, 1}; tri.tangents[k] = Vec3{1, 0, 0}; tri.uvs[k] = Vec2{uvs[2 * k], uvs[2 * k + 1]}; tri.alphas[k] = 0.5f;
+            normals[3 * k] = 0; normals[3 * k + 1] = 0; normals[3 * k + 2] = 1; tangents[3 * k] = 1; tangents[3 * k + 1] = 0; tangents[3 * k + 2] = 0;
+        }
+        tri.material = 0;
+        const float p0[3] = {0, 0, 0}, p1[3] = {1, 0, 0}, p2[3] = {0, 1, 0};
+        vto_tri ot;
+        vto_tri_setup(p0, p1, p2, 0, &ot);
+        Entity ent; ent.id = 1;
+        Material mat;
+        auto agree = [&](const float dir[3], float cw, float ca, bool want_front, int want_lod) {
+            TraceResult r(Vec3{dir[0], dir[1], dir[2]}, 2.f, cw, ca, tri, 0, Vec2{0.25f, 0.25f}, ent, mat);
+            vto_attrs oa;
+            vto_hit_attrs(&ot, dir, 0.25f, 0.25f, &oa);
+            vto_tbn ob;
+            vto_hit_tbn(&ot, dir, 2.f, 0.25f, 0.25f, normals, tangents, uvs, cw, ca, &ob);
+            CHECK(r.frontFacing == (oa.front != 0) && r.frontFacing == want_front);
+            CHECK(same3(r.GetNormal(), ob.normal) && same3(r.GetTangent(), ob.tangent) && same3(r.GetBinormal(), ob.binormal));
+            Vec2 lod;
+            const bool set = r.GetTextureLodInfo(lod);
+            CHECK(set == (ob.lod_set != 0) && int(set) == want_lod);
+            return r.wo.z;
+        };
+        // frontFacing = dot(wo, geometricNormal) >= 0 (TraceResult.cpp:85) AT zero: rays inside the triangle's plane
+        const float flat[3][3] = {{1, 0, 0}, {0, -2, 0}, {3, 4, 0}};
+        for (const float* d : flat) agree(d, -1.f, -1.f, true, 0);
+        // mipOverride = coneWidth < 0 || coneAngle <= 0 (:54): an angle of exactly 0 switches the footprint off, a tiny one does not
+        const float down[3] = {0.1f, 0.2f, -1.f};
+        agree(down, 0.25f, 0.f, false, 0);
+        agree(down, 0.25f, 1e-30f, false, 1);
+        agree(down, 0.f, 0.004f, false, 1);                                               // a width of exactly 0 is a valid cone
+        agree(down, -1e-30f, 0.004f, false, 0);
+        // the grazing correction runs on cosTheta <= 0.1 (:175-176): a direction whose normalised z is 0.1f to the bit, found by search
+        int found = 0;
+        for (int i = -2000; i <= 2000 && !found; ++i) {
+            float a = 0.99498743f;
+            for (int s = 0; s < std::abs(i); ++s) a = std::nextafter(a, i < 0 ? 0.f : 2.f);
+            const float d[3] = {a, 0.f, -0.1f};
+            const float inv = 1.0f / std::sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+            if (-(d[2] * inv) == 0.1f) {
+                found = 1;
+                // shading normal (0, 0, 1), wo.z = 0.1f exactly: cosTheta == the threshold -> corrected.  With a vertex tangent that is
+                // NOT perpendicular to the normal the correction shows (tangent re-orthogonalised to (1, 0, 0), binormal = cross(tangent,
+                // normal)); just above the threshold the frame stays as interpolated
+                for (int k = 0; k < 3; ++k) {
+                    tri.tangents[k] = Vec3{0.8f, 0.f, 0.6f};
+                    tangents[3 * k] = 0.8f; tangents[3 * k + 1] = 0.f; tangents[3 * k + 2] = 0.6f;
+                }
+                CHECK(agree(d, -1.f, -1.f, false, 0) == 0.1f);
+                {
+                    TraceResult at(Vec3{d[0], d[1], d[2]}, 2.f, -1.f, -1.f, tri, 0, Vec2{0.25f, 0.25f}, ent, mat);
+                    CHECK(at.GetTangent().x == 1.f && at.GetTangent().z == 0.f);
+                }
+                const float just_above[3] = {a, 0.f, -std::nextafter(0.1f, 1.f)};
+                agree(just_above, -1.f, -1.f, false, 0);
+            }
+        }
+        CHECK(found == 1);
+    }
     std::printf("trace result (cpu): %d checks, %d failed; %d grazing hits\n", g_run, g_fail, grazing);
     return g_fail ? 1 : 0;
 }

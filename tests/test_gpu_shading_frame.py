@@ -213,3 +213,48 @@ def test_shading_frame_golden_fixture(va, engine):
     scene.set_skin(verts, sf["skin"].view(va.SKIN_VERTEX), sf["matrix_base"])
     scene.skin_refit(sf["bones"], sf["binds"])
     assert (scene.read_tri_frames().view(np.uint32).reshape(-1, 18) == sf["skinned_frames"].view(np.uint32)).all()
+
+
+def test_hit_tbn_at_the_grazing_threshold(va, engine, O):
+    """CalcTBN's correction runs on cosTheta <= 0.1 (source/objects/TraceResult.cpp:175-176).  A direction whose normalised z is
+    0.1f to the bit (found by search), a shading normal of (0, 0, 1) and a vertex tangent that is NOT perpendicular to it: AT the
+    threshold the frame is corrected (tangent re-orthogonalised to (1, 0, 0)), one float above it is not.  Synthetic (ray, hit)
+    records through vt_hit_tbn_dev; the random cases of the other tests never sit on the branch point (round 6: the `<` mutant of
+    the host class survived them)."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    verts = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32)
+    tris = va.tris_setup(verts)
+    scene = va.Scene.from_tree(engine, va.HostBvh(tris))
+    attribs = np.zeros(1, va.TRI_ATTRIBS)
+    attribs["uv"][0] = [[0, 0], [1, 0], [0, 1]]
+    frames = np.zeros(1, va.TRI_FRAME)
+    frames["normal"][0] = [[0, 0, 1]] * 3
+    frames["tangent"][0] = [[0.8, 0, 0.6]] * 3
+    scene.set_tri_attribs(attribs)
+    scene.set_tri_frames(frames)
+    found, base = None, np.float32(0.99498743)
+    for i in sorted(range(-2000, 2001), key=abs):
+        d = np.array([base + np.float32(i) * np.spacing(base), 0.0, -0.1], np.float32)
+        inv = np.float32(1.0) / np.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2], dtype=np.float32)
+        if -(d[2] * inv) == np.float32(0.1):
+            found = d
+            break
+    assert found is not None, "no direction with a normalised z of exactly 0.1f found"
+    above = found.copy()
+    above[2] = -np.nextafter(np.float32(0.1), np.float32(1))
+    rays = va.make_rays([[0.25, 0.25, 1.0]] * 2, [found, above])
+    hits = np.zeros(2, va.HIT)
+    hits["prim"], hits["t"], hits["u"], hits["v"] = 0, 2.0, 0.25, 0.25
+    dev = torch.device("cuda", 0)
+    d_rays, d_hits = tp.to_device(rays, dev), tp.to_device(hits, dev)
+    d_out = tp.empty_records(2, va.HIT_TBN, dev)
+    scene.hit_tbn_dev(d_rays.data_ptr(), d_hits.data_ptr(), 2, d_out.data_ptr(), -1.0, -1.0, tp.current_stream_handle(dev))
+    torch.cuda.synchronize()
+    got = tp.to_host(d_out, va.HIT_TBN)
+    ref = O.hit_tbn(O.tris_from_tri64(tris), rays, hits, frames.view(np.float32).reshape(-1, 18), attribs["uv"].reshape(-1, 6))
+    for k in ("normal", "tangent", "binormal"):
+        assert (got[k].view(np.uint32) == ref[k].view(np.uint32)).all(), k
+    assert got["tangent"][0, 0] == 1.0 and got["tangent"][0, 2] == 0.0            # at the threshold: corrected
+    assert got["tangent"][1, 2] != 0.0                                             # one float above: as interpolated
+    scene.free()

@@ -3,6 +3,13 @@
 
 #include <cmath>
 
+// mutation sites (scripts/mutants_host.sh: tests/cpp/test_trace_result built with -DVT_MUTANT=<k>); the product never defines VT_MUTANT
+#ifdef VT_MUTANT
+#define VT_MUT(k, wrong, right) ((VT_MUTANT == (k)) ? (wrong) : (right))
+#else
+#define VT_MUT(k, wrong, right) (right)
+#endif
+
 namespace vistrace {
 
 int TraceResult::id = -1;
@@ -23,7 +30,7 @@ static inline Vec3 weighted(const Vec3& uvw, const Vec3 a[3])     // uvw[2] * a[
 
 TraceResult::TraceResult(const Vec3& direction, float dist, float cw, float ca, const Triangle& tri, size_t prim,
                          const Vec2& uv, const Entity& ent, const Material& mat)
-    : distance(dist), primitiveIndex(prim), coneWidth(cw), coneAngle(ca), mipOverride(cw < 0.f || ca <= 0.f),
+    : distance(dist), primitiveIndex(prim), coneWidth(cw), coneAngle(ca), mipOverride(cw < 0.f || VT_MUT(44, ca < 0.f, ca <= 0.f)),
       materialFlags(mat.flags), surfFlags(mat.surfFlags), water(mat.water)
 {
     // caller passes glm::normalize(direction) in the reference (AccelStruct.cpp:826); wo = -direction (:56)
@@ -44,7 +51,7 @@ TraceResult::TraceResult(const Vec3& direction, float dist, float cw, float ca, 
         vB[i] = cross(vT[i], vN[i]);
     }
 
-    uvw = Vec3{uv.x, uv.y, 1.f - uv.x - uv.y};                                     // :70
+    uvw = Vec3{uv.x, uv.y, VT_MUT(41, 1.f - (uv.x + uv.y), 1.f - uv.x - uv.y)};    // :70
     // geometricNormal = nNorm = n / |n|, n = cross(e1, e2)   (Primitives.h:93-100, TraceResult.cpp:71)
     const Vec3 n{e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x};
     const float len = std::sqrt(dot(n, n));
@@ -55,13 +62,13 @@ TraceResult::TraceResult(const Vec3& direction, float dist, float cw, float ca, 
     lodOffset = 0.5f * std::log2(std::fabs(uv10x * uv20y - uv20x * uv10y) / len);
 
     blendFactor = uvw.z * tri.alphas[0] + uvw.x * tri.alphas[1] + uvw.y * tri.alphas[2];   // :73
-    texUV = Vec2{uvw.z * tri.uvs[0].x + uvw.x * tri.uvs[1].x + uvw.y * tri.uvs[2].x,       // :74
+    texUV = Vec2{uvw.z * tri.uvs[0].x + VT_MUT(46, uvw.y, uvw.x) * tri.uvs[1].x + VT_MUT(46, uvw.x, uvw.y) * tri.uvs[2].x,       // :74
                  uvw.z * tri.uvs[0].y + uvw.x * tri.uvs[1].y + uvw.y * tri.uvs[2].y};
     entIdx = ent.id;                                                                // :76
     rawEnt = ent.rawEntity;
     submatIdx = uint32_t(tri.material);
     hitSky = (mat.surfFlags & SURF_SKY) != SURF_NONE;                               // :83
-    frontFacing = dot(wo, geometricNormal) >= 0.f;                                  // :85
+    frontFacing = VT_MUT(42, dot(wo, geometricNormal) > 0.f, dot(wo, geometricNormal) >= 0.f);   // :85
 }
 
 const Vec3& TraceResult::GetPos()                                                   // :255-262
@@ -93,15 +100,16 @@ void TraceResult::CalcTBN()                                                     
 
     const float kCosThetaThreshold = 0.1f;                                          // :175
     const float cosTheta = std::fabs(dot(wo, normal));
-    if (cosTheta <= kCosThetaThreshold) {
+    if (VT_MUT(43, cosTheta < kCosThetaThreshold, cosTheta <= kCosThetaThreshold)) {
         float t = cosTheta * (1.f / kCosThetaThreshold);                            // saturate
         t = t < 0.f ? 0.f : t; t = t > 1.f ? 1.f : t;
         const float s = 1.f - t;                                                    // lerp(x, y, a) = x * (1 - a) + y * a
+        if (VT_MUT(48, true, false)) t = s;                                         // (mutant 48: both weights the geometric normal's)
         normal = normalize(Vec3{geometricNormal.x * s + normal.x * t, geometricNormal.y * s + normal.y * t,
                                 geometricNormal.z * s + normal.z * t});
         const float tn = dot(tangent, normal);
         tangent = normalize(Vec3{tangent.x - normal.x * tn, tangent.y - normal.y * tn, tangent.z - normal.z * tn});
-        binormal = cross(tangent, normal);
+        binormal = VT_MUT(45, cross(normal, tangent), cross(tangent, normal));
     }
     tbnSet = true;
 }

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void lin_offsets(LinArgs a)
         if (first && leaf) {
             at += (right && pcL != 0) ? pcL : 0u;          // a leaf sits in its pair's own block: behind the left sibling leaf
         } else {
-            ap += 1u + ((right && pcL == 0) ? a.cnt[L] : 0u);
+            ap += 1u + ((VT_MUT(31, true, right) && pcL == 0) ? a.cnt[L] : 0u);      // (VT_MUT: mutation sites, vt_internal.h)
             at += pcL + pcR + ((right && pcL == 0) ? a.tcount[L] : 0u);   // pcX = 0 for an inner child: only leaf children count here
         }
         first = false;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void level_starts(const uint32_t* sorted_keys,
 {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= n) return;
-    if (j == 0 || sorted_keys[j] != sorted_keys[j - 1]) begin[sorted_keys[j]] = j;
+    if (j == 0 || sorted_keys[j] != sorted_keys[j - 1]) begin[sorted_keys[j]] = VT_MUT(32, j + (j != 0), j);
 }
 
 // classic path (records linearised on the host): the two index tables from what is already on the device

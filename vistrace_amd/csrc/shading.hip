@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlockThreads) void hit_tbn_kernel(HitTbnArgs a)
         normalise(n); normalise(t); normalise(b);
         const float kCosThetaThreshold = 0.1f;                                      // :175
         const float cos_theta = fabsf(dot_lr(wo, n));
-        if (cos_theta <= kCosThetaThreshold) {
+        if (VT_MUT(43, cos_theta < kCosThetaThreshold, cos_theta <= kCosThetaThreshold)) {     // (VT_MUT: mutation sites, vt_internal.h)
             float s = cos_theta * (1.f / kCosThetaThreshold);                       // :178
             s = s < 0.f ? 0.f : s; s = s > 1.f ? 1.f : s;
             for (int k = 0; k < 3; ++k) n[k] = ngeo[k] * (1.f - s) + n[k] * s;      // :179
@@ -68,10 +68,10 @@ __global__ __launch_bounds__(kBlockThreads) void hit_tbn_kernel(HitTbnArgs a)
             const float tn = dot_lr(t, n);                                          // :181
             for (int k = 0; k < 3; ++k) t[k] = t[k] - n[k] * tn;
             normalise(t);
-            cross_of(t, n, b);                                                      // :182
+            VT_MUT(45, cross_of(n, t, b), cross_of(t, n, b));                        // :182
         }
         for (int k = 0; k < 3; ++k) { o.normal[k] = n[k]; o.tangent[k] = t[k]; o.binormal[k] = b[k]; }
-        if (!(a.cone_width < 0.f || a.cone_angle <= 0.f)) {                         // :54 mipOverride, :91
+        if (!(a.cone_width < 0.f || VT_MUT(44, a.cone_angle < 0.f, a.cone_angle <= 0.f))) {   // :54 mipOverride, :91
             const vt_tri_attribs A = a.attribs[h.prim];
             const float cw = a.cone_angle * h.t + a.cone_width;                     // :95
             const float normal_term = dot_lr(wo, ngeo);                             // :97
