@@ -39,11 +39,15 @@ for members in (1, 2, 8):
     skin_ms = (time.perf_counter() - t0) / 20 * 1e3
     scene.refit(moved)
     t0 = time.perf_counter()
+    r_enq, r_wait = [], []
     for _ in range(5):
         scene.refit(moved)
+        r_enq.append(eng.get_option("last_update_enqueue_us")); r_wait.append(eng.get_option("last_update_wait_us"))
     refit_ms = (time.perf_counter() - t0) / 5 * 1e3
     print(f"members {members}: vt_scene_skin_refit {skin_ms:.3f} ms per frame ({skin_ms / members:.3f} per member), vt_scene_refit {refit_ms:.2f} ms "
           f"({refit_ms / members:.2f} per member); early waits {eng.get_option('last_update_early_waits')} of {eng.get_option('last_update_members')} members; "
-          f"skin refit host time: prepare + enqueue of all members {np.median(enq):.0f} us, waits {np.median(wait):.0f} us", flush=True)
+          f"skin refit host time: prepare + enqueue of all members {np.median(enq):.0f} us, waits {np.median(wait):.0f} us; "
+          f"refit host time: prepare + enqueue of all members {np.median(r_enq):.0f} us ({np.median(r_enq) / members:.0f} per member; includes staging "
+          f"the 36 MB of vertices once), waits {np.median(r_wait):.0f} us (the members' device work, serialised here on ONE GPU)", flush=True)
     scene.free()
     eng.close()
