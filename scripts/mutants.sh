@@ -10,7 +10,7 @@
 # offset cannot make bash re-read lines -- round 6's first run listed three mutants twice)
 main() {
 OUT=${1:-gpurun_out/mutants.txt}; shift
-KS=${@:-1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 21 22 23 24 25 26 27 28 31 32 43 44 45}        # 16 only on request: it hangs the kernel (killed by the timeout)
+KS=${@:-1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 21 22 23 24 25 26 27 28 31 32 43 44 45 51 52 53 54 55 56 57 58}        # 16 only on request: it hangs the kernel (killed by the timeout)
 declare -A WHAT=(
  [1]="near/far swap on fl >= fr instead of >"
  [2]="hit accepted on t < tmax instead of <="
@@ -41,6 +41,14 @@ declare -A WHAT=(
  [43]="CalcTBN correction on cosTheta < 0.1 instead of <="
  [44]="footprint off on coneAngle < 0 instead of <= 0"
  [45]="corrected binormal = cross(normal, tangent)"
+ [51]="queue count: one entry behind a short queue is counted"
+ [52]="queue scan: the carry between 16-B groups drops a count"
+ [53]="queue scan of the partials: thread d skips its add"
+ [54]="queue emit: a hit's slot counts the hit itself"
+ [55]="miss fill skipped when ONE path has died"
+ [56]="queue emit: rows of paths that missed are not written"
+ [57]="range check: tMax < tMin instead of <="
+ [58]="range check: index within the chunk, not within the batch"
 )
 # mutant 9 is EQUIVALENT (trace_kernels.hip's VT_MUT list says why): it must survive; every other one must be killed
 FIRST="tests/test_gpu_parity.py tests/test_gpu_shading_frame.py tests/test_gpu_rebuild.py tests/test_gpu_configs.py"

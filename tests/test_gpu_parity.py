@@ -749,6 +749,65 @@ def test_bounce_loop_matches_composition_and_oracle(va, engine, make_bundle, nam
     assert scene.bounce_loop_dev(d_start.data_ptr(), 0, 3, seed, d_rows.data_ptr()) == [0, 0, 0]
 
 
+def test_bounce_loop_dead_paths_and_long_queues(va, O):
+    """Branch points of the queue step that a 20 001-path loop does not reach, each named by a mutant that survived the suite
+    (scripts/mutants.sh 52 / 55 / 56): (a) every path alive going INTO a depth at which some die -- the miss fill is skipped and the
+    queue step itself writes the rows of the paths that missed; (b) exactly ONE path dead -- the fill may not be skipped; (c) a queue
+    of more than 4096 x 256 entries -- every thread of the one-block scan owns several 16-byte groups of counts and carries between
+    them.  The rows are handed over full of garbage and compared with the call-by-call composition."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    dev = torch.device("cuda", 0)
+    verts, tflags = W.make_terrain()                     # one-sided heightfield, |x|, |y| <= 100, heights 0 .. 20
+    eng = va.Engine(0)
+    scene = va.Scene.from_tree(eng, va.HostBvh(va.tris_setup(verts, tflags)))
+    stream = tp.current_stream_handle(dev)
+
+    def loop_and_composition(start, depth, seed):
+        n = len(start)
+        d_start = tp.to_device(start, dev)
+        d_rows = torch.full((depth * n * 16,), 0xAB, dtype=torch.uint8, device=dev)
+        live = scene.bounce_loop_dev(d_start.data_ptr(), n, depth, seed, d_rows.data_ptr(), stream)
+        torch.cuda.synchronize()
+        rows = tp.to_host(d_rows, va.HIT).reshape(depth, n)
+        d_rays, alive = d_start, n
+        for d in range(depth):
+            assert live[d] == alive, (d, live)
+            d_hits = tp.trace_closest(scene, d_rays, n)
+            hits = tp.to_host(d_hits, va.HIT)
+            assert_hits_equal(rows[d], hits)
+            alive = int((hits["prim"] != O_MISS).sum())
+            d_attrs = tp.hit_attrs(scene, d_rays, d_hits, n)
+            d_next = tp.empty_records(n, va.RAY, dev)
+            eng.gen_bounce_dev(d_attrs.data_ptr(), n, seed + d, d_next.data_ptr(), stream=stream)
+            d_rays = d_next
+        return live
+
+    def rays_from_below(n, seed):                        # (the stored normals of this heightfield point down: its front is its underside)
+        xy = (W.uniform01(seed, 0, 2 * n).reshape(n, 2) * 160.0 - 80.0)
+        jit = (W.uniform01(seed, 2 * n, 2 * n).reshape(n, 2) * 0.2 - 0.1)
+        rays = np.zeros(n, dtype=va.RAY)
+        rays["org"] = np.concatenate([xy, np.full((n, 1), -50.0)], 1).astype(np.float32)
+        rays["dir"] = np.concatenate([jit, np.full((n, 1), 1.0)], 1).astype(np.float32)
+        rays["tmax"] = np.float32(3.0e38)
+        return rays
+
+    n = 30011
+    up = rays_from_below(n, 31)
+    live = loop_and_composition(up, 4, 7)
+    assert live[1] == n and live[2] < n                  # (a): nobody dies at depth 0, many at depth 1
+    one_down = up.copy()
+    one_down["dir"][12345] = (0.0, 0.0, -1.0)
+    live = loop_and_composition(one_down, 3, 7)
+    assert live[1] == n - 1                              # (b)
+    big = 2 * 4096 * 256 + 12345                         # (c)
+    live = loop_and_composition(W.sphere_rays(big, 9, origin=(3.0, -4.0, 60.0)), 3, 11)
+    assert live[1] < big and live[2] < live[1]
+    scene.free()
+    eng.close()
+
+
 def test_bounce_loop_kernel_forms_and_alpha_scene(va, O):
     """The loop's traces behind depth 0 read their ray count from device memory (trace_kernel_devn): persistent with and without
     the DMA fetch, one ray per lane, and a batch far smaller than the grid give the same rows as the call-by-call composition.

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void check_ranges_kernel(const vt_ray* rays, u
     const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
     if (i >= n) return;
     const float tmin = rays[i].tmin, tmax = rays[i].tmax;
-    if (tmin < 0.f || tmax <= tmin) atomicMin(first_bad, static_cast<unsigned long long>(base + i));
+    if (tmin < 0.f || VT_MUT(57, tmax < tmin, tmax <= tmin)) atomicMin(first_bad, static_cast<unsigned long long>(VT_MUT(58, i, base + i)));   // (VT_MUT: vt_internal.h)
 }
 
 constexpr size_t kBatchTail = 256;       // bytes behind a batch's arrays in its device block: the first-bad-ray word of its upload

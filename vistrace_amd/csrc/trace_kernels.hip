@@ -62,6 +62,11 @@
 //  21 GetPos with w = 1 - (u + v)          22 frontFacing on dot(wo, n) > 0      23 texUV weights u and v swapped
 //  24 refit: e1 = p1 - p0                  25 refit: a leaf's box misses vertex 2  26 skinning: weight of bone 0 for every bone
 //  27 CalcRayOrigin: |pos| <= 1/32         28 bounce direction: sin and cos of phi swapped
+// The bounce loop's queue step (killed by the bounce-loop tests):
+//  51 count: one entry behind a short queue is counted     52 scan: carry between 16-B groups drops a count
+//  53 scan of the partials: thread d skips its add           54 emit: a hit's slot counts the hit itself
+//  55 miss fill skipped when ONE path has died              56 emit: rows of paths that missed are not written
+// (31-32: scene_build.hip, 43-45: shading.hip, 57-58: batch.hip's range check)
 // (9 is an EQUIVALENT mutant, kept as the record of why: with n.d == +-0 the test goes on to inv_det = +-inf, and then u, v are
 //  NaN or infinite -- if both are +inf, w = 1 - u - v is -inf -- so the triangle is rejected either way: no input tells 9 apart.)
 #ifdef VT_MUTANT
@@ -971,7 +976,7 @@ __global__ __launch_bounds__(kBlockThreads) void queue_count_kernel(QueueArgs a)
     const uint32_t chunks = uint32_t((m + kBlockThreads - 1) / kBlockThreads);
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
         const uint64_t j = uint64_t(chunk) * kBlockThreads + threadIdx.x;
-        const bool live = j < m && a.hits_q[j].prim != VT_MISS;
+        const bool live = VT_MUT(51, j < m + (m < a.m ? 1u : 0u), j < m) && a.hits_q[j].prim != VT_MISS;
         const uint64_t mask = __ballot(live);
         if ((threadIdx.x & 63u) == 0) wave_count[threadIdx.x >> 6] = uint32_t(__popcll(mask));
         __syncthreads();
@@ -997,7 +1002,7 @@ __global__ __launch_bounds__(1024) void queue_scan_kernel(QueueArgs a, uint32_t*
     part[threadIdx.x] = sum;
     __syncthreads();
     for (uint32_t d = 1; d < 1024u; d <<= 1) {                    // Hillis-Steele inclusive scan of the partials
-        const uint32_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        const uint32_t add = VT_MUT(53, threadIdx.x > d, threadIdx.x >= d) ? part[threadIdx.x - d] : 0u;
         __syncthreads();
         part[threadIdx.x] += add;
         __syncthreads();
@@ -1007,7 +1012,7 @@ __global__ __launch_bounds__(1024) void queue_scan_kernel(QueueArgs a, uint32_t*
         const uint4 c = *reinterpret_cast<const uint4*>(counts + k);
         uint4 o;
         o.x = run; o.y = o.x + c.x; o.z = o.y + c.y; o.w = o.z + c.z;
-        run = o.w + c.w;
+        run = o.w + VT_MUT(52, c.z, c.w);
         *reinterpret_cast<uint4*>(counts + k) = o;
     }
     for (uint32_t k = hi4; k < hi; ++k) { const uint32_t c = counts[k]; counts[k] = run; run += c; }
@@ -1027,14 +1032,14 @@ __global__ __launch_bounds__(kBlockThreads) void queue_emit_kernel(QueueArgs a)
         vt_hit h{VT_MISS, 0.f, 0.f, 0.f};
         if (valid) h = a.hits_q[j];
         const uint32_t path = valid ? (a.ids_q ? a.ids_q[j] : uint32_t(j)) : 0u;
-        if (valid && a.hits_out) a.hits_out[path] = h;
+        if (VT_MUT(56, valid && h.prim != VT_MISS, valid) && a.hits_out) a.hits_out[path] = h;
         if (!a.rays_next) continue;                                // last depth: nothing to emit (wave-uniform)
         const bool live = valid && h.prim != VT_MISS;
         const uint64_t mask = __ballot(live);
         if (lane == 0) wave_count[wave] = uint32_t(__popcll(mask));
         __syncthreads();
         if (live) {
-            uint32_t dst = a.block_offsets[chunk] + uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1)));
+            uint32_t dst = a.block_offsets[chunk] + uint32_t(__popcll(mask & ((uint64_t(VT_MUT(54, 2, 1)) << lane) - 1)));
             for (uint32_t w = 0; w < wave; ++w) dst += wave_count[w];
             const vt_hit_attrs A = make_hit_attrs(a.tris[a.prim_to_slot[h.prim]], a.rays_q[j], h);
             a.rays_next[dst] = make_bounce_ray(A, a.seed, path);
@@ -1046,7 +1051,7 @@ __global__ __launch_bounds__(kBlockThreads) void queue_emit_kernel(QueueArgs a)
 
 __global__ __launch_bounds__(kBlockThreads) void fill_miss_kernel(vt_hit* hits, uint64_t n, const uint32_t* count)
 {
-    if (count && uint64_t(*count) == n) return;        // every path is still alive: the queue step writes the whole row
+    if (count && VT_MUT(55, uint64_t(*count) + 1 >= n, uint64_t(*count) == n)) return;        // every path is still alive: the queue step writes the whole row
     for (uint64_t i = uint64_t(blockIdx.x) * kBlockThreads + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlockThreads)
         hits[i] = vt_hit{VT_MISS, 0.f, 0.f, 0.f};
 }
