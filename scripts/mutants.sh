@@ -10,7 +10,7 @@
 # offset cannot make bash re-read lines -- round 6's first run listed three mutants twice)
 main() {
 OUT=${1:-gpurun_out/mutants.txt}; shift
-KS=${@:-1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 21 22 23 24 25 26 27 28 31 32 43 44 45 51 52 53 54 55 56 57 58}        # 16 only on request: it hangs the kernel (killed by the timeout)
+KS=${@:-1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 21 22 23 24 25 26 27 28 31 32 43 44 45 51 52 53 54 55 56 57 58 61 62 63 64 65 66 71 73}        # 16 only on request: it hangs the kernel (killed by the timeout)
 declare -A WHAT=(
  [1]="near/far swap on fl >= fr instead of >"
  [2]="hit accepted on t < tmax instead of <="
@@ -48,6 +48,14 @@ declare -A WHAT=(
  [55]="miss fill skipped when ONE path has died"
  [56]="queue emit: rows of paths that missed are not written"
  [57]="range check: tMax < tMin instead of <="
+ [61]="alpha test passes on alpha > ref instead of >="
+ [62]="alpha texel: negative index mirrored, not repeated"
+ [63]="alpha bilinear without the half-texel shift in x"
+ [64]="alpha bilinear: right neighbour clamped, not wrapped"
+ [65]="untextured alpha material passes whatever its ref"
+ [66]="alpha nearest: a / 256 instead of a / 255"
+ [71]="merged launch: first block of a set looked up in the set before it"
+ [73]="a NaN range costs no step (per-ray counters)"
  [58]="range check: index within the chunk, not within the batch"
 )
 # mutant 9 is EQUIVALENT (trace_kernels.hip's VT_MUT list says why): it must survive; every other one must be killed

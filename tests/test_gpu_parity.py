@@ -1000,6 +1000,70 @@ def test_host_buffer_pipeline_ragged(va, engine, make_bundle):
     assert_hits_equal(again, ref[: 2 * (1 << 20) + 1])
 
 
+def test_alpha_test_at_its_thresholds(va, engine, O):
+    """Known answers of the alpha comparison (Primitives.h:205: the hit is dropped when alpha < alphaRef, so alpha == alphaRef
+    PASSES) at its branch points, which random textures do not reach (scripts/mutants.sh 61 / 65 / 66 survived them): texel a
+    against a reference between a / 256 and a / 255, alpha exactly equal to the reference, and a material without a texture
+    (alpha 1) under references on both sides of 1.  One flagged triangle per case above an unflagged floor: a dropped hit shows
+    as the floor's index."""
+    cases = [  # (texel or None = no texture, alphaRef, passes)
+        (255, 1.0, True), (0, 0.0, True), (179, 0.7, True), (178, 0.7, False), (128, 0.5, True), (127, 0.5, False),
+        (None, 1.0, True), (None, 1.5, False), (None, 0.0, True), (1, 0.003921569, True), (254, 1.0, False),
+    ]
+    k = len(cases)
+    verts = np.zeros((k + 1, 3, 3), np.float32)
+    for i in range(k):
+        verts[i] = [[4.0 * i, 0.0, 1.0], [4.0 * i + 3.0, 0.0, 1.0], [4.0 * i, 3.0, 1.0]]
+    verts[k] = [[-100.0, -100.0, 0.0], [500.0, -100.0, 0.0], [-100.0, 500.0, 0.0]]           # the floor: no alpha test
+    flags = np.full(k + 1, 2, np.uint8); flags[k] = 0
+    from vistrace_amd import workloads as W
+    _, attribs, mats, _ = W.alpha_test_rig(k + 1, nmats=k)
+    attribs["uv"] = 0.25
+    attribs["material"] = np.arange(k + 1) % k
+    texels = []
+    for i, (a, ref, _) in enumerate(cases):
+        mats["tex_mat"][i] = [[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0]]
+        mats["tex_scale"][i] = 1.0
+        mats["alpha_ref"][i] = np.float32(ref)
+        mats["width"][i] = mats["height"][i] = 0 if a is None else 1
+        mats["filter"][i] = 0
+        mats["offset"][i] = len(texels)
+        if a is not None:
+            texels.append(a)
+    texels = np.array(texels, np.uint8)
+    tris = va.tris_setup(verts, flags)
+    bvh = va.HostBvh(tris)
+    scene = va.Scene(engine, va.HostScene(bvh))
+    scene.set_tri_attribs(attribs.view(va.TRI_ATTRIBS))
+    scene.set_alpha(mats.view(va.ALPHA_MATERIAL), texels)
+    rays = np.zeros(k, va.RAY)
+    rays["org"] = [[4.0 * i + 0.75, 0.75, 5.0] for i in range(k)]
+    rays["dir"] = (0.0, 0.0, -1.0)
+    rays["tmax"] = np.float32(100.0)
+    otris = O.tris_from_tri64(tris)
+    try:
+        O.set_alpha(otris, attribs["uv"].reshape(k + 1, 6), attribs["material"], mats.view(O.ALPHA_MATERIAL), texels)
+        ref = O.traverse_batch(bvh.nodes().view(O.NODE), bvh.prim_indices(), otris, rays)[0]
+    finally:
+        O.set_alpha()
+    expect = np.array([i if ok else k for i, (_, _, ok) in enumerate(cases)], np.uint32)
+    assert (ref["prim"] == expect).all(), (ref["prim"], expect)          # the oracle agrees with the reading of :205
+    saved = {key: engine.get_option(key) for key in ("persistent", "fetch_dma")}
+    try:
+        for cfg in (dict(persistent=1, fetch_dma=1), dict(persistent=1, fetch_dma=0), dict(persistent=0)):
+            for key, v in cfg.items():
+                engine.set_option(key, v)
+            got = scene.trace_closest(rays)
+            assert (got["prim"] == expect).all(), (cfg, got["prim"], expect)
+            assert_hits_equal(got, ref)
+            assert_hits_equal(stats_on_device(va, scene, rays)[0], ref)
+            assert (scene.trace_any(rays) == 1).all()                    # (the floor is always there)
+    finally:
+        for key, v in saved.items():
+            engine.set_option(key, v)
+    scene.free()
+
+
 def test_alpha_test_in_kernel(va, engine, O):
     """Primitives.h:196-208 on the device (ALPHA kernel variants): texUV, TransformTexcoord, the alpha plane lookup
     defined in include/vistrace_hip.h and the reference comparison -- hits, any-hit flags and counters equal the

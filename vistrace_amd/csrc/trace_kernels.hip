@@ -66,6 +66,10 @@
 //  51 count: one entry behind a short queue is counted     52 scan: carry between 16-B groups drops a count
 //  53 scan of the partials: thread d skips its add           54 emit: a hit's slot counts the hit itself
 //  55 miss fill skipped when ONE path has died              56 emit: rows of paths that missed are not written
+// The alpha test of the ALPHA variants (Primitives.h:196-208; killed by the alpha parity tests):
+//  61 pass on alpha > ref instead of >=   62 negative texel index mirrored, not repeated   63 bilinear without the half-texel shift
+//  64 right neighbour clamped at the border, not wrapped   65 untextured material passes whatever its ref   66 nearest: a / 256
+//  71 merged launch: the first block of a set is looked up in the set before it     73 a NaN range costs no step (STATS counters)
 // (31-32: scene_build.hip, 43-45: shading.hip, 57-58: batch.hip's range check)
 // (9 is an EQUIVALENT mutant, kept as the record of why: with n.d == +-0 the test goes on to inv_det = +-inf, and then u, v are
 //  NaN or infinite -- if both are +inf, w = 1 - u - v is -inf -- so the triangle is rejected either way: no input tells 9 apart.)
@@ -201,13 +205,13 @@ __device__ __forceinline__ uint32_t wrap_index(float f, uint32_t n)
 {
     const int i = int(f);                        // f is integral and |f| < 1e9: fits; n <= 65535
     const int m = i % int(n);
-    return uint32_t(m < 0 ? m + int(n) : m);
+    return uint32_t(m < 0 ? VT_MUT(62, -m, m + int(n)) : m);
 }
 
 // alpha of the material's plane from the texel(s) read (a / 255; bilinear with texel centres at (i + 0.5) / W): ax < 0 = nearest
 __device__ __forceinline__ float alpha_from_texels(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, float ax, float ay)
 {
-    if (ax < 0.0f) return float(t0) / 255.0f;
+    if (ax < 0.0f) return float(t0) / VT_MUT(66, 256.0f, 255.0f);
     const float a00 = float(t0), a10 = float(t1), a01 = float(t2), a11 = float(t3);
     const float top = a00 * (1.0f - ax) + a10 * ax;
     const float bot = a01 * (1.0f - ax) + a11 * ax;
@@ -340,7 +344,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
             uint32_t lo = 0, hi = a.nseg;              // table[lo].first_block <= b < table[hi].first_block
             while (hi - lo > 1u) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (table[mid].first_block <= b) lo = mid; else hi = mid;
+                if (VT_MUT(71, table[mid].first_block < b, table[mid].first_block <= b)) lo = mid; else hi = mid;
             }
             cur = table + lo;
             first = cur->first_block;
@@ -380,7 +384,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
         // A NaN tmin or tmax makes every slab test and every triangle range test of the
         // reference false: the ray misses after one step (or after testing a leaf root).
         if (L.tmin != L.tmin || L.tmax != L.tmax) {
-            L.steps = (a.root_leaf_count == 0 && a.npairs != 0) ? 1u : 0u;
+            L.steps = (a.root_leaf_count == 0 && a.npairs != 0) ? VT_MUT(73, 0u, 1u) : 0u;
             L.tests = a.root_leaf_count;
             L.node = kDone; L.tri_cur = 0; L.tri_end = 0;
         }
@@ -665,7 +669,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                     asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v76\n\tv_mov_b32 %1, v77\n\tv_mov_b32 %2, v78\n\tv_mov_b32 %3, v79"
                                  : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3) : : "memory");
                     const float alpha = alpha_from_texels(t0, t1, t2, t3, L.ax, L.ay);
-                    decided = true; pass = !(alpha < L.aref);
+                    decided = true; pass = !VT_MUT(61, alpha <= L.aref, alpha < L.aref);
                 }
                 if (do_alpha1) {
                     // ---- ALPHA 1: the triangle's AlphaRec has arrived: texUV (:198), TransformTexcoord, texel addresses
@@ -677,7 +681,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                     const uint32_t dims = __float_as_uint(q3.z), of = __float_as_uint(q3.w);
                     L.aref = q3.y;
                     if (dims == kAlphaAlwaysPass) { decided = true; pass = true; }
-                    else if (dims == 0u) { decided = true; pass = !(1.0f < L.aref); }         // no texture: alpha 1
+                    else if (dims == 0u) { decided = true; pass = VT_MUT(65, true, !(1.0f < L.aref)); }         // no texture: alpha 1
                     else {
                         const uint32_t W = dims & 0xFFFFu, H = dims >> 16;
                         const uint32_t plane = of & 0x7FFFFFFFu;          // texel offsets fit 32 bits (vt_scene_set_alpha: < 2 GiB)
@@ -694,10 +698,10 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a)
                             p0 = plane + yi * W + xi;
                             L.ax = -1.0f; L.ay = 0.0f;
                         } else {
-                            const float fx = x - 0.5f, fy = y - 0.5f;
+                            const float fx = x - VT_MUT(63, 0.0f, 0.5f), fy = y - 0.5f;
                             const float x0 = floorf(fx), y0 = floorf(fy);
                             L.ax = fx - x0; L.ay = fy - y0;
-                            const uint32_t i0 = wrap_index(x0, W), i1 = wrap_index(x0 + 1.0f, W);
+                            const uint32_t i0 = wrap_index(x0, W), i1 = VT_MUT(64, min(i0 + 1u, W - 1u), wrap_index(x0 + 1.0f, W));
                             const uint32_t j0 = wrap_index(y0, H), j1 = wrap_index(y0 + 1.0f, H);
                             p0 = plane + j0 * W + i0; p1 = plane + j0 * W + i1;
                             p2 = plane + j1 * W + i0; p3 = plane + j1 * W + i1;
