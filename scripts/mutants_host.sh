@@ -38,6 +38,23 @@ for k in 41 42 43 44 45 46 48; do
   if /tmp/ttr_$k > /tmp/ttr_$k.log 2>&1; then v=SURVIVED; else v=KILLED; fi
   printf "class mutant %-2s %-48s %-8s %s\n" "$k" "${TWHAT[$k]}" "$v" "$(tail -1 /tmp/ttr_$k.log)" >> "$OUT"
 done
+# the shard rule of the multi-GPU path (host_api.cpp: vt_shard_capacity / vt_shard_bounds; gather_schedule.h: gather_chunk_bounds)
+echo "# shard rule: tests/test_multigpu_gloo.py (properties + world_size-2 gloo runs), tests/cpp/test_gather_schedule (83: the header compiled -DVT_MUTANT=83)" >> "$OUT"
+declare -A SWHAT=([81]="shard capacity not rounded to whole 64-ray blocks" [82]="the tail shard's end not clamped to n" [83]="a chunk's end not clamped to the shard" [84]="rays per shard rounded DOWN")
+for k in 81 82 84; do
+  make -C vistrace_amd/csrc host_mutant K=$k > /tmp/hm_build_$k.log 2>&1 || { echo "mutant $k: build failed" >> "$OUT"; continue; }
+  L=$PWD/vistrace_amd/lib/variants/libvistrace_hip_hostmut_$k.so
+  verdict=SURVIVED; by=""
+  if ! VISTRACE_HIP_LIB=$L timeout 900 python -m pytest tests/test_multigpu_gloo.py -m "not gpu" -x -q -p no:cacheprovider > /tmp/hm_$k.log 2>&1; then
+    by=$(grep -m1 -E "^(FAILED|ERROR) " /tmp/hm_$k.log | sed -E 's/ - .*//'); verdict=KILLED
+  fi
+  printf "shard mutant %-2s %-52s %-8s %s\n" "$k" "${SWHAT[$k]}" "$verdict" "$by" >> "$OUT"
+  rm -rf vistrace_amd/csrc/_build_hostmut_$k "$L"
+done
+if g++ -O2 -g -std=c++17 -DVT_MUTANT=83 -Ivistrace_amd/csrc -o /tmp/tgs_83 tests/cpp/test_gather_schedule.cpp 2> /dev/null; then
+  if timeout 600 /tmp/tgs_83 > /tmp/tgs_83.log 2>&1; then v=SURVIVED; else v=KILLED; fi
+  printf "shard mutant %-2s %-52s %-8s %s\n" 83 "${SWHAT[83]}" "$v" "$(tail -1 /tmp/tgs_83.log | cut -c1-120)" >> "$OUT"
+fi
 cat "$OUT"
 }
 main "$@"; exit

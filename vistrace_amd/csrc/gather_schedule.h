@@ -23,6 +23,14 @@
 #include <cstdint>
 #include <vector>
 
+#ifndef VT_MUT   // mutation sites (vt_internal.h; scripts/mutants_host.sh builds the schedule test with -DVT_MUTANT=83)
+#ifdef VT_MUTANT
+#define VT_MUT(k, wrong, right) ((VT_MUTANT == (k)) ? (wrong) : (right))
+#else
+#define VT_MUT(k, wrong, right) (right)
+#endif
+#endif
+
 namespace vt {
 
 enum class GatherOp : uint8_t {
@@ -94,7 +102,7 @@ inline void gather_chunk_bounds(uint64_t cap, int K, int c, uint64_t* lo, uint64
     const uint64_t per = ((cap + uint64_t(K) - 1) / uint64_t(K) + 63) / 64 * 64;
     const uint64_t a = per * uint64_t(c), b = a + per;
     *lo = a < cap ? a : cap;
-    *hi = b < cap ? b : cap;
+    *hi = VT_MUT(83, b, b < cap ? b : cap);
 }
 
 } // namespace vt

@@ -121,8 +121,8 @@ int vt_abi_version(void) { return VT_ABI_VERSION; }
 uint64_t vt_shard_capacity(uint64_t n, int ndev)
 {
     if (ndev <= 0) return 0;
-    const uint64_t per = (n + uint64_t(ndev) - 1) / uint64_t(ndev);
-    return (per + 63) / 64 * 64;                       // whole 64-ray wave blocks: shard boundaries never split one
+    const uint64_t per = (n + VT_MUT(84, 0u, uint64_t(ndev) - 1)) / uint64_t(ndev);        // (VT_MUT: mutation sites, vt_internal.h)
+    return VT_MUT(81, per, (per + 63) / 64 * 64);                       // whole 64-ray wave blocks: shard boundaries never split one
 }
 
 void vt_shard_bounds(uint64_t n, int ndev, int g, uint64_t* lo, uint64_t* hi)
@@ -131,7 +131,7 @@ void vt_shard_bounds(uint64_t n, int ndev, int g, uint64_t* lo, uint64_t* hi)
     const bool valid = g >= 0 && g < ndev;
     const uint64_t a = valid ? std::min(n, cap * uint64_t(g)) : n;
     if (lo) *lo = a;
-    if (hi) *hi = valid ? std::min(n, a + cap) : a;
+    if (hi) *hi = valid ? VT_MUT(82, a + cap, std::min(n, a + cap)) : a;
 }
 
 int vt_tris_setup(const float* verts, const uint8_t* flags, uint32_t n, vt_tri64* out)
