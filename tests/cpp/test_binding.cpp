@@ -317,6 +317,13 @@ static void test_gpu_side()
     CHECK(e == "Valid cone width but invalid cone angle passed");
     e = error_of([&] { call_traverse(L, accel, {State::Vec(0, 0, 1), State::Vec(0, 0, -1), State::Nil(), State::Nil(), State::Num(-1), State::Num(0.1)}); });
     CHECK(e == "Valid cone angle but invalid cone width passed");
+    // ... and the branch points of the two cone checks (:802-803): a width of exactly 0 is a VALID width (scripts/mutants_binding.sh 92 / 96)
+    e = error_of([&] { call_traverse(L, accel, {State::Vec(0, 0, 1), State::Vec(0, 0, -1), State::Nil(), State::Nil(), State::Num(0), State::Num(0)}); });
+    CHECK(e == "Valid cone width but invalid cone angle passed");
+    e = error_of([&] { call_traverse(L, accel, {State::Vec(0, 0, 1), State::Vec(0, 0, -1), State::Nil(), State::Nil(), State::Num(0), State::Num(-1)}); });
+    CHECK(e == "Valid cone width but invalid cone angle passed");
+    CHECK(call_traverse(L, accel, {State::Vec(1, 1, 8), State::Vec(0, 0, -1), State::Nil(), State::Nil(), State::Num(0), State::Num(0.25)}) == 1);
+    delete L.GetUserType<TraceResult>(1, TraceResult::id);
     e = error_of([&] { call_traverse(L, accel, {State::Num(1), State::Vec(0, 0, -1)}); }, &arg);
     CHECK(contains(e, "Vector expected") && arg == 2);
     e = error_of([&] { call_traverse(L, accel, {State::Vec(0, 0, 1), State::Vec(0, 0, -1), State::Str("x")}); }, &arg);
@@ -352,6 +359,10 @@ static void test_gpu_side()
         std::string be = error_of([&] { call_method(L, accelValue, "TraverseBatch", {State::Array({State::Array({State::Vec(0, 0, 1)})})}); });
         CHECK(be == "Each ray must be a table {origin, direction[, tMin[, tMax]]}");
         be = error_of([&] { call_method(L, accelValue, "TraverseBatch", {State::Array({State::Array({State::Vec(0, 0, 1), State::Vec(0, 0, 1), State::Num(3), State::Num(2)})})}); });
+        CHECK(be == "tMax must be greater than tMin");
+        be = error_of([&] {                                   // tMax == tMin is refused too (:806 is <=)
+            call_method(L, accelValue, "TraverseBatch", {State::Array({State::Array({State::Vec(1, 1, 8), State::Vec(0, 0, -1), State::Num(2), State::Num(2)})})});
+        });
         CHECK(be == "tMax must be greater than tMin");
 
         // 400 rays over the three surfaces: above AccelStruct::kDeviceBatchMin -> the device; each must equal the

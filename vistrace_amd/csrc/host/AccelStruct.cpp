@@ -13,6 +13,13 @@
 #include "TraceResult.h"
 #include "TraceResultBatch.h"
 
+// mutation sites (scripts/mutants_binding.sh: tests/cpp/test_binding built with -DVT_MUTANT=<k>); the product never defines VT_MUTANT
+#ifdef VT_MUTANT
+#define VT_MUT(k, wrong, right) ((VT_MUTANT == (k)) ? (wrong) : (right))
+#else
+#define VT_MUT(k, wrong, right) (right)
+#endif
+
 using namespace GarrysMod::Lua;
 
 namespace vistrace {
@@ -248,10 +255,10 @@ int AccelStruct::Traverse(ILuaBase* LUA)
     const float coneAngle = optional_number(7, -1.f);      // :799-800
 
     // same checks, order and messages as :802-806
-    if (coneWidth >= 0 && coneAngle <= 0.f) LUA->ThrowError("Valid cone width but invalid cone angle passed");
-    if (coneWidth < 0 && coneAngle > 0.f) LUA->ThrowError("Valid cone angle but invalid cone width passed");
+    if (VT_MUT(96, coneWidth > 0, coneWidth >= 0) && VT_MUT(91, coneAngle < 0.f, coneAngle <= 0.f)) LUA->ThrowError("Valid cone width but invalid cone angle passed");
+    if (VT_MUT(92, coneWidth <= 0, coneWidth < 0) && coneAngle > 0.f) LUA->ThrowError("Valid cone angle but invalid cone width passed");
     if (tMin < 0.f) LUA->ArgError(4, "tMin cannot be less than 0");
-    if (tMax <= tMin) LUA->ArgError(5, "tMax must be greater than tMin");
+    if (VT_MUT(94, tMax < tMin, tMax <= tMin)) LUA->ArgError(5, "tMax must be greater than tMin");
 
     LUA->Pop(LUA->Top());
 
@@ -334,7 +341,7 @@ int AccelStruct::TraverseBatch(ILuaBase* LUA)
             }
             if (pass == 0) {
                 if (r.tmin < 0.f) LUA->ThrowError("tMin cannot be less than 0");
-                if (r.tmax <= r.tmin) LUA->ThrowError("tMax must be greater than tMin");
+                if (VT_MUT(95, r.tmax < r.tmin, r.tmax <= r.tmin)) LUA->ThrowError("tMax must be greater than tMin");
             } else {
                 mBatchRays[i] = r;
             }
