@@ -608,6 +608,12 @@ int vt_engine_launch_info(vt_engine* e, uint32_t* blocks, uint32_t* threads, uin
  *                                    does on such paths: delete-before-throw (source/VisTrace.cpp:782-785,
  *                                    source/objects/AccelStruct.cpp:186-203, :780); here: a non-zero status, vt_last_error set,
  *                                    nothing leaked, the engine still usable (tests/test_gpu_fault_injection.py).
+ *   VT_TEST_FAIL_HIP=<k>             the same for every OTHER HIP call the library checks (copies, event and stream calls, launch
+ *                                    checks, synchronisations): the k-th checked call reports a failure instead of being made (the
+ *                                    devices are drained first, as after a real sticky error).  Contract under test: a non-zero
+ *                                    status, vt_last_error set, nothing leaked, the engine still usable; an object that was being
+ *                                    UPDATED in place (refit, skin refit, new tables) is unspecified until the same call succeeds
+ *                                    on it or it is freed.  vt_test_fail_hip(k) re-arms it at run time.
  * Not hooks but configuration, always honoured: VT_RCCL_LIB (path of the RCCL library to dlopen instead of librccl.so),
  * VT_BUILDER (default builder of vt_bvh_build), VT_BATCH_UPLOAD (staged | direct), VT_COPY_THREADS (staging-copy threads). */
 
@@ -616,6 +622,9 @@ int vt_engine_launch_info(vt_engine* e, uint32_t* blocks, uint32_t* threads, uin
 int vt_test_fail_alloc(uint64_t k);
 /* Allocations the library has attempted since the last vt_test_fail_alloc (or since it was loaded); 0 with the hooks off. */
 uint64_t vt_test_alloc_count(void);
+/* The same pair for VT_TEST_FAIL_HIP: the k-th checked HIP call from now on fails (once); checked calls passed since. */
+int vt_test_fail_hip(uint64_t k);
+uint64_t vt_test_hip_count(void);
 
 #ifdef __cplusplus
 }

@@ -780,8 +780,13 @@ static void bench_batch_forms()
 // Every device / pinned allocation behind vistrace.CreateAccel, accel:Rebuild and accel:TraverseBatch is made to fail in turn
 // (vt_test_fail_alloc).  The reference's convention on such paths is delete-before-throw (source/VisTrace.cpp:782-785,
 // source/objects/AccelStruct.cpp:186-203, :780): the script sees a Lua error, never an abort, and the module stays usable.
+// the hook under test: allocations (--fail-alloc) or every other checked HIP call (--fail-hip: vt_test_fail_hip)
+static int (*g_arm)(uint64_t) = vt_test_fail_alloc;
+static uint64_t (*g_passed)(void) = vt_test_alloc_count;
+
 static void test_fail_alloc_side()
 {
+    const bool hip = g_arm == vt_test_fail_hip;
     State L;
     RegisterTracingApi(&L);
     install_entity_global(L);
@@ -795,7 +800,7 @@ static void test_fail_alloc_side()
     SetWorld(&world);
     int dummyEntity = 0;
     g_entityByIndex[42] = &dummyEntity;
-    if (vt_test_fail_alloc(0) != VT_OK) { ++g_fail; std::printf("FAIL: --fail-alloc needs VT_ENABLE_TEST_HOOKS=1\n"); return; }
+    if (vt_test_fail_alloc(0) != VT_OK || vt_test_fail_hip(0) != VT_OK) { ++g_fail; std::printf("FAIL: --fail-alloc / --fail-hip need VT_ENABLE_TEST_HOOKS=1\n"); return; }
 
     auto create = [&]() -> fakelua::Value {
         L.Pop(L.Top());
@@ -823,27 +828,27 @@ static void test_fail_alloc_side()
 
     // a clean run counts the allocations of each call (the first CreateAccel also opens the engine)
     fakelua::Value ref = create();
-    const uint64_t n_create = vt_test_alloc_count();
+    const uint64_t n_create = g_passed();
     CHECK(ref.type == AccelStruct_id && works(ref) && n_create >= 4);
-    (void)vt_test_fail_alloc(0);
+    (void)g_arm(0);
     const int ref_hits = batch_hits(ref);
-    const uint64_t n_batch = vt_test_alloc_count();
+    const uint64_t n_batch = g_passed();
     CHECK(ref_hits > 0 && n_batch >= 1);
     int failed_create = 0, failed_rebuild = 0, failed_batch = 0;
     for (uint64_t k = 1; k <= n_create; ++k) {               // vistrace.CreateAccel with its k-th allocation failing
-        (void)vt_test_fail_alloc(k);
+        (void)g_arm(k);
         fakelua::Value got;
         const std::string e = error_of([&] { got = create(); });
-        (void)vt_test_fail_alloc(0);
+        (void)g_arm(0);
         if (!e.empty()) { ++failed_create; CHECK(contains(e.c_str(), "VisTrace:")); }
         else { CHECK(got.type == AccelStruct_id && works(got)); CHECK(call_method(L, got, "__gc") == 0); }
         CHECK(works(ref) && batch_hits(ref) == ref_hits);    // the module is still usable, the older accel untouched
     }
     for (uint64_t k = 1; k <= n_create; ++k) {               // accel:Rebuild: a failure leaves the accel invalid, the next Rebuild heals it
         fakelua::Value a = create();
-        (void)vt_test_fail_alloc(k);
+        (void)g_arm(k);
         const std::string e = error_of([&] { call_method(L, a, "Rebuild", {State::Array({State::User(&dummyEntity, LT::Entity)}), State::Bool(true)}); });
-        (void)vt_test_fail_alloc(0);
+        (void)g_arm(0);
         if (!e.empty()) {
             ++failed_rebuild;
             AccelStruct* accel = static_cast<AccelStruct*>(*a.ud);
@@ -858,9 +863,31 @@ static void test_fail_alloc_side()
     // spare device and pinned blocks), so a repeated call of the same size allocates nothing: every round asks for a batch 3 x
     // larger than the last, which needs a new device block and a new pinned block for its hit records -- allocations 1 and 2 of
     // the call (the staging pipeline and the launch scratch exist since the clean call above).
+    // (--fail-hip: every checked HIP call of one TraverseBatch of 40 000 rays in turn, the size kept)
     size_t rays_n = 40000;
-    for (uint64_t k = 1; k <= 2; ++k) {
-        for (int round = 0; round < 2; ++round, rays_n *= 3) {
+    uint64_t k_max = 2;
+    int rounds = 2, injected_batch = 0;
+    if (hip) {
+        std::string packed(rays_n * sizeof(vt_ray), '\0');
+        for (size_t i = 0; i < rays_n; ++i) {
+            const vt_ray r{{float((i * 37) % 320) * 0.1f - 1.f, float((i * 53) % 120) * 0.1f - 1.f, 9.f}, {0.01f * float(i % 7), 0.02f, -1.f}, 0.f, FLT_MAX};
+            std::memcpy(&packed[i * sizeof(vt_ray)], &r, sizeof(r));
+        }
+        fakelua::Value bufv;
+        bufv.type = LT::String; bufv.str = packed;
+        for (int warm = 0; warm < 2; ++warm) {
+            (void)g_arm(0);
+            CHECK(call_method(L, ref, "TraverseBatch", {bufv}) == 1 && L.GetType(1) == TraceResultBatch::id);
+            const fakelua::Value rb = L.stack.back();
+            CHECK(call_method(L, rb, "Hits") == 1);
+            (void)call_method(L, rb, "__gc");
+            k_max = g_passed();
+        }
+        rounds = 1;
+    }
+    for (uint64_t k = 1; k <= k_max; ++k) {
+        for (int round = 0; round < rounds; ++round, rays_n *= (hip ? 1 : 3)) {
+            ++injected_batch;
             std::string packed(rays_n * sizeof(vt_ray), '\0');
             for (size_t i = 0; i < rays_n; ++i) {
                 const vt_ray r{{float((i * 37) % 320) * 0.1f - 1.f, float((i * 53) % 120) * 0.1f - 1.f, 9.f}, {0.01f * float(i % 7), 0.02f, -1.f}, 0.f, FLT_MAX};
@@ -878,10 +905,10 @@ static void test_fail_alloc_side()
                 (void)call_method(L, rb, "__gc");
                 return nhit;
             };
-            (void)vt_test_fail_alloc(k);
+            (void)g_arm(k);
             long got = -2;
             const std::string e = error_of([&] { got = hits_of(); });
-            (void)vt_test_fail_alloc(0);
+            (void)g_arm(0);
             const long clean = hits_of();                     // the same buffer once more: now it must work
             CHECK(clean > 0);
             if (!e.empty()) { ++failed_batch; CHECK(contains(e.c_str(), "VisTrace:")); }
@@ -889,9 +916,9 @@ static void test_fail_alloc_side()
             CHECK(batch_hits(ref) == ref_hits && works(ref));
         }
     }
-    std::printf("fail-alloc through Lua: CreateAccel %d of %llu (the first call also opened the engine: later ones need fewer allocations), Rebuild %d, "
-                "TraverseBatch %d of 4 injected failures surfaced as Lua errors\n",
-                failed_create, (unsigned long long)n_create, failed_rebuild, failed_batch);
+    std::printf("%s through Lua: CreateAccel %d of %llu (the first call also opened the engine: later ones pass fewer), Rebuild %d, "
+                "TraverseBatch %d of %d injected failures surfaced as Lua errors\n", hip ? "fail-hip" : "fail-alloc",
+                failed_create, (unsigned long long)n_create, failed_rebuild, failed_batch, injected_batch);
     CHECK(failed_create >= 3 && failed_rebuild >= 3 && failed_batch >= 2);
     CHECK(call_method(L, ref, "__gc") == 0);
     SetWorld(nullptr);
@@ -899,9 +926,10 @@ static void test_fail_alloc_side()
 
 int main(int argc, char** argv)
 {
-    if (argc > 1 && std::strcmp(argv[1], "--fail-alloc") == 0) {
+    if (argc > 1 && (std::strcmp(argv[1], "--fail-alloc") == 0 || std::strcmp(argv[1], "--fail-hip") == 0)) {
+        if (std::strcmp(argv[1], "--fail-hip") == 0) { g_arm = vt_test_fail_hip; g_passed = vt_test_hip_count; }
         test_fail_alloc_side();
-        std::printf("binding (fail-alloc): %d checks, %d failed\n", g_run, g_fail);
+        std::printf("binding (%s): %d checks, %d failed\n", argv[1] + 2, g_run, g_fail);
         return g_fail ? 1 : 0;
     }
     if (argc > 1 && std::strcmp(argv[1], "--bench") == 0) {

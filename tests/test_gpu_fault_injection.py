@@ -48,6 +48,35 @@ def test_allocation_failures_surface_as_lua_errors():
     assert "surfaced as Lua errors" in out.stdout
 
 
+@pytest.mark.gpu
+def test_every_checked_hip_call_failure_is_reported_and_leaves_the_engine_usable():
+    """The second hook (vt_test_fail_hip): every OTHER HIP call the library checks -- copies, event and stream calls, launch checks,
+    synchronisations -- reports a failure in turn instead of being made, over the same operations.  A status + message (or a second
+    way with correct results: the group's replication falls back to per-member uploads), nothing leaked, the engine still
+    reproduces the golden fixture; an object that was being updated in place is healed by repeating the call."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "fake_rccl"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fault_injection_check.py"), "hip"], capture_output=True, text=True,
+                         timeout=2400, env=_env())
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
+    assert "fault injection: ok" in out.stdout
+    lines = {m.group(1): (int(m.group(2)), int(m.group(3)), int(m.group(4)))
+             for m in re.finditer(r"^(.+?): (\d+) checked HIP calls, (\d+) injected failures reported as errors, (\d+) absorbed", out.stdout, re.M)}
+    assert len(lines) >= 16, out.stdout
+    assert sum(c for c, _, _ in lines.values()) >= 300                  # the sweep is over hundreds of early returns
+    for name, (count, failed, absorbed) in lines.items():               # single-engine calls have no second way: every failure is an error
+        if "members" not in name and name.startswith(("vt_engine_open", "vt_scene_", "vt_trace_closest (", "vt_batch_")):
+            assert count >= 1 and failed == count and absorbed == 0, (name, count, failed, absorbed)
+
+
+@pytest.mark.gpu
+def test_checked_hip_call_failures_surface_as_lua_errors():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "test_binding")
+    out = subprocess.run([exe, "--fail-hip"], capture_output=True, text=True, timeout=600, env=dict(os.environ, VT_ENABLE_TEST_HOOKS="1"))
+    assert out.returncode == 0 and " 0 failed" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "surfaced as Lua errors" in out.stdout
+
+
 def test_the_hook_is_dead_without_the_switch(va):
     """vt_test_fail_alloc refuses to arm unless VT_ENABLE_TEST_HOOKS=1 (this process: unset)."""
     if os.environ.get("VT_ENABLE_TEST_HOOKS") == "1":

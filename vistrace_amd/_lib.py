@@ -152,6 +152,8 @@ SYMBOLS = {
     "vt_engine_launch_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "vt_test_fail_alloc": (C.c_int, [_u64]),
     "vt_test_alloc_count": (_u64, []),
+    "vt_test_fail_hip": (C.c_int, [_u64]),
+    "vt_test_hip_count": (_u64, []),
 }
 
 

@@ -471,10 +471,21 @@ int vt_device_count(int* count)
     return VT_OK;
 }
 
+// what the fault-injection hook on checked HIP calls runs before it reports its failure (vt_internal.h: test_hip_fails)
+static void drain_every_device()
+{
+    int count = 0, before = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || hipGetDevice(&before) != hipSuccess) return;
+    for (int d = 0; d < count; ++d)
+        if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+    (void)hipSetDevice(before);
+}
+
 int vt_engine_open(int device, vt_engine** out)
 {
     if (!out) return fail(VT_ERR_INVALID_ARG, "vt_engine_open: out is NULL");
     *out = nullptr;
+    set_test_drain(&drain_every_device);
     int count = 0;
     VT_HIP(hipGetDeviceCount(&count));
     if (count <= 0) return fail(VT_ERR_HIP, "vt_engine_open: no HIP device (this library has no CPU fallback)");

@@ -15,9 +15,11 @@
 #include "trace_kernels.h"
 #include "vt_internal.h"
 
+// (test_hip_fails: the second fault-injection hook, vt_internal.h -- the k-th VT_HIP site the library passes reports a failure
+// INSTEAD of making its call; false, at the cost of one relaxed load, unless VT_ENABLE_TEST_HOOKS=1)
 #define VT_HIP(call)                                                                              \
     do {                                                                                          \
-        hipError_t err__ = (call);                                                                \
+        hipError_t err__ = vt::test_hip_fails() ? hipErrorUnknown : (call);                       \
         if (err__ != hipSuccess)                                                                  \
             return fail(VT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(err__));        \
     } while (0)

@@ -50,6 +50,8 @@ namespace {
 std::atomic<int>      g_alloc_hooks{-1};       // -1 unknown, 0 off, 1 on (VT_ENABLE_TEST_HOOKS=1, read once)
 std::atomic<uint64_t> g_alloc_count{0};        // attempts since the hook was last armed
 std::atomic<uint64_t> g_alloc_fail_at{0};      // 0 = none
+std::atomic<uint64_t> g_hip_count{0}, g_hip_fail_at{0};      // the same pair for the checked HIP calls (VT_HIP sites)
+std::atomic<void (*)()> g_test_drain{nullptr};
 
 bool alloc_hooks_on()
 {
@@ -58,11 +60,27 @@ bool alloc_hooks_on()
         const char* en = std::getenv("VT_ENABLE_TEST_HOOKS");
         on = en && en[0] == '1' && en[1] == '\0' ? 1 : 0;
         if (on) if (const char* v = test_hook("VT_TEST_FAIL_ALLOC")) g_alloc_fail_at.store(std::strtoull(v, nullptr, 10), std::memory_order_release);
+        if (on) if (const char* v = test_hook("VT_TEST_FAIL_HIP")) g_hip_fail_at.store(std::strtoull(v, nullptr, 10), std::memory_order_release);
         g_alloc_hooks.store(on, std::memory_order_release);
     }
     return on == 1;
 }
 } // namespace
+
+void set_test_drain(void (*drain)()) { g_test_drain.store(drain, std::memory_order_release); }
+
+bool test_hip_fails()
+{
+    if (g_alloc_hooks.load(std::memory_order_relaxed) == 0) return false;          // the product: one relaxed load
+    if (!alloc_hooks_on()) return false;
+    const uint64_t mine = g_hip_count.fetch_add(1, std::memory_order_acq_rel) + 1;
+    const uint64_t at = g_hip_fail_at.load(std::memory_order_acquire);
+    if (at == 0 || mine != at) return false;
+    g_hip_fail_at.store(0, std::memory_order_release);
+    if (auto drain = g_test_drain.load(std::memory_order_acquire)) drain();
+    std::fprintf(stderr, "[vistrace_hip] TEST HOOK: checked HIP call %llu fails on purpose\n", static_cast<unsigned long long>(mine));
+    return true;
+}
 
 bool test_alloc_fails()
 {
@@ -234,5 +252,15 @@ int vt_test_fail_alloc(uint64_t k)
 }
 
 uint64_t vt_test_alloc_count(void) { return vt::alloc_hooks_on() ? vt::g_alloc_count.load(std::memory_order_acquire) : 0; }
+
+int vt_test_fail_hip(uint64_t k)
+{
+    if (!vt::alloc_hooks_on()) return vt::fail(VT_ERR_UNSUPPORTED, "vt_test_fail_hip: test hooks are off (VT_ENABLE_TEST_HOOKS=1)");
+    vt::g_hip_count.store(0, std::memory_order_release);
+    vt::g_hip_fail_at.store(k, std::memory_order_release);
+    return VT_OK;
+}
+
+uint64_t vt_test_hip_count(void) { return vt::alloc_hooks_on() ? vt::g_hip_count.load(std::memory_order_acquire) : 0; }
 
 } // extern "C"

@@ -67,6 +67,12 @@ const char* test_hook(const char* name);
 // fault injection (VT_TEST_FAIL_ALLOC / vt_test_fail_alloc, dead without VT_ENABLE_TEST_HOOKS=1): counts one allocation attempt of
 // the library; true = this is the one that must fail.  Called by dev_malloc / pinned_malloc (engine_internal.h) only.
 bool test_alloc_fails();
+// ... and on every other HIP call the library checks (VT_TEST_FAIL_HIP / vt_test_fail_hip): counts one pass through a VT_HIP site
+// (engine_internal.h); true = this one reports hipErrorUnknown and its call is NOT made.  Before it answers true it drains every
+// device (the function registered with set_test_drain: engine.hip's), so that what the failing function leaves behind -- buffers
+// it frees, events it never recorded -- meets an idle device, as after a real sticky error.
+bool test_hip_fails();
+void set_test_drain(void (*drain)());
 
 void set_error(const std::string& msg);
 int  fail(int code, const std::string& msg);
