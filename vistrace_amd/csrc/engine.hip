@@ -472,8 +472,10 @@ int vt_device_count(int* count)
 }
 
 // what the fault-injection hook on checked HIP calls runs before it reports its failure (vt_internal.h: test_hip_fails)
+static thread_local bool t_capturing = false;     // this thread is between hipStreamBeginCapture and hipStreamEndCapture
 static void drain_every_device()
 {
+    if (t_capturing) return;                       // (a synchronisation would invalidate the capture: nothing it records runs yet)
     int count = 0, before = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || hipGetDevice(&before) != hipSuccess) return;
     for (int d = 0; d < count; ++d)
@@ -1026,8 +1028,10 @@ static int enqueue_levels_and_verdict(vt_scene* s)
     if (!s->refit_graph && levels > 4) {
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            t_capturing = true;
             const int rc = enqueue();
             const hipError_t end = hipStreamEndCapture(e->stream, &graph);
+            t_capturing = false;
             if (rc == VT_OK && end == hipSuccess && graph &&
                 hipGraphInstantiate(&s->refit_graph, graph, nullptr, nullptr, 0) != hipSuccess)
                 s->refit_graph = nullptr;
