@@ -222,8 +222,8 @@ int batch_new(vt_scene* s, uint64_t n, vt_batch** out)
             }
     }
     if (!b->d_mem) { err = dev_malloc(reinterpret_cast<void**>(&b->d_mem), need); b->d_mem_bytes = need; }
-    if (err == hipSuccess) err = hipEventCreateWithFlags(&b->done, hipEventDisableTiming);
-    if (err == hipSuccess) err = hipEventCreateWithFlags(&b->hits_down, hipEventDisableTiming);
+    if (err == hipSuccess) err = VT_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+    if (err == hipSuccess) err = VT_TRY(hipEventCreateWithFlags(&b->hits_down, hipEventDisableTiming));
     if (err != hipSuccess) {
         if (b->d_mem) (void)hipFree(b->d_mem);
         if (b->done) (void)hipEventDestroy(b->done);
@@ -252,7 +252,7 @@ int batch_finish(vt_scene* s, vt_batch* b)
     }
     // the shading frame, cone switched off as by accel:Traverse's defaults (coneWidth = coneAngle = -1, AccelStruct.cpp:796-806)
     if (err == hipSuccess && b->d_tbn) err = launch_hit_tbn(s, b->d_mem, b->d_hits, b->n, -1.f, -1.f, b->d_tbn, e->stream);
-    if (err == hipSuccess) err = hipEventRecord(b->done, e->stream);
+    if (err == hipSuccess) err = VT_TRY(hipEventRecord(b->done, e->stream));
     if (err != hipSuccess) return fail(VT_ERR_HIP, std::string("vt_batch_trace_closest: ") + hipGetErrorString(err));
     return VT_OK;
 }
@@ -412,7 +412,7 @@ static int trace_host(vt_scene* s, const vt_ray* rays, uint64_t n, void* out, si
 int vt_host_register(void* p, size_t bytes)
 {
     if (!p || bytes == 0) return fail(VT_ERR_INVALID_ARG, "vt_host_register: empty range");
-    const hipError_t err = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    const hipError_t err = VT_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
     if (err == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return VT_OK; }
     if (err != hipSuccess) { (void)hipGetLastError(); return fail(VT_ERR_HIP, std::string("vt_host_register: ") + hipGetErrorString(err)); }
     return VT_OK;
@@ -606,13 +606,13 @@ int vt_batch_set_trace(vt_batch_set* set, vt_batch** out)
         for (uint32_t k = 0; k < nb; ++k) reqs[k] = BatchReq{set->batches[k]->d_mem, set->batches[k]->d_hits, set->batches[k]->n, set->widths[k]};
         rc = launch_batches(s, reqs.data(), nb, nullptr, false, false, e->stream);
         if (rc == VT_OK && (set->flags & VT_BATCH_FETCH_HITS)) {
-            hipError_t err = hipEventRecord(e->ev_k[0], e->stream);
-            if (err == hipSuccess) err = hipStreamWaitEvent(e->s_out, e->ev_k[0], 0);
+            hipError_t err = VT_TRY(hipEventRecord(e->ev_k[0], e->stream));
+            if (err == hipSuccess) err = VT_TRY(hipStreamWaitEvent(e->s_out, e->ev_k[0], 0));
             for (uint32_t k = 0; k < nb && err == hipSuccess; ++k) {
                 vt_batch* b = set->batches[k];
                 if (b->n == 0) continue;
-                err = hipMemcpyAsync(b->h_hits.p, b->d_hits, b->n * sizeof(vt_hit), hipMemcpyDeviceToHost, e->s_out);
-                if (err == hipSuccess) err = hipEventRecord(b->hits_down, e->s_out);
+                err = VT_TRY(hipMemcpyAsync(b->h_hits.p, b->d_hits, b->n * sizeof(vt_hit), hipMemcpyDeviceToHost, e->s_out));
+                if (err == hipSuccess) err = VT_TRY(hipEventRecord(b->hits_down, e->s_out));
                 b->hits_in_flight = err == hipSuccess;
             }
             if (err != hipSuccess) rc = fail(VT_ERR_HIP, std::string("vt_batch_set_trace: ") + hipGetErrorString(err));

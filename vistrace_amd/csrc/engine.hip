@@ -419,8 +419,8 @@ int ensure_alpha_room(vt_scene* s)
         const size_t cap = size_t(base) + s->ntris;
         char* grown = nullptr;
         VT_HIP(dev_malloc(reinterpret_cast<void**>(&grown), cap * 64));
-        hipError_t err = hipMemset(grown, 0, cap * 64);
-        if (err == hipSuccess) err = hipMemcpy(grown, s->d_records, s->record_capacity * 64, hipMemcpyDeviceToDevice);
+        hipError_t err = VT_TRY(hipMemset(grown, 0, cap * 64));
+        if (err == hipSuccess) err = VT_TRY(hipMemcpy(grown, s->d_records, s->record_capacity * 64, hipMemcpyDeviceToDevice));
         if (err != hipSuccess) { (void)hipFree(grown); return fail(VT_ERR_HIP, std::string("alpha records: ") + hipGetErrorString(err)); }
         {   // launches read these under launch_mu; the device is idle (the callers synchronised), so the old block can go
             std::lock_guard<std::mutex> swap_lock(e->launch_mu);
@@ -509,20 +509,20 @@ int vt_engine_open(int device, vt_engine** out)
     e->refill_threshold = uint32_t(env_long("VT_REFILL_THRESHOLD", e->refill_threshold));
     e->tri_threshold = uint32_t(env_long("VT_TRI_THRESHOLD", e->tri_threshold));
     e->fetch_dma = int(env_long("VT_FETCH_DMA", e->fetch_dma));
-    hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    hipError_t err = VT_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     if (err == hipSuccess) err = dev_malloc(reinterpret_cast<void**>(&e->d_slot_ctl), vt_engine::kLaunchSlots * vt_engine::kSlotCtlBytes);
-    if (err == hipSuccess) err = hipMemset(e->d_slot_ctl, 0, vt_engine::kLaunchSlots * vt_engine::kSlotCtlBytes);
+    if (err == hipSuccess) err = VT_TRY(hipMemset(e->d_slot_ctl, 0, vt_engine::kLaunchSlots * vt_engine::kSlotCtlBytes));
     for (uint32_t k = 0; k < vt_engine::kLaunchSlots && err == hipSuccess; ++k) {
         e->slots[k].d_ctl = reinterpret_cast<uint32_t*>(e->d_slot_ctl + k * vt_engine::kSlotCtlBytes);
-        err = hipEventCreateWithFlags(&e->slots[k].done, hipEventDisableTiming);
+        err = VT_TRY(hipEventCreateWithFlags(&e->slots[k].done, hipEventDisableTiming));
     }
-    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_loop, hipEventDisableTiming);
+    if (err == hipSuccess) err = VT_TRY(hipEventCreateWithFlags(&e->ev_loop, hipEventDisableTiming));
     if (err == hipSuccess) err = pinned_malloc(reinterpret_cast<void**>(&e->h_tiny_rays), vt_engine::kTinyRays * sizeof(vt_ray), hipHostMallocMapped);
     if (err == hipSuccess) err = pinned_malloc(reinterpret_cast<void**>(&e->h_tiny_out), vt_engine::kTinyRays * sizeof(vt_hit), hipHostMallocMapped);
-    if (err == hipSuccess) err = hipHostGetDevicePointer(&e->d_tiny_rays, e->h_tiny_rays, 0);
-    if (err == hipSuccess) err = hipHostGetDevicePointer(&e->d_tiny_out, e->h_tiny_out, 0);
-    if (err == hipSuccess) err = hipEventCreate(&e->ev_start);
-    if (err == hipSuccess) err = hipEventCreate(&e->ev_stop);
+    if (err == hipSuccess) err = VT_TRY(hipHostGetDevicePointer(&e->d_tiny_rays, e->h_tiny_rays, 0));
+    if (err == hipSuccess) err = VT_TRY(hipHostGetDevicePointer(&e->d_tiny_out, e->h_tiny_out, 0));
+    if (err == hipSuccess) err = VT_TRY(hipEventCreate(&e->ev_start));
+    if (err == hipSuccess) err = VT_TRY(hipEventCreate(&e->ev_stop));
     if (err != hipSuccess) {
         vt_engine_close(e);
         return fail(VT_ERR_HIP, std::string("vt_engine_open: ") + hipGetErrorString(err));
@@ -706,10 +706,10 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
         const size_t rec_bytes = s->record_capacity * 64;
         err = dev_malloc(reinterpret_cast<void**>(&s->d_records), rec_bytes);
         // zeros only where no copy lands: the padding between pairs and triangles (+ the test gap), the AlphaRec room
-        if (err == hipSuccess && tri_off > pair_bytes) err = hipMemsetAsync(s->d_records + pair_bytes, 0, tri_off - pair_bytes, e->stream);
-        if (err == hipSuccess && rec_bytes > tri_off + tri_bytes) err = hipMemsetAsync(s->d_records + tri_off + tri_bytes, 0, rec_bytes - tri_off - tri_bytes, e->stream);
-        if (err == hipSuccess && pair_bytes) err = hipMemcpyAsync(s->d_records, hs.pairs.data(), pair_bytes, hipMemcpyHostToDevice, e->stream);
-        if (err == hipSuccess && tri_bytes) err = hipMemcpyAsync(s->d_records + tri_off, hs.tris.data(), tri_bytes, hipMemcpyHostToDevice, e->stream);
+        if (err == hipSuccess && tri_off > pair_bytes) err = VT_TRY(hipMemsetAsync(s->d_records + pair_bytes, 0, tri_off - pair_bytes, e->stream));
+        if (err == hipSuccess && rec_bytes > tri_off + tri_bytes) err = VT_TRY(hipMemsetAsync(s->d_records + tri_off + tri_bytes, 0, rec_bytes - tri_off - tri_bytes, e->stream));
+        if (err == hipSuccess && pair_bytes) err = VT_TRY(hipMemcpyAsync(s->d_records, hs.pairs.data(), pair_bytes, hipMemcpyHostToDevice, e->stream));
+        if (err == hipSuccess && tri_bytes) err = VT_TRY(hipMemcpyAsync(s->d_records + tri_off, hs.tris.data(), tri_bytes, hipMemcpyHostToDevice, e->stream));
         s->d_tris = reinterpret_cast<vt_tri64*>(s->d_records + tri_off);
         s->bytes += rec_bytes;
         s->upload_stats.bytes_h2d = pair_bytes + tri_bytes + hs.pair_depth.size() * 4;
@@ -965,7 +965,7 @@ int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t dep
         if (depth > 1) {
             VT_HIP(hipMemcpyAsync(e->h_live, d_live + 1, size_t(depth - 1) * 4, hipMemcpyDeviceToHost, stream));
             LiveCopy* job = new LiveCopy{e->h_live, live_out + 1, depth - 1};
-            const hipError_t herr = hipLaunchHostFunc(stream, copy_live_counts, job);
+            const hipError_t herr = VT_TRY(hipLaunchHostFunc(stream, copy_live_counts, job));
             if (herr != hipSuccess) { delete job; return fail(VT_ERR_HIP, std::string("vt_bounce_loop_dev: ") + hipGetErrorString(herr)); }
         }
     }
@@ -1351,8 +1351,8 @@ int vt_scene_set_alpha(vt_scene* s, const vt_alpha_material* mats, uint32_t nmat
     void *d_mats = nullptr, *d_tex = nullptr;
     hipError_t err = dev_malloc(&d_mats, mats_b);
     if (err == hipSuccess) err = dev_malloc(&d_tex, tex_b);
-    if (err == hipSuccess) err = hipMemcpy(d_mats, mats, mats_b, hipMemcpyHostToDevice);
-    if (err == hipSuccess && ntexels) err = hipMemcpy(d_tex, texels, ntexels, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = VT_TRY(hipMemcpy(d_mats, mats, mats_b, hipMemcpyHostToDevice));
+    if (err == hipSuccess && ntexels) err = VT_TRY(hipMemcpy(d_tex, texels, ntexels, hipMemcpyHostToDevice));
     if (err != hipSuccess) {
         (void)hipGetLastError();
         if (d_mats) (void)hipFree(d_mats);
@@ -1493,9 +1493,9 @@ int scene_replicate(vt_scene* s, const std::function<int(vt_engine*, vt_scene**)
             vt_engine* p = r->engine;
             DeviceGuard guard(p->device);
             hipError_t err = guard.ok ? hipSuccess : hipErrorInvalidDevice;
-            if (err == hipSuccess) err = hipMemcpyPeerAsync(r->d_records, p->device, s->d_records, e->device, rec_b, p->stream);
-            if (err == hipSuccess && slot_b) err = hipMemcpyPeerAsync(r->d_prim_to_slot, p->device, s->d_prim_to_slot, e->device, slot_b, p->stream);
-            if (err == hipSuccess && lvl_b) err = hipMemcpyPeerAsync(r->d_level_pairs, p->device, s->d_level_pairs, e->device, lvl_b, p->stream);
+            if (err == hipSuccess) err = VT_TRY(hipMemcpyPeerAsync(r->d_records, p->device, s->d_records, e->device, rec_b, p->stream));
+            if (err == hipSuccess && slot_b) err = VT_TRY(hipMemcpyPeerAsync(r->d_prim_to_slot, p->device, s->d_prim_to_slot, e->device, slot_b, p->stream));
+            if (err == hipSuccess && lvl_b) err = VT_TRY(hipMemcpyPeerAsync(r->d_level_pairs, p->device, s->d_level_pairs, e->device, lvl_b, p->stream));
             log.push_back('E');
             if (err != hipSuccess) { (void)hipGetLastError(); copy_refused = true; rc = fail(VT_ERR_HIP, std::string("scene replica: ") + hipGetErrorString(err)); break; }
         }
@@ -1504,7 +1504,7 @@ int scene_replicate(vt_scene* s, const std::function<int(vt_engine*, vt_scene**)
     for (vt_scene* r : reps) {                            // finish: the first host waits of the call (also behind a failure: nothing may be in flight when the shells go)
         DeviceGuard guard(r->engine->device);
         if (log.find('E') != std::string::npos) log.push_back('W');
-        const hipError_t err = hipStreamSynchronize(r->engine->stream);
+        const hipError_t err = VT_TRY(hipStreamSynchronize(r->engine->stream));
         if (err != hipSuccess && rc == VT_OK) { copy_refused = true; rc = fail(VT_ERR_HIP, std::string("scene replica: ") + hipGetErrorString(err)); }
     }
     const size_t last_e = log.rfind('E');

@@ -15,6 +15,10 @@
 #include "trace_kernels.h"
 #include "vt_internal.h"
 
+// VT_TRY(call): the call's own status, for the places that collect a status and clean up themselves instead of returning at once
+// (counted by the same fault-injection hook as VT_HIP)
+#define VT_TRY(call) (vt::test_hip_fails() ? hipErrorUnknown : (call))
+
 // (test_hip_fails: the second fault-injection hook, vt_internal.h -- the k-th VT_HIP site the library passes reports a failure
 // INSTEAD of making its call; false, at the cost of one relaxed load, unless VT_ENABLE_TEST_HOOKS=1)
 #define VT_HIP(call)                                                                              \

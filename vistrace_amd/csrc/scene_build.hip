@@ -409,17 +409,17 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
     // only what the kernels do not write needs zeros: the padding record between pairs and triangles (+ the test gap), the AlphaRec room
     const size_t pair_end = size_t(np) * 64, tri_off = size_t(s->tri_base) * 64, tri_end = tri_off + size_t(ntris) * 64;
     herr = hipSuccess;
-    if (tri_off > pair_end) herr = hipMemsetAsync(s->d_records + pair_end, 0, tri_off - pair_end, st);
-    if (herr == hipSuccess && rec_bytes > tri_end) herr = hipMemsetAsync(s->d_records + tri_end, 0, rec_bytes - tri_end, st);
+    if (tri_off > pair_end) herr = VT_TRY(hipMemsetAsync(s->d_records + pair_end, 0, tri_off - pair_end, st));
+    if (herr == hipSuccess && rec_bytes > tri_end) herr = VT_TRY(hipMemsetAsync(s->d_records + tri_end, 0, rec_bytes - tri_end, st));
     if (herr != hipSuccess) { vt_scene_free(s); return fail(VT_ERR_HIP, std::string("vt_scene_upload_tree: ") + hipGetErrorString(herr)); }
     hipLaunchKernelGGL(lin_emit, dim3(blocks_for(N)), dim3(256), 0, st, a, reinterpret_cast<vt_node_pair*>(s->d_records), s->d_tris,
                        s->d_prim_to_slot, keys, vals, max_depth);
     rc = hipGetLastError() == hipSuccess ? VT_OK : fail(VT_ERR_HIP, "vt_scene_upload_tree: kernel launch failed");
     if (rc == VT_OK) rc = build_level_lists(s, keys, vals, keys_out, begin, sort_tmp, sort_b, h + kLevelWord);
     if (rc == VT_OK) {
-        herr = hipMemcpyAsync(h + 8, a.status, 4, hipMemcpyDeviceToHost, st);
-        if (herr == hipSuccess) herr = hipMemcpyAsync(h + kRootWord, s->d_records, sizeof(vt_node_pair), hipMemcpyDeviceToHost, st);   // the root pair: packet radius
-        if (herr == hipSuccess) herr = hipStreamSynchronize(st);
+        herr = VT_TRY(hipMemcpyAsync(h + 8, a.status, 4, hipMemcpyDeviceToHost, st));
+        if (herr == hipSuccess) herr = VT_TRY(hipMemcpyAsync(h + kRootWord, s->d_records, sizeof(vt_node_pair), hipMemcpyDeviceToHost, st));   // the root pair: packet radius
+        if (herr == hipSuccess) herr = VT_TRY(hipStreamSynchronize(st));
         if (herr != hipSuccess) rc = fail(VT_ERR_HIP, std::string("vt_scene_upload_tree: ") + hipGetErrorString(herr));
     }
     if (rc == VT_OK && h[8] != 0) rc = fail(VT_ERR_INVALID_ARG, "vt_scene_upload_tree: bad prim index");
@@ -478,7 +478,7 @@ int vt_host_scene_download(vt_scene* s, vt_host_scene** out)
         // depth of every pair from the level lists: level k (deepest first) holds pairs of depth max_depth - k
         std::vector<uint32_t> order(s->npairs);
         DeviceGuard guard(s->engine->device);
-        const hipError_t err = hipMemcpy(order.data(), s->d_level_pairs, size_t(s->npairs) * 4, hipMemcpyDeviceToHost);
+        const hipError_t err = VT_TRY(hipMemcpy(order.data(), s->d_level_pairs, size_t(s->npairs) * 4, hipMemcpyDeviceToHost));
         if (err != hipSuccess) rc = fail(VT_ERR_HIP, std::string("vt_host_scene_download: ") + hipGetErrorString(err));
         for (size_t k = 0; rc == VT_OK && k + 1 < s->level_begin.size(); ++k)
             for (uint32_t j = s->level_begin[k]; j < s->level_begin[k + 1]; ++j) hs.pair_depth[order[j]] = s->max_depth - uint32_t(k);
