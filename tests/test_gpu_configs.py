@@ -199,6 +199,113 @@ def test_concurrent_launches_on_two_streams(va, eng, make_bundle):
     scene.free()
 
 
+def test_host_threads_share_an_engine(va, eng, make_bundle):
+    """include/vistrace_hip.h, "Threading and streams": host threads may share an engine.  Six threads hammer ONE engine for a few
+    seconds with everything the header allows at once -- `_dev` launches on their own streams (two scenes), host-pointer traces,
+    batch objects with fetched hits, merged sets, the bounce loop, a single-ray host walk, and one thread that refits a scene of its
+    own back and forth between two poses and traces it after each -- and every result is compared with what the same call returns
+    single-threaded (which the other tests hold against the oracle).  ctypes releases the GIL inside a call, so the calls overlap."""
+    import threading
+    import time
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    dev = torch.device("cuda", 0)
+    ba, bb = make_bundle("S10k"), make_bundle("terrain")
+    scene_a, scene_b = va.Scene(eng, ba.host_scene), va.Scene(eng, bb.host_scene)
+    verts_c = W.make_scene("S1k")
+    moved_c = (verts_c + np.float32(0.5)).astype(np.float32)
+    scene_c = va.Scene.from_tree(eng, va.HostBvh(va.tris_setup(verts_c)))
+    rays_a = W.sphere_rays(200001, 7, origin=(10.0, -20.0, 30.0))
+    rays_b = W.sphere_rays(150000, 8, origin=(3.0, -4.0, 60.0))
+    rays_c = W.sphere_rays(40000, 9, origin=(1.0, 2.0, 3.0))
+    ref_a, ref_b = ba.oracle(rays_a), bb.oracle(rays_b)
+    ref_c0 = scene_c.trace_closest(rays_c)
+    scene_c.refit(moved_c)
+    ref_c1 = scene_c.trace_closest(rays_c)
+    scene_c.refit(verts_c)
+    assert (scene_c.trace_closest(rays_c).view(np.uint8) == ref_c0.view(np.uint8)).all() and (ref_c0.view(np.uint8) != ref_c1.view(np.uint8)).any()
+    d_loop = tp.to_device(rays_b[:30000], dev)
+    rows_ref, live_ref = tp.bounce_loop(scene_b, d_loop, 30000, 3, 5)
+    torch.cuda.synchronize()
+    rows_ref = tp.to_host(rows_ref, va.HIT).copy()
+    deadline = time.time() + 6.0
+    errors, counts = [], {}
+
+    def same(x, y):
+        return x.view(np.uint8).tobytes() == y.view(np.uint8).tobytes()
+
+    def guard(name, body):
+        def run():
+            k = 0
+            try:
+                while time.time() < deadline and not errors:
+                    body(k)
+                    k += 1
+            except Exception as exc:                     # noqa: BLE001 -- reported by the main thread
+                errors.append(f"{name}: {type(exc).__name__}: {exc}")
+            counts[name] = k
+        return threading.Thread(target=run, name=name)
+
+    def dev_launches(scene, rays, ref, label):
+        stream = torch.cuda.Stream(dev)
+        with torch.cuda.stream(stream):
+            d_rays = tp.to_device(rays, dev)
+        stream.synchronize()
+
+        def body(k):
+            outs = [tp.empty_records(len(rays), va.HIT, dev) for _ in range(3)]
+            for h in outs:
+                scene.trace_closest_dev(d_rays.data_ptr(), len(rays), h.data_ptr(), stream.cuda_stream)
+            stream.synchronize()
+            for h in outs:
+                if not same(tp.to_host(h, va.HIT), ref):
+                    raise AssertionError(f"{label}: device launch {k} differs")
+        return body
+
+    def host_calls(k):
+        lo = (k * 7919) % 100000
+        if not same(scene_a.trace_closest(rays_a[lo:lo + 50000]), ref_a[lo:lo + 50000]):
+            raise AssertionError(f"host-pointer trace {k} differs")
+        occ = scene_b.trace_any(rays_b[:20000])
+        if not (occ == (ref_b["prim"][:20000] != O_MISS)).all():
+            raise AssertionError(f"any-hit {k} differs")
+
+    def batches(k):
+        b = scene_a.trace_batch(rays_a[:60000], check_ranges=True, fetch_hits=True)
+        ok = same(b.hits(), ref_a[:60000])
+        b.free()
+        bs = scene_b.trace_batch_set([rays_b[:5000], rays_b[5000:5100], rays_b[70000:]], fetch_hits=True)
+        ok = ok and same(bs[0].hits(), ref_b[:5000]) and same(bs[1].hits(), ref_b[5000:5100]) and same(bs[2].hits(), ref_b[70000:])
+        for x in bs:
+            x.free()
+        if not ok:
+            raise AssertionError(f"batch objects {k} differ")
+
+    def loops(k):
+        rows, live = tp.bounce_loop(scene_b, d_loop, 30000, 3, 5)
+        if list(live) != list(live_ref) or not same(tp.to_host(rows, va.HIT), rows_ref):
+            raise AssertionError(f"bounce loop {k} differs")
+
+    def refits(k):
+        pose = k % 2 == 0
+        scene_c.refit(moved_c if pose else verts_c)
+        if not same(scene_c.trace_closest(rays_c), ref_c1 if pose else ref_c0):
+            raise AssertionError(f"refit {k}: the refitted scene differs")
+
+    threads = [guard("dev A", dev_launches(scene_a, rays_a, ref_a, "scene A")), guard("dev B", dev_launches(scene_b, rays_b, ref_b, "scene B")),
+               guard("host", host_calls), guard("batches", batches), guard("loops", loops), guard("refits", refits)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a thread hangs"
+    assert not errors, errors
+    assert all(counts.get(t.name, 0) >= 2 for t in threads), counts          # every kind of call really overlapped with the others
+    for sc in (scene_a, scene_b, scene_c):
+        sc.free()
+
+
 def test_refit_while_traces_are_in_flight(va, eng, O):
     """vt_scene_skin_refit / vt_scene_refit rewrite records in place: they wait for traces still running on caller
     streams, so the natural per-frame loop (trace_dev on a stream, then refit) never lets rays see half-updated boxes."""
