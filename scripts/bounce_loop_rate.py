@@ -49,11 +49,16 @@ for name, fn in (("vt_bounce_loop_dev", loop), ("call-by-call composition", comp
     ref = d_rows.clone() if name.startswith("vt_") else ref
     if not name.startswith("vt_"):
         assert torch.equal(ref, d_rows), "loop and composition disagree"
-    t0 = time.perf_counter()
-    for _ in range(3):
-        out = fn()
+    for _ in range(2):                    # clocks and caches: the first launches on a cold device are up to 20 % slower (profiles/r6/notes.md section 4)
+        fn()
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 3 * 1e3
+    each = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        each.append((time.perf_counter() - t0) * 1e3)
+    ms = float(np.median(each))
     rays = sum(live) if live else n * args.depth
     print(f"{name:28s} {args.scene} {n} paths x depth {args.depth}: {ms:8.2f} ms  live per depth {live if live else '(all n)'}"
-          f"  {rays / ms / 1e3:8.1f} Mrays/s (live rays)")
+          f"  {rays / ms / 1e3:8.1f} Mrays/s (live rays)  [median of 7 calls; min {min(each):.2f}, max {max(each):.2f} ms]")

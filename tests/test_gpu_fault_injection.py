@@ -66,7 +66,8 @@ def test_every_checked_hip_call_failure_is_reported_and_leaves_the_engine_usable
     for name, (count, failed, absorbed) in lines.items():
         # no second way on these paths: every failure is an error.  (The refits capture their level-by-level launches into a
         # hipGraph on first use; a capture that fails falls back to plain launches -- those failures are absorbed by design.)
-        if "refit" not in name and name.startswith(("vt_engine_open", "vt_scene_", "vt_trace_closest (", "vt_batch_")):
+        # (and a group's device-to-device replication falls back to per-member uploads)
+        if "refit" not in name and "members" not in name and name.startswith(("vt_engine_open", "vt_scene_", "vt_trace_closest (", "vt_batch_")):
             assert count >= 1 and failed == count and absorbed == 0, (name, count, failed, absorbed)
         if "refit" in name:
             assert failed >= 10 and absorbed >= 1, (name, count, failed, absorbed)
