@@ -906,71 +906,77 @@ int vt_bounce_loop_dev(vt_scene* s, const void* d_rays, uint64_t n, uint32_t dep
         VT_HIP(pinned_malloc(reinterpret_cast<void**>(&e->h_live), live_b));
         e->h_live_bytes = live_b;
     }
-    char* base = static_cast<char*>(e->d_loop);
-    vt_ray* R[2] = {reinterpret_cast<vt_ray*>(base), reinterpret_cast<vt_ray*>(base + ray_b)};
-    uint32_t* I[2] = {reinterpret_cast<uint32_t*>(base + 2 * ray_b), reinterpret_cast<uint32_t*>(base + 2 * ray_b + id_b)};
-    vt_hit* hits_scratch = reinterpret_cast<vt_hit*>(base + 2 * ray_b + 2 * id_b);
-    uint32_t* offsets = reinterpret_cast<uint32_t*>(base + 2 * ray_b + 2 * id_b + hit_b);
-    uint32_t* d_live = reinterpret_cast<uint32_t*>(base + 2 * ray_b + 2 * id_b + hit_b + off_b);   // [d] = paths alive at depth d (d >= 1)
-    vt_hit* H = static_cast<vt_hit*>(d_hits);
+    // (the body is a function of its own: whatever it returns, the event behind what it DID enqueue is recorded -- a loop that
+    // failed half-way has work in flight that still uses the engine's queues, and the next loop must wait for it)
+    auto enqueue_loop = [&]() -> int {
+        char* base = static_cast<char*>(e->d_loop);
+        vt_ray* R[2] = {reinterpret_cast<vt_ray*>(base), reinterpret_cast<vt_ray*>(base + ray_b)};
+        uint32_t* I[2] = {reinterpret_cast<uint32_t*>(base + 2 * ray_b), reinterpret_cast<uint32_t*>(base + 2 * ray_b + id_b)};
+        vt_hit* hits_scratch = reinterpret_cast<vt_hit*>(base + 2 * ray_b + 2 * id_b);
+        uint32_t* offsets = reinterpret_cast<uint32_t*>(base + 2 * ray_b + 2 * id_b + hit_b);
+        uint32_t* d_live = reinterpret_cast<uint32_t*>(base + 2 * ray_b + 2 * id_b + hit_b + off_b);   // [d] = paths alive at depth d (d >= 1)
+        vt_hit* H = static_cast<vt_hit*>(d_hits);
 
-    const vt_ray* rays_q = static_cast<const vt_ray*>(d_rays);
-    const uint32_t* ids_q = nullptr;
-    if (s->has_alpha) {
-        // ---- older form: the live count comes back to the host once per depth (alpha-test kernels take their ray count from the host)
-        uint64_t m = n;
-        if (live_out) live_out[0] = n;
+        const vt_ray* rays_q = static_cast<const vt_ray*>(d_rays);
+        const uint32_t* ids_q = nullptr;
+        if (s->has_alpha) {
+            // ---- older form: the live count comes back to the host once per depth (alpha-test kernels take their ray count from the host)
+            uint64_t m = n;
+            if (live_out) live_out[0] = n;
+            for (uint32_t d = 0; d < depth; ++d) {
+                vt_hit* row = H + uint64_t(d) * n;
+                if (m < n) VT_HIP(launch_fill_miss(row, n, nullptr, stream));   // paths that ended earlier read as misses
+                const bool last = d + 1 == depth;
+                if (m != 0) {
+                    vt_hit* hits_q = d == 0 ? row : hits_scratch;               // depth 0: queue order = path order
+                    rc = launch(s, rays_q, m, hits_q, nullptr, nullptr, false, false, stream);
+                    if (rc != VT_OK) return rc;
+                    QueueArgs qa{s->d_tris, s->d_prim_to_slot, rays_q, hits_q, ids_q, m, nullptr, d == 0 ? nullptr : row,
+                                 last ? nullptr : R[d & 1], last ? nullptr : I[d & 1], offsets, seed + d};
+                    VT_HIP(launch_queue_step(qa, d_live, stream));
+                    if (!last) {
+                        VT_HIP(hipMemcpyAsync(e->h_live, d_live, 4, hipMemcpyDeviceToHost, stream));
+                        VT_HIP(hipStreamSynchronize(stream));
+                        m = *e->h_live;
+                        rays_q = R[d & 1];
+                        ids_q = I[d & 1];
+                    }
+                }
+                if (live_out && !last) live_out[d + 1] = m;
+            }
+            return VT_OK;
+        }
         for (uint32_t d = 0; d < depth; ++d) {
             vt_hit* row = H + uint64_t(d) * n;
-            if (m < n) VT_HIP(launch_fill_miss(row, n, nullptr, stream));   // paths that ended earlier read as misses
+            const uint32_t* count = d == 0 ? nullptr : d_live + d;          // depth 0: all n paths, known here
+            if (d != 0) VT_HIP(launch_fill_miss(row, n, count, stream));    // paths that ended earlier read as misses
             const bool last = d + 1 == depth;
-            if (m != 0) {
-                vt_hit* hits_q = d == 0 ? row : hits_scratch;               // depth 0: queue order = path order
-                rc = launch(s, rays_q, m, hits_q, nullptr, nullptr, false, false, stream);
-                if (rc != VT_OK) return rc;
-                QueueArgs qa{s->d_tris, s->d_prim_to_slot, rays_q, hits_q, ids_q, m, nullptr, d == 0 ? nullptr : row,
-                             last ? nullptr : R[d & 1], last ? nullptr : I[d & 1], offsets, seed + d};
-                VT_HIP(launch_queue_step(qa, d_live, stream));
-                if (!last) {
-                    VT_HIP(hipMemcpyAsync(e->h_live, d_live, 4, hipMemcpyDeviceToHost, stream));
-                    VT_HIP(hipStreamSynchronize(stream));
-                    m = *e->h_live;
-                    rays_q = R[d & 1];
-                    ids_q = I[d & 1];
-                }
+            vt_hit* hits_q = d == 0 ? row : hits_scratch;                   // depth 0: queue order = path order
+            const BatchReq req{rays_q, hits_q, n, 0, count};
+            rc = launch_batches(s, &req, 1, nullptr, false, false, stream);
+            if (rc != VT_OK) return rc;
+            QueueArgs qa{s->d_tris, s->d_prim_to_slot, rays_q, hits_q, ids_q, n, count, d == 0 ? nullptr : row,
+                         last ? nullptr : R[d & 1], last ? nullptr : I[d & 1], offsets, seed + d};
+            VT_HIP(launch_queue_step(qa, d_live + d + 1, stream));
+            rays_q = R[d & 1];
+            ids_q = I[d & 1];
+        }
+        if (live_out) {
+            live_out[0] = n;
+            if (depth > 1) {
+                VT_HIP(hipMemcpyAsync(e->h_live, d_live + 1, size_t(depth - 1) * 4, hipMemcpyDeviceToHost, stream));
+                LiveCopy* job = new LiveCopy{e->h_live, live_out + 1, depth - 1};
+                const hipError_t herr = VT_TRY(hipLaunchHostFunc(stream, copy_live_counts, job));
+                if (herr != hipSuccess) { delete job; return fail(VT_ERR_HIP, std::string("vt_bounce_loop_dev: ") + hipGetErrorString(herr)); }
             }
-            if (live_out && !last) live_out[d + 1] = m;
         }
-        VT_HIP(hipEventRecord(e->ev_loop, stream));
-        e->loop_used = true;
         return VT_OK;
-    }
-    for (uint32_t d = 0; d < depth; ++d) {
-        vt_hit* row = H + uint64_t(d) * n;
-        const uint32_t* count = d == 0 ? nullptr : d_live + d;          // depth 0: all n paths, known here
-        if (d != 0) VT_HIP(launch_fill_miss(row, n, count, stream));    // paths that ended earlier read as misses
-        const bool last = d + 1 == depth;
-        vt_hit* hits_q = d == 0 ? row : hits_scratch;                   // depth 0: queue order = path order
-        const BatchReq req{rays_q, hits_q, n, 0, count};
-        rc = launch_batches(s, &req, 1, nullptr, false, false, stream);
-        if (rc != VT_OK) return rc;
-        QueueArgs qa{s->d_tris, s->d_prim_to_slot, rays_q, hits_q, ids_q, n, count, d == 0 ? nullptr : row,
-                     last ? nullptr : R[d & 1], last ? nullptr : I[d & 1], offsets, seed + d};
-        VT_HIP(launch_queue_step(qa, d_live + d + 1, stream));
-        rays_q = R[d & 1];
-        ids_q = I[d & 1];
-    }
-    if (live_out) {
-        live_out[0] = n;
-        if (depth > 1) {
-            VT_HIP(hipMemcpyAsync(e->h_live, d_live + 1, size_t(depth - 1) * 4, hipMemcpyDeviceToHost, stream));
-            LiveCopy* job = new LiveCopy{e->h_live, live_out + 1, depth - 1};
-            const hipError_t herr = VT_TRY(hipLaunchHostFunc(stream, copy_live_counts, job));
-            if (herr != hipSuccess) { delete job; return fail(VT_ERR_HIP, std::string("vt_bounce_loop_dev: ") + hipGetErrorString(herr)); }
-        }
-    }
-    VT_HIP(hipEventRecord(e->ev_loop, stream));
-    e->loop_used = true;
+    };
+    const int loop_rc = enqueue_loop();
+    const hipError_t rec = hipEventRecord(e->ev_loop, stream);
+    if (rec == hipSuccess) e->loop_used = true;
+    if (loop_rc != VT_OK) return loop_rc;
+    if (rec != hipSuccess) return fail(VT_ERR_HIP, std::string("vt_bounce_loop_dev: hipEventRecord: ") + hipGetErrorString(rec));
     return VT_OK;
 }
 
