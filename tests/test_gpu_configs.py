@@ -200,6 +200,43 @@ def test_concurrent_launches_on_two_streams(va, eng, make_bundle):
     scene.free()
 
 
+def test_kernel_timing_agrees_with_events_on_the_callers_stream(va, eng, make_bundle):
+    """bench.py's `roofline.achieved` divides by vt_engine_last_kernel_ms (HIP events the library records around the launch on the
+    stream it is launched on).  Checked here against events of the caller's own around the same call, on a non-default stream and
+    on the current one, for a long and a short launch: the library's figure lies inside the caller's bracket and within 3 % + 30 us
+    of it; vt_engine_launch_info describes the launch that was timed."""
+    import torch
+    from vistrace_amd import torch_plumbing as tp
+    from vistrace_amd import workloads as W
+    b = make_bundle("S100k")
+    scene = va.Scene(eng, b.host_scene)
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(dev)
+    eng.set_timing(True)
+    try:
+        for n in (1 << 22, 1 << 16):
+            rays = W.sphere_rays(n, 21, origin=(10.0, -20.0, 30.0))
+            d_rays, d_hits = tp.to_device(rays, dev), tp.empty_records(n, va.HIT, dev)
+            for stream in (side, torch.cuda.current_stream(dev)):
+                for _ in range(3):                                       # warm: launch-slot allocations, clocks
+                    scene.trace_closest_dev(d_rays.data_ptr(), n, d_hits.data_ptr(), stream.cuda_stream)
+                stream.synchronize()
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(stream)
+                scene.trace_closest_dev(d_rays.data_ptr(), n, d_hits.data_ptr(), stream.cuda_stream)
+                t1.record(stream)
+                stream.synchronize()
+                outer, inner = t0.elapsed_time(t1), eng.last_kernel_ms()
+                assert 0.0 < inner <= outer + 0.005, (n, inner, outer)
+                assert outer - inner <= 0.03 * outer + 0.030, (n, inner, outer)
+                info = eng.launch_info()
+                assert info["threads"] == 256 and info["blocks"] >= 1 and info["lds_bytes"] >= 256, info
+        assert_hits_equal(tp.to_host(d_hits, va.HIT), b.oracle(rays))
+    finally:
+        eng.set_timing(False)
+    scene.free()
+
+
 def test_host_threads_share_an_engine(va, eng, make_bundle):
     """include/vistrace_hip.h, "Threading and streams": host threads may share an engine.  Six threads hammer ONE engine for a few
     seconds with everything the header allows at once -- `_dev` launches on their own streams (two scenes), host-pointer traces,
