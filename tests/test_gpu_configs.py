@@ -203,7 +203,7 @@ def test_concurrent_launches_on_two_streams(va, eng, make_bundle):
 def test_kernel_timing_agrees_with_events_on_the_callers_stream(va, eng, make_bundle):
     """bench.py's `roofline.achieved` divides by vt_engine_last_kernel_ms (HIP events the library records around the launch on the
     stream it is launched on).  Checked here against events of the caller's own around the same call, on a non-default stream and
-    on the current one, for a long and a short launch: the library's figure lies inside the caller's bracket and within 3 % + 30 us
+    on the current one, for a long and a short launch: the library's figure lies inside the caller's bracket and within 3 % + 50 us
     of it; vt_engine_launch_info describes the launch that was timed."""
     import torch
     from vistrace_amd import torch_plumbing as tp
@@ -228,7 +228,7 @@ def test_kernel_timing_agrees_with_events_on_the_callers_stream(va, eng, make_bu
                 stream.synchronize()
                 outer, inner = t0.elapsed_time(t1), eng.last_kernel_ms()
                 assert 0.0 < inner <= outer + 0.005, (n, inner, outer)
-                assert outer - inner <= 0.03 * outer + 0.030, (n, inner, outer)
+                assert outer - inner <= 0.03 * outer + 0.050, (n, inner, outer)
                 info = eng.launch_info()
                 assert info["threads"] == 256 and info["blocks"] >= 1 and info["lds_bytes"] >= 256, info
         assert_hits_equal(tp.to_host(d_hits, va.HIT), b.oracle(rays))
