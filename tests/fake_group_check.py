@@ -169,6 +169,60 @@ checks += 1
 scene.free()
 eng.close()
 
+# ---- two host threads on one group: Rebuilds of one scene beside refits of another (advisor, round 5: vt_scene_upload_tree held the
+# root's lock while it asked its peers, the group-wide refits hold every member's lock, peers first -- opposite orders; the upload
+# now lets go of the root before it goes to the peers).  Both threads must get through, with right answers. ----------------------
+import time
+eng = va.Engine([0, 0, 0])
+keep = va.Scene.from_tree(eng, bvh)
+small = big[:20000]
+ref_small = oracle(small)
+moved_v = (verts + np.float32(0.25)).astype(np.float32)
+moved_b = va.HostBvh(tris)
+moved_b.refit(va.tris_setup(moved_v))
+ref_moved = O.traverse_batch(moved_b.nodes().view(O.NODE), moved_b.prim_indices(), O.tris_from_tri64(va.tris_setup(moved_v)), small)[0]
+stop_at = time.time() + 3.0
+errors, rounds = [], {"rebuild": 0, "refit": 0}
+
+
+def rebuilds():
+    try:
+        while time.time() < stop_at and not errors:
+            sc = va.Scene.from_tree(eng, bvh)                      # vt_scene_upload_tree on the root, replicas on the peers
+            if not same(sc.trace_closest(small), ref_small):
+                errors.append("a scene rebuilt beside a refit answers wrongly")
+            sc.free()
+            rounds["rebuild"] += 1
+    except Exception as exc:                                        # noqa: BLE001
+        errors.append(f"rebuild thread: {exc}")
+
+
+def refits():
+    try:
+        k = 0
+        while time.time() < stop_at and not errors:
+            keep.refit(moved_v if k % 2 == 0 else verts)           # every member's lock at once
+            if not same(keep.trace_closest(small), ref_moved if k % 2 == 0 else ref_small):
+                errors.append("a scene refitted beside a Rebuild answers wrongly")
+            k += 1
+            rounds["refit"] += 1
+    except Exception as exc:                                        # noqa: BLE001
+        errors.append(f"refit thread: {exc}")
+
+
+pair = [threading.Thread(target=rebuilds, daemon=True), threading.Thread(target=refits, daemon=True)]      # (daemon: a deadlocked pair must not keep the process)
+for t in pair:
+    t.start()
+for t in pair:
+    t.join(60)
+    if t.is_alive():
+        print("Rebuild beside refit on a group: a thread hangs (lock order)", flush=True)
+        os._exit(3)
+assert not errors and rounds["rebuild"] >= 3 and rounds["refit"] >= 3, (errors, rounds)
+checks += 2
+keep.free()
+eng.close()
+
 # ---- one engine per rank, one thread per rank: vt_engine_comm_init_rank + vt_gather_hits[_part]_dev -------------------------------
 for nranks in (2, 4):
     uid = va.comm_unique_id()

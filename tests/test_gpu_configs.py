@@ -238,10 +238,11 @@ def test_kernel_timing_agrees_with_events_on_the_callers_stream(va, eng, make_bu
 
 
 def test_host_threads_share_an_engine(va, eng, make_bundle):
-    """include/vistrace_hip.h, "Threading and streams": host threads may share an engine.  Six threads hammer ONE engine for a few
+    """include/vistrace_hip.h, "Threading and streams": host threads may share an engine.  Eight threads hammer ONE engine for a few
     seconds with everything the header allows at once -- `_dev` launches on their own streams (two scenes), host-pointer traces,
-    batch objects with fetched hits, merged sets, the bounce loop, a single-ray host walk, and one thread that refits a scene of its
-    own back and forth between two poses and traces it after each -- and every result is compared with what the same call returns
+    batch objects with fetched hits, merged sets, the bounce loop, one thread that refits a scene of its own back and forth between two
+    poses and traces it after each, two threads that upload, trace and free scenes (round 6 found the engine's scene list changing
+    without a lock there) -- and every result is compared with what the same call returns
     single-threaded (which the other tests hold against the oracle).  ctypes releases the GIL inside a call, so the calls overlap."""
     import threading
     import time
@@ -331,8 +332,18 @@ def test_host_threads_share_an_engine(va, eng, make_bundle):
         if not same(scene_c.trace_closest(rays_c), ref_c1 if pose else ref_c0):
             raise AssertionError(f"refit {k}: the refitted scene differs")
 
+    bvh_c = va.HostBvh(va.tris_setup(verts_c))
+
+    def rebuilds(k):                                     # Rebuild's upload and vt_scene_free beside everything else (both forms of upload)
+        sc = va.Scene.from_tree(eng, bvh_c) if k % 2 == 0 else va.Scene(eng, va.HostScene(bvh_c))
+        ok = same(sc.trace_closest(rays_c), ref_c0)
+        sc.free()
+        if not ok:
+            raise AssertionError(f"rebuild {k}: the new scene differs")
+
     threads = [guard("dev A", dev_launches(scene_a, rays_a, ref_a, "scene A")), guard("dev B", dev_launches(scene_b, rays_b, ref_b, "scene B")),
-               guard("host", host_calls), guard("batches", batches), guard("loops", loops), guard("refits", refits)]
+               guard("host", host_calls), guard("batches", batches), guard("loops", loops), guard("refits", refits),
+               guard("rebuilds", rebuilds), guard("rebuilds 2", rebuilds)]
     for t in threads:
         t.start()
     for t in threads:

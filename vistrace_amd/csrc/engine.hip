@@ -541,11 +541,12 @@ void vt_engine_close(vt_engine* e)
     DeviceGuard guard(e->device);
     (void)hipDeviceSynchronize();               // launches on caller streams may still use the cursor / overflow areas
     multi_release(e);
-    for (vt_scene* sc : e->scenes) {            // scenes that outlive their engine become inert shells
+    std::vector<vt_scene*> left;
+    { std::lock_guard<std::mutex> lock(e->launch_mu); left.swap(e->scenes); }
+    for (vt_scene* sc : left) {                 // scenes that outlive their engine become inert shells
         release_scene_device(sc);
         sc->engine = nullptr;
     }
-    e->scenes.clear();
     for (vt_batch* b : e->batches) {            // batches that outlive their engine keep what they have downloaded
         if (b->d_mem) (void)hipFree(b->d_mem);
         if (b->done) (void)hipEventDestroy(b->done);
@@ -716,11 +717,11 @@ int vt_scene_upload(vt_engine* e, const vt_host_scene* hsw, vt_scene** out)
     }
     s->upload_stats.copy_ms = float(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     if (err != hipSuccess) {
-        e->scenes.push_back(s);
+        track_scene(e, s);
         vt_scene_free(s);
         return fail(VT_ERR_HIP, std::string("vt_scene_upload: ") + hipGetErrorString(err));
     }
-    e->scenes.push_back(s);
+    track_scene(e, s);
     {
         // triangle -> slot (refits) and the pairs by depth, deepest first (level-wise refit): built on the device from the
         // records just uploaded and the pairs' depths (scene_build.hip) -- round 4 made both on the host, serially
@@ -770,7 +771,7 @@ void vt_scene_free(vt_scene* s)
         DeviceGuard guard(e->device);
         (void)hipDeviceSynchronize();           // traces of this scene may be in flight on caller streams
         release_scene_device(s);
-        e->scenes.erase(std::remove(e->scenes.begin(), e->scenes.end(), s), e->scenes.end());
+        untrack_scene(e, s);
     }
     delete s;
 }
@@ -1483,7 +1484,7 @@ int scene_replicate(vt_scene* s, const std::function<int(vt_engine*, vt_scene**)
         r->record_capacity = s->record_capacity; r->coherent_radius2 = s->coherent_radius2; r->level_begin = s->level_begin;
         r->upload_stats = s->upload_stats;
         r->host_copies = s->host_copies;                  // the host copies the root was uploaded from go stale with this member's refits too
-        p->scenes.push_back(r);
+        track_scene(p, r);
         reps.push_back(r);
         hipError_t err = dev_malloc(reinterpret_cast<void**>(&r->d_records), rec_b);
         if (err == hipSuccess && slot_b) err = dev_malloc(reinterpret_cast<void**>(&r->d_prim_to_slot), slot_b);

@@ -123,7 +123,8 @@ struct vt_engine {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool       ev_valid = false;
 
-    // scenes uploaded through this engine: closing the engine releases their device memory and detaches them
+    // scenes uploaded through this engine: closing the engine releases their device memory and detaches them.  Like `batches`
+    // below the list changes under launch_mu: uploads and frees may come from any host thread (track_scene / untrack_scene)
     std::vector<vt_scene*> scenes;
     std::vector<vt_batch*> batches;          // live vt_batch objects (their device arrays go with the engine)
     std::vector<std::pair<char*, size_t>> device_spare;   // device blocks of freed batches, for the next ones that fit (at most 32)
@@ -246,6 +247,13 @@ struct DeviceGuard {
 };
 
 namespace vt {
+
+inline void track_scene(vt_engine* e, vt_scene* s) { std::lock_guard<std::mutex> lock(e->launch_mu); e->scenes.push_back(s); }
+inline void untrack_scene(vt_engine* e, vt_scene* s)
+{
+    std::lock_guard<std::mutex> lock(e->launch_mu);
+    e->scenes.erase(std::remove(e->scenes.begin(), e->scenes.end(), s), e->scenes.end());
+}
 
 // EVERY device / pinned-host allocation of the library goes through these two (tests/test_abi_symbols.py greps for strays): one
 // place for the fault injection of include/vistrace_hip.h's "Test hooks" (VT_TEST_FAIL_ALLOC); a plain call otherwise.

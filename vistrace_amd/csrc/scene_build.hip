@@ -399,11 +399,11 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
     if (herr == hipSuccess) herr = dev_malloc(reinterpret_cast<void**>(&s->d_prim_to_slot), size_t(ntris) * 4);
     if (herr == hipSuccess) herr = dev_malloc(reinterpret_cast<void**>(&s->d_level_pairs), size_t(np) * 4);
     if (herr != hipSuccess) {
-        e->scenes.push_back(s);
+        track_scene(e, s);
         vt_scene_free(s);
         return fail(VT_ERR_HIP, std::string("vt_scene_upload_tree: ") + hipGetErrorString(herr));
     }
-    e->scenes.push_back(s);
+    track_scene(e, s);
     s->bytes = rec_bytes + size_t(ntris) * 4 + size_t(np) * 4;
     s->d_tris = reinterpret_cast<vt_tri64*>(s->d_records + size_t(s->tri_base) * 64);
     // only what the kernels do not write needs zeros: the padding record between pairs and triangles (+ the test gap), the AlphaRec room
@@ -436,7 +436,7 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
     s->upload_stats.bytes_h2d = uint64_t(N) * 32 + uint64_t(M) * 4 + uint64_t(ntris) * 64;
     s->upload_stats.linearised_on_device = 1;
 
-    host_lock.unlock();
+    VT_MUT(33, (void)0, host_lock.unlock());      // (mutant 33 keeps the root's lock while the peers are asked: the round-5 lock order)
     // a group's scene lives on every device: the finished records and index tables go from this device to the
     // others as device-to-device copies (engine.hip: scene_replicate) -- the host uploads the tree once
     rc = scene_replicate(s, [&](vt_engine* p, vt_scene** rep) { return vt_scene_upload_tree(p, bvhw, tris, ntris, rep); });
