@@ -20,7 +20,8 @@
  * counters, stack overflow area) from a ring of 16 launch slots, so `_dev` launches of one engine may be
  * in flight on any number of streams at once and host threads may share an engine (enqueueing is
  * serialised internally; the host-pointer entry points and vt_bounce_loop_dev, which use engine-wide
- * staging, run one at a time per engine).  Calls that rewrite a scene in place (vt_scene_refit,
+ * staging, run one at a time per engine; scenes and batch objects may be created and freed from any host
+ * thread).  Calls that rewrite a scene in place (vt_scene_refit,
  * vt_scene_skin_refit, vt_scene_set_alpha, vt_scene_free) first wait for every launch in flight on the
  * device.  vt_engine_set_timing / vt_engine_last_kernel_ms describe the last launch only.
  *
