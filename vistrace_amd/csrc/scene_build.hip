@@ -436,7 +436,7 @@ int vt_scene_upload_tree(vt_engine* e, const vt_bvh* bvhw, const vt_tri64* tris,
     s->upload_stats.bytes_h2d = uint64_t(N) * 32 + uint64_t(M) * 4 + uint64_t(ntris) * 64;
     s->upload_stats.linearised_on_device = 1;
 
-    VT_MUT(33, (void)0, host_lock.unlock());      // (mutant 33 keeps the root's lock while the peers are asked: the round-5 lock order)
+    host_lock.unlock();      // (tests/fake_group_check.py runs Rebuilds beside refits on a group from two threads)
     // a group's scene lives on every device: the finished records and index tables go from this device to the
     // others as device-to-device copies (engine.hip: scene_replicate) -- the host uploads the tree once
     rc = scene_replicate(s, [&](vt_engine* p, vt_scene** rep) { return vt_scene_upload_tree(p, bvhw, tris, ntris, rep); });
