@@ -4,7 +4,7 @@
 the product library: tests/test_abi_symbols.py): 2 = a hit accepted on `t < tmax` instead of `t <= tmax`
 (source/objects/Primitives.h:189), 7 = a node accepted on `first < second` instead of `<=` (bvh v1's slab test).
 Each is put in front of the golden-vector check through VISTRACE_HIP_LIB in a child process: the product library reproduces the
-committed fixtures bit for bit, both mutants must not.  The whole list of sixteen: scripts/mutants.sh, profiles/r6/mutants.txt."""
+committed fixtures bit for bit, both mutants must not.  The whole campaign (73 mutants): scripts/mutants*.sh, profiles/r6/mutants*.txt."""
 import os
 import subprocess
 import sys
