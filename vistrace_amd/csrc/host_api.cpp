@@ -97,7 +97,7 @@ void parallel_copy(void* dst, const void* src, size_t bytes)
 {
     const long long piece = 1 << 20;
     const long long pieces = (static_cast<long long>(bytes) + piece - 1) / piece;
-    static const long long cap = std::getenv("VT_COPY_THREADS") ? std::atoll(std::getenv("VT_COPY_THREADS")) : 8;
+    static const long long cap = [] { const char* v = std::getenv("VT_COPY_THREADS"); return v ? std::atoll(v) : 8ll; }();
     const int threads = int(std::max<long long>(1, std::min<long long>({cap, pieces, omp_get_max_threads()})));
 #pragma omp parallel for num_threads(threads) schedule(static)
     for (long long k = 0; k < pieces; ++k) {
