@@ -372,7 +372,9 @@ for case in cases:
         del e, ctx, r
     level = free_bytes()            # (after the clean run: torch's caching allocator holds what the case's device tensors need)
     failed = survived = 0
-    for k in range(1, count + 1):
+
+    def inject(k):
+        """one run with the k-th step failing; returns (reported as an error, absorbed)"""
         if case.run is None:
             arm(k)
             try:
@@ -380,30 +382,44 @@ for case in cases:
                 raise AssertionError(f"vt_engine_open with its {k}-th step failing must fail")
             except Err as exc:
                 assert exc.code != 0 and str(exc), "no message"
-                failed += 1
             arm(0)
             e = va.Engine(0)                       # the next open works
             assert golden_ok(e)
             e.close()
-        else:
-            e = open_engine(case.members)
-            ctx = case.setup(e) if case.setup else {}
-            arm(k)
-            r = None
-            try:
-                r = case.run(e, ctx)
-                survived += 1
-                assert case.may_absorb or HIP_MODE, f"{case.name}: allocation {k} failed but the call reported success"
-            except Err as exc:
-                assert exc.code != 0 and len(str(exc)) > 8, f"{case.name} k={k}: no message"
-                failed += 1
-            arm(0)
-            assert case.check is None or case.check(e, ctx, r), f"{case.name} k={k}: wrong results after the injected failure"
-            assert golden_ok(e), f"{case.name} k={k}: the engine no longer reproduces the golden fixture"
-            e.close()
-            del e, ctx, r
+            return 1, 0
+        e = open_engine(case.members)
+        ctx = case.setup(e) if case.setup else {}
+        arm(k)
+        r, rep, absorbed = None, 0, 0
+        try:
+            r = case.run(e, ctx)
+            absorbed = 1
+            assert case.may_absorb or HIP_MODE, f"{case.name}: allocation {k} failed but the call reported success"
+        except Err as exc:
+            assert exc.code != 0 and len(str(exc)) > 8, f"{case.name} k={k}: no message"
+            rep = 1
+        arm(0)
+        assert case.check is None or case.check(e, ctx, r), f"{case.name} k={k}: wrong results after the injected failure"
+        assert golden_ok(e), f"{case.name} k={k}: the engine no longer reproduces the golden fixture"
+        e.close()
+        return rep, absorbed
+
+    for k in range(1, count + 1):
+        rep, absorbed = inject(k)
+        failed += rep
+        survived += absorbed
         now = free_bytes()
-        assert abs(now - level) <= (2 << 20), f"{case.name} k={k}: device memory not back at its level ({(level - now) / 1e6:.1f} MB missing)"
+        if abs(now - level) > (2 << 20):
+            # A leak of the library repeats; a block the HIP runtime keeps for itself (staging chunks, signal pools: seen once in
+            # a while, a few MB) does not.  The same injection once more: the level may not move again.
+            first = now
+            inject(k)
+            now = free_bytes()
+            assert abs(now - first) <= (1 << 20), (f"{case.name} k={k}: device memory not back at its level "
+                                                   f"({(level - first) / 1e6:.1f} MB missing, {(first - now) / 1e6:.1f} MB more on the repeat)")
+            print(f"    {case.name} k={k}: the free-memory level moved by {(level - first) / 1e6:.1f} MB once and not again on the repeat "
+                  f"(the runtime's own blocks); new level", flush=True)
+            level = now
     total_k += count
     total_failed += failed
     assert failed + survived == count and (case.may_absorb or HIP_MODE or failed == count), f"{case.name}: {failed} of {count} injected failures surfaced"
